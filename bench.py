@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the kwage search path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2]
+
+A "step" is one pass of the hot path over one batch of synthetic queries against the
+HBM-resident synthetic database (k-mer pack + MurmurHash3 + row gather + AND/count + hit
+compaction + D2H of the sorted hit list).  Inputs (database and query strings) are resident in
+HBM before the timed region.  Metric = BASELINE.json's: G k-mer.sample bit-tests/s, with the
+achieved HBM GB/s of the gather kernel against the 8 TB/s roofline beside it.
+
+N > 1: one process per GPU (launched by torch.distributed.run); the sample (column) axis is
+sharded -- every rank holds its own block of `num_samples` columns (weak scaling), searches it
+independently, and the per-rank hit lists are concatenated on rank 0 by one padded RCCL gather.
+No row data ever crosses xGMI.
+
+The CPU baseline (rank 0, N=1 only) times the REFERENCE binary (oracle/_ref/kwage, OpenMP over
+<=2048-column .db files) when it travelled with the snapshot, else the repo's C restatement, on
+a bounded column subset of the same workload.  It is a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("KWAGE_BENCH_WORKLOAD", "c2"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--early-exit", action="store_true", help="enable the reference's early exit (not the nominal figure)")
+    ap.add_argument("--cpu-files", type=int, default=0, help="number of 2048-column .db files of the CPU sample (default: host cores, max 16)")
+    return ap.parse_args()
+
+
+def cpu_baseline(w, queries, n_files):
+    """Time the reference CPU `kwage` (or the oracle port) on a bounded sample of workload w:
+    n_files .db files x 2048 columns, 2^min(L,20) rows, SAME k / hashes / threshold / queries.
+    Every file holds the planted genomes in one column so that the reference's early exit
+    (kwage.cpp:466-470) never fires: it reads every addressed row, like the nominal GPU figure."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import kwage_oracle as oracle
+    cores = os.cpu_count() or 1
+    if n_files <= 0:
+        n_files = min(cores, 16)
+    L = min(w.log_2_filter_len, 20)
+    ncol = 2048
+    k, nh = w.kmer_len, w.num_hash
+    rng = np.random.default_rng(99)
+    # sample of the query set sized so the CPU leg stays ~10-30 s
+    qs = [q for q in queries if len(q) >= k][:max(1, min(len(queries), 1000))]
+    tmp = tempfile.mkdtemp(prefix="kwage_cpu_", dir="/tmp")
+    try:
+        # rows addressed by the queries' k-mers (so the planted column matches every query)
+        uniq = [oracle.unique_kmers(q, k) for q in qs]
+        total_kmers = int(sum(len(u) for u in uniq))
+        addressed = np.unique(np.concatenate([oracle.row_indices(u, k, nh, L).reshape(-1) for u in uniq[:200]])) \
+            if total_kmers else np.zeros(0, np.uint32)
+        infos = [oracle.FilterInfo(run_accession=oracle.str_to_accession("SRR%07d" % j)) for j in range(ncol)]
+        image = None
+        for f in range(n_files):
+            a = rng.integers(0, 1 << 63, size=(1 << L, ncol // 64), dtype=np.uint64)
+            b = rng.integers(0, 1 << 63, size=(1 << L, ncol // 64), dtype=np.uint64)
+            rows = (a & b).view(np.uint8).reshape(1 << L, ncol // 8).copy()    # density ~0.25
+            rows[addressed, 0] |= 1                                           # column 0 matches the first 200 queries
+            oracle.write_db(os.path.join(tmp, "s%02d.db" % f), k, nh, L, rows, ncol, infos)
+            if f == 0:
+                image = rows
+        qfile = os.path.join(tmp, "q.fa")
+        with open(qfile, "w") as fh:
+            for i, q in enumerate(qs):
+                fh.write(">q%d\n%s\n" % (i, q))
+        bit_tests = total_kmers * nh * ncol * n_files
+        if os.access(oracle.REF_KWAGE, os.X_OK):
+            env = dict(os.environ, OMP_NUM_THREADS=str(cores))
+            best = None
+            for _ in range(2):     # first run warms the page cache
+                t0 = time.perf_counter()
+                r = subprocess.run([oracle.REF_KWAGE, "-d", tmp, "-i", qfile, "-t", repr(float(w.threshold)), "--o.csv",
+                                    "-o", os.path.join(tmp, "out.csv")], env=env, capture_output=True)
+                dt = time.perf_counter() - t0
+                if r.returncode != 0:
+                    raise RuntimeError("reference kwage failed: " + r.stderr.decode())
+                best = dt if best is None else min(best, dt)
+            return {"value": bit_tests / best / 1e9, "unit": "G bit-tests/s", "cores": min(cores, n_files), "kind": "reference",
+                    "sample": "reference kwage (OpenMP over files), %d files x %d columns x 2^%d rows, %d queries x %d bp, "
+                              "page cache warm, best of 2, wall %.2f s; early exit mostly defeated by a planted column"
+                              % (n_files, ncol, L, len(qs), w.query_len, best)}
+        # fallback: the repo's own C restatement, one thread, one file image in memory
+        t0 = time.perf_counter()
+        thr = float(np.float32(w.threshold))
+        for u in uniq:
+            oracle.search_image(image, image.shape[1], k, nh, L, ncol, u, thr, early_exit=True)
+        dt = time.perf_counter() - t0
+        return {"value": total_kmers * nh * ncol / dt / 1e9, "unit": "G bit-tests/s", "cores": 1, "kind": "port",
+                "sample": "oracle C restatement, 1 thread, 1 file x %d columns x 2^%d rows in memory, %d queries, wall %.2f s"
+                          % (ncol, L, len(qs), dt)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    import kwage_amd as ka
+    from kwage_amd import synth
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    w = synth.WORKLOADS[args.workload]
+    ctx = ka.Context(local_rank)
+    t_build = time.perf_counter()
+    s = synth.build(ctx, w, seed=1, column_seed=rank)
+    t_build = time.perf_counter() - t_build
+    flags = ka.SEARCH_TIMING | (ka.SEARCH_EARLY_EXIT if args.early_exit else 0)
+    threshold = w.threshold
+
+    hits_dev = None
+    if world > 1:
+        cap = 1 << 20
+        hits_dev = torch.empty((cap, 3), dtype=torch.int32, device="cuda")
+
+    def step():
+        """One pass of the hot path; returns (result-or-None, search_kernel_ms, n_hits_total_on_rank0)."""
+        if world == 1:
+            r = s.group.search(s.batch, threshold, flags)
+            return r, r.search_kernel_ms, len(r.hits)
+        # multi-GPU: leave hits on the device, exchange with ONE padded gather over RCCL
+        nonlocal hits_dev
+        import ctypes as C
+        from kwage_amd.native import lib, check
+        n = C.c_uint64()
+        while True:
+            check(lib().kwage_search_device(s.group._h, s.batch._h, C.c_float(threshold), flags,
+                                            hits_dev.data_ptr(), hits_dev.shape[0], C.byref(n), None))
+            if n.value <= hits_dev.shape[0]:
+                break
+            hits_dev = torch.empty((int(n.value * 1.25), 3), dtype=torch.int32, device="cuda")
+        cnt = torch.tensor([n.value], dtype=torch.int64, device="cuda")
+        counts = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(counts, cnt)
+        mx = max(int(c.item()) for c in counts)
+        total = 0
+        if mx:
+            mine = hits_dev[:mx].contiguous() if mx <= hits_dev.shape[0] else torch.cat(
+                [hits_dev, torch.zeros((mx - hits_dev.shape[0], 3), dtype=torch.int32, device="cuda")])
+            outs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+            dist.gather(mine, outs, dst=0)
+            if rank == 0:
+                parts = []
+                for r_, (o, c) in enumerate(zip(outs, counts)):
+                    p = o[: int(c.item())].cpu().numpy().astype(np.uint32)
+                    p[:, 1] += np.uint32(0)   # columns are local to the rank's block; global id = (rank, column)
+                    parts.append(np.concatenate([np.full((len(p), 1), r_, np.uint32), p], axis=1))
+                allhits = np.concatenate(parts) if parts else np.zeros((0, 4), np.uint32)
+                order = np.lexsort((allhits[:, 2], allhits[:, 0], allhits[:, 1]))   # by query, rank, column
+                allhits = allhits[order]
+                total = len(allhits)
+        return None, 0.0, total
+
+    def sync_all():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    last = None
+    nhits = 0
+    for _ in range(args.steps):
+        last, ms, nhits = step()
+        kernel_ms.append(ms)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # work per step (identical on every rank: same queries, same column count)
+    probe = last if last is not None else s.group.search(s.batch, threshold, flags)
+    bit_tests_rank = int(probe.bit_tests)
+    alg_bytes_rank = int(probe.algorithmic_bytes)
+    if world > 1:
+        kernel_ms = []
+        for _ in range(3):
+            kernel_ms.append(s.group.search(s.batch, threshold, flags).search_kernel_ms)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = bit_tests_rank * world * args.steps / dt / 1e9
+        k_ms = float(np.mean(kernel_ms)) if kernel_ms else 0.0
+        achieved = alg_bytes_rank / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        stream_gbps = s.group.stream_read_gbps(min(s.group.device_bytes, 8 << 30), 3)
+        out = {
+            "metric": "G k-mer*sample bit-tests/sec",
+            "value": round(value, 3),
+            "unit": "G bit-tests/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 (bitwise AND / bit-sliced integer counters)",
+            "data": "synthetic",
+            "config": {"workload": w.name, "samples_per_gpu": w.num_samples, "log_2_filter_len": w.log_2_filter_len,
+                       "kmer_len": w.kmer_len, "num_hash": w.num_hash, "queries": w.num_queries, "query_len": w.query_len,
+                       "threshold": w.threshold, "early_exit": bool(args.early_exit), "density": w.density_q8 / 256.0,
+                       "db_bytes_per_gpu": int(s.group.device_bytes), "sharding": "columns (samples) over %d GPU(s)" % world,
+                       "total_kmers_per_step": int(probe.total_kmers), "hits_per_step": int(nhits),
+                       "db_build_s": round(t_build, 2)},
+            "hbm_gbps_algorithmic_whole_step": round(alg_bytes_rank * world * args.steps / dt / 1e9, 1),
+            "roofline": {"bound": "hbm", "kernel": "and_kernel" if threshold == 1.0 else "count_kernel",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": alg_bytes_rank,
+                         "measured_stream_read_gbps": round(stream_gbps, 1),
+                         "frac_of_measured_stream": round(achieved / stream_gbps, 4) if stream_gbps else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(w, s.queries, args.cpu_files)
+            except Exception as e:   # the baseline is informative; never lose the GPU number over it
+                out["cpu_baseline"] = {"value": None, "unit": "G bit-tests/s", "cores": 0, "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+
+    s.batch.close()
+    s.group.close()
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,231 @@
+/* include/kwage_amd.h -- C ABI of the MI355X-native `kwage` search engine.
+ *
+ * This is the drop-in boundary for the one hot path of LANL-Bioinformatics/KWAGE: the body
+ * of `search()` (reference kwage.cpp:26-31 declaration, :340-541 body) and the two loops in
+ * `main` that call it (kwage.cpp:116-148).  The reference has no FFI of its own; a
+ * maintainer replaces those loops with the calls below (INTEGRATION.md shows the patch).
+ *
+ * Conventions
+ *   - plain C types only; every function returns KWAGE_OK (0) or a negative status and
+ *     records a message retrievable with kwage_last_error() (thread local) -- this replaces
+ *     the reference's `throw "file:func: msg"` literals (kwage.cpp:419,452; hash.cpp:92).
+ *   - objects are opaque handles, created/destroyed explicitly; buffers returned by the
+ *     library stay owned by it until the matching free / destroy call.
+ *   - one kwage_ctx == one GPU == one HIP stream.  A ctx and the objects made from it may be
+ *     used from one thread at a time; different ctxs are independent (this mirrors the
+ *     reference's per-OpenMP-thread ifstream + result map, kwage.cpp:76-89).
+ *   - there is NO CPU fallback: without a usable gfx950 device kwage_init fails.
+ */
+#ifndef KWAGE_AMD_H
+#define KWAGE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KWAGE_AMD_ABI_VERSION 1
+
+enum {
+	KWAGE_OK = 0,
+	KWAGE_ERR_ARG = -1,        /* bad argument / unsupported parameter                    */
+	KWAGE_ERR_DEVICE = -2,     /* HIP error (no device, out of memory, launch failure)    */
+	KWAGE_ERR_IO = -3,         /* file could not be opened / read / is truncated          */
+	KWAGE_ERR_FORMAT = -4,     /* not a KWAGE database / unsupported compression          */
+	KWAGE_ERR_HASH = -5,       /* unknown hash function (reference hash.cpp:92)           */
+	KWAGE_ERR_STATE = -6       /* call order violated (e.g. search before finalize)       */
+};
+
+/* Limits the reference compiles in (word.h:10, bloom.h:20-21). */
+#define KWAGE_MAX_WORD_LEN 32
+#define KWAGE_MIN_NUM_HASH 1
+#define KWAGE_MAX_NUM_HASH 5
+#define KWAGE_HASH_MURMUR32 0      /* hash.h:9 MURMUR_HASH_32 */
+
+/* search flags */
+#define KWAGE_SEARCH_EARLY_EXIT 1u /* kwage.cpp:437-483: stop a query tile once no column can
+                                      still match. Never changes results, only work done.   */
+#define KWAGE_SEARCH_TIMING     2u /* record HIP-event durations of the kernels in the result */
+
+const char *kwage_last_error(void);
+uint32_t kwage_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Device context
+ * ---------------------------------------------------------------------------------- */
+typedef struct kwage_ctx kwage_ctx;
+
+/* Number of visible HIP devices (0 if none / no driver). Never fails. */
+int kwage_device_count(void);
+/* Bind a context to HIP device `device` and create its stream. */
+int kwage_init(int device, kwage_ctx **out);
+void kwage_shutdown(kwage_ctx *ctx);
+/* Free / total device memory in bytes. */
+int kwage_mem_info(kwage_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
+/* Block until everything queued on the context's stream has finished. */
+int kwage_sync(kwage_ctx *ctx);
+
+/* ------------------------------------------------------------------------------------
+ * Database group: all columns (samples) that share (kmer_len, num_hash, log_2_filter_len,
+ * hash_func), concatenated into ONE wide row-major bit matrix resident in HBM.
+ * Replaces the per-file `seekg + slice.read` of kwage.cpp:414-416 / :447-449.
+ * Row r, global column c  <->  byte r*row_stride + c/8, bit c%8 (LSB first, bloom.h:143,162).
+ * ---------------------------------------------------------------------------------- */
+typedef struct kwage_group kwage_group;
+
+typedef struct {
+	uint32_t kmer_len;          /* 1..32                    (DBFileHeader::kmer_len)         */
+	uint32_t num_hash;          /* 1..5                     (DBFileHeader::num_hash)         */
+	uint32_t log_2_filter_len;  /* rows = 1 << this, <= 32  (DBFileHeader::log_2_filter_len) */
+	int32_t  hash_func;         /* KWAGE_HASH_MURMUR32      (DBFileHeader::hash_func)        */
+} kwage_params;
+
+/* Allocate a group able to hold `column_capacity` columns (rounded up internally so that the
+ * row stride is a multiple of 128 bytes). Rows are zero-initialised. */
+int kwage_group_create(kwage_ctx *ctx, const kwage_params *params, uint64_t column_capacity,
+                       kwage_group **out);
+void kwage_group_destroy(kwage_group *g);
+
+/* Append `num_filter` columns from a host image of a file's bit-slice block
+ * (2^L rows of ceil(num_filter/8) bytes, `host_row_stride` bytes apart).  The block is placed at
+ * the next byte-aligned column; *first_column receives the global index of its column 0. */
+int kwage_group_add_columns(kwage_group *g, const void *host_rows, uint64_t host_row_stride,
+                            uint32_t num_filter, uint64_t *first_column);
+
+/* Append every column of a NO_COMPRESSION `.db` file (header kwage.h:30-72; body
+ * build_db.cpp:243-315), streaming the slice block to the device through pinned staging
+ * buffers.  The file's parameters must equal the group's. */
+int kwage_group_add_db_file(kwage_group *g, const char *path, uint64_t *first_column,
+                            uint32_t *num_filter);
+
+/* Append `num_columns` synthetic columns: i.i.d. Bernoulli(density_q8/256) bits from a
+ * counter-based generator keyed by (seed, row, 64-bit word index) -- generated ON the device. */
+int kwage_group_add_random_columns(kwage_group *g, uint64_t num_columns, uint64_t seed,
+                                   uint32_t density_q8, uint64_t *first_column);
+
+/* Set individual bits (planting known positives into a synthetic database). */
+int kwage_group_set_bits(kwage_group *g, const uint32_t *rows, const uint64_t *columns, uint64_t n);
+
+/* Copy `n` whole rows (row_bytes() bytes each) back to the host, `out_stride` bytes apart. */
+int kwage_group_read_rows(kwage_group *g, const uint32_t *rows, uint64_t n, void *out,
+                          uint64_t out_stride);
+
+/* No more columns will be added; uploads the valid-column mask. Required before searching. */
+int kwage_group_finalize(kwage_group *g);
+
+uint64_t kwage_group_num_columns(const kwage_group *g);   /* valid columns added so far       */
+uint64_t kwage_group_column_span(const kwage_group *g);   /* next free global column index    */
+uint64_t kwage_group_row_bytes(const kwage_group *g);     /* ceil(column_span/8)              */
+uint64_t kwage_group_row_stride(const kwage_group *g);    /* bytes between rows in HBM        */
+uint64_t kwage_group_device_bytes(const kwage_group *g);  /* HBM held by the bit matrix       */
+int kwage_group_params(const kwage_group *g, kwage_params *out);
+
+/* ------------------------------------------------------------------------------------
+ * Query batch: raw sequences (any case, any characters -- exactly what the reference hands to
+ * search(), kwage.cpp:119,137), concatenated, uploaded once and kept resident in HBM.
+ * ---------------------------------------------------------------------------------- */
+typedef struct kwage_batch kwage_batch;
+
+/* `offsets` has n_queries+1 entries; query i is bytes [offsets[i], offsets[i+1]) of `seqs`. */
+int kwage_batch_create(kwage_ctx *ctx, const char *seqs, const uint64_t *offsets,
+                       uint32_t n_queries, kwage_batch **out);
+void kwage_batch_destroy(kwage_batch *b);
+uint32_t kwage_batch_num_queries(const kwage_batch *b);
+
+/* ------------------------------------------------------------------------------------
+ * Search: for every query of the batch against every column of the group, what
+ * search() computes (kwage.cpp:340-541): canonical k-mer set, MurmurHash3 row indices,
+ * row gather + AND (threshold == 1.0f) or per-column counts (threshold < 1), hit extraction.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+	uint32_t query;      /* index into the batch                                            */
+	uint32_t column;     /* global column of the group                                      */
+	uint32_t num_match;  /* MatchResult::num_kmers_found (kwage.cpp:517-518)                */
+} kwage_hit;
+
+typedef struct {
+	uint64_t n_hits;
+	const kwage_hit *hits;          /* sorted by (query, column)                              */
+	uint32_t n_queries;
+	const uint32_t *num_query_kmer; /* per query: distinct canonical k-mers (kwage.cpp:366)   */
+	const uint32_t *query_threshold;/* per query: (unsigned)(float t * n) (kwage.cpp:388); 0 at t==1 */
+	uint64_t total_kmers;           /* sum of num_query_kmer                                  */
+	uint64_t bit_tests;             /* total_kmers * num_hash * num_columns                   */
+	uint64_t algorithmic_bytes;     /* total_kmers * num_hash * ceil(num_columns/8)           */
+	float kmer_kernel_ms;           /* with KWAGE_SEARCH_TIMING, else 0                       */
+	float search_kernel_ms;         /* the gather + AND / count kernel                        */
+	uint32_t search_kernel_launches;/* >1 if the hit buffer had to grow and the kernel re-ran */
+} kwage_result;
+
+int kwage_search(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
+                 kwage_result **out);
+void kwage_result_free(kwage_result *r);
+
+/* Device-side variant for multi-GPU hosts that exchange hit lists themselves (RCCL): hits are
+ * left UNSORTED in the caller's device buffer of `capacity` records; *n_hits receives the total
+ * found (which may exceed capacity: grow and call again).  num_query_kmer_dev may be NULL or a
+ * device buffer of n_queries uint32. */
+int kwage_search_device(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
+                        void *hits_dev, uint64_t capacity, uint64_t *n_hits,
+                        void *num_query_kmer_dev);
+
+/* K-mer stage alone (word.h:73-104 + kwage.cpp:362-366 + hash.cpp:176-234 on the device):
+ * for query i writes its distinct canonical k-mers to kmers[kmer_offsets[i] ...] (unordered)
+ * and their row indices to rows[(kmer_offsets[i]+j)*num_hash + h].  kmer_offsets must hold
+ * n_queries+1 entries and is filled with the per-query capacity prefix (max(len-k+1,0));
+ * num_query_kmer[i] receives the distinct count.  kmers / rows may be NULL. */
+int kwage_hash_batch(kwage_ctx *ctx, const kwage_params *params, kwage_batch *b,
+                     uint64_t *kmer_offsets, uint32_t *num_query_kmer,
+                     uint64_t *kmers, uint32_t *rows);
+
+/* Streaming-read microbenchmark over the group's bit matrix (achievable HBM peak on this box):
+ * reads `bytes` (clamped to the matrix size) `iters` times; returns GB/s. */
+int kwage_stream_read_gbps(kwage_group *g, uint64_t bytes, uint32_t iters, double *gbps);
+
+/* ------------------------------------------------------------------------------------
+ * Host-side helpers that mirror the reference's host code for this path (no device needed).
+ * ---------------------------------------------------------------------------------- */
+
+/* DBFileHeader, kwage.h:30-72, as serialized by binary_io.cpp:243-265 (44 bytes, LE). */
+typedef struct {
+	uint32_t magic, version, crc32, kmer_len, num_hash, log_2_filter_len, num_filter;
+	int32_t  hash_func;
+	uint32_t compression;
+	uint64_t info_start;
+} kwage_db_header;
+
+int kwage_db_read_header(const char *path, kwage_db_header *out);
+
+/* Database metadata reader: info_loc[] + FilterInfo records (kwage.cpp:505-515,
+ * binary_io.cpp:154-176), loaded once per file instead of two seeks per hit. */
+typedef struct kwage_dbinfo kwage_dbinfo;
+int kwage_dbinfo_open(const char *path, kwage_dbinfo **out);
+void kwage_dbinfo_close(kwage_dbinfo *d);
+uint32_t kwage_dbinfo_num_filter(const kwage_dbinfo *d);
+/* FilterInfo::csv_string() (bloom.cpp:124-127): the run accession. */
+int kwage_dbinfo_csv_string(const kwage_dbinfo *d, uint32_t column, char *buf, size_t buflen);
+/* FilterInfo::json_string(prefix) (bloom.cpp:129-326). Returns needed length (excluding NUL). */
+int64_t kwage_dbinfo_json_string(const kwage_dbinfo *d, uint32_t column, const char *prefix,
+                                 char *buf, size_t buflen);
+
+/* sra_accession.cpp:27-96 */
+int kwage_str_to_accession(const char *s, uint64_t *out);
+int kwage_accession_to_str(uint64_t acc, char *buf, size_t buflen);
+
+/* SequenceIterator (parse_sequence.cpp:13-262): FASTA / FASTQ, gz transparent. */
+typedef struct kwage_seqfile kwage_seqfile;
+int kwage_seqfile_open(const char *path, kwage_seqfile **out);
+/* Returns 1 and sets the views (valid until the next call) or 0 at end of file, <0 on error. */
+int kwage_seqfile_next(kwage_seqfile *f, const char **defline, const char **seq, uint64_t *seq_len);
+void kwage_seqfile_close(kwage_seqfile *f);
+
+/* (unsigned)(float threshold * n), kwage.cpp:388 */
+uint32_t kwage_query_threshold(float threshold, uint32_t num_query_kmer);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* KWAGE_AMD_H */

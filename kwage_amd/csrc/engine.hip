@@ -1,0 +1,893 @@
+// kwage_amd/csrc/engine.hip -- device side of the C ABI declared in include/kwage_amd.h.
+//
+// One kwage_ctx = one GPU = one HIP stream.  A kwage_group owns the HBM-resident bit matrix of
+// all same-parameter columns; kwage_search() runs, on the context's stream,
+//     kmer_kernel  ->  and_kernel | count_kernel  ->  D2H of the hit list
+// which together replace the reference's search() (kwage.cpp:340-541) for a whole batch of
+// queries.  There is no CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "internal.h"
+#include "kernels.hpp"
+
+using namespace kwage;
+
+#define HIP_TRY(expr)                                                                          \
+	do {                                                                                       \
+		hipError_t _e = (expr);                                                                \
+		if(_e != hipSuccess){                                                                  \
+			return fail(KWAGE_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+			            __FILE__, __LINE__);                                                   \
+		}                                                                                      \
+	} while(0)
+
+namespace {
+
+// A device buffer that only ever grows (scratch reused across searches).
+struct DevBuf {
+	void *p = nullptr;
+	uint64_t cap = 0;
+	int reserve(uint64_t bytes)
+	{
+		if(bytes <= cap){ return KWAGE_OK; }
+		if(p){ (void)hipFree(p); p = nullptr; cap = 0; }
+		const uint64_t want = std::max<uint64_t>(bytes + bytes/4, 4096);
+		HIP_TRY(hipMalloc(&p, want));
+		cap = want;
+		return KWAGE_OK;
+	}
+	void release()
+	{
+		if(p){ (void)hipFree(p); }
+		p = nullptr; cap = 0;
+	}
+};
+
+struct PinBuf {
+	void *p = nullptr;
+	uint64_t cap = 0;
+	int reserve(uint64_t bytes)
+	{
+		if(bytes <= cap){ return KWAGE_OK; }
+		if(p){ (void)hipHostFree(p); p = nullptr; cap = 0; }
+		const uint64_t want = std::max<uint64_t>(bytes + bytes/4, 4096);
+		HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+		cap = want;
+		return KWAGE_OK;
+	}
+	void release()
+	{
+		if(p){ (void)hipHostFree(p); }
+		p = nullptr; cap = 0;
+	}
+};
+
+}  // namespace
+
+struct kwage_ctx {
+	int device = -1;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+	// scratch, grown on demand and reused
+	DevBuf rows, nkmer, qthr, tables, hits, counters, kmers;
+	PinBuf h_counters;
+};
+
+struct kwage_group {
+	kwage_ctx *ctx = nullptr;
+	kwage_params params{};
+	uint64_t nrows = 0;
+	uint64_t stride = 0;           // bytes, multiple of 128
+	uint64_t next_byte = 0;        // next free byte column within a row
+	uint64_t num_columns = 0;      // valid columns
+	uint8_t *d_bits = nullptr;
+	uint8_t *d_valid = nullptr;
+	uint64_t alloc_bytes = 0;
+	std::vector<uint8_t> h_valid;
+	bool finalized = false;
+};
+
+struct kwage_batch {
+	kwage_ctx *ctx = nullptr;
+	uint32_t n = 0;
+	uint64_t total_len = 0;
+	char *d_seqs = nullptr;
+	uint64_t *d_seq_off = nullptr;
+	std::vector<uint64_t> h_seq_off;
+	// per-k layout, cached between searches with the same k-mer length
+	uint32_t cached_k = 0;
+	uint64_t total_pos = 0;
+	uint64_t max_pos = 0;
+	uint64_t table_slots = 0;      // global hash-set slots needed by long queries
+	uint64_t *d_pos_off = nullptr; // n+1
+	uint64_t *d_tab_off = nullptr; // n
+	std::vector<uint64_t> h_pos_off;
+};
+
+namespace {
+
+int set_device(kwage_ctx *ctx)
+{
+	HIP_TRY(hipSetDevice(ctx->device));
+	return KWAGE_OK;
+}
+
+uint32_t grid_for(uint64_t work_items, uint32_t block, uint32_t cap_blocks = 256*8)
+{
+	const uint64_t b = (work_items + block - 1)/block;
+	return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(b, cap_blocks));
+}
+
+uint32_t host_table_log2(uint64_t npos)
+{
+	uint32_t lg = 6;
+	while((1ull << lg) < 2*npos){ ++lg; }
+	return lg;
+}
+
+// (Re)build the per-k layout of a batch: position prefix and global hash-set offsets.
+int batch_prepare(kwage_batch *b, uint32_t k)
+{
+	if(b->cached_k == k){ return KWAGE_OK; }
+	const uint32_t n = b->n;
+	b->h_pos_off.assign((size_t)n + 1, 0);
+	std::vector<uint64_t> tab_off(n, 0);
+	uint64_t slots = 0, maxp = 0;
+	for(uint32_t i = 0; i < n; ++i){
+		const uint64_t len = b->h_seq_off[i + 1] - b->h_seq_off[i];
+		const uint64_t npos = (len >= k) ? (len - k + 1) : 0;
+		b->h_pos_off[i + 1] = b->h_pos_off[i] + npos;
+		maxp = std::max(maxp, npos);
+		if(npos){
+			const uint32_t lg = host_table_log2(npos);
+			if((1ull << lg) > KM_LDS_SLOTS){
+				tab_off[i] = slots;
+				slots += (1ull << lg);
+			}
+		}
+	}
+	if(!b->d_pos_off){ HIP_TRY(hipMalloc(&b->d_pos_off, ((size_t)n + 1)*sizeof(uint64_t))); }
+	if(!b->d_tab_off){ HIP_TRY(hipMalloc(&b->d_tab_off, std::max<size_t>(n, 1)*sizeof(uint64_t))); }
+	HIP_TRY(hipMemcpyAsync(b->d_pos_off, b->h_pos_off.data(), ((size_t)n + 1)*sizeof(uint64_t),
+	                       hipMemcpyHostToDevice, b->ctx->stream));
+	if(n){
+		HIP_TRY(hipMemcpyAsync(b->d_tab_off, tab_off.data(), (size_t)n*sizeof(uint64_t),
+		                       hipMemcpyHostToDevice, b->ctx->stream));
+	}
+	HIP_TRY(hipStreamSynchronize(b->ctx->stream));   // tab_off is a local
+	b->total_pos = b->h_pos_off[n];
+	b->max_pos = maxp;
+	b->table_slots = slots;
+	b->cached_k = k;
+	return KWAGE_OK;
+}
+
+// Launch the k-mer stage on the ctx stream. rows/kmers_out may be null.
+int launch_kmer_stage(kwage_ctx *ctx, const kwage_params &p, kwage_batch *b, float threshold,
+                      uint32_t *d_rows, uint64_t *d_kmers)
+{
+	int rc = batch_prepare(b, p.kmer_len);
+	if(rc){ return rc; }
+	if((rc = ctx->nkmer.reserve(std::max<uint64_t>(b->n, 1)*sizeof(uint32_t)))){ return rc; }
+	if((rc = ctx->qthr.reserve(std::max<uint64_t>(b->n, 1)*sizeof(uint32_t)))){ return rc; }
+	if((rc = ctx->counters.reserve(4*sizeof(uint64_t)))){ return rc; }
+	if(b->table_slots){
+		if((rc = ctx->tables.reserve(b->table_slots*sizeof(uint64_t)))){ return rc; }
+		HIP_TRY(hipMemsetAsync(ctx->tables.p, 0xFF, b->table_slots*sizeof(uint64_t), ctx->stream));
+	}
+	HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 4*sizeof(uint64_t), ctx->stream));
+	if(b->n == 0){ return KWAGE_OK; }
+
+	KmerArgs a;
+	a.seqs = b->d_seqs;
+	a.seq_off = b->d_seq_off;
+	a.pos_off = b->d_pos_off;
+	a.tab_off = b->d_tab_off;
+	a.g_tables = (unsigned long long*)ctx->tables.p;
+	a.k = p.kmer_len;
+	a.num_hash = p.num_hash;
+	a.row_mask = (p.log_2_filter_len >= 32) ? 0xFFFFFFFFu : ((1u << p.log_2_filter_len) - 1u);
+	a.threshold = threshold;
+	a.complete_match = (threshold == 1.0f) ? 1 : 0;      // kwage.cpp:349
+	a.rows = d_rows;
+	a.kmers_out = d_kmers;
+	a.nkmer = (uint32_t*)ctx->nkmer.p;
+	a.qthr = (uint32_t*)ctx->qthr.p;
+	a.total_kmers = (unsigned long long*)ctx->counters.p + 1;
+	hipLaunchKernelGGL(kmer_kernel, dim3(b->n), dim3(KM_THREADS), 0, ctx->stream, a);
+	HIP_TRY(hipGetLastError());
+	return KWAGE_OK;
+}
+
+template <int VEC, int UNROLL>
+void launch_and(const SearchArgs &a, uint64_t tiles, hipStream_t s)
+{
+	const uint32_t blocks = (uint32_t)((tiles + 3)/4);
+	hipLaunchKernelGGL((and_kernel<VEC, UNROLL>), dim3(blocks), dim3(SEARCH_THREADS), 0, s, a);
+}
+
+template <int PLANES>
+void launch_count_nh(const SearchArgs &a, uint64_t tiles, hipStream_t s)
+{
+	const uint32_t blocks = (uint32_t)((tiles + 3)/4);
+	switch(a.num_hash){
+		case 1: hipLaunchKernelGGL((count_kernel<PLANES, 1>), dim3(blocks), dim3(SEARCH_THREADS), 0, s, a); break;
+		case 2: hipLaunchKernelGGL((count_kernel<PLANES, 2>), dim3(blocks), dim3(SEARCH_THREADS), 0, s, a); break;
+		case 3: hipLaunchKernelGGL((count_kernel<PLANES, 3>), dim3(blocks), dim3(SEARCH_THREADS), 0, s, a); break;
+		case 4: hipLaunchKernelGGL((count_kernel<PLANES, 4>), dim3(blocks), dim3(SEARCH_THREADS), 0, s, a); break;
+		default: hipLaunchKernelGGL((count_kernel<PLANES, 5>), dim3(blocks), dim3(SEARCH_THREADS), 0, s, a); break;
+	}
+}
+
+// tile width (16-byte vectors per lane) of the AND kernel; tunable through KWAGE_AND_VEC
+int and_vec_choice(uint32_t units_per_row)
+{
+	static int forced = -1;
+	if(forced < 0){
+		const char *e = getenv("KWAGE_AND_VEC");
+		forced = e ? atoi(e) : 0;
+	}
+	if(forced == 1 || forced == 2 || forced == 4){ return forced; }
+	return (units_per_row >= 4*WAVE) ? 2 : 1;
+}
+
+// Launch the gather+reduce kernel for the current batch. Returns tiles per query via *chunks.
+int launch_search_stage(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
+                        kwage_hit *d_hits, uint64_t cap)
+{
+	kwage_ctx *ctx = g->ctx;
+	SearchArgs a;
+	a.db = g->d_bits;
+	a.stride = g->stride;
+	a.units_per_row = (uint32_t)(g->stride/16);
+	a.valid = g->d_valid;
+	a.rows = (const uint32_t*)ctx->rows.p;
+	a.pos_off = b->d_pos_off;
+	a.nkmer = (const uint32_t*)ctx->nkmer.p;
+	a.qthr = (const uint32_t*)ctx->qthr.p;
+	a.num_hash = g->params.num_hash;
+	a.n_queries = b->n;
+	a.hits = d_hits;
+	a.cap = cap;
+	a.hit_count = (unsigned long long*)ctx->counters.p;
+	a.early_exit = (flags & KWAGE_SEARCH_EARLY_EXIT) ? 1 : 0;
+
+	if(threshold == 1.0f){
+		const int vec = and_vec_choice(a.units_per_row);
+		a.chunks = (a.units_per_row + WAVE*vec - 1)/(WAVE*vec);
+		const uint64_t tiles = (uint64_t)a.n_queries*a.chunks;
+		if(tiles/4 + 1 > 0x7FFFFFFFull){ return fail(KWAGE_ERR_ARG, "batch too large for one launch"); }
+		switch(vec){
+			case 1: launch_and<1, 8>(a, tiles, ctx->stream); break;
+			case 2: launch_and<2, 8>(a, tiles, ctx->stream); break;
+			default: launch_and<4, 4>(a, tiles, ctx->stream); break;
+		}
+	}
+	else{
+		a.chunks = (a.units_per_row + WAVE - 1)/WAVE;
+		const uint64_t tiles = (uint64_t)a.n_queries*a.chunks;
+		if(tiles/4 + 1 > 0x7FFFFFFFull){ return fail(KWAGE_ERR_ARG, "batch too large for one launch"); }
+		// counter planes: enough bits for the largest possible num_query_kmer of the batch
+		uint32_t bits = 1;
+		while(bits < 32 && (b->max_pos >> bits) != 0){ ++bits; }
+		if(bits <= 7){ launch_count_nh<7>(a, tiles, ctx->stream); }
+		else if(bits <= 10){ launch_count_nh<10>(a, tiles, ctx->stream); }
+		else if(bits <= 14){ launch_count_nh<14>(a, tiles, ctx->stream); }
+		else if(bits <= 20){ launch_count_nh<20>(a, tiles, ctx->stream); }
+		else{ launch_count_nh<32>(a, tiles, ctx->stream); }
+	}
+	HIP_TRY(hipGetLastError());
+	return KWAGE_OK;
+}
+
+struct SearchOutcome {
+	uint64_t n_hits = 0;
+	uint64_t total_kmers = 0;
+	float kmer_ms = 0, search_ms = 0;
+	uint32_t launches = 0;
+};
+
+// Full device pipeline. If own_hits, results land in ctx->hits (grown as needed and the search
+// kernel re-run on overflow); otherwise in the caller's buffer (no re-run: the caller grows).
+int run_search(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
+               kwage_hit *ext_hits, uint64_t ext_cap, bool own_hits, SearchOutcome *out)
+{
+	kwage_ctx *ctx = g->ctx;
+	int rc;
+	if(!g->finalized){ return fail(KWAGE_ERR_STATE, "kwage_group_finalize() must be called before searching"); }
+	if(b->ctx != ctx){ return fail(KWAGE_ERR_ARG, "batch and group belong to different contexts"); }
+	if(!(threshold > 0.0f) || threshold > 1.0f){      // options.cpp:186-191
+		return fail(KWAGE_ERR_ARG, "search threshold must satisfy 0 < t <= 1");
+	}
+	if((rc = set_device(ctx))){ return rc; }
+	if((rc = batch_prepare(b, g->params.kmer_len))){ return rc; }
+	if((rc = ctx->rows.reserve(std::max<uint64_t>(b->total_pos*g->params.num_hash, 1)*sizeof(uint32_t)))){ return rc; }
+	if((rc = ctx->h_counters.reserve(4*sizeof(uint64_t)))){ return rc; }
+
+	const bool timing = (flags & KWAGE_SEARCH_TIMING) != 0;
+	if(timing){ HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream)); }
+	if((rc = launch_kmer_stage(ctx, g->params, b, threshold, (uint32_t*)ctx->rows.p, nullptr))){ return rc; }
+	if(timing){ HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream)); }
+
+	uint64_t cap = ext_cap;
+	kwage_hit *d_hits = ext_hits;
+	if(own_hits){
+		if(ctx->hits.cap == 0 && (rc = ctx->hits.reserve((1u << 20)*sizeof(kwage_hit)))){ return rc; }
+		cap = ctx->hits.cap/sizeof(kwage_hit);
+		d_hits = (kwage_hit*)ctx->hits.p;
+	}
+
+	volatile uint64_t *hc = (volatile uint64_t*)ctx->h_counters.p;
+	out->launches = 0;
+	while(true){
+		if(b->n && g->num_columns){
+			if(timing){ HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream)); }
+			if((rc = launch_search_stage(g, b, threshold, flags, d_hits, cap))){ return rc; }
+			if(timing){ HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream)); }
+			++out->launches;
+		}
+		HIP_TRY(hipMemcpyAsync(ctx->h_counters.p, ctx->counters.p, 2*sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(hipStreamSynchronize(ctx->stream));
+		out->n_hits = hc[0];
+		out->total_kmers = hc[1];
+		if(!own_hits || out->n_hits <= cap){ break; }
+		// hit buffer too small (e.g. threshold truncated to 0: every column matches): grow, re-run
+		if((rc = ctx->hits.reserve(out->n_hits*sizeof(kwage_hit)))){ return rc; }
+		cap = ctx->hits.cap/sizeof(kwage_hit);
+		d_hits = (kwage_hit*)ctx->hits.p;
+		HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(uint64_t), ctx->stream));   // hit counter only
+	}
+	if(timing){
+		HIP_TRY(hipEventElapsedTime(&out->kmer_ms, ctx->ev[0], ctx->ev[1]));
+		if(out->launches){ HIP_TRY(hipEventElapsedTime(&out->search_ms, ctx->ev[2], ctx->ev[3])); }
+	}
+	return KWAGE_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+extern "C" int kwage_device_count(void)
+{
+	int n = 0;
+	if(hipGetDeviceCount(&n) != hipSuccess){ return 0; }
+	return n;
+}
+
+extern "C" int kwage_init(int device, kwage_ctx **out)
+{
+	if(!out){ return fail(KWAGE_ERR_ARG, "kwage_init: out is NULL"); }
+	*out = nullptr;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if(e != hipSuccess || n == 0){
+		return fail(KWAGE_ERR_DEVICE, "kwage_init: no HIP device available (%s); this engine has no CPU fallback",
+		            e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+	}
+	if(device < 0 || device >= n){ return fail(KWAGE_ERR_ARG, "kwage_init: device %d out of range [0,%d)", device, n); }
+	HIP_TRY(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device));
+	if(strncmp(prop.gcnArchName, "gfx950", 6) != 0){
+		return fail(KWAGE_ERR_DEVICE, "kwage_init: device %d is %s; this library is built for gfx950 (MI355X) only",
+		            device, prop.gcnArchName);
+	}
+	kwage_ctx *ctx = new (std::nothrow) kwage_ctx();
+	if(!ctx){ return fail(KWAGE_ERR_DEVICE, "out of host memory"); }
+	ctx->device = device;
+	HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+	for(int i = 0; i < 4; ++i){ HIP_TRY(hipEventCreate(&ctx->ev[i])); }
+	*out = ctx;
+	return KWAGE_OK;
+}
+
+extern "C" void kwage_shutdown(kwage_ctx *ctx)
+{
+	if(!ctx){ return; }
+	(void)hipSetDevice(ctx->device);
+	if(ctx->stream){ (void)hipStreamSynchronize(ctx->stream); }
+	ctx->rows.release(); ctx->nkmer.release(); ctx->qthr.release(); ctx->tables.release();
+	ctx->hits.release(); ctx->counters.release(); ctx->kmers.release(); ctx->h_counters.release();
+	for(int i = 0; i < 4; ++i){ if(ctx->ev[i]){ (void)hipEventDestroy(ctx->ev[i]); } }
+	if(ctx->stream){ (void)hipStreamDestroy(ctx->stream); }
+	delete ctx;
+}
+
+extern "C" int kwage_mem_info(kwage_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes)
+{
+	if(!ctx){ return fail(KWAGE_ERR_ARG, "kwage_mem_info: ctx is NULL"); }
+	int rc = set_device(ctx);
+	if(rc){ return rc; }
+	size_t f = 0, t = 0;
+	HIP_TRY(hipMemGetInfo(&f, &t));
+	if(free_bytes){ *free_bytes = f; }
+	if(total_bytes){ *total_bytes = t; }
+	return KWAGE_OK;
+}
+
+extern "C" int kwage_sync(kwage_ctx *ctx)
+{
+	if(!ctx){ return fail(KWAGE_ERR_ARG, "kwage_sync: ctx is NULL"); }
+	int rc = set_device(ctx);
+	if(rc){ return rc; }
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return KWAGE_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// database group
+// ------------------------------------------------------------------------------------------
+extern "C" int kwage_group_create(kwage_ctx *ctx, const kwage_params *params, uint64_t column_capacity,
+                                  kwage_group **out)
+{
+	if(!ctx || !params || !out){ return fail(KWAGE_ERR_ARG, "kwage_group_create: NULL argument"); }
+	*out = nullptr;
+	int rc = check_params(params);
+	if(rc){ return rc; }
+	if(column_capacity == 0){ return fail(KWAGE_ERR_ARG, "kwage_group_create: column_capacity is 0"); }
+	if((rc = set_device(ctx))){ return rc; }
+
+	kwage_group *g = new (std::nothrow) kwage_group();
+	if(!g){ return fail(KWAGE_ERR_DEVICE, "out of host memory"); }
+	g->ctx = ctx;
+	g->params = *params;
+	g->nrows = 1ull << params->log_2_filter_len;
+	const uint64_t row_bytes = (column_capacity + 7)/8;
+	g->stride = (row_bytes + 127)/128*128;
+	if(g->stride/16 > 0x7FFFFFFFull){ delete g; return fail(KWAGE_ERR_ARG, "kwage_group_create: row too wide"); }
+	g->alloc_bytes = g->stride*g->nrows;
+	hipError_t e = hipMalloc((void**)&g->d_bits, g->alloc_bytes);
+	if(e != hipSuccess){
+		const double gb = (double)g->alloc_bytes/1e9;
+		delete g;
+		return fail(KWAGE_ERR_DEVICE, "kwage_group_create: hipMalloc of %.3f GB for the bit matrix failed: %s",
+		            gb, hipGetErrorString(e));
+	}
+	e = hipMalloc((void**)&g->d_valid, g->stride);
+	if(e != hipSuccess){
+		(void)hipFree(g->d_bits);
+		delete g;
+		return fail(KWAGE_ERR_DEVICE, "kwage_group_create: hipMalloc(valid mask) failed: %s", hipGetErrorString(e));
+	}
+	e = hipMemsetAsync(g->d_bits, 0, g->alloc_bytes, ctx->stream);
+	if(e == hipSuccess){ e = hipMemsetAsync(g->d_valid, 0, g->stride, ctx->stream); }
+	if(e == hipSuccess){ e = hipStreamSynchronize(ctx->stream); }
+	if(e != hipSuccess){
+		(void)hipFree(g->d_bits); (void)hipFree(g->d_valid);
+		delete g;
+		return fail(KWAGE_ERR_DEVICE, "kwage_group_create: clearing the bit matrix failed: %s", hipGetErrorString(e));
+	}
+	g->h_valid.assign(g->stride, 0);
+	*out = g;
+	return KWAGE_OK;
+}
+
+extern "C" void kwage_group_destroy(kwage_group *g)
+{
+	if(!g){ return; }
+	(void)hipSetDevice(g->ctx->device);
+	(void)hipStreamSynchronize(g->ctx->stream);
+	if(g->d_bits){ (void)hipFree(g->d_bits); }
+	if(g->d_valid){ (void)hipFree(g->d_valid); }
+	delete g;
+}
+
+namespace {
+
+// Reserve a 16-byte aligned byte range for `num_filter` new columns; mark them valid.
+int group_reserve_columns(kwage_group *g, uint64_t num_filter, uint64_t *byte0)
+{
+	if(g->finalized){ return fail(KWAGE_ERR_STATE, "group is finalized; no more columns can be added"); }
+	if(num_filter == 0){ return fail(KWAGE_ERR_ARG, "cannot add 0 columns"); }
+	const uint64_t start = (g->next_byte + 15)/16*16;
+	const uint64_t width = (num_filter + 7)/8;
+	if(start + width > g->stride){
+		return fail(KWAGE_ERR_ARG, "group capacity exceeded: need byte %llu of a %llu-byte row",
+		            (unsigned long long)(start + width), (unsigned long long)g->stride);
+	}
+	for(uint64_t c = 0; c < num_filter; ++c){ g->h_valid[start + c/8] |= (uint8_t)(1u << (c%8)); }
+	g->next_byte = start + width;
+	g->num_columns += num_filter;
+	*byte0 = start;
+	return KWAGE_OK;
+}
+
+}  // namespace
+
+extern "C" int kwage_group_add_columns(kwage_group *g, const void *host_rows, uint64_t host_row_stride,
+                                       uint32_t num_filter, uint64_t *first_column)
+{
+	if(!g || !host_rows){ return fail(KWAGE_ERR_ARG, "kwage_group_add_columns: NULL argument"); }
+	const uint64_t width = ((uint64_t)num_filter + 7)/8;
+	if(host_row_stride < width){ return fail(KWAGE_ERR_ARG, "kwage_group_add_columns: host_row_stride < ceil(num_filter/8)"); }
+	kwage_ctx *ctx = g->ctx;
+	int rc = set_device(ctx);
+	if(rc){ return rc; }
+	uint64_t byte0 = 0;
+	if((rc = group_reserve_columns(g, num_filter, &byte0))){ return rc; }
+
+	// stage through a device buffer in chunks of rows, then scatter into the strided matrix
+	const uint64_t chunk_rows = std::max<uint64_t>(1, std::min<uint64_t>(g->nrows, (64ull << 20)/host_row_stride));
+	DevBuf stage;
+	if((rc = stage.reserve(chunk_rows*host_row_stride))){ return rc; }
+	const uint8_t *src = (const uint8_t*)host_rows;
+	for(uint64_t r0 = 0; r0 < g->nrows; r0 += chunk_rows){
+		const uint64_t nr = std::min(chunk_rows, g->nrows - r0);
+		hipError_t e = hipMemcpyAsync(stage.p, src + r0*host_row_stride, (nr - 1)*host_row_stride + width,
+		                              hipMemcpyHostToDevice, ctx->stream);
+		if(e == hipSuccess){
+			hipLaunchKernelGGL(place_rows_kernel, dim3(grid_for(nr*width/4 + 1, 256)), dim3(256), 0, ctx->stream,
+			                   g->d_bits, g->stride, r0, byte0, (const uint8_t*)stage.p, host_row_stride, width, nr);
+			e = hipGetLastError();
+		}
+		if(e == hipSuccess){ e = hipStreamSynchronize(ctx->stream); }
+		if(e != hipSuccess){ stage.release(); return fail(KWAGE_ERR_DEVICE, "kwage_group_add_columns: %s", hipGetErrorString(e)); }
+	}
+	stage.release();
+	if(first_column){ *first_column = byte0*8; }
+	return KWAGE_OK;
+}
+
+extern "C" int kwage_group_add_db_file(kwage_group *g, const char *path, uint64_t *first_column, uint32_t *num_filter)
+{
+	if(!g || !path){ return fail(KWAGE_ERR_ARG, "kwage_group_add_db_file: NULL argument"); }
+	kwage_db_header h;
+	int rc = kwage_db_read_header(path, &h);
+	if(rc){ return rc; }
+	if(h.compression != 0){
+		return fail(KWAGE_ERR_FORMAT, "%s: compression %u is not supported (the reference defines no compressed container)", path, h.compression);
+	}
+	if(h.kmer_len != g->params.kmer_len || h.num_hash != g->params.num_hash ||
+	   h.log_2_filter_len != g->params.log_2_filter_len || h.hash_func != g->params.hash_func){
+		return fail(KWAGE_ERR_ARG, "%s: parameters (k=%u, hashes=%u, log2 len=%u, func=%d) differ from the group's",
+		            path, h.kmer_len, h.num_hash, h.log_2_filter_len, h.hash_func);
+	}
+	if(h.num_filter == 0){ return fail(KWAGE_ERR_FORMAT, "%s: num_filter is 0", path); }
+	kwage_ctx *ctx = g->ctx;
+	if((rc = set_device(ctx))){ return rc; }
+
+	const uint64_t width = ((uint64_t)h.num_filter + 7)/8;
+	const int fd = open(path, O_RDONLY);
+	if(fd < 0){ return fail(KWAGE_ERR_IO, "Unable to open database file %s for reading", path); }
+	struct stat st;
+	if(fstat(fd, &st) != 0 || (uint64_t)st.st_size < DB_HEADER_BYTES + width*g->nrows){
+		close(fd);
+		return fail(KWAGE_ERR_IO, "%s: file is shorter than header + 2^%u slices of %llu bytes", path,
+		            h.log_2_filter_len, (unsigned long long)width);
+	}
+	uint64_t byte0 = 0;
+	if((rc = group_reserve_columns(g, h.num_filter, &byte0))){ close(fd); return rc; }
+
+	// double-buffered: read() into pinned buffer A while buffer B is copied + scattered
+	const uint64_t chunk_rows = std::max<uint64_t>(1, std::min<uint64_t>(g->nrows, (32ull << 20)/width));
+	const uint64_t chunk_bytes = chunk_rows*width;
+	PinBuf pin[2];
+	DevBuf dev[2];
+	hipEvent_t done[2] = {nullptr, nullptr};
+	bool used[2] = {false, false};
+	hipError_t e = hipSuccess;
+	for(int i = 0; i < 2 && rc == KWAGE_OK; ++i){
+		rc = pin[i].reserve(chunk_bytes);
+		if(!rc){ rc = dev[i].reserve(chunk_bytes); }
+		if(!rc && hipEventCreate(&done[i]) != hipSuccess){ rc = fail(KWAGE_ERR_DEVICE, "hipEventCreate failed"); }
+	}
+	uint64_t file_off = DB_HEADER_BYTES;
+	int cur = 0;
+	for(uint64_t r0 = 0; r0 < g->nrows && rc == KWAGE_OK; r0 += chunk_rows, cur ^= 1){
+		const uint64_t nr = std::min(chunk_rows, g->nrows - r0);
+		const uint64_t nb = nr*width;
+		if(used[cur]){ e = hipEventSynchronize(done[cur]); if(e != hipSuccess){ rc = fail(KWAGE_ERR_DEVICE, "%s", hipGetErrorString(e)); break; } }
+		uint64_t got = 0;
+		while(got < nb){
+			const ssize_t k = pread(fd, (char*)pin[cur].p + got, nb - got, (off_t)(file_off + got));
+			if(k <= 0){ rc = fail(KWAGE_ERR_IO, "%s: Error reading slice from file", path); break; }
+			got += (uint64_t)k;
+		}
+		if(rc){ break; }
+		file_off += nb;
+		e = hipMemcpyAsync(dev[cur].p, pin[cur].p, nb, hipMemcpyHostToDevice, ctx->stream);
+		if(e == hipSuccess){
+			hipLaunchKernelGGL(place_rows_kernel, dim3(grid_for(nb/4 + 1, 256)), dim3(256), 0, ctx->stream,
+			                   g->d_bits, g->stride, r0, byte0, (const uint8_t*)dev[cur].p, width, width, nr);
+			e = hipGetLastError();
+		}
+		if(e == hipSuccess){ e = hipEventRecord(done[cur], ctx->stream); }
+		if(e != hipSuccess){ rc = fail(KWAGE_ERR_DEVICE, "kwage_group_add_db_file: %s", hipGetErrorString(e)); break; }
+		used[cur] = true;
+	}
+	(void)hipStreamSynchronize(ctx->stream);
+	for(int i = 0; i < 2; ++i){
+		pin[i].release(); dev[i].release();
+		if(done[i]){ (void)hipEventDestroy(done[i]); }
+	}
+	close(fd);
+	if(rc){ return rc; }
+	if(first_column){ *first_column = byte0*8; }
+	if(num_filter){ *num_filter = h.num_filter; }
+	return KWAGE_OK;
+}
+
+extern "C" int kwage_group_add_random_columns(kwage_group *g, uint64_t num_columns, uint64_t seed,
+                                              uint32_t density_q8, uint64_t *first_column)
+{
+	if(!g){ return fail(KWAGE_ERR_ARG, "kwage_group_add_random_columns: NULL group"); }
+	if(density_q8 > 256){ return fail(KWAGE_ERR_ARG, "density_q8 must be in [0,256]"); }
+	kwage_ctx *ctx = g->ctx;
+	int rc = set_device(ctx);
+	if(rc){ return rc; }
+	uint64_t byte0 = 0;
+	if((rc = group_reserve_columns(g, num_columns, &byte0))){ return rc; }
+	const uint64_t width = (num_columns + 7)/8;
+	const uint64_t words = g->nrows*((width + 7)/8);
+	hipLaunchKernelGGL(fill_random_kernel, dim3(grid_for(words, 256, 256*16)), dim3(256), 0, ctx->stream,
+	                   g->d_bits, g->stride, g->nrows, byte0, width, seed, density_q8);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	if(first_column){ *first_column = byte0*8; }
+	return KWAGE_OK;
+}
+
+extern "C" int kwage_group_set_bits(kwage_group *g, const uint32_t *rows, const uint64_t *columns, uint64_t n)
+{
+	if(!g || (n && (!rows || !columns))){ return fail(KWAGE_ERR_ARG, "kwage_group_set_bits: NULL argument"); }
+	if(n == 0){ return KWAGE_OK; }
+	kwage_ctx *ctx = g->ctx;
+	int rc = set_device(ctx);
+	if(rc){ return rc; }
+	for(uint64_t i = 0; i < n; ++i){
+		if(rows[i] >= g->nrows || columns[i] >= g->next_byte*8){
+			return fail(KWAGE_ERR_ARG, "kwage_group_set_bits: (row %u, column %llu) outside the matrix", rows[i], (unsigned long long)columns[i]);
+		}
+	}
+	DevBuf dr, dc;
+	if((rc = dr.reserve(n*sizeof(uint32_t))) || (rc = dc.reserve(n*sizeof(uint64_t)))){ dr.release(); dc.release(); return rc; }
+	hipError_t e = hipMemcpyAsync(dr.p, rows, n*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+	if(e == hipSuccess){ e = hipMemcpyAsync(dc.p, columns, n*sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream); }
+	if(e == hipSuccess){
+		hipLaunchKernelGGL(set_bits_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream,
+		                   g->d_bits, g->stride, (const uint32_t*)dr.p, (const uint64_t*)dc.p, n);
+		e = hipGetLastError();
+	}
+	if(e == hipSuccess){ e = hipStreamSynchronize(ctx->stream); }
+	dr.release(); dc.release();
+	if(e != hipSuccess){ return fail(KWAGE_ERR_DEVICE, "kwage_group_set_bits: %s", hipGetErrorString(e)); }
+	return KWAGE_OK;
+}
+
+extern "C" int kwage_group_read_rows(kwage_group *g, const uint32_t *rows, uint64_t n, void *out, uint64_t out_stride)
+{
+	if(!g || (n && (!rows || !out))){ return fail(KWAGE_ERR_ARG, "kwage_group_read_rows: NULL argument"); }
+	if(n == 0){ return KWAGE_OK; }
+	const uint64_t row_bytes = g->next_byte;
+	if(row_bytes == 0){ return fail(KWAGE_ERR_STATE, "kwage_group_read_rows: group has no columns"); }
+	if(out_stride < row_bytes){ return fail(KWAGE_ERR_ARG, "kwage_group_read_rows: out_stride < row_bytes"); }
+	for(uint64_t i = 0; i < n; ++i){
+		if(rows[i] >= g->nrows){ return fail(KWAGE_ERR_ARG, "kwage_group_read_rows: row %u out of range", rows[i]); }
+	}
+	kwage_ctx *ctx = g->ctx;
+	int rc = set_device(ctx);
+	if(rc){ return rc; }
+	DevBuf dr, dout;
+	if((rc = dr.reserve(n*sizeof(uint32_t))) || (rc = dout.reserve(n*row_bytes))){ dr.release(); dout.release(); return rc; }
+	hipError_t e = hipMemcpyAsync(dr.p, rows, n*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+	if(e == hipSuccess){
+		hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n*row_bytes, 256)), dim3(256), 0, ctx->stream,
+		                   (const uint8_t*)g->d_bits, g->stride, (const uint32_t*)dr.p, n, row_bytes, (uint8_t*)dout.p);
+		e = hipGetLastError();
+	}
+	if(e == hipSuccess){
+		e = hipMemcpy2DAsync(out, out_stride, dout.p, row_bytes, row_bytes, n, hipMemcpyDeviceToHost, ctx->stream);
+	}
+	if(e == hipSuccess){ e = hipStreamSynchronize(ctx->stream); }
+	dr.release(); dout.release();
+	if(e != hipSuccess){ return fail(KWAGE_ERR_DEVICE, "kwage_group_read_rows: %s", hipGetErrorString(e)); }
+	return KWAGE_OK;
+}
+
+extern "C" int kwage_group_finalize(kwage_group *g)
+{
+	if(!g){ return fail(KWAGE_ERR_ARG, "kwage_group_finalize: NULL group"); }
+	kwage_ctx *ctx = g->ctx;
+	int rc = set_device(ctx);
+	if(rc){ return rc; }
+	HIP_TRY(hipMemcpyAsync(g->d_valid, g->h_valid.data(), g->stride, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	g->finalized = true;
+	return KWAGE_OK;
+}
+
+extern "C" uint64_t kwage_group_num_columns(const kwage_group *g) { return g ? g->num_columns : 0; }
+extern "C" uint64_t kwage_group_column_span(const kwage_group *g) { return g ? g->next_byte*8 : 0; }
+extern "C" uint64_t kwage_group_row_bytes(const kwage_group *g) { return g ? g->next_byte : 0; }
+extern "C" uint64_t kwage_group_row_stride(const kwage_group *g) { return g ? g->stride : 0; }
+extern "C" uint64_t kwage_group_device_bytes(const kwage_group *g) { return g ? g->alloc_bytes : 0; }
+
+extern "C" int kwage_group_params(const kwage_group *g, kwage_params *out)
+{
+	if(!g || !out){ return fail(KWAGE_ERR_ARG, "kwage_group_params: NULL argument"); }
+	*out = g->params;
+	return KWAGE_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// query batch
+// ------------------------------------------------------------------------------------------
+extern "C" int kwage_batch_create(kwage_ctx *ctx, const char *seqs, const uint64_t *offsets, uint32_t n_queries,
+                                  kwage_batch **out)
+{
+	if(!ctx || !offsets || !out){ return fail(KWAGE_ERR_ARG, "kwage_batch_create: NULL argument"); }
+	*out = nullptr;
+	for(uint32_t i = 0; i < n_queries; ++i){
+		if(offsets[i + 1] < offsets[i]){ return fail(KWAGE_ERR_ARG, "kwage_batch_create: offsets must be non-decreasing"); }
+		if(offsets[i + 1] - offsets[i] >= (1ull << 31)){ return fail(KWAGE_ERR_ARG, "kwage_batch_create: query %u is longer than 2^31-1 bases", i); }
+	}
+	const uint64_t total = offsets[n_queries] - offsets[0];
+	if(total && !seqs){ return fail(KWAGE_ERR_ARG, "kwage_batch_create: seqs is NULL"); }
+	int rc = set_device(ctx);
+	if(rc){ return rc; }
+	kwage_batch *b = new (std::nothrow) kwage_batch();
+	if(!b){ return fail(KWAGE_ERR_DEVICE, "out of host memory"); }
+	b->ctx = ctx;
+	b->n = n_queries;
+	b->total_len = total;
+	b->h_seq_off.resize((size_t)n_queries + 1);
+	for(uint32_t i = 0; i <= n_queries; ++i){ b->h_seq_off[i] = offsets[i] - offsets[0]; }
+	hipError_t e = hipMalloc((void**)&b->d_seqs, std::max<uint64_t>(total, 16));
+	if(e == hipSuccess){ e = hipMalloc((void**)&b->d_seq_off, ((size_t)n_queries + 1)*sizeof(uint64_t)); }
+	if(e == hipSuccess && total){ e = hipMemcpyAsync(b->d_seqs, seqs + offsets[0], total, hipMemcpyHostToDevice, ctx->stream); }
+	if(e == hipSuccess){ e = hipMemcpyAsync(b->d_seq_off, b->h_seq_off.data(), ((size_t)n_queries + 1)*sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream); }
+	if(e == hipSuccess){ e = hipStreamSynchronize(ctx->stream); }
+	if(e != hipSuccess){
+		kwage_batch_destroy(b);
+		return fail(KWAGE_ERR_DEVICE, "kwage_batch_create: %s", hipGetErrorString(e));
+	}
+	*out = b;
+	return KWAGE_OK;
+}
+
+extern "C" void kwage_batch_destroy(kwage_batch *b)
+{
+	if(!b){ return; }
+	(void)hipSetDevice(b->ctx->device);
+	(void)hipStreamSynchronize(b->ctx->stream);
+	if(b->d_seqs){ (void)hipFree(b->d_seqs); }
+	if(b->d_seq_off){ (void)hipFree(b->d_seq_off); }
+	if(b->d_pos_off){ (void)hipFree(b->d_pos_off); }
+	if(b->d_tab_off){ (void)hipFree(b->d_tab_off); }
+	delete b;
+}
+
+extern "C" uint32_t kwage_batch_num_queries(const kwage_batch *b) { return b ? b->n : 0; }
+
+// ------------------------------------------------------------------------------------------
+// search
+// ------------------------------------------------------------------------------------------
+namespace {
+struct ResultStorage {
+	kwage_result pub;
+	std::vector<kwage_hit> hits;
+	std::vector<uint32_t> nkmer, qthr;
+};
+}
+
+extern "C" int kwage_search(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags, kwage_result **out)
+{
+	if(!g || !b || !out){ return fail(KWAGE_ERR_ARG, "kwage_search: NULL argument"); }
+	*out = nullptr;
+	SearchOutcome so;
+	int rc = run_search(g, b, threshold, flags, nullptr, 0, true, &so);
+	if(rc){ return rc; }
+	kwage_ctx *ctx = g->ctx;
+
+	ResultStorage *rs = new (std::nothrow) ResultStorage();
+	if(!rs){ return fail(KWAGE_ERR_DEVICE, "out of host memory"); }
+	rs->hits.resize(so.n_hits);
+	rs->nkmer.resize(b->n);
+	rs->qthr.resize(b->n);
+	hipError_t e = hipSuccess;
+	if(so.n_hits){ e = hipMemcpyAsync(rs->hits.data(), ctx->hits.p, so.n_hits*sizeof(kwage_hit), hipMemcpyDeviceToHost, ctx->stream); }
+	if(e == hipSuccess && b->n){ e = hipMemcpyAsync(rs->nkmer.data(), ctx->nkmer.p, (size_t)b->n*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream); }
+	if(e == hipSuccess && b->n){ e = hipMemcpyAsync(rs->qthr.data(), ctx->qthr.p, (size_t)b->n*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream); }
+	if(e == hipSuccess){ e = hipStreamSynchronize(ctx->stream); }
+	if(e != hipSuccess){ delete rs; return fail(KWAGE_ERR_DEVICE, "kwage_search: copying results failed: %s", hipGetErrorString(e)); }
+
+	// deterministic order; the reference's own order among ties is unspecified (sort.h:22-27)
+	std::sort(rs->hits.begin(), rs->hits.end(), [](const kwage_hit &x, const kwage_hit &y){
+		return (x.query != y.query) ? (x.query < y.query) : (x.column < y.column);
+	});
+
+	kwage_result &r = rs->pub;
+	r.n_hits = so.n_hits;
+	r.hits = rs->hits.data();
+	r.n_queries = b->n;
+	r.num_query_kmer = rs->nkmer.data();
+	r.query_threshold = rs->qthr.data();
+	r.total_kmers = so.total_kmers;
+	r.bit_tests = so.total_kmers*g->params.num_hash*g->num_columns;
+	r.algorithmic_bytes = so.total_kmers*g->params.num_hash*((g->num_columns + 7)/8);
+	r.kmer_kernel_ms = so.kmer_ms;
+	r.search_kernel_ms = so.search_ms;
+	r.search_kernel_launches = so.launches;
+	*out = &rs->pub;
+	return KWAGE_OK;
+}
+
+extern "C" void kwage_result_free(kwage_result *r)
+{
+	if(!r){ return; }
+	delete reinterpret_cast<ResultStorage*>(r);     // pub is the first member
+}
+
+extern "C" int kwage_search_device(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
+                                   void *hits_dev, uint64_t capacity, uint64_t *n_hits, void *num_query_kmer_dev)
+{
+	if(!g || !b || !n_hits || (capacity && !hits_dev)){ return fail(KWAGE_ERR_ARG, "kwage_search_device: NULL argument"); }
+	SearchOutcome so;
+	int rc = run_search(g, b, threshold, flags, (kwage_hit*)hits_dev, capacity, false, &so);
+	if(rc){ return rc; }
+	*n_hits = so.n_hits;
+	if(num_query_kmer_dev && b->n){
+		HIP_TRY(hipMemcpyAsync(num_query_kmer_dev, g->ctx->nkmer.p, (size_t)b->n*sizeof(uint32_t), hipMemcpyDeviceToDevice, g->ctx->stream));
+		HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+	}
+	return KWAGE_OK;
+}
+
+extern "C" int kwage_hash_batch(kwage_ctx *ctx, const kwage_params *params, kwage_batch *b,
+                                uint64_t *kmer_offsets, uint32_t *num_query_kmer, uint64_t *kmers, uint32_t *rows)
+{
+	if(!ctx || !params || !b || !kmer_offsets || !num_query_kmer){ return fail(KWAGE_ERR_ARG, "kwage_hash_batch: NULL argument"); }
+	int rc = check_params(params);
+	if(rc){ return rc; }
+	if(b->ctx != ctx){ return fail(KWAGE_ERR_ARG, "kwage_hash_batch: batch belongs to another context"); }
+	if((rc = set_device(ctx))){ return rc; }
+	if((rc = batch_prepare(b, params->kmer_len))){ return rc; }
+	const uint64_t np = std::max<uint64_t>(b->total_pos, 1);
+	if((rc = ctx->rows.reserve(np*params->num_hash*sizeof(uint32_t)))){ return rc; }
+	if((rc = ctx->kmers.reserve(np*sizeof(uint64_t)))){ return rc; }
+	if((rc = launch_kmer_stage(ctx, *params, b, 1.0f, (uint32_t*)ctx->rows.p, (uint64_t*)ctx->kmers.p))){ return rc; }
+	memcpy(kmer_offsets, b->h_pos_off.data(), ((size_t)b->n + 1)*sizeof(uint64_t));
+	if(b->n){ HIP_TRY(hipMemcpyAsync(num_query_kmer, ctx->nkmer.p, (size_t)b->n*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
+	if(kmers && b->total_pos){ HIP_TRY(hipMemcpyAsync(kmers, ctx->kmers.p, b->total_pos*sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream)); }
+	if(rows && b->total_pos){ HIP_TRY(hipMemcpyAsync(rows, ctx->rows.p, b->total_pos*params->num_hash*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return KWAGE_OK;
+}
+
+extern "C" int kwage_stream_read_gbps(kwage_group *g, uint64_t bytes, uint32_t iters, double *gbps)
+{
+	if(!g || !gbps || iters == 0){ return fail(KWAGE_ERR_ARG, "kwage_stream_read_gbps: bad argument"); }
+	kwage_ctx *ctx = g->ctx;
+	int rc = set_device(ctx);
+	if(rc){ return rc; }
+	bytes = std::min(bytes, g->alloc_bytes)/16*16;
+	if(bytes == 0){ return fail(KWAGE_ERR_ARG, "kwage_stream_read_gbps: nothing to read"); }
+	if((rc = ctx->counters.reserve(4*sizeof(uint64_t)))){ return rc; }
+	uint32_t *sink = (uint32_t*)((uint64_t*)ctx->counters.p + 3);
+	const uint64_t n16 = bytes/16;
+	hipLaunchKernelGGL(stream_read_kernel, dim3(256*8), dim3(256), 0, ctx->stream, (const uint4*)g->d_bits, n16, sink);   // warm-up
+	HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+	for(uint32_t i = 0; i < iters; ++i){
+		hipLaunchKernelGGL(stream_read_kernel, dim3(256*8), dim3(256), 0, ctx->stream, (const uint4*)g->d_bits, n16, sink);
+	}
+	HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	float ms = 0;
+	HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+	*gbps = (double)bytes*iters/((double)ms*1e-3)/1e9;
+	return KWAGE_OK;
+}

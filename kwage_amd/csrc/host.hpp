@@ -1,0 +1,64 @@
+// kwage_amd/csrc/host.hpp -- host-side types shared by the C ABI wrappers and the kwage CLI.
+#ifndef KWAGE_AMD_HOST_HPP
+#define KWAGE_AMD_HOST_HPP
+
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "kwage_amd.h"
+
+namespace kwage {
+
+// Sample metadata of one column: the 18 serialized members of the reference's FilterInfo
+// (bloom.h:478-496) in file order.
+struct FilterInfo {
+	uint64_t run_accession = 0, experiment_accession = 0;
+	std::string experiment_title, experiment_design_description, experiment_library_name,
+	            experiment_library_strategy, experiment_library_source, experiment_library_selection,
+	            experiment_instrument_model;
+	uint64_t sample_accession = 0;
+	std::string sample_taxa;
+	std::unordered_map<std::string, std::string> sample_attributes;   // bloom.h:16 MAP
+	uint64_t study_accession = 0;
+	std::string study_title, study_abstract;
+	uint64_t number_of_spots = 0, number_of_bases = 0;
+	uint32_t day = 0, month = 0, year = 0;
+
+	std::string csv_string() const;
+	std::string json_string(const std::string &prefix) const;
+};
+
+bool parse_filter_info(const unsigned char *buf, size_t len, FilterInfo &fi);
+bool str_to_accession(const std::string &s, uint64_t &out);
+std::string accession_to_str(uint64_t acc);
+bool find_file_extension(const std::string &path, const char *ext);
+
+// info_loc[] + FilterInfo records of one `.db` file, read once.
+struct DbInfo {
+	kwage_db_header header{};
+	uint64_t tail_start = 0;
+	std::vector<unsigned char> tail;
+	std::vector<uint64_t> info_loc;
+	bool open(const std::string &path, std::string &err);
+	bool info(uint32_t column, FilterInfo &fi) const;
+};
+
+// FASTA / FASTQ record iterator with the reference SequenceIterator's exact behaviour.
+struct SeqFile {
+	void *fin;
+	int type;
+	std::string seq, curr_defline, next_defline;
+	SeqFile();
+	~SeqFile();
+	bool open(const std::string &path, std::string &err);
+	int next(std::string &err);
+	void close();
+	SeqFile(const SeqFile&) = delete;
+	SeqFile& operator=(const SeqFile&) = delete;
+};
+
+}  // namespace kwage
+
+#endif

@@ -1,0 +1,28 @@
+// kwage_amd/csrc/internal.h -- shared by the HIP engine and the host-side helpers.
+#ifndef KWAGE_AMD_INTERNAL_H
+#define KWAGE_AMD_INTERNAL_H
+
+#include <cstdarg>
+#include <cstdint>
+#include <string>
+
+#include "kwage_amd.h"
+
+namespace kwage {
+
+// Thread-local error text behind kwage_last_error().
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// Parse the 44-byte little-endian DBFileHeader (reference kwage.h:30-72, binary_io.cpp:255-265).
+void unpack_db_header(const unsigned char *b, kwage_db_header *h);
+
+// Validate parameters against the limits the reference compiles in.
+int check_params(const kwage_params *p);
+
+static const uint32_t KWAGE_MAGIC_NUMBER = 0x20191025u;   // reference kwage.h:22
+static const uint32_t DB_HEADER_BYTES = 44;
+
+}  // namespace kwage
+
+#endif

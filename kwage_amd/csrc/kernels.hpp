@@ -1,0 +1,592 @@
+// kwage_amd/csrc/kernels.hpp -- hand-written gfx950 (CDNA4, wave64) kernels of the kwage
+// search path.  Integer / bit work only, HBM-bandwidth bound: no MFMA anywhere.
+//
+//   kmer_kernel   word.h:73-104,161-165 (2-bit canonical k-mers) + kwage.cpp:362-366 (distinct
+//                 set) + hash.cpp:176-234 (MurmurHash3_x86_32 of the ASCII k-mer) + kwage.cpp:411-412
+//                 (row index) + kwage.cpp:388 (float32 threshold).
+//   and_kernel    kwage.cpp:404-470 at threshold == 1.0f: gather the addressed bit-slice rows,
+//                 AND them (bloom.h:245-262), extract hits (kwage.cpp:489-538).
+//   count_kernel  the threshold < 1 path: per k-mer AND over hashes, then bit-sliced (vertical)
+//                 per-column counters in registers instead of bloom.h:291-330's per-bit loop.
+//
+// Data layout in HBM: one row-major bit matrix per database group; row r starts
+// at r*stride (stride a multiple of 128 B); global column c is byte c/8, bit c%8 of the row.
+// A wave owns a "tile" = (query, 64*VEC*16 contiguous bytes of every addressed row): each lane
+// holds VEC 16-byte vectors, so one global_load_dwordx4 per lane reads 1 KiB of a row per wave,
+// fully coalesced; UNROLL rows are kept in flight per wave.
+#ifndef KWAGE_AMD_KERNELS_HPP
+#define KWAGE_AMD_KERNELS_HPP
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kwage_amd.h"
+
+namespace kwage {
+
+static constexpr int WAVE = 64;
+static constexpr int KM_THREADS = 256;
+static constexpr uint32_t KM_LDS_SLOTS = 4096;      // 32 KiB of u64 slots: queries up to 2048 positions
+static constexpr uint64_t KM_EMPTY = ~0ull;         // never a canonical word: min(w, rc) < all-ones
+static constexpr int SEARCH_THREADS = 256;          // 4 waves, one tile each
+
+// ------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+__device__ __forceinline__ uint32_t fmix32(uint32_t h)
+{
+	h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+	return h;
+}
+
+// MurmurHash3_x86_32 over the k ASCII bases of `word` (most significant base first),
+// reference hash.cpp:176-234.  The per-block key schedule does not depend on the seed, so it is
+// computed once and reused for every seed.
+struct MurmurKeys {
+	uint32_t k1[8];      // mixed 4-byte blocks (k <= 32 -> at most 8)
+	uint32_t tail;       // mixed tail (0 if k % 4 == 0)
+};
+
+__device__ __forceinline__ uint32_t base_ascii(uint64_t word, uint32_t k, uint32_t i)
+{
+	// "ACGT"[code] packed as bytes 0x41,0x43,0x47,0x54 (reference word.h:31-34)
+	const uint32_t code = (uint32_t)(word >> (2*(k - 1 - i))) & 3u;
+	return (0x54474341u >> (8*code)) & 0xFFu;
+}
+
+__device__ __forceinline__ void murmur_keys(uint64_t word, uint32_t k, MurmurKeys &mk)
+{
+	const uint32_t c1 = 0xcc9e2d51u, c2 = 0x1b873593u;
+	const uint32_t nblocks = k >> 2;
+#pragma unroll
+	for(uint32_t b = 0; b < 8; ++b){
+		uint32_t v = 0;
+		if(b < nblocks){
+			v = base_ascii(word, k, 4*b) | (base_ascii(word, k, 4*b + 1) << 8) |
+			    (base_ascii(word, k, 4*b + 2) << 16) | (base_ascii(word, k, 4*b + 3) << 24);
+			v *= c1; v = rotl32(v, 15); v *= c2;
+		}
+		mk.k1[b] = v;
+	}
+	uint32_t t = 0;
+	const uint32_t off = nblocks*4;
+	switch(k & 3u){
+		case 3: t ^= base_ascii(word, k, off + 2) << 16; [[fallthrough]];
+		case 2: t ^= base_ascii(word, k, off + 1) << 8;  [[fallthrough]];
+		case 1: t ^= base_ascii(word, k, off);
+			t *= c1; t = rotl32(t, 15); t *= c2;
+	}
+	mk.tail = t;
+}
+
+__device__ __forceinline__ uint32_t murmur_finish(const MurmurKeys &mk, uint32_t k, uint32_t seed)
+{
+	const uint32_t nblocks = k >> 2;
+	uint32_t h1 = seed;
+#pragma unroll
+	for(uint32_t b = 0; b < 8; ++b){
+		if(b < nblocks){
+			h1 ^= mk.k1[b]; h1 = rotl32(h1, 13); h1 = h1*5u + 0xe6546b64u;
+		}
+	}
+	h1 ^= mk.tail;      // zero when k % 4 == 0, exactly like skipping the tail switch
+	h1 ^= k;
+	return fmix32(h1);
+}
+
+// Reverse complement of the low 2k bits (A=0,C=1,G=2,T=3 so complement == bitwise NOT);
+// equals the reference's rolling __comp_w & mask (word.h:87-99,164).
+__device__ __forceinline__ uint64_t revcomp2(uint64_t w, uint32_t k)
+{
+	uint64_t x = ~w;
+	x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+	x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+	x = __builtin_bswap64(x);
+	return x >> (64 - 2*k);
+}
+
+__device__ __forceinline__ uint32_t base_code(char ch)
+{
+	// word.h:84-104: ACGT in either case are bases, anything else resets the run.
+	switch(ch){
+		case 'A': case 'a': return 0;
+		case 'C': case 'c': return 1;
+		case 'G': case 'g': return 2;
+		case 'T': case 't': return 3;
+		default: return 4;
+	}
+}
+
+__device__ __forceinline__ uint32_t table_log2(uint64_t npos)
+{
+	// smallest power of two >= 2*npos, at least 64 slots
+	uint32_t lg = 6;
+	while((1ull << lg) < 2*npos){ ++lg; }
+	return lg;
+}
+
+// Insert into an open-addressing set. Returns true when this call created the entry.
+template <typename PTR>
+__device__ __forceinline__ bool set_insert(PTR tab, uint32_t lg, uint64_t w)
+{
+	const uint32_t mask = (1u << lg) - 1u;
+	uint32_t s = (uint32_t)((w * 0x9E3779B97F4A7C15ull) >> (64 - lg)) & mask;
+	while(true){
+		const unsigned long long old = atomicCAS(&tab[s], (unsigned long long)KM_EMPTY, (unsigned long long)w);
+		if(old == KM_EMPTY){ return true; }
+		if(old == w){ return false; }
+		s = (s + 1) & mask;
+	}
+}
+
+struct KmerArgs {
+	const char *seqs;               // concatenated queries
+	const uint64_t *seq_off;        // n_queries + 1
+	const uint64_t *pos_off;        // n_queries + 1: prefix of max(len-k+1, 0)
+	const uint64_t *tab_off;        // per query: slot offset into g_tables (only read for long queries)
+	unsigned long long *g_tables;   // pre-filled with KM_EMPTY
+	uint32_t k, num_hash, row_mask;
+	float threshold;
+	int complete_match;
+	uint32_t *rows;                 // [pos_off[q] + j][num_hash] row indices (may be null)
+	uint64_t *kmers_out;            // [pos_off[q] + j] distinct canonical words (may be null)
+	uint32_t *nkmer;                // per query
+	uint32_t *qthr;                 // per query threshold (kwage.cpp:388)
+	unsigned long long *total_kmers;
+};
+
+template <bool LDS_TAB, typename TAB>
+__device__ __forceinline__ void kmer_body(const KmerArgs &a, uint32_t q, uint64_t s0, uint64_t len,
+                                          uint64_t npos, TAB tab, uint32_t lg,
+                                          uint8_t *codes, uint32_t *count)
+{
+	const uint32_t k = a.k;
+	const uint64_t base = a.pos_off[q];
+	const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2*k)) - 1ull);
+
+	if(LDS_TAB){
+		for(uint32_t i = threadIdx.x; i < (1u << lg); i += KM_THREADS){ tab[i] = KM_EMPTY; }
+	}
+	if(threadIdx.x == 0){ *count = 0; }
+	__syncthreads();
+
+	for(uint64_t t0 = 0; t0 < npos; t0 += KM_THREADS){
+		// stage the 2-bit codes of characters [t0, t0 + KM_THREADS + k - 1)
+		const uint32_t nchar = (uint32_t)min((uint64_t)(KM_THREADS + k - 1), len - t0);
+		for(uint32_t i = threadIdx.x; i < nchar; i += KM_THREADS){
+			codes[i] = (uint8_t)base_code(a.seqs[s0 + t0 + i]);
+		}
+		__syncthreads();
+
+		const uint64_t p = t0 + threadIdx.x;
+		if(p < npos){
+			uint64_t w = 0;
+			uint32_t bad = 0;
+			for(uint32_t j = 0; j < k; ++j){
+				const uint32_t c = codes[threadIdx.x + j];
+				bad |= c >> 2;
+				w = (w << 2) | (c & 3u);
+			}
+			if(!bad){   // ValidWord: k consecutive good bases end here (word.h:162)
+				w &= kmask;
+				const uint64_t rc = revcomp2(w, k);
+				const uint64_t canon = (w < rc) ? w : rc;          // word.h:165
+				if(set_insert(tab, lg, canon)){                    // first time this k-mer is seen
+					const uint32_t idx = atomicAdd(count, 1u);
+					if(a.kmers_out){ a.kmers_out[base + idx] = canon; }
+					if(a.rows){
+						MurmurKeys mk;
+						murmur_keys(canon, k, mk);
+						for(uint32_t h = 0; h < a.num_hash; ++h){  // seed = hash index, kwage.cpp:409-412
+							a.rows[(base + idx)*a.num_hash + h] = murmur_finish(mk, k, h) & a.row_mask;
+						}
+					}
+				}
+			}
+		}
+		__syncthreads();
+	}
+
+	if(threadIdx.x == 0){
+		const uint32_t n = *count;
+		a.nkmer[q] = n;
+		// kwage.cpp:388: unsigned = float * unsigned  ->  float32 product, truncation
+		a.qthr[q] = a.complete_match ? 0u : (uint32_t)__fmul_rn(a.threshold, (float)n);
+		if(n){ atomicAdd(a.total_kmers, (unsigned long long)n); }
+	}
+}
+
+__global__ __launch_bounds__(KM_THREADS) void kmer_kernel(KmerArgs a)
+{
+	__shared__ unsigned long long lds_tab[KM_LDS_SLOTS];
+	__shared__ uint8_t codes[KM_THREADS + KWAGE_MAX_WORD_LEN];
+	__shared__ uint32_t count;
+
+	const uint32_t q = blockIdx.x;
+	const uint64_t s0 = a.seq_off[q];
+	const uint64_t len = a.seq_off[q + 1] - s0;
+	const uint64_t npos = (len >= a.k) ? (len - a.k + 1) : 0;
+
+	if(npos == 0){    // kwage.cpp:369-371: query too short
+		if(threadIdx.x == 0){ a.nkmer[q] = 0; a.qthr[q] = 0; }
+		return;
+	}
+
+	const uint32_t lg = table_log2(npos);
+	if((1ull << lg) <= KM_LDS_SLOTS){
+		kmer_body<true>(a, q, s0, len, npos, lds_tab, lg, codes, &count);
+	}
+	else{
+		kmer_body<false>(a, q, s0, len, npos, a.g_tables + a.tab_off[q], lg, codes, &count);
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// search kernels
+// ------------------------------------------------------------------------------------------
+struct SearchArgs {
+	const uint8_t *db;              // bit matrix
+	uint64_t stride;                // bytes between rows (multiple of 128)
+	uint32_t units_per_row;         // stride / 16
+	const uint8_t *valid;           // stride bytes: 1 bits = real columns
+	const uint32_t *rows;           // row indices from kmer_kernel
+	const uint64_t *pos_off;
+	const uint32_t *nkmer;
+	const uint32_t *qthr;
+	uint32_t num_hash;
+	uint32_t chunks;                // tiles per query = ceil(units_per_row / (64*VEC))
+	uint32_t n_queries;
+	kwage_hit *hits;
+	unsigned long long cap;
+	unsigned long long *hit_count;
+	int early_exit;
+};
+
+__device__ __forceinline__ uint4 and4(uint4 a, uint4 b)
+{
+	return make_uint4(a.x & b.x, a.y & b.y, a.z & b.z, a.w & b.w);
+}
+
+__device__ __forceinline__ bool nonzero4(uint4 a) { return (a.x | a.y | a.z | a.w) != 0; }
+
+__device__ __forceinline__ void emit_hit(const SearchArgs &a, uint32_t q, uint32_t col, uint32_t nm)
+{
+	const unsigned long long slot = atomicAdd(a.hit_count, 1ull);
+	if(slot < a.cap){
+		kwage_hit h; h.query = q; h.column = col; h.num_match = nm;
+		a.hits[slot] = h;
+	}
+}
+
+// threshold == 1.0f: AND of every addressed row (kwage.cpp:404-470).
+template <int VEC, int UNROLL>
+__global__ __launch_bounds__(SEARCH_THREADS) void and_kernel(SearchArgs a)
+{
+	const uint32_t lane = threadIdx.x & (WAVE - 1);
+	const uint64_t tile = (uint64_t)blockIdx.x*(SEARCH_THREADS/WAVE) + (threadIdx.x >> 6);
+	if(tile >= (uint64_t)a.n_queries*a.chunks){ return; }
+
+	// wave-uniform values -> SGPRs, so row indices come through the scalar cache
+	const uint32_t q = __builtin_amdgcn_readfirstlane((uint32_t)(tile / a.chunks));
+	const uint32_t c = __builtin_amdgcn_readfirstlane((uint32_t)(tile % a.chunks));
+	const uint32_t n = a.nkmer[q];
+	if(n == 0){ return; }
+	const uint32_t nrows = n*a.num_hash;
+	const uint32_t *rq = a.rows + a.pos_off[q]*a.num_hash;
+
+	uint32_t unit[VEC];     // this lane's 16-byte units within a row (clamped in range: no divergence)
+	bool live[VEC];
+	uint4 acc[VEC];
+#pragma unroll
+	for(int v = 0; v < VEC; ++v){
+		const uint32_t u = c*(WAVE*VEC) + v*WAVE + lane;
+		live[v] = (u < a.units_per_row);
+		unit[v] = live[v] ? u : (a.units_per_row - 1);
+		acc[v] = make_uint4(~0u, ~0u, ~0u, ~0u);     // set_all_bits, bloom.h:182-187
+	}
+
+	uint32_t i = 0;
+	for(; i + UNROLL <= nrows; i += UNROLL){
+		uint4 x[UNROLL][VEC];
+#pragma unroll
+		for(int u = 0; u < UNROLL; ++u){
+			const uint32_t r = rq[i + u];
+			const uint4 *p = reinterpret_cast<const uint4*>(a.db + (uint64_t)r*a.stride);
+#pragma unroll
+			for(int v = 0; v < VEC; ++v){ x[u][v] = p[unit[v]]; }
+		}
+#pragma unroll
+		for(int u = 0; u < UNROLL; ++u){
+#pragma unroll
+			for(int v = 0; v < VEC; ++v){ acc[v] = and4(acc[v], x[u][v]); }
+		}
+		if(a.early_exit){     // kwage.cpp:466-470 per tile: nothing left that could match
+			bool nz = false;
+#pragma unroll
+			for(int v = 0; v < VEC; ++v){ nz |= nonzero4(acc[v]); }
+			if(!__any(nz)){ return; }
+		}
+	}
+	for(; i < nrows; ++i){
+		const uint32_t r = rq[i];
+		const uint4 *p = reinterpret_cast<const uint4*>(a.db + (uint64_t)r*a.stride);
+#pragma unroll
+		for(int v = 0; v < VEC; ++v){ acc[v] = and4(acc[v], p[unit[v]]); }
+	}
+
+	// hit extraction (kwage.cpp:489-499), restricted to real columns
+#pragma unroll
+	for(int v = 0; v < VEC; ++v){
+		if(!live[v]){ continue; }
+		const uint4 m = and4(acc[v], reinterpret_cast<const uint4*>(a.valid)[unit[v]]);
+		const uint32_t w[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+		for(int d = 0; d < 4; ++d){
+			uint32_t bits = w[d];
+			while(bits){
+				const uint32_t b = __ffs(bits) - 1;
+				bits &= bits - 1;
+				emit_hit(a, q, unit[v]*128u + d*32u + b, n);    // num_match = num_query_kmer, kwage.cpp:517-518
+			}
+		}
+	}
+}
+
+// threshold < 1: count, per column, the k-mers whose every hash row has the bit set
+// (kwage.cpp:404-433 with increment_count, bloom.h:291-330).  Counters are bit-sliced:
+// plane[p] holds bit p of the counter of each of the lane's 128 columns.
+template <int PLANES>
+__device__ __forceinline__ void planes_add(uint4 (&plane)[PLANES], uint4 carry, int from)
+{
+#pragma unroll
+	for(int p = 0; p < PLANES; ++p){
+		if(p < from){ continue; }
+		const uint4 t = and4(plane[p], carry);
+		plane[p] = make_uint4(plane[p].x ^ carry.x, plane[p].y ^ carry.y, plane[p].z ^ carry.z, plane[p].w ^ carry.w);
+		carry = t;
+	}
+}
+
+__device__ __forceinline__ uint4 xor4(uint4 a, uint4 b) { return make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w); }
+__device__ __forceinline__ uint4 or4(uint4 a, uint4 b) { return make_uint4(a.x | b.x, a.y | b.y, a.z | b.z, a.w | b.w); }
+__device__ __forceinline__ uint4 not4(uint4 a) { return make_uint4(~a.x, ~a.y, ~a.z, ~a.w); }
+
+// carry-save adder: (sum, carry) of three 1-bit vectors
+__device__ __forceinline__ void csa(uint4 &sum, uint4 &carry, uint4 a, uint4 b, uint4 c)
+{
+	const uint4 u = xor4(a, b);
+	carry = or4(and4(a, b), and4(u, c));
+	sum = xor4(u, c);
+}
+
+template <int PLANES, int NH>
+__global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
+{
+	const uint32_t lane = threadIdx.x & (WAVE - 1);
+	const uint64_t tile = (uint64_t)blockIdx.x*(SEARCH_THREADS/WAVE) + (threadIdx.x >> 6);
+	if(tile >= (uint64_t)a.n_queries*a.chunks){ return; }
+
+	const uint32_t q = __builtin_amdgcn_readfirstlane((uint32_t)(tile / a.chunks));
+	const uint32_t c = __builtin_amdgcn_readfirstlane((uint32_t)(tile % a.chunks));
+	const uint32_t n = a.nkmer[q];
+	if(n == 0){ return; }
+	const uint32_t thr = a.qthr[q];
+	const uint32_t *rq = a.rows + a.pos_off[q]*NH;
+
+	const uint32_t u0 = c*WAVE + lane;
+	const bool live = (u0 < a.units_per_row);
+	const uint32_t unit = live ? u0 : (a.units_per_row - 1);
+
+	uint4 plane[PLANES];
+#pragma unroll
+	for(int p = 0; p < PLANES; ++p){ plane[p] = make_uint4(0, 0, 0, 0); }
+
+	// four k-mers per step: 4*NH row loads in flight, then a carry-save tree so that the ripple
+	// through the upper planes happens once per four k-mers (planes 0,1 are the CSA residues).
+	uint32_t i = 0;
+	for(; i + 4 <= n; i += 4){
+		uint4 m[4];
+#pragma unroll
+		for(int u = 0; u < 4; ++u){
+			uint4 x[NH];
+#pragma unroll
+			for(int h = 0; h < NH; ++h){
+				const uint32_t r = rq[(i + u)*NH + h];
+				x[h] = reinterpret_cast<const uint4*>(a.db + (uint64_t)r*a.stride)[unit];
+			}
+			m[u] = x[0];
+#pragma unroll
+			for(int h = 1; h < NH; ++h){ m[u] = and4(m[u], x[h]); }    // kmer_match &= slice
+		}
+		if(PLANES >= 3){
+			uint4 twoA, twoB, four, s;
+			csa(s, twoA, plane[0], m[0], m[1]);
+			csa(plane[0], twoB, s, m[2], m[3]);
+			csa(plane[1], four, plane[1], twoA, twoB);
+			planes_add<PLANES>(plane, four, 2);
+		}
+		else{
+#pragma unroll
+			for(int u = 0; u < 4; ++u){ planes_add<PLANES>(plane, m[u], 0); }
+		}
+	}
+	for(; i < n; ++i){
+		uint4 mm = make_uint4(~0u, ~0u, ~0u, ~0u);
+#pragma unroll
+		for(int h = 0; h < NH; ++h){
+			const uint32_t r = rq[i*NH + h];
+			mm = and4(mm, reinterpret_cast<const uint4*>(a.db + (uint64_t)r*a.stride)[unit]);
+		}
+		planes_add<PLANES>(plane, mm, 0);
+	}
+
+	if(!live){ return; }
+
+	// columns with count >= thr (kwage.cpp:497), compared plane by plane from the top
+	uint4 gt = make_uint4(0, 0, 0, 0);
+	uint4 eq = make_uint4(~0u, ~0u, ~0u, ~0u);
+#pragma unroll
+	for(int p = PLANES - 1; p >= 0; --p){
+		const uint32_t tb = ((thr >> p) & 1u) ? ~0u : 0u;
+		const uint4 t4 = make_uint4(tb, tb, tb, tb);
+		gt = or4(gt, and4(eq, and4(plane[p], not4(t4))));
+		eq = and4(eq, not4(xor4(plane[p], t4)));
+	}
+	uint4 ge = or4(gt, eq);
+	if(PLANES < 32 && (thr >> PLANES) != 0){ ge = make_uint4(0, 0, 0, 0); }   // unreachable: thr <= n < 2^PLANES
+	ge = and4(ge, reinterpret_cast<const uint4*>(a.valid)[unit]);
+
+	const uint32_t w[4] = {ge.x, ge.y, ge.z, ge.w};
+#pragma unroll
+	for(int d = 0; d < 4; ++d){
+		uint32_t bits = w[d];
+		while(bits){
+			const uint32_t b = __ffs(bits) - 1;
+			bits &= bits - 1;
+			uint32_t cnt = 0;
+#pragma unroll
+			for(int p = 0; p < PLANES; ++p){
+				const uint32_t pw = (d == 0) ? plane[p].x : (d == 1) ? plane[p].y : (d == 2) ? plane[p].z : plane[p].w;
+				cnt |= ((pw >> b) & 1u) << p;
+			}
+			emit_hit(a, q, unit*128u + d*32u + b, cnt);      // num_match = match_count[i], kwage.cpp:517-518
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// database construction / inspection kernels
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t &x)
+{
+	x += 0x9E3779B97F4A7C15ull;
+	uint64_t z = x;
+	z = (z ^ (z >> 30))*0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27))*0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+
+// 64 i.i.d. Bernoulli(q8/256) bits: fold random words along the binary expansion of q8
+// (bit set -> OR, bit clear -> AND), least significant set bit first.
+__device__ __forceinline__ uint64_t bernoulli64(uint64_t key, uint32_t q8)
+{
+	if(q8 >= 256){ return ~0ull; }
+	if(q8 == 0){ return 0; }
+	uint64_t x = key;
+	uint64_t r = 0;
+	bool started = false;
+	for(int b = 0; b < 8; ++b){
+		const bool bit = (q8 >> b) & 1u;
+		if(!started){
+			if(bit){ r = splitmix64(x); started = true; }
+		}
+		else{
+			const uint64_t d = splitmix64(x);
+			r = bit ? (r | d) : (r & d);
+		}
+	}
+	return r;
+}
+
+// Fill bytes [byte0, byte0+nbytes) of every row with random bits. byte0 is 8-byte aligned.
+__global__ void fill_random_kernel(uint8_t *db, uint64_t stride, uint64_t nrows, uint64_t byte0,
+                                   uint64_t nbytes, uint64_t seed, uint32_t q8)
+{
+	const uint64_t words_per_row = (nbytes + 7)/8;
+	const uint64_t total = nrows*words_per_row;
+	for(uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x*blockDim.x){
+		const uint64_t r = i / words_per_row;
+		const uint64_t w = i % words_per_row;
+		const uint64_t key = seed ^ (r*0xD1342543DE82EF95ull) ^ ((byte0/8 + w)*0xA24BAED4963EE407ull);
+		const uint64_t bits = bernoulli64(key, q8);
+		uint8_t *dst = db + r*stride + byte0 + w*8;
+		const uint64_t remain = nbytes - w*8;
+		if(remain >= 8){
+			*reinterpret_cast<uint64_t*>(dst) = bits;
+		}
+		else{
+			for(uint64_t b = 0; b < remain; ++b){ dst[b] = (uint8_t)(bits >> (8*b)); }
+		}
+	}
+}
+
+// Copy a contiguous block of rows (src: nrows x width) into the strided matrix at byte offset byte0.
+__global__ void place_rows_kernel(uint8_t *db, uint64_t stride, uint64_t row0, uint64_t byte0,
+                                  const uint8_t *src, uint64_t src_stride, uint64_t width, uint64_t nrows)
+{
+	if(((width | byte0 | src_stride) & 3ull) == 0 && ((uintptr_t)src & 3ull) == 0){
+		const uint64_t wpr = width/4;
+		const uint64_t total = nrows*wpr;
+		for(uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x*blockDim.x){
+			const uint64_t r = i / wpr, w = i % wpr;
+			*reinterpret_cast<uint32_t*>(db + (row0 + r)*stride + byte0 + 4*w) =
+				*reinterpret_cast<const uint32_t*>(src + r*src_stride + 4*w);
+		}
+	}
+	else{
+		const uint64_t total = nrows*width;
+		for(uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x*blockDim.x){
+			const uint64_t r = i / width, b = i % width;
+			db[(row0 + r)*stride + byte0 + b] = src[r*src_stride + b];
+		}
+	}
+}
+
+__global__ void set_bits_kernel(uint8_t *db, uint64_t stride, const uint32_t *rows, const uint64_t *cols, uint64_t n)
+{
+	for(uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x*blockDim.x){
+		const uint64_t c = cols[i];
+		uint32_t *word = reinterpret_cast<uint32_t*>(db + (uint64_t)rows[i]*stride + (c/32)*4);
+		atomicOr(word, 1u << (c % 32));      // little endian: bit c%8 of byte c/8 (bloom.h:162)
+	}
+}
+
+__global__ void gather_rows_kernel(const uint8_t *db, uint64_t stride, const uint32_t *rows, uint64_t n,
+                                   uint64_t row_bytes, uint8_t *out)
+{
+	const uint64_t total = n*row_bytes;
+	for(uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x*blockDim.x){
+		const uint64_t r = i / row_bytes, b = i % row_bytes;
+		out[i] = db[(uint64_t)rows[r]*stride + b];
+	}
+}
+
+// Streaming read of the matrix (measures the achievable HBM read rate on this box).
+__global__ __launch_bounds__(256) void stream_read_kernel(const uint4 *src, uint64_t n16, uint32_t *sink)
+{
+	uint4 acc = make_uint4(0, 0, 0, 0);
+	const uint64_t step = (uint64_t)gridDim.x*blockDim.x;
+	uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x;
+	for(; i + 3*step < n16; i += 4*step){
+		const uint4 a0 = src[i], a1 = src[i + step], a2 = src[i + 2*step], a3 = src[i + 3*step];
+		acc = xor4(acc, xor4(xor4(a0, a1), xor4(a2, a3)));
+	}
+	for(; i < n16; i += step){ acc = xor4(acc, src[i]); }
+	if((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u){ *sink = 1; }   // keep the loads alive
+}
+
+}  // namespace kwage
+
+#endif

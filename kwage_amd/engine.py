@@ -1,0 +1,192 @@
+"""Python mirror of the C ABI objects (include/kwage_amd.h): Context, Group, Batch, search.
+
+Names and argument meaning follow the reference's search path: a Group is what the
+reference reads slice by slice from `.db` files (kwage.cpp:414-416), a Batch is the set of query
+strings handed to search() (kwage.cpp:119,137), SearchResult carries what search() appends to
+its result map (MatchResult: num_kmers_found, num_query_kmer; kwage.cpp:534).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import native
+from .native import Params, check, lib
+
+SEARCH_EARLY_EXIT = 1
+SEARCH_TIMING = 2
+
+HIT_DTYPE = np.dtype([("query", "<u4"), ("column", "<u4"), ("num_match", "<u4")])
+
+
+class Context:
+    """One GPU + one HIP stream (kwage_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        check(lib().kwage_init(device, C.byref(self._h)))
+        self.device = device
+
+    def close(self) -> None:
+        if self._h:
+            lib().kwage_shutdown(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def mem_info(self) -> Tuple[int, int]:
+        f, t = C.c_uint64(), C.c_uint64()
+        check(lib().kwage_mem_info(self._h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
+    def sync(self) -> None:
+        check(lib().kwage_sync(self._h))
+
+
+class Group:
+    """HBM-resident bit matrix of all columns sharing (kmer_len, num_hash, log_2_filter_len, hash_func)."""
+
+    def __init__(self, ctx: Context, kmer_len: int, num_hash: int, log_2_filter_len: int,
+                 column_capacity: int, hash_func: int = 0):
+        self.ctx = ctx
+        self.params = Params(kmer_len, num_hash, log_2_filter_len, hash_func)
+        self._h = C.c_void_p()
+        check(lib().kwage_group_create(ctx._h, C.byref(self.params), column_capacity, C.byref(self._h)))
+
+    def close(self) -> None:
+        if self._h:
+            lib().kwage_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def add_columns(self, rows: np.ndarray, num_filter: int) -> int:
+        """rows: uint8 [2^L, >= ceil(num_filter/8)] host image of a file's bit-slice block."""
+        assert rows.dtype == np.uint8 and rows.ndim == 2 and rows.strides[1] == 1
+        assert rows.shape[0] == (1 << self.params.log_2_filter_len)
+        first = C.c_uint64()
+        check(lib().kwage_group_add_columns(self._h, rows.ctypes.data, rows.strides[0], num_filter, C.byref(first)))
+        return first.value
+
+    def add_db_file(self, path: str) -> Tuple[int, int]:
+        first, nf = C.c_uint64(), C.c_uint32()
+        check(lib().kwage_group_add_db_file(self._h, path.encode(), C.byref(first), C.byref(nf)))
+        return first.value, nf.value
+
+    def add_random_columns(self, num_columns: int, seed: int, density_q8: int) -> int:
+        first = C.c_uint64()
+        check(lib().kwage_group_add_random_columns(self._h, num_columns, seed, density_q8, C.byref(first)))
+        return first.value
+
+    def set_bits(self, rows: np.ndarray, columns: np.ndarray) -> None:
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        columns = np.ascontiguousarray(columns, dtype=np.uint64)
+        assert rows.shape == columns.shape
+        check(lib().kwage_group_set_bits(self._h, rows.ctypes.data, columns.ctypes.data, rows.size))
+
+    def read_rows(self, rows: Sequence[int]) -> np.ndarray:
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        out = np.empty((rows.size, self.row_bytes), dtype=np.uint8)
+        check(lib().kwage_group_read_rows(self._h, rows.ctypes.data, rows.size, out.ctypes.data, out.strides[0] if rows.size else self.row_bytes))
+        return out
+
+    def finalize(self) -> None:
+        check(lib().kwage_group_finalize(self._h))
+
+    num_columns = property(lambda self: lib().kwage_group_num_columns(self._h))
+    column_span = property(lambda self: lib().kwage_group_column_span(self._h))
+    row_bytes = property(lambda self: lib().kwage_group_row_bytes(self._h))
+    row_stride = property(lambda self: lib().kwage_group_row_stride(self._h))
+    device_bytes = property(lambda self: lib().kwage_group_device_bytes(self._h))
+
+    def stream_read_gbps(self, nbytes: int, iters: int = 3) -> float:
+        g = C.c_double()
+        check(lib().kwage_stream_read_gbps(self._h, nbytes, iters, C.byref(g)))
+        return g.value
+
+
+class Batch:
+    """Query strings resident in HBM (kwage_batch)."""
+
+    def __init__(self, ctx: Context, seqs: Sequence[bytes | str]):
+        bs = [s.encode("latin-1") if isinstance(s, str) else bytes(s) for s in seqs]
+        offs = np.zeros(len(bs) + 1, dtype=np.uint64)
+        if bs:
+            offs[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+        concat = b"".join(bs)
+        self.ctx = ctx
+        self.n = len(bs)
+        self._h = C.c_void_p()
+        check(lib().kwage_batch_create(ctx._h, concat, offs.ctypes.data, self.n, C.byref(self._h)))
+
+    def close(self) -> None:
+        if self._h:
+            lib().kwage_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+@dataclass
+class SearchResult:
+    hits: np.ndarray                 # HIT_DTYPE, sorted by (query, column)
+    num_query_kmer: np.ndarray       # uint32 per query
+    query_threshold: np.ndarray      # uint32 per query
+    total_kmers: int
+    bit_tests: int
+    algorithmic_bytes: int
+    kmer_kernel_ms: float
+    search_kernel_ms: float
+    search_kernel_launches: int
+
+    def per_query(self) -> List[List[Tuple[int, int]]]:
+        out: List[List[Tuple[int, int]]] = [[] for _ in range(len(self.num_query_kmer))]
+        for q, c, m in self.hits.tolist():
+            out[q].append((c, m))
+        return out
+
+
+def search(group: Group, batch: Batch, threshold: float, flags: int = 0) -> SearchResult:
+    """kwage_search(): every query of the batch against every column of the group."""
+    res = C.POINTER(native.Result)()
+    check(lib().kwage_search(group._h, batch._h, C.c_float(threshold), flags, C.byref(res)))
+    try:
+        r = res.contents
+        n = r.n_hits
+        hits = np.empty(n, dtype=HIT_DTYPE)
+        if n:
+            C.memmove(hits.ctypes.data, r.hits, n * HIT_DTYPE.itemsize)
+        nq = r.n_queries
+        nk = np.ctypeslib.as_array(r.num_query_kmer, shape=(nq,)).copy() if nq else np.zeros(0, np.uint32)
+        qt = np.ctypeslib.as_array(r.query_threshold, shape=(nq,)).copy() if nq else np.zeros(0, np.uint32)
+        return SearchResult(hits, nk, qt, r.total_kmers, r.bit_tests, r.algorithmic_bytes,
+                            r.kmer_kernel_ms, r.search_kernel_ms, r.search_kernel_launches)
+    finally:
+        lib().kwage_result_free(res)
+
+
+Group.search = lambda self, batch, threshold, flags=0: search(self, batch, threshold, flags)
+
+
+def hash_batch(ctx: Context, kmer_len: int, num_hash: int, log_2_filter_len: int, batch: Batch
+               ) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+    """Device k-mer stage alone: per query (distinct canonical k-mers, row indices [n, num_hash])."""
+    p = Params(kmer_len, num_hash, log_2_filter_len, 0)
+    offs = np.zeros(batch.n + 1, dtype=np.uint64)
+    nk = np.zeros(max(batch.n, 1), dtype=np.uint32)
+    # first call sizes the outputs (offsets are host-side arithmetic)
+    check(lib().kwage_hash_batch(ctx._h, C.byref(p), batch._h, offs.ctypes.data, nk.ctypes.data, None, None))
+    total = int(offs[-1])
+    kmers = np.zeros(max(total, 1), dtype=np.uint64)
+    rows = np.zeros(max(total, 1) * num_hash, dtype=np.uint32)
+    check(lib().kwage_hash_batch(ctx._h, C.byref(p), batch._h, offs.ctypes.data, nk.ctypes.data,
+                                 kmers.ctypes.data, rows.ctypes.data))
+    out_k, out_r = [], []
+    for i in range(batch.n):
+        o, n = int(offs[i]), int(nk[i])
+        out_k.append(kmers[o:o + n].copy())
+        out_r.append(rows[o * num_hash:(o + n) * num_hash].reshape(n, num_hash).copy())
+    return out_k, out_r

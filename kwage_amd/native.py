@@ -1,0 +1,126 @@
+"""ctypes loader for kwage_amd/lib/libkwage_amd.so (the C ABI of include/kwage_amd.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_LIB = os.path.join(_HERE, "lib", "libkwage_amd.so")
+KWAGE_BIN = os.path.join(_HERE, "bin", "kwage")
+
+
+class KwageError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("kwage_amd error %d: %s" % (code, msg))
+        self.code = code
+        self.message = msg
+
+
+def lib_path() -> str:
+    return _LIB
+
+
+def build_native(force: bool = False) -> str:
+    """Compile the HIP engine + CLI for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", _CSRC, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", _CSRC, "-j4", "all"])
+    return _LIB
+
+
+class Hit(C.Structure):
+    _fields_ = [("query", C.c_uint32), ("column", C.c_uint32), ("num_match", C.c_uint32)]
+
+
+class Params(C.Structure):
+    _fields_ = [("kmer_len", C.c_uint32), ("num_hash", C.c_uint32),
+                ("log_2_filter_len", C.c_uint32), ("hash_func", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("n_hits", C.c_uint64), ("hits", C.POINTER(Hit)), ("n_queries", C.c_uint32),
+                ("num_query_kmer", C.POINTER(C.c_uint32)), ("query_threshold", C.POINTER(C.c_uint32)),
+                ("total_kmers", C.c_uint64), ("bit_tests", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
+                ("kmer_kernel_ms", C.c_float), ("search_kernel_ms", C.c_float),
+                ("search_kernel_launches", C.c_uint32)]
+
+
+class DbHeader(C.Structure):
+    _fields_ = [("magic", C.c_uint32), ("version", C.c_uint32), ("crc32", C.c_uint32),
+                ("kmer_len", C.c_uint32), ("num_hash", C.c_uint32), ("log_2_filter_len", C.c_uint32),
+                ("num_filter", C.c_uint32), ("hash_func", C.c_int32), ("compression", C.c_uint32),
+                ("info_start", C.c_uint64)]
+
+
+# every symbol include/kwage_amd.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_SIGNATURES = [
+    ("kwage_last_error", C.c_char_p, []),
+    ("kwage_abi_version", C.c_uint32, []),
+    ("kwage_device_count", C.c_int, []),
+    ("kwage_init", C.c_int, [C.c_int, C.POINTER(_P)]),
+    ("kwage_shutdown", None, [_P]),
+    ("kwage_mem_info", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("kwage_sync", C.c_int, [_P]),
+    ("kwage_group_create", C.c_int, [_P, C.POINTER(Params), C.c_uint64, C.POINTER(_P)]),
+    ("kwage_group_destroy", None, [_P]),
+    ("kwage_group_add_columns", C.c_int, [_P, _P, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]),
+    ("kwage_group_add_db_file", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    ("kwage_group_add_random_columns", C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]),
+    ("kwage_group_set_bits", C.c_int, [_P, _P, _P, C.c_uint64]),
+    ("kwage_group_read_rows", C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64]),
+    ("kwage_group_finalize", C.c_int, [_P]),
+    ("kwage_group_num_columns", C.c_uint64, [_P]),
+    ("kwage_group_column_span", C.c_uint64, [_P]),
+    ("kwage_group_row_bytes", C.c_uint64, [_P]),
+    ("kwage_group_row_stride", C.c_uint64, [_P]),
+    ("kwage_group_device_bytes", C.c_uint64, [_P]),
+    ("kwage_group_params", C.c_int, [_P, C.POINTER(Params)]),
+    ("kwage_batch_create", C.c_int, [_P, C.c_char_p, _P, C.c_uint32, C.POINTER(_P)]),
+    ("kwage_batch_destroy", None, [_P]),
+    ("kwage_batch_num_queries", C.c_uint32, [_P]),
+    ("kwage_search", C.c_int, [_P, _P, C.c_float, C.c_uint32, C.POINTER(C.POINTER(Result))]),
+    ("kwage_result_free", None, [C.POINTER(Result)]),
+    ("kwage_search_device", C.c_int, [_P, _P, C.c_float, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64), _P]),
+    ("kwage_hash_batch", C.c_int, [_P, C.POINTER(Params), _P, _P, _P, _P, _P]),
+    ("kwage_stream_read_gbps", C.c_int, [_P, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
+    ("kwage_db_read_header", C.c_int, [C.c_char_p, C.POINTER(DbHeader)]),
+    ("kwage_dbinfo_open", C.c_int, [C.c_char_p, C.POINTER(_P)]),
+    ("kwage_dbinfo_close", None, [_P]),
+    ("kwage_dbinfo_num_filter", C.c_uint32, [_P]),
+    ("kwage_dbinfo_csv_string", C.c_int, [_P, C.c_uint32, C.c_char_p, C.c_size_t]),
+    ("kwage_dbinfo_json_string", C.c_int64, [_P, C.c_uint32, C.c_char_p, C.c_char_p, C.c_size_t]),
+    ("kwage_str_to_accession", C.c_int, [C.c_char_p, C.POINTER(C.c_uint64)]),
+    ("kwage_accession_to_str", C.c_int, [C.c_uint64, C.c_char_p, C.c_size_t]),
+    ("kwage_seqfile_open", C.c_int, [C.c_char_p, C.POINTER(_P)]),
+    ("kwage_seqfile_next", C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]),
+    ("kwage_seqfile_close", None, [_P]),
+    ("kwage_query_threshold", C.c_uint32, [C.c_float, C.c_uint32]),
+]
+
+EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """The loaded C-ABI library. Raises (loudly) if it has not been built: no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            raise KwageError(-2, "%s is missing: build it with `make -C kwage_amd/csrc` "
+                                 "(or __graft_entry__.build()); there is no CPU fallback" % _LIB)
+        L = C.CDLL(_LIB)
+        for name, res, args in _SIGNATURES:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise KwageError(rc, lib().kwage_last_error().decode("latin-1"))

@@ -1,0 +1,104 @@
+"""Synthetic workloads for the kwage search path (SURVEY.md section 8d / BASELINE.md section 5):
+a random Bernoulli(p) bit matrix generated ON the device, `planted` genomes inserted into known
+columns (so every configuration has known true positives), and queries that are substrings of
+planted genomes mixed with random sequences.  Used by bench.py and the full-size GPU tests.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+from .engine import Batch, Context, Group, hash_batch
+
+
+@dataclass
+class Workload:
+    name: str
+    num_samples: int          # columns per GPU
+    log_2_filter_len: int
+    kmer_len: int
+    num_hash: int
+    num_queries: int
+    query_len: int
+    threshold: float
+    density_q8: int = 64      # per-bit density 64/256 = 0.25 (the reference's per-k-mer FP design point, 1 hash)
+    num_genomes: int = 8
+    genome_len: int = 4000
+    columns_per_genome: int = 3
+    hit_fraction: float = 0.5
+
+
+WORKLOADS: Dict[str, Workload] = {
+    # BASELINE.json configs[0]: plumbing
+    "c1": Workload("C1: 1k samples x 2^20 bits, 1 hash, one 10 kb query", 1000, 20, 31, 1, 1, 10000, 1.0,
+                   genome_len=20000),
+    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    "c2": Workload("C2: 100k samples x 2^23-bit filters, 1k x 1 kb queries, 1 hash, t=1.0", 100_000, 23, 31, 1,
+                   1000, 1000, 1.0),
+    # BASELINE.json configs[2]
+    "c3": Workload("C3: 1M samples x 2^20-bit filters, 100k x 150 bp queries, 1 hash, t=1.0", 1_000_000, 20, 31, 1,
+                   100_000, 150, 1.0, num_genomes=64, genome_len=2000),
+    # count path (threshold < 1), 5 hashes: the C5 flavour on one filter size
+    "c5s": Workload("C5-single-group: 200k samples x 2^22-bit filters, 5 hashes, 1k x 1 kb queries, t=0.8", 200_000, 22,
+                    31, 5, 1000, 1000, 0.8, density_q8=194),
+    # small shapes for tests
+    "tiny": Workload("tiny", 5000, 14, 31, 2, 64, 300, 1.0, density_q8=128, num_genomes=4, genome_len=1000),
+}
+
+
+@dataclass
+class Synth:
+    workload: Workload
+    group: Group
+    genomes: List[str]
+    planted: List[List[int]]                 # per genome: columns holding it
+    queries: List[str]
+    query_genome: List[int]                  # per query: source genome or -1 (random)
+    batch: Batch = field(default=None)
+
+
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def _rand_seq(rng: np.random.Generator, n: int) -> str:
+    return _ACGT[rng.integers(0, 4, size=n)].tobytes().decode("ascii")
+
+
+def build(ctx: Context, w: Workload, seed: int = 1, column_seed: int = 0) -> Synth:
+    """Create the device-resident database + the query batch for workload `w`.
+    `seed` fixes genomes/queries (identical on every rank); `column_seed` varies the random
+    columns per rank (each rank holds a different block of samples)."""
+    rng = np.random.default_rng(seed)
+    g = Group(ctx, w.kmer_len, w.num_hash, w.log_2_filter_len, w.num_samples)
+    g.add_random_columns(w.num_samples, seed * 1_000_003 + column_seed, w.density_q8)
+
+    genomes = [_rand_seq(rng, w.genome_len) for _ in range(w.num_genomes)]
+    # rows addressed by each genome's k-mers: computed by the device k-mer stage itself
+    gb = Batch(ctx, genomes)
+    _, rows = hash_batch(ctx, w.kmer_len, w.num_hash, w.log_2_filter_len, gb)
+    gb.close()
+    crng = np.random.default_rng(seed * 7919 + column_seed)
+    planted: List[List[int]] = []
+    for gi in range(w.num_genomes):
+        cols = sorted(int(c) for c in crng.choice(w.num_samples, size=min(w.columns_per_genome, w.num_samples), replace=False))
+        planted.append(cols)
+        r = rows[gi].reshape(-1)
+        for c in cols:
+            g.set_bits(r, np.full(r.shape, c, dtype=np.uint64))
+    g.finalize()
+
+    queries, qsrc = [], []
+    for qi in range(w.num_queries):
+        if rng.random() < w.hit_fraction and w.genome_len >= w.query_len:
+            gi = int(rng.integers(w.num_genomes))
+            off = int(rng.integers(w.genome_len - w.query_len + 1))
+            queries.append(genomes[gi][off:off + w.query_len])
+            qsrc.append(gi)
+        else:
+            queries.append(_rand_seq(rng, w.query_len))
+            qsrc.append(-1)
+    s = Synth(w, g, genomes, planted, queries, qsrc)
+    s.batch = Batch(ctx, queries)
+    return s

@@ -1,0 +1,255 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on identical inputs -- bit-exact hit lists, counts and k-mer sets."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ka():
+    import kwage_amd
+    return kwage_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(ka):
+    c = ka.Context(0)
+    yield c
+    c.close()
+
+
+def rand_seq(rng, n):
+    return "".join(rng.choice(list("ACGT"), size=n))
+
+
+# ---------------------------------------------------------------------------------------------
+# k-mer stage: word.h:73-104 + kwage.cpp:362-366 + hash.cpp:176-234 on the device
+# ---------------------------------------------------------------------------------------------
+def test_kmer_stage_golden_vectors(ka, ctx, oracle):
+    for case in json.load(open(os.path.join(GOLDEN, "kat_kmers.json"))):
+        k, nh, seq = case["k"], case["num_hash"], case["seq"]
+        b = ka.Batch(ctx, [seq])
+        kmers, rows = ka.hash_batch(ctx, k, nh, 32, b)
+        b.close()
+        exp = {}
+        for e in case["kmers"]:
+            exp[int(e["canon"], 16)] = [int(h, 16) for h in e["hash"]]
+        got = {int(w): [int(x) for x in r] for w, r in zip(kmers[0], rows[0])}
+        assert got == exp, (k, seq)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 8, 15, 16, 17, 21, 27, 28, 29, 30, 31, 32])
+def test_kmer_stage_vs_oracle(ka, ctx, oracle, k):
+    rng = np.random.default_rng(1000 + k)
+    seqs = ["", "A", "ACGT" * 3, "N" * 50, rand_seq(rng, 31), rand_seq(rng, 32), rand_seq(rng, 33),
+            rand_seq(rng, 150), rand_seq(rng, 150).lower(), rand_seq(rng, 1000),
+            rand_seq(rng, 255 + k), rand_seq(rng, 256 + k), rand_seq(rng, 257 + k),
+            rand_seq(rng, 400) + "N" + rand_seq(rng, 10) + "xyz" + rand_seq(rng, 300),
+            "ACGTACGTAC" * 100,                       # heavy duplication
+            rand_seq(rng, 2047 + k), rand_seq(rng, 2048 + k), rand_seq(rng, 2049 + k),   # LDS/global table edge
+            rand_seq(rng, 30000), ("ACGTTGCA" * 8 + "N") * 300]
+    b = ka.Batch(ctx, seqs)
+    nh, L = 3, 20
+    kmers, rows = ka.hash_batch(ctx, k, nh, L, b)
+    b.close()
+    for s, km, rw in zip(seqs, kmers, rows):
+        exp = oracle.unique_kmers(s, k)
+        order = np.argsort(km)
+        assert np.array_equal(km[order], exp), (k, len(s))
+        assert np.array_equal(rw[order], oracle.row_indices(exp, k, nh, L)), (k, len(s))
+
+
+# ---------------------------------------------------------------------------------------------
+# whole search against the reference-written golden databases
+# ---------------------------------------------------------------------------------------------
+def _device_search(ka, ctx, db_path, seqs, threshold, flags=0):
+    from kwage_oracle import read_db
+    hdr = read_db(db_path).header
+    g = ka.Group(ctx, hdr.kmer_len, hdr.num_hash, hdr.log_2_filter_len, hdr.num_filter)
+    first, nf = g.add_db_file(db_path)
+    assert (first, nf) == (0, hdr.num_filter)
+    g.finalize()
+    b = ka.Batch(ctx, seqs)
+    r = g.search(b, threshold, flags)
+    b.close()
+    g.close()
+    return r
+
+
+@pytest.mark.parametrize("rel,qfile", [("basic/db/basic.db", "basic/q.fa"), ("k32/k32.db", "k32/q.fna"),
+                                        ("multi/dbs/b/k15_L11_h2.DB", "multi/reads.fastq"),
+                                        ("multi/dbs/a/k31_L10_h1.db", "multi/contigs.fa.gz")])
+@pytest.mark.parametrize("threshold", [1.0, 0.8, 0.5, 0.05, 0.0001])
+def test_search_golden_db_vs_oracle(ka, ctx, oracle, rel, qfile, threshold):
+    db_path = os.path.join(GOLDEN, rel)
+    db = oracle.read_db(db_path)
+    h = db.header
+    seqs = [s for _, s in oracle.read_sequences(os.path.join(GOLDEN, qfile))] + ["", "ACGTNACGT"]
+    for flags in (0, ka.SEARCH_EARLY_EXIT):
+        r = _device_search(ka, ctx, db_path, seqs, threshold, flags)
+        per_q = r.per_query()
+        thr32 = float(np.float32(threshold))
+        for i, s in enumerate(seqs):
+            kmers = oracle.unique_kmers(s, h.kmer_len)
+            assert r.num_query_kmer[i] == len(kmers)
+            exp, _ = oracle.search_image(db.rows, h.slice_size, h.kmer_len, h.num_hash,
+                                         h.log_2_filter_len, h.num_filter, kmers, thr32)
+            assert per_q[i] == exp, (rel, threshold, i)
+            if threshold != 1.0 and len(kmers):
+                assert r.query_threshold[i] == oracle.query_threshold(thr32, len(kmers))
+
+
+def _make_random_db(rng, L, n_cols, density):
+    nbytes = (n_cols + 7) // 8
+    rows = (rng.random((1 << L, nbytes * 8)) < density)
+    rows[:, n_cols:] = True      # garbage in the pad bits of the last byte must never surface
+    return np.packbits(rows, axis=1, bitorder="little")
+
+
+@pytest.mark.parametrize("n_cols,num_hash,k,L", [(1, 1, 31, 8), (7, 2, 21, 9), (8, 3, 31, 10), (100, 1, 31, 10),
+                                                  (1000, 5, 15, 9), (8191, 1, 31, 8), (8192, 2, 31, 8),
+                                                  (8193, 1, 32, 8), (20000, 3, 31, 7), (70001, 1, 31, 6)])
+def test_search_random_db_vs_oracle(ka, ctx, oracle, n_cols, num_hash, k, L):
+    """Ragged widths (1 column ... several 1-KiB tiles), every num_hash, AND and count paths."""
+    rng = np.random.default_rng(n_cols * 7 + num_hash)
+    image = _make_random_db(rng, L, n_cols, 0.5 ** (1.0 / num_hash) if n_cols < 5000 else 0.9)
+    seqs = [rand_seq(rng, n) for n in (k, k + 1, 40, 60, 150, 5)] + [rand_seq(rng, 45) * 3, ""]
+    g = ka.Group(ctx, k, num_hash, L, n_cols)
+    assert g.add_columns(image, n_cols) == 0
+    g.finalize()
+    # read_rows returns exactly what was uploaded
+    some = [0, 1, (1 << L) - 1]
+    assert np.array_equal(g.read_rows(some)[:, :image.shape[1]], image[some])
+    b = ka.Batch(ctx, seqs)
+    for threshold in (1.0, 0.9, 0.5, 0.02):
+        thr32 = float(np.float32(threshold))
+        for flags in (0, ka.SEARCH_EARLY_EXIT):
+            r = g.search(b, threshold, flags)
+            per_q = r.per_query()
+            for i, s in enumerate(seqs):
+                kmers = oracle.unique_kmers(s, k)
+                exp, _ = oracle.search_image(image, image.shape[1], k, num_hash, L, n_cols, kmers, thr32)
+                assert r.num_query_kmer[i] == len(kmers)
+                assert per_q[i] == exp, (n_cols, num_hash, threshold, flags, i)
+    b.close()
+    g.close()
+
+
+def test_multiple_files_in_one_group(ka, ctx, oracle):
+    """Column concatenation: two reference files with equal parameters share one matrix; hits map
+    back to (file, column) and equal the per-file oracle results."""
+    pa = os.path.join(GOLDEN, "multi/dbs/a/k31_L10_h1.db")
+    pb = os.path.join(GOLDEN, "multi/dbs/a/deeper/k31_L10_h1_b.db")
+    da, db = oracle.read_db(pa), oracle.read_db(pb)
+    g = ka.Group(ctx, 31, 1, 10, 16 * 8 + 21)
+    fa, na = g.add_db_file(pa)
+    fb, nb = g.add_db_file(pb)
+    assert (fa, na, nb) == (0, 13, 21) and fb == 128        # second file starts 16-byte aligned
+    g.finalize()
+    assert g.num_columns == 34
+    seqs = [s for _, s in oracle.read_sequences(os.path.join(GOLDEN, "multi/contigs.fa.gz"))]
+    seqs += [s for _, s in oracle.read_sequences(os.path.join(GOLDEN, "multi/reads.fastq"))]
+    b = ka.Batch(ctx, seqs)
+    for threshold in (1.0, 0.7, 0.001):
+        r = g.search(b, threshold)
+        per_q = r.per_query()
+        for i, s in enumerate(seqs):
+            kmers = oracle.unique_kmers(s, 31)
+            ea, _ = oracle.search_image(da.rows, da.header.slice_size, 31, 1, 10, 13, kmers, float(np.float32(threshold)))
+            eb, _ = oracle.search_image(db.rows, db.header.slice_size, 31, 1, 10, 21, kmers, float(np.float32(threshold)))
+            assert per_q[i] == ea + [(c + fb, m) for c, m in eb], (threshold, i)
+    b.close()
+    g.close()
+
+
+def test_hit_buffer_growth(ka, ctx, oracle):
+    """threshold truncating to 0 makes EVERY column match (kwage.cpp:388,497): more hits than the
+    initial device buffer holds -> the engine must grow it and still return all of them."""
+    n_cols, L, k = 40000, 6, 31
+    g = ka.Group(ctx, k, 1, L, n_cols)
+    g.add_random_columns(n_cols, 7, 64)
+    g.finalize()
+    rng = np.random.default_rng(5)
+    seqs = [rand_seq(rng, 60) for _ in range(40)]
+    b = ka.Batch(ctx, seqs)
+    r = g.search(b, 0.001)
+    assert len(r.hits) == n_cols * len(seqs) and r.search_kernel_launches == 2
+    assert np.array_equal(r.hits["query"], np.repeat(np.arange(len(seqs), dtype=np.uint32), n_cols))
+    assert np.array_equal(r.hits["column"][:n_cols], np.arange(n_cols, dtype=np.uint32))
+    # counts: against the oracle on the rows actually resident on the device
+    image = g.read_rows(np.arange(1 << L))
+    for i in (0, 17, 39):
+        kmers = oracle.unique_kmers(seqs[i], k)
+        exp, _ = oracle.search_image(image, image.shape[1], k, 1, L, n_cols, kmers, float(np.float32(0.001)))
+        got = r.hits[r.hits["query"] == i]
+        assert [(int(c), int(m)) for c, m in zip(got["column"], got["num_match"])] == exp
+    b.close()
+    g.close()
+
+
+def test_errors_are_reported_not_swallowed(ka, ctx):
+    with pytest.raises(ka.KwageError):
+        ka.Group(ctx, 33, 1, 10, 8)                    # k > MAX_WORD_LEN
+    with pytest.raises(ka.KwageError):
+        ka.Group(ctx, 31, 6, 10, 8)                    # > MAX_NUM_HASH
+    with pytest.raises(ka.KwageError) as e:
+        ka.Group(ctx, 31, 1, 10, 8, hash_func=1)       # hash.cpp:92
+    assert "Unknown hash function" in str(e.value)
+    g = ka.Group(ctx, 31, 1, 8, 64)
+    g.add_random_columns(64, 1, 128)
+    b = ka.Batch(ctx, ["ACGT" * 20])
+    with pytest.raises(ka.KwageError):
+        g.search(b, 1.0)                               # not finalized
+    g.finalize()
+    with pytest.raises(ka.KwageError):
+        g.search(b, 0.0)                               # options.cpp:186
+    with pytest.raises(ka.KwageError):
+        g.add_random_columns(8, 1, 128)                # finalized
+    with pytest.raises(ka.KwageError):
+        g.add_db_file(os.path.join(GOLDEN, "k32/k32.db"))
+    b.close()
+    g.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# the drop-in CLI against the reference binary's recorded output
+# ---------------------------------------------------------------------------------------------
+def _cases():
+    return json.load(open(os.path.join(GOLDEN, "manifest.json")))["cases"]
+
+
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: "%s-%s" % (c["name"], c["expected"]))
+def test_cli_matches_reference_output(ka, oracle, case):
+    from kwage_amd import native
+    cdir = os.path.join(GOLDEN, case["name"])
+    args = [native.KWAGE_BIN]
+    for d in case["db"]:
+        args += ["-d", d]
+    for q in case["queries"]:
+        args += ["-i", q]
+    args += ["-t", case["threshold"], "--o." + case["format"]] + case["cmdline"]
+    r = subprocess.run(args, cwd=cdir, capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    got = r.stdout.decode("latin-1")
+    exp = open(os.path.join(cdir, case["expected"]), encoding="latin-1").read()
+    if case["format"] == "csv":
+        g, e = oracle.parse_csv(got), oracle.parse_csv(exp)
+        assert list(g) == list(e)                       # same queries, same order
+        for q in e:
+            assert sorted(g[q]) == sorted(e[q]), q
+            assert [x[2] for x in g[q]] == [x[2] for x in e[q]]    # descending by hits, as the reference prints
+    else:
+        # order among equal-score hits is unspecified in the reference; compare as multisets of
+        # lines plus the exact sequence of scores
+        assert sorted(got.splitlines()) == sorted(exp.splitlines())
+        score = lambda t: [ln for ln in t.splitlines() if "num_kmers_found" in ln or '"query"' in ln]
+        assert score(got) == score(exp)
+    if len(case["db"]) == 1 and case["name"] != "multi":
+        assert got == exp                               # single file: byte-identical
