@@ -36,13 +36,13 @@ WORKLOADS: Dict[str, Workload] = {
                    genome_len=20000),
     # BASELINE.json configs[1]: the configuration the metric is quoted on
     "c2": Workload("C2: 100k samples x 2^23-bit filters, 1k x 1 kb queries, 1 hash, t=1.0", 100_000, 23, 31, 1,
-                   1000, 1000, 1.0),
+                   1000, 1000, 1.0, num_genomes=32, genome_len=50_000),
     # BASELINE.json configs[2]
     "c3": Workload("C3: 1M samples x 2^20-bit filters, 100k x 150 bp queries, 1 hash, t=1.0", 1_000_000, 20, 31, 1,
-                   100_000, 150, 1.0, num_genomes=64, genome_len=2000),
+                   100_000, 150, 1.0, num_genomes=64, genome_len=150_000),
     # count path (threshold < 1), 5 hashes: the C5 flavour on one filter size
     "c5s": Workload("C5-single-group: 200k samples x 2^22-bit filters, 5 hashes, 1k x 1 kb queries, t=0.8", 200_000, 22,
-                    31, 5, 1000, 1000, 0.8, density_q8=194),
+                    31, 5, 1000, 1000, 0.8, density_q8=194, num_genomes=32, genome_len=50_000),
     # small shapes for tests
     "tiny": Workload("tiny", 5000, 14, 31, 2, 64, 300, 1.0, density_q8=128, num_genomes=4, genome_len=1000),
 }
@@ -89,12 +89,27 @@ def build(ctx: Context, w: Workload, seed: int = 1, column_seed: int = 0) -> Syn
             g.set_bits(r, np.full(r.shape, c, dtype=np.uint64))
     g.finalize()
 
+    # Hit queries are DISTINCT windows of the planted genomes (no two share a k-mer by construction),
+    # so the benchmark gets no cross-query row reuse out of the caches: every addressed row is a fresh
+    # random row of the matrix, as the metric's algorithmic-byte count assumes.
+    is_hit = rng.random(w.num_queries) < w.hit_fraction
+    win_per_genome = w.genome_len // w.query_len if w.genome_len >= w.query_len else 0
+    total_windows = win_per_genome * w.num_genomes
+    n_hit = int(is_hit.sum())
+    if total_windows == 0:
+        is_hit[:] = False
+        windows = np.zeros(0, dtype=np.int64)
+    elif n_hit <= total_windows:
+        windows = rng.choice(total_windows, size=n_hit, replace=False)
+    else:
+        windows = rng.integers(0, total_windows, size=n_hit)      # pool too small: some reuse (tiny shapes only)
     queries, qsrc = [], []
+    wi = 0
     for qi in range(w.num_queries):
-        if rng.random() < w.hit_fraction and w.genome_len >= w.query_len:
-            gi = int(rng.integers(w.num_genomes))
-            off = int(rng.integers(w.genome_len - w.query_len + 1))
-            queries.append(genomes[gi][off:off + w.query_len])
+        if is_hit[qi]:
+            gi, wn = divmod(int(windows[wi]), win_per_genome)
+            wi += 1
+            queries.append(genomes[gi][wn * w.query_len:(wn + 1) * w.query_len])
             qsrc.append(gi)
         else:
             queries.append(_rand_seq(rng, w.query_len))
