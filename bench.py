@@ -127,11 +127,18 @@ def main():
     import kwage_amd as ka
     from kwage_amd import synth
 
+    # KWAGE_BENCH_BACKEND=gloo + KWAGE_BENCH_ONE_DEVICE=1 rehearse the N>1 code path on a one-GPU box
+    backend = os.environ.get("KWAGE_BENCH_BACKEND", "nccl")
+    if os.environ.get("KWAGE_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     dist = None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     w = synth.WORKLOADS[args.workload]
     ctx = ka.Context(local_rank)
@@ -141,48 +148,21 @@ def main():
     flags = ka.SEARCH_TIMING | (ka.SEARCH_EARLY_EXIT if args.early_exit else 0)
     threshold = w.threshold
 
-    hits_dev = None
+    ss = None
     if world > 1:
-        cap = 1 << 20
-        hits_dev = torch.empty((cap, 3), dtype=torch.int32, device="cuda")
+        from kwage_amd.distributed import ShardedSearch, device_tensor_search_fn
+        dev = "cuda:%d" % local_rank
+        ss = ShardedSearch(dist, rank, world, int(s.group.column_span),
+                           device_tensor_search_fn(s.group, flags, dev), device=dev if backend == "nccl" else "cpu")
 
     def step():
-        """One pass of the hot path; returns (result-or-None, search_kernel_ms, n_hits_total_on_rank0)."""
+        """One pass of the hot path; returns (result-or-None, search_kernel_ms, hits delivered to rank 0)."""
         if world == 1:
             r = s.group.search(s.batch, threshold, flags)
             return r, r.search_kernel_ms, len(r.hits)
-        # multi-GPU: leave hits on the device, exchange with ONE padded gather over RCCL
-        nonlocal hits_dev
-        import ctypes as C
-        from kwage_amd.native import lib, check
-        n = C.c_uint64()
-        while True:
-            check(lib().kwage_search_device(s.group._h, s.batch._h, C.c_float(threshold), flags,
-                                            hits_dev.data_ptr(), hits_dev.shape[0], C.byref(n), None))
-            if n.value <= hits_dev.shape[0]:
-                break
-            hits_dev = torch.empty((int(n.value * 1.25), 3), dtype=torch.int32, device="cuda")
-        cnt = torch.tensor([n.value], dtype=torch.int64, device="cuda")
-        counts = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(counts, cnt)
-        mx = max(int(c.item()) for c in counts)
-        total = 0
-        if mx:
-            mine = hits_dev[:mx].contiguous() if mx <= hits_dev.shape[0] else torch.cat(
-                [hits_dev, torch.zeros((mx - hits_dev.shape[0], 3), dtype=torch.int32, device="cuda")])
-            outs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-            dist.gather(mine, outs, dst=0)
-            if rank == 0:
-                parts = []
-                for r_, (o, c) in enumerate(zip(outs, counts)):
-                    p = o[: int(c.item())].cpu().numpy().astype(np.uint32)
-                    p[:, 1] += np.uint32(0)   # columns are local to the rank's block; global id = (rank, column)
-                    parts.append(np.concatenate([np.full((len(p), 1), r_, np.uint32), p], axis=1))
-                allhits = np.concatenate(parts) if parts else np.zeros((0, 4), np.uint32)
-                order = np.lexsort((allhits[:, 2], allhits[:, 0], allhits[:, 1]))   # by query, rank, column
-                allhits = allhits[order]
-                total = len(allhits)
-        return None, 0.0, total
+        # multi-GPU: hits stay in HBM, ONE gatherv over RCCL, rank 0 concatenates + sorts
+        merged, _ = ss.search(s.batch, threshold)
+        return None, 0.0, (len(merged) if merged is not None else 0)
 
     def sync_all():
         ctx.sync()
@@ -204,7 +184,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -223,6 +203,13 @@ def main():
         k_ms = float(np.mean(kernel_ms)) if kernel_ms else 0.0
         achieved = alg_bytes_rank / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         stream_gbps = s.group.stream_read_gbps(min(s.group.device_bytes, 8 << 30), 3)
+        traffic = None
+        try:     # PMC numbers come from a separate rocprofv3 --pmc pass of this same command (profiles/)
+            t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
+            if t and not args.early_exit:
+                traffic = t["hbm_read_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "G k-mer*sample bit-tests/sec",
             "value": round(value, 3),
@@ -241,7 +228,7 @@ def main():
             "hbm_gbps_algorithmic_whole_step": round(alg_bytes_rank * world * args.steps / dt / 1e9, 1),
             "roofline": {"bound": "hbm", "kernel": "and_kernel" if threshold == 1.0 else "count_kernel",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": alg_bytes_rank,
                          "measured_stream_read_gbps": round(stream_gbps, 1),
                          "frac_of_measured_stream": round(achieved / stream_gbps, 4) if stream_gbps else None},

@@ -210,11 +210,11 @@ int launch_kmer_stage(kwage_ctx *ctx, const kwage_params &p, kwage_batch *b, flo
 	return KWAGE_OK;
 }
 
-template <int VEC, int UNROLL>
+template <int VEC, int UNROLL, bool NT>
 void launch_and(const SearchArgs &a, uint64_t tiles, hipStream_t s)
 {
 	const uint32_t blocks = (uint32_t)((tiles + 3)/4);
-	hipLaunchKernelGGL((and_kernel<VEC, UNROLL>), dim3(blocks), dim3(SEARCH_THREADS), 0, s, a);
+	hipLaunchKernelGGL((and_kernel<VEC, UNROLL, NT>), dim3(blocks), dim3(SEARCH_THREADS), 0, s, a);
 }
 
 template <int PLANES>
@@ -230,16 +230,41 @@ void launch_count_nh(const SearchArgs &a, uint64_t tiles, hipStream_t s)
 	}
 }
 
-// tile width (16-byte vectors per lane) of the AND kernel; tunable through KWAGE_AND_VEC
-int and_vec_choice(uint32_t units_per_row)
+// Shape of the AND kernel: VEC 16-byte vectors per lane, UNROLL rows in flight, nontemporal loads.
+// Defaults come from measurements on MI355X; KWAGE_AND_CFG="vec,unroll,nt" overrides
+// them for tuning runs (read on every launch so one process can sweep variants).
+struct AndCfg { int vec, unroll, nt; };
+
+AndCfg and_config(uint32_t units_per_row)
 {
-	static int forced = -1;
-	if(forced < 0){
-		const char *e = getenv("KWAGE_AND_VEC");
-		forced = e ? atoi(e) : 0;
+	AndCfg c;
+	c.vec = (units_per_row >= 4*WAVE) ? 2 : 1;
+	c.unroll = 8;
+	c.nt = 1;      // +4-5 % on MI355X: each row byte is consumed once per (query, tile)
+	const char *e = getenv("KWAGE_AND_CFG");
+	if(e){
+		int v = 0, u = 0, n = 0;
+		if(sscanf(e, "%d,%d,%d", &v, &u, &n) == 3 && (v == 1 || v == 2 || v == 4) && (u == 4 || u == 8 || u == 16)){
+			c.vec = v; c.unroll = u; c.nt = n ? 1 : 0;
+		}
 	}
-	if(forced == 1 || forced == 2 || forced == 4){ return forced; }
-	return (units_per_row >= 4*WAVE) ? 2 : 1;
+	return c;
+}
+
+template <int VEC, bool NT>
+void launch_and_u(const SearchArgs &a, uint64_t tiles, hipStream_t s, int unroll)
+{
+	if(unroll == 4){ launch_and<VEC, 4, NT>(a, tiles, s); }
+	else if(unroll == 16 && VEC < 4){ launch_and<VEC, 16, NT>(a, tiles, s); }
+	else{ launch_and<VEC, 8, NT>(a, tiles, s); }
+}
+
+template <bool NT>
+void launch_and_v(const SearchArgs &a, uint64_t tiles, hipStream_t s, const AndCfg &c)
+{
+	if(c.vec == 1){ launch_and_u<1, NT>(a, tiles, s, c.unroll); }
+	else if(c.vec == 2){ launch_and_u<2, NT>(a, tiles, s, c.unroll); }
+	else{ launch_and_u<4, NT>(a, tiles, s, c.unroll); }
 }
 
 // Launch the gather+reduce kernel for the current batch. Returns tiles per query via *chunks.
@@ -264,15 +289,12 @@ int launch_search_stage(kwage_group *g, kwage_batch *b, float threshold, uint32_
 	a.early_exit = (flags & KWAGE_SEARCH_EARLY_EXIT) ? 1 : 0;
 
 	if(threshold == 1.0f){
-		const int vec = and_vec_choice(a.units_per_row);
-		a.chunks = (a.units_per_row + WAVE*vec - 1)/(WAVE*vec);
+		const AndCfg cfg = and_config(a.units_per_row);
+		a.chunks = (a.units_per_row + WAVE*cfg.vec - 1)/(WAVE*cfg.vec);
 		const uint64_t tiles = (uint64_t)a.n_queries*a.chunks;
 		if(tiles/4 + 1 > 0x7FFFFFFFull){ return fail(KWAGE_ERR_ARG, "batch too large for one launch"); }
-		switch(vec){
-			case 1: launch_and<1, 8>(a, tiles, ctx->stream); break;
-			case 2: launch_and<2, 8>(a, tiles, ctx->stream); break;
-			default: launch_and<4, 4>(a, tiles, ctx->stream); break;
-		}
+		if(cfg.nt){ launch_and_v<true>(a, tiles, ctx->stream, cfg); }
+		else{ launch_and_v<false>(a, tiles, ctx->stream, cfg); }
 	}
 	else{
 		a.chunks = (a.units_per_row + WAVE - 1)/WAVE;
@@ -878,10 +900,10 @@ extern "C" int kwage_stream_read_gbps(kwage_group *g, uint64_t bytes, uint32_t i
 	if((rc = ctx->counters.reserve(4*sizeof(uint64_t)))){ return rc; }
 	uint32_t *sink = (uint32_t*)((uint64_t*)ctx->counters.p + 3);
 	const uint64_t n16 = bytes/16;
-	hipLaunchKernelGGL(stream_read_kernel, dim3(256*8), dim3(256), 0, ctx->stream, (const uint4*)g->d_bits, n16, sink);   // warm-up
+	hipLaunchKernelGGL(stream_read_kernel, dim3(256*8), dim3(256), 0, ctx->stream, (const u32x4*)g->d_bits, n16, sink);   // warm-up
 	HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
 	for(uint32_t i = 0; i < iters; ++i){
-		hipLaunchKernelGGL(stream_read_kernel, dim3(256*8), dim3(256), 0, ctx->stream, (const uint4*)g->d_bits, n16, sink);
+		hipLaunchKernelGGL(stream_read_kernel, dim3(256*8), dim3(256), 0, ctx->stream, (const u32x4*)g->d_bits, n16, sink);
 	}
 	HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
 	HIP_TRY(hipGetLastError());

@@ -280,8 +280,22 @@ __device__ __forceinline__ void emit_hit(const SearchArgs &a, uint32_t q, uint32
 	}
 }
 
+// 16 bytes of columns as a clang vector: bitwise operators apply lane-wise, and the nontemporal
+// load builtin accepts it.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ __forceinline__ u32x4 load16(const u32x4 *p)
+{
+	if(NT){ return __builtin_nontemporal_load(p); }
+	return *p;
+}
+
 // threshold == 1.0f: AND of every addressed row (kwage.cpp:404-470).
-template <int VEC, int UNROLL>
+//   VEC    16-byte vectors per lane per row (tile = 64*VEC*16 bytes of each row per wave)
+//   UNROLL rows in flight per wave
+//   NT     nontemporal loads: every row byte is used exactly once per (query, tile)
+template <int VEC, int UNROLL, bool NT>
 __global__ __launch_bounds__(SEARCH_THREADS) void and_kernel(SearchArgs a)
 {
 	const uint32_t lane = threadIdx.x & (WAVE - 1);
@@ -298,49 +312,49 @@ __global__ __launch_bounds__(SEARCH_THREADS) void and_kernel(SearchArgs a)
 
 	uint32_t unit[VEC];     // this lane's 16-byte units within a row (clamped in range: no divergence)
 	bool live[VEC];
-	uint4 acc[VEC];
+	u32x4 acc[VEC];
 #pragma unroll
 	for(int v = 0; v < VEC; ++v){
 		const uint32_t u = c*(WAVE*VEC) + v*WAVE + lane;
 		live[v] = (u < a.units_per_row);
 		unit[v] = live[v] ? u : (a.units_per_row - 1);
-		acc[v] = make_uint4(~0u, ~0u, ~0u, ~0u);     // set_all_bits, bloom.h:182-187
+		acc[v] = ~(u32x4)(0u);                       // set_all_bits, bloom.h:182-187
 	}
 
 	uint32_t i = 0;
 	for(; i + UNROLL <= nrows; i += UNROLL){
-		uint4 x[UNROLL][VEC];
+		u32x4 x[UNROLL][VEC];
 #pragma unroll
 		for(int u = 0; u < UNROLL; ++u){
 			const uint32_t r = rq[i + u];
-			const uint4 *p = reinterpret_cast<const uint4*>(a.db + (uint64_t)r*a.stride);
+			const u32x4 *p = reinterpret_cast<const u32x4*>(a.db + (uint64_t)r*a.stride);
 #pragma unroll
-			for(int v = 0; v < VEC; ++v){ x[u][v] = p[unit[v]]; }
+			for(int v = 0; v < VEC; ++v){ x[u][v] = load16<NT>(p + unit[v]); }
 		}
 #pragma unroll
 		for(int u = 0; u < UNROLL; ++u){
 #pragma unroll
-			for(int v = 0; v < VEC; ++v){ acc[v] = and4(acc[v], x[u][v]); }
+			for(int v = 0; v < VEC; ++v){ acc[v] &= x[u][v]; }
 		}
 		if(a.early_exit){     // kwage.cpp:466-470 per tile: nothing left that could match
 			bool nz = false;
 #pragma unroll
-			for(int v = 0; v < VEC; ++v){ nz |= nonzero4(acc[v]); }
+			for(int v = 0; v < VEC; ++v){ nz |= ((acc[v].x | acc[v].y | acc[v].z | acc[v].w) != 0); }
 			if(!__any(nz)){ return; }
 		}
 	}
 	for(; i < nrows; ++i){
 		const uint32_t r = rq[i];
-		const uint4 *p = reinterpret_cast<const uint4*>(a.db + (uint64_t)r*a.stride);
+		const u32x4 *p = reinterpret_cast<const u32x4*>(a.db + (uint64_t)r*a.stride);
 #pragma unroll
-		for(int v = 0; v < VEC; ++v){ acc[v] = and4(acc[v], p[unit[v]]); }
+		for(int v = 0; v < VEC; ++v){ acc[v] &= load16<NT>(p + unit[v]); }
 	}
 
 	// hit extraction (kwage.cpp:489-499), restricted to real columns
 #pragma unroll
 	for(int v = 0; v < VEC; ++v){
 		if(!live[v]){ continue; }
-		const uint4 m = and4(acc[v], reinterpret_cast<const uint4*>(a.valid)[unit[v]]);
+		const u32x4 m = acc[v] & reinterpret_cast<const u32x4*>(a.valid)[unit[v]];
 		const uint32_t w[4] = {m.x, m.y, m.z, m.w};
 #pragma unroll
 		for(int d = 0; d < 4; ++d){
@@ -575,19 +589,19 @@ __global__ void gather_rows_kernel(const uint8_t *db, uint64_t stride, const uin
 
 // Streaming read of the matrix (measures the achievable HBM read rate on this box): every wave
 // keeps eight 1-KiB loads in flight, blocks walk the buffer grid-stride.
-__global__ __launch_bounds__(256) void stream_read_kernel(const uint4 *src, uint64_t n16, uint32_t *sink)
+__global__ __launch_bounds__(256) void stream_read_kernel(const u32x4 *src, uint64_t n16, uint32_t *sink)
 {
-	uint4 acc = make_uint4(0, 0, 0, 0);
+	u32x4 acc = (u32x4)(0u);
 	const uint64_t step = (uint64_t)gridDim.x*blockDim.x;
 	uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x;
 	for(; i + 7*step < n16; i += 8*step){
-		uint4 a[8];
+		u32x4 a[8];
 #pragma unroll
-		for(int u = 0; u < 8; ++u){ a[u] = src[i + u*step]; }
+		for(int u = 0; u < 8; ++u){ a[u] = __builtin_nontemporal_load(src + i + u*step); }
 #pragma unroll
-		for(int u = 0; u < 8; ++u){ acc = xor4(acc, a[u]); }
+		for(int u = 0; u < 8; ++u){ acc ^= a[u]; }
 	}
-	for(; i < n16; i += step){ acc = xor4(acc, src[i]); }
+	for(; i < n16; i += step){ acc ^= src[i]; }
 	if((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u){ *sink = 1; }   // keep the loads alive
 }
 

@@ -1,0 +1,179 @@
+"""Multi-GPU host for the kwage search path: one process per GPU over torch.distributed
+(backend "nccl" == RCCL over xGMI on ROCm; "gloo" for CPU rehearsal).
+
+The path shards on the SAMPLE (column) axis -- a hit for sample j depends only on column j of
+the addressed rows -- so every rank holds all rows of its own contiguous
+block of columns, searches it independently (queries are replicated: kilobytes), and the only
+exchange is the variable-length gather of hit records to rank 0:
+
+    counts  <- all_gather(one int64 per rank)
+    hits    <- gatherv: one grouped send/recv (RCCL has no native gatherv), exact sizes, no padding
+
+Rank 0 concatenates; no merge is needed because column ranges are disjoint.  No row data ever
+crosses xGMI.  The reference has no counterpart (its only parallel axis is OpenMP over .db files,
+kwage.cpp:76-87); this is what replaces it at node scale.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+COLUMN_ALIGN = 1024          # shard boundaries fall on 128-byte (1024-column) multiples
+
+
+def partition_columns(num_columns: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous [start, end) column blocks, one per rank, boundaries multiples of COLUMN_ALIGN
+    (except the last end).  Ranks may get an empty block when there are fewer aligned blocks than
+    ranks."""
+    units = (num_columns + COLUMN_ALIGN - 1) // COLUMN_ALIGN
+    out, start_u = [], 0
+    for r in range(world):
+        n_u = units // world + (1 if r < units % world else 0)
+        s, e = start_u * COLUMN_ALIGN, min((start_u + n_u) * COLUMN_ALIGN, num_columns)
+        out.append((min(s, num_columns), e))
+        start_u += n_u
+    return out
+
+
+def partition_files(num_filters: Sequence[int], world: int) -> List[Tuple[int, int]]:
+    """Assign whole `.db` files (never split: each is a <=2048-column block written by the
+    reference's build_db) to ranks as contiguous [first_file, last_file) ranges with balanced
+    column totals (greedy prefix split)."""
+    total = int(sum(num_filters))
+    owner, prefix = [], 0
+    for nf in num_filters:            # a file goes to the rank that owns its middle column
+        owner.append(min(world - 1, int((prefix + nf / 2.0) * world / max(total, 1))))
+        prefix += nf
+    out = []
+    for r in range(world):
+        idx = [i for i, o in enumerate(owner) if o == r]
+        out.append((idx[0], idx[-1] + 1) if idx else ((out[-1][1], out[-1][1]) if out else (0, 0)))
+    return out
+
+
+def gatherv_hits(local_hits, dist, rank: int, world: int, dst: int = 0, device=None):
+    """Variable-length gather of [n_i, 3] int32 hit records (query, local column, num_match).
+
+    local_hits: torch tensor on the backend's device (cuda for nccl, cpu for gloo).
+    Returns on dst a list of per-rank tensors (exact sizes); elsewhere None."""
+    import torch
+    dev = local_hits.device if device is None else device
+    cnt = torch.tensor([local_hits.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt)
+    counts = [int(c.item()) for c in counts]
+    if rank == dst:
+        outs = [torch.empty((c, 3), dtype=torch.int32, device=dev) for c in counts]
+        outs[dst] = local_hits
+        ops = [dist.P2POp(dist.irecv, outs[r], r) for r in range(world) if r != dst and counts[r] > 0]
+    else:
+        outs = None
+        ops = [dist.P2POp(dist.isend, local_hits.contiguous(), dst)] if counts[rank] > 0 else []
+    if ops:
+        for req in dist.batch_isend_irecv(ops):     # ONE grouped ncclSend/ncclRecv launch on RCCL
+            req.wait()
+    return outs
+
+
+def merge_hits(parts: Sequence[np.ndarray], column_base: Sequence[int]) -> np.ndarray:
+    """Concatenate per-rank [n,3] (query, local column, num_match) records into global columns,
+    sorted by (query, column).  Column ranges are disjoint, so this is a plain concatenation."""
+    rows = []
+    for r, p in enumerate(parts):
+        p = np.asarray(p, dtype=np.int64).reshape(-1, 3)
+        if len(p):
+            q = p.copy()
+            q[:, 1] += int(column_base[r])
+            rows.append(q)
+    if not rows:
+        return np.zeros((0, 3), dtype=np.int64)
+    allh = np.concatenate(rows)
+    order = np.lexsort((allh[:, 1], allh[:, 0]))
+    return allh[order]
+
+
+@dataclass
+class ShardedSearch:
+    """One rank's view of a column-sharded search.
+
+    search_fn(seqs, threshold) -> ([n,3] int array of (query, LOCAL column, num_match),
+                                   per-query num_query_kmer array)
+    is the rank-local searcher: on a GPU box the HIP engine (device_search_fn below); tests inject
+    a CPU stand-in to rehearse the exchange under gloo."""
+    dist: object
+    rank: int
+    world: int
+    local_columns: int                 # column span of this rank's block
+    search_fn: Callable
+    device: str = "cpu"
+
+    def __post_init__(self):
+        import torch
+        span = torch.tensor([self.local_columns], dtype=torch.int64, device=self.device)
+        spans = [torch.zeros_like(span) for _ in range(self.world)]
+        self.dist.all_gather(spans, span)
+        spans = [int(s.item()) for s in spans]
+        self.column_base = [int(sum(spans[:r])) for r in range(self.world)]
+        self.total_columns = int(sum(spans))
+
+    def search(self, queries, threshold: float):
+        """`queries` is handed to search_fn unchanged (a list of strings, or a resident Batch for the
+        device searchers).  Returns (hits [n,3] with GLOBAL columns sorted by (query, column),
+        num_query_kmer) on rank 0, (None, num_query_kmer) elsewhere."""
+        import torch
+        local, nk = self.search_fn(queries, threshold)
+        if isinstance(local, torch.Tensor):
+            t = local                      # already on the backend's device (RCCL: stays in HBM)
+            if self.device == "cpu" and t.is_cuda:
+                t = t.cpu()                # gloo rehearsal of the device searcher
+        else:
+            t = torch.as_tensor(np.ascontiguousarray(np.asarray(local, dtype=np.int32).reshape(-1, 3)))
+            if self.device != "cpu":
+                t = t.to(self.device)
+        outs = gatherv_hits(t, self.dist, self.rank, self.world, 0, device=t.device)
+        if self.rank != 0:
+            return None, nk
+        parts = [o.cpu().numpy() for o in outs]
+        return merge_hits(parts, self.column_base), nk
+
+
+def device_search_fn(group, ctx, flags: int = 0):
+    """Rank-local searcher backed by the HIP engine (kwage_amd.engine)."""
+    from .engine import Batch
+
+    def fn(seqs, threshold):
+        b = Batch(ctx, seqs)
+        try:
+            r = group.search(b, threshold, flags)
+        finally:
+            b.close()
+        h = np.stack([r.hits["query"], r.hits["column"], r.hits["num_match"]], axis=1).astype(np.int64) \
+            if len(r.hits) else np.zeros((0, 3), np.int64)
+        return h, r.num_query_kmer
+    return fn
+
+
+def device_tensor_search_fn(group, flags: int = 0, device: str = "cuda", initial_capacity: int = 1 << 20):
+    """Rank-local searcher that leaves the hit records in HBM (a torch int32 [n,3] tensor written
+    directly by kwage_search_device), so the RCCL gatherv sends them without a host round trip.
+    `queries` must be a resident kwage_amd.Batch."""
+    import ctypes as C
+    import torch
+    from .native import check, lib
+
+    state = {"buf": torch.empty((initial_capacity, 3), dtype=torch.int32, device=device)}
+
+    def fn(batch, threshold):
+        n = C.c_uint64()
+        nk = torch.empty((max(batch.n, 1),), dtype=torch.int32, device=device)
+        while True:
+            buf = state["buf"]
+            check(lib().kwage_search_device(group._h, batch._h, C.c_float(threshold), flags,
+                                            buf.data_ptr(), buf.shape[0], C.byref(n), nk.data_ptr()))
+            if n.value <= buf.shape[0]:
+                break
+            state["buf"] = torch.empty((int(n.value * 1.25) + 1, 3), dtype=torch.int32, device=device)
+        return state["buf"][: n.value], nk[: batch.n]
+    return fn

@@ -1,0 +1,99 @@
+"""N>1 path rehearsed on CPU: world_size-2 gloo, the real partition + gatherv + merge code of
+kwage_amd.distributed with the CPU oracle injected as the rank-local searcher (the HIP engine is
+the searcher on GPU boxes).  Checks that column sharding + one variable-length gather reproduces
+the unsharded hit list exactly."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+def test_partition_columns():
+    from kwage_amd.distributed import partition_columns, COLUMN_ALIGN
+    for n in (1, 1000, 1024, 1025, 100_000, 10_000_000):
+        for w in (1, 2, 3, 8):
+            parts = partition_columns(n, w)
+            assert len(parts) == w and parts[0][0] == 0 and parts[-1][1] == n
+            for (s0, e0), (s1, e1) in zip(parts, parts[1:]):
+                assert e0 == s1 and (s1 % COLUMN_ALIGN == 0 or s1 == n)
+            sizes = [e - s for s, e in parts]
+            assert max(sizes) - min(sizes) <= 2 * COLUMN_ALIGN or n < COLUMN_ALIGN * w
+
+
+def test_partition_files():
+    from kwage_amd.distributed import partition_files
+    nf = [2048] * 10 + [100]
+    for w in (1, 2, 4, 8):
+        parts = partition_files(nf, w)
+        assert parts[0][0] == 0 and parts[-1][1] == len(nf)
+        for (s0, e0), (s1, e1) in zip(parts, parts[1:]):
+            assert e0 == s1                      # contiguous, no file split or lost
+        loads = [sum(nf[s:e]) for s, e in parts]
+        assert max(loads) - min(loads) <= 2 * 2048
+    assert sum(e - s for s, e in partition_files([5], 4)) == 1
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import kwage_oracle as oracle
+    from kwage_amd.distributed import ShardedSearch
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        db = oracle.read_db(os.path.join(GOLDEN, "basic", "db", "basic.db"))
+        h = db.header
+        # shard the 100 columns at a byte boundary (the engine shards at 1024-column boundaries; a
+        # smaller alignment keeps this CPU rehearsal meaningful on a 100-column fixture)
+        bounds = [(0, 56), (56, 100)]
+        s, e = bounds[rank]
+        shard = np.ascontiguousarray(db.rows[:, s // 8:(e + 7) // 8])
+        seqs = [q for _, q in oracle.read_sequences(os.path.join(GOLDEN, "basic", "q.fa"))]
+
+        def search_fn(seqs, threshold):
+            rows, nk = [], []
+            for qi, q in enumerate(seqs):
+                kmers = oracle.unique_kmers(q, h.kmer_len)
+                nk.append(len(kmers))
+                hits, _ = oracle.search_image(shard, shard.shape[1], h.kmer_len, h.num_hash, h.log_2_filter_len,
+                                              e - s, kmers, float(np.float32(threshold)))
+                rows += [(qi, c, m) for c, m in hits]
+            return np.array(rows, dtype=np.int64).reshape(-1, 3), np.array(nk, dtype=np.uint32)
+
+        ss = ShardedSearch(dist, rank, world, e - s, search_fn)
+        assert ss.total_columns == 100 and ss.column_base == [b[0] for b in bounds]
+        for threshold in (1.0, 0.5, 0.0001):
+            merged, nk = ss.search(seqs, threshold)
+            if rank == 0:
+                exp = []
+                for qi, q in enumerate(seqs):
+                    kmers = oracle.unique_kmers(q, h.kmer_len)
+                    hits, _ = oracle.search_image(db.rows, h.slice_size, h.kmer_len, h.num_hash, h.log_2_filter_len,
+                                                  h.num_filter, kmers, float(np.float32(threshold)))
+                    exp += [(qi, c, m) for c, m in hits]
+                assert merged.tolist() == [list(x) for x in exp], threshold
+        # an empty local hit list on one rank must not hang the gather
+        ss2 = ShardedSearch(dist, rank, world, e - s,
+                            lambda q, t: (np.zeros((0, 3), np.int64) if rank else np.array([[0, 1, 2]]), np.zeros(1, np.uint32)))
+        merged, _ = ss2.search(["A"], 1.0)
+        if rank == 0:
+            assert merged.tolist() == [[0, 1, 2]]
+        open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_sharded_search_gloo_world2(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
