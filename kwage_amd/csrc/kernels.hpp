@@ -372,27 +372,23 @@ __global__ __launch_bounds__(SEARCH_THREADS) void and_kernel(SearchArgs a)
 // (kwage.cpp:404-433 with increment_count, bloom.h:291-330).  Counters are bit-sliced:
 // plane[p] holds bit p of the counter of each of the lane's 128 columns.
 template <int PLANES>
-__device__ __forceinline__ void planes_add(uint4 (&plane)[PLANES], uint4 carry, int from)
+__device__ __forceinline__ void planes_add(u32x4 (&plane)[PLANES], u32x4 carry, int from)
 {
 #pragma unroll
 	for(int p = 0; p < PLANES; ++p){
 		if(p < from){ continue; }
-		const uint4 t = and4(plane[p], carry);
-		plane[p] = make_uint4(plane[p].x ^ carry.x, plane[p].y ^ carry.y, plane[p].z ^ carry.z, plane[p].w ^ carry.w);
+		const u32x4 t = plane[p] & carry;
+		plane[p] ^= carry;
 		carry = t;
 	}
 }
 
-__device__ __forceinline__ uint4 xor4(uint4 a, uint4 b) { return make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w); }
-__device__ __forceinline__ uint4 or4(uint4 a, uint4 b) { return make_uint4(a.x | b.x, a.y | b.y, a.z | b.z, a.w | b.w); }
-__device__ __forceinline__ uint4 not4(uint4 a) { return make_uint4(~a.x, ~a.y, ~a.z, ~a.w); }
-
 // carry-save adder: (sum, carry) of three 1-bit vectors
-__device__ __forceinline__ void csa(uint4 &sum, uint4 &carry, uint4 a, uint4 b, uint4 c)
+__device__ __forceinline__ void csa(u32x4 &sum, u32x4 &carry, u32x4 a, u32x4 b, u32x4 c)
 {
-	const uint4 u = xor4(a, b);
-	carry = or4(and4(a, b), and4(u, c));
-	sum = xor4(u, c);
+	const u32x4 u = a ^ b;
+	carry = (a & b) | (u & c);
+	sum = u ^ c;
 }
 
 template <int PLANES, int NH>
@@ -413,29 +409,29 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 	const bool live = (u0 < a.units_per_row);
 	const uint32_t unit = live ? u0 : (a.units_per_row - 1);
 
-	uint4 plane[PLANES];
+	u32x4 plane[PLANES];
 #pragma unroll
-	for(int p = 0; p < PLANES; ++p){ plane[p] = make_uint4(0, 0, 0, 0); }
+	for(int p = 0; p < PLANES; ++p){ plane[p] = (u32x4)(0u); }
 
 	// four k-mers per step: 4*NH row loads in flight, then a carry-save tree so that the ripple
 	// through the upper planes happens once per four k-mers (planes 0,1 are the CSA residues).
 	uint32_t i = 0;
 	for(; i + 4 <= n; i += 4){
-		uint4 m[4];
+		u32x4 m[4];
 #pragma unroll
 		for(int u = 0; u < 4; ++u){
-			uint4 x[NH];
+			u32x4 x[NH];
 #pragma unroll
 			for(int h = 0; h < NH; ++h){
 				const uint32_t r = rq[(i + u)*NH + h];
-				x[h] = reinterpret_cast<const uint4*>(a.db + (uint64_t)r*a.stride)[unit];
+				x[h] = load16<true>(reinterpret_cast<const u32x4*>(a.db + (uint64_t)r*a.stride) + unit);
 			}
 			m[u] = x[0];
 #pragma unroll
-			for(int h = 1; h < NH; ++h){ m[u] = and4(m[u], x[h]); }    // kmer_match &= slice
+			for(int h = 1; h < NH; ++h){ m[u] &= x[h]; }    // kmer_match &= slice
 		}
 		if(PLANES >= 3){
-			uint4 twoA, twoB, four, s;
+			u32x4 twoA, twoB, four, s;
 			csa(s, twoA, plane[0], m[0], m[1]);
 			csa(plane[0], twoB, s, m[2], m[3]);
 			csa(plane[1], four, plane[1], twoA, twoB);
@@ -447,11 +443,11 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 		}
 	}
 	for(; i < n; ++i){
-		uint4 mm = make_uint4(~0u, ~0u, ~0u, ~0u);
+		u32x4 mm = ~(u32x4)(0u);
 #pragma unroll
 		for(int h = 0; h < NH; ++h){
 			const uint32_t r = rq[i*NH + h];
-			mm = and4(mm, reinterpret_cast<const uint4*>(a.db + (uint64_t)r*a.stride)[unit]);
+			mm &= load16<true>(reinterpret_cast<const u32x4*>(a.db + (uint64_t)r*a.stride) + unit);
 		}
 		planes_add<PLANES>(plane, mm, 0);
 	}
@@ -459,18 +455,17 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 	if(!live){ return; }
 
 	// columns with count >= thr (kwage.cpp:497), compared plane by plane from the top
-	uint4 gt = make_uint4(0, 0, 0, 0);
-	uint4 eq = make_uint4(~0u, ~0u, ~0u, ~0u);
+	u32x4 gt = (u32x4)(0u);
+	u32x4 eq = ~(u32x4)(0u);
 #pragma unroll
 	for(int p = PLANES - 1; p >= 0; --p){
-		const uint32_t tb = ((thr >> p) & 1u) ? ~0u : 0u;
-		const uint4 t4 = make_uint4(tb, tb, tb, tb);
-		gt = or4(gt, and4(eq, and4(plane[p], not4(t4))));
-		eq = and4(eq, not4(xor4(plane[p], t4)));
+		const u32x4 t4 = (u32x4)(((thr >> p) & 1u) ? ~0u : 0u);
+		gt |= eq & plane[p] & ~t4;
+		eq &= ~(plane[p] ^ t4);
 	}
-	uint4 ge = or4(gt, eq);
-	if(PLANES < 32 && (thr >> PLANES) != 0){ ge = make_uint4(0, 0, 0, 0); }   // unreachable: thr <= n < 2^PLANES
-	ge = and4(ge, reinterpret_cast<const uint4*>(a.valid)[unit]);
+	u32x4 ge = gt | eq;
+	if(PLANES < 32 && (thr >> PLANES) != 0){ ge = (u32x4)(0u); }   // unreachable: thr <= n < 2^PLANES
+	ge &= reinterpret_cast<const u32x4*>(a.valid)[unit];
 
 	const uint32_t w[4] = {ge.x, ge.y, ge.z, ge.w};
 #pragma unroll
@@ -482,8 +477,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 			uint32_t cnt = 0;
 #pragma unroll
 			for(int p = 0; p < PLANES; ++p){
-				const uint32_t pw = (d == 0) ? plane[p].x : (d == 1) ? plane[p].y : (d == 2) ? plane[p].z : plane[p].w;
-				cnt |= ((pw >> b) & 1u) << p;
+				cnt |= ((plane[p][d] >> b) & 1u) << p;
 			}
 			emit_hit(a, q, unit*128u + d*32u + b, cnt);      // num_match = match_count[i], kwage.cpp:517-518
 		}
