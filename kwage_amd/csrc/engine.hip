@@ -80,8 +80,9 @@ struct kwage_ctx {
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 	// scratch, grown on demand and reused
-	DevBuf rows, nkmer, qthr, tables, hits, counters, kmers;
+	DevBuf rows, nkmer, qthr, tables, hits, counters, kmers, partial;
 	PinBuf h_counters;
+	PinBuf h_stage;        // [nkmer n][qthr n][hits ...] staged D2H with the counters: one sync per search
 };
 
 struct kwage_group {
@@ -210,29 +211,54 @@ int launch_kmer_stage(kwage_ctx *ctx, const kwage_params &p, kwage_batch *b, flo
 	return KWAGE_OK;
 }
 
-template <int VEC, int UNROLL, bool NT>
-void launch_and(const SearchArgs &a, uint64_t tiles, hipStream_t s)
+static int g_and_lds_bytes = 0;     // tuning only: dynamic LDS per workgroup caps waves per CU
+
+uint32_t search_blocks(const SearchArgs &a)
 {
-	const uint32_t blocks = (uint32_t)((tiles + 3)/4);
-	hipLaunchKernelGGL((and_kernel<VEC, UNROLL, NT>), dim3(blocks), dim3(SEARCH_THREADS), 0, s, a);
+	const uint64_t tiles = (uint64_t)a.n_queries*a.segs*a.chunks;
+	return (uint32_t)((tiles + 3)/4);
+}
+
+template <int VEC, int UNROLL, bool NT>
+void launch_and(const SearchArgs &a, hipStream_t s)
+{
+	if(a.segs > 1){
+		hipLaunchKernelGGL((and_kernel<VEC, UNROLL, NT, true>), dim3(search_blocks(a)), dim3(SEARCH_THREADS), (size_t)g_and_lds_bytes, s, a);
+	}
+	else{
+		hipLaunchKernelGGL((and_kernel<VEC, UNROLL, NT, false>), dim3(search_blocks(a)), dim3(SEARCH_THREADS), (size_t)g_and_lds_bytes, s, a);
+	}
+}
+
+template <int PLANES, int NH>
+void launch_count(const SearchArgs &a, hipStream_t s)
+{
+	if(a.segs > 1){
+		hipLaunchKernelGGL((count_kernel<PLANES, NH, true>), dim3(search_blocks(a)), dim3(SEARCH_THREADS), 0, s, a);
+	}
+	else{
+		hipLaunchKernelGGL((count_kernel<PLANES, NH, false>), dim3(search_blocks(a)), dim3(SEARCH_THREADS), 0, s, a);
+	}
 }
 
 template <int PLANES>
-void launch_count_nh(const SearchArgs &a, uint64_t tiles, hipStream_t s)
+void launch_count_nh(const SearchArgs &a, hipStream_t s)
 {
-	const uint32_t blocks = (uint32_t)((tiles + 3)/4);
 	switch(a.num_hash){
-		case 1: hipLaunchKernelGGL((count_kernel<PLANES, 1>), dim3(blocks), dim3(SEARCH_THREADS), 0, s, a); break;
-		case 2: hipLaunchKernelGGL((count_kernel<PLANES, 2>), dim3(blocks), dim3(SEARCH_THREADS), 0, s, a); break;
-		case 3: hipLaunchKernelGGL((count_kernel<PLANES, 3>), dim3(blocks), dim3(SEARCH_THREADS), 0, s, a); break;
-		case 4: hipLaunchKernelGGL((count_kernel<PLANES, 4>), dim3(blocks), dim3(SEARCH_THREADS), 0, s, a); break;
-		default: hipLaunchKernelGGL((count_kernel<PLANES, 5>), dim3(blocks), dim3(SEARCH_THREADS), 0, s, a); break;
+		case 1: launch_count<PLANES, 1>(a, s); break;
+		case 2: launch_count<PLANES, 2>(a, s); break;
+		case 3: launch_count<PLANES, 3>(a, s); break;
+		case 4: launch_count<PLANES, 4>(a, s); break;
+		default: launch_count<PLANES, 5>(a, s); break;
+	}
+	if(a.segs > 1){
+		hipLaunchKernelGGL((count_combine_kernel<PLANES>), dim3((a.units_per_row + 255)/256, a.n_queries), dim3(256), 0, s, a);
 	}
 }
 
 // Shape of the AND kernel: VEC 16-byte vectors per lane, UNROLL rows in flight, nontemporal loads.
-// Defaults come from measurements on MI355X; KWAGE_AND_CFG="vec,unroll,nt" overrides
-// them for tuning runs (read on every launch so one process can sweep variants).
+// Defaults come from measurements on MI355X; KWAGE_AND_CFG="vec,unroll,nt[,ldsKB]"
+// overrides them for tuning runs (read on every launch so one process can sweep variants).
 struct AndCfg { int vec, unroll, nt; };
 
 AndCfg and_config(uint32_t units_per_row)
@@ -240,34 +266,60 @@ AndCfg and_config(uint32_t units_per_row)
 	AndCfg c;
 	c.vec = (units_per_row >= 4*WAVE) ? 2 : 1;
 	c.unroll = 8;
-	c.nt = 1;      // +4-5 % on MI355X: each row byte is consumed once per (query, tile)
+	c.nt = 1;      // +4-10 % on MI355X: each row byte is consumed once per (query, tile)
 	const char *e = getenv("KWAGE_AND_CFG");
 	if(e){
-		int v = 0, u = 0, n = 0;
-		if(sscanf(e, "%d,%d,%d", &v, &u, &n) == 3 && (v == 1 || v == 2 || v == 4) && (u == 4 || u == 8 || u == 16)){
+		int v = 0, u = 0, n = 0, l = 0;
+		const int got = sscanf(e, "%d,%d,%d,%d", &v, &u, &n, &l);
+		if(got >= 3 && (v == 1 || v == 2 || v == 4) && (u == 4 || u == 8 || u == 16 || u == 32)){
 			c.vec = v; c.unroll = u; c.nt = n ? 1 : 0;
+			g_and_lds_bytes = (got == 4 && l > 0 && l <= 160) ? l*1024 : 0;
 		}
 	}
 	return c;
 }
 
 template <int VEC, bool NT>
-void launch_and_u(const SearchArgs &a, uint64_t tiles, hipStream_t s, int unroll)
+void launch_and_u(const SearchArgs &a, hipStream_t s, int unroll)
 {
-	if(unroll == 4){ launch_and<VEC, 4, NT>(a, tiles, s); }
-	else if(unroll == 16 && VEC < 4){ launch_and<VEC, 16, NT>(a, tiles, s); }
-	else{ launch_and<VEC, 8, NT>(a, tiles, s); }
+	if(unroll == 4){ launch_and<VEC, 4, NT>(a, s); }
+	else if(unroll == 16 && VEC < 4){ launch_and<VEC, 16, NT>(a, s); }
+	else if(unroll == 32 && VEC == 1){ launch_and<VEC, 32, NT>(a, s); }
+	else{ launch_and<VEC, 8, NT>(a, s); }
 }
 
 template <bool NT>
-void launch_and_v(const SearchArgs &a, uint64_t tiles, hipStream_t s, const AndCfg &c)
+void launch_and_v(const SearchArgs &a, hipStream_t s, const AndCfg &c)
 {
-	if(c.vec == 1){ launch_and_u<1, NT>(a, tiles, s, c.unroll); }
-	else if(c.vec == 2){ launch_and_u<2, NT>(a, tiles, s, c.unroll); }
-	else{ launch_and_u<4, NT>(a, tiles, s, c.unroll); }
+	if(c.vec == 1){ launch_and_u<1, NT>(a, s, c.unroll); }
+	else if(c.vec == 2){ launch_and_u<2, NT>(a, s, c.unroll); }
+	else{ launch_and_u<4, NT>(a, s, c.unroll); }
 }
 
-// Launch the gather+reduce kernel for the current batch. Returns tiles per query via *chunks.
+// How many segments to cut each query's k-mer list into: none while the launch already has
+// enough waves to fill the chip; otherwise enough to reach ~TARGET_TILES waves (about 8 per CU, ~2x the bytes in flight that cover HBM latency), but never segments
+// shorter than MIN_SEG_KMERS k-mers.  KWAGE_FORCE_SEGS=<n> forces n (tests).
+void choose_segments(SearchArgs &a, uint64_t max_kmers, uint64_t max_segs)
+{
+	static const uint64_t TARGET_TILES = 2048, MIN_SEG_KMERS = 64;
+	const uint64_t MAX_SEGS = max_segs;
+	a.segs = 1;
+	a.seg_kmers = (uint32_t)std::max<uint64_t>(max_kmers, 1);
+	uint64_t want = 1;
+	const char *f = getenv("KWAGE_FORCE_SEGS");
+	if(f && atoi(f) > 0){ want = (uint64_t)atoi(f); }
+	else{
+		const uint64_t tiles = (uint64_t)a.n_queries*a.chunks;
+		if(tiles >= TARGET_TILES || max_kmers < 2*MIN_SEG_KMERS){ return; }
+		want = std::min<uint64_t>((TARGET_TILES + tiles - 1)/tiles, max_kmers/MIN_SEG_KMERS);
+	}
+	want = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(want, MAX_SEGS), std::max<uint64_t>(max_kmers, 1)));
+	if(want <= 1){ return; }
+	a.seg_kmers = (uint32_t)((max_kmers + want - 1)/want);
+	a.segs = (uint32_t)((max_kmers + a.seg_kmers - 1)/a.seg_kmers);
+}
+
+// Launch the gather+reduce kernel(s) for the current batch.
 int launch_search_stage(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
                         kwage_hit *d_hits, uint64_t cap)
 {
@@ -287,33 +339,61 @@ int launch_search_stage(kwage_group *g, kwage_batch *b, float threshold, uint32_
 	a.cap = cap;
 	a.hit_count = (unsigned long long*)ctx->counters.p;
 	a.early_exit = (flags & KWAGE_SEARCH_EARLY_EXIT) ? 1 : 0;
+	a.partial = nullptr;
+	int rc;
 
 	if(threshold == 1.0f){
 		const AndCfg cfg = and_config(a.units_per_row);
 		a.chunks = (a.units_per_row + WAVE*cfg.vec - 1)/(WAVE*cfg.vec);
-		const uint64_t tiles = (uint64_t)a.n_queries*a.chunks;
-		if(tiles/4 + 1 > 0x7FFFFFFFull){ return fail(KWAGE_ERR_ARG, "batch too large for one launch"); }
-		if(cfg.nt){ launch_and_v<true>(a, tiles, ctx->stream, cfg); }
-		else{ launch_and_v<false>(a, tiles, ctx->stream, cfg); }
+		choose_segments(a, b->max_pos, 4096);
+		if((uint64_t)a.n_queries*a.segs*a.chunks/4 + 1 > 0x7FFFFFFFull){ return fail(KWAGE_ERR_ARG, "batch too large for one launch"); }
+		if(a.segs > 1){
+			const uint64_t bytes = (uint64_t)a.n_queries*g->stride;
+			if((rc = ctx->partial.reserve(bytes))){ return rc; }
+			HIP_TRY(hipMemsetAsync(ctx->partial.p, 0xFF, bytes, ctx->stream));
+			a.partial = (uint32_t*)ctx->partial.p;
+		}
+		if(cfg.nt){ launch_and_v<true>(a, ctx->stream, cfg); }
+		else{ launch_and_v<false>(a, ctx->stream, cfg); }
+		if(a.segs > 1){
+			hipLaunchKernelGGL(and_combine_kernel, dim3((a.units_per_row + 255)/256, a.n_queries), dim3(256), 0, ctx->stream, a);
+		}
 	}
 	else{
 		a.chunks = (a.units_per_row + WAVE - 1)/WAVE;
-		const uint64_t tiles = (uint64_t)a.n_queries*a.chunks;
-		if(tiles/4 + 1 > 0x7FFFFFFFull){ return fail(KWAGE_ERR_ARG, "batch too large for one launch"); }
 		// counter planes: enough bits for the largest possible num_query_kmer of the batch
 		uint32_t bits = 1;
 		while(bits < 32 && (b->max_pos >> bits) != 0){ ++bits; }
-		if(bits <= 7){ launch_count_nh<7>(a, tiles, ctx->stream); }
-		else if(bits <= 10){ launch_count_nh<10>(a, tiles, ctx->stream); }
-		else if(bits <= 14){ launch_count_nh<14>(a, tiles, ctx->stream); }
-		else if(bits <= 20){ launch_count_nh<20>(a, tiles, ctx->stream); }
-		else{ launch_count_nh<32>(a, tiles, ctx->stream); }
+		const uint32_t planes = (bits <= 7) ? 7 : (bits <= 10) ? 10 : (bits <= 14) ? 14 : (bits <= 20) ? 20 : 32;
+		// the combine pass walks a query's segments serially per 16-byte unit: keep them few
+		choose_segments(a, b->max_pos, 64);
+		// keep the slab of partial counters bounded (1 GiB)
+		while(a.segs > 1 && (uint64_t)a.n_queries*a.segs*planes*g->stride > (1ull << 30)){
+			const uint64_t want = a.segs/2;
+			a.seg_kmers = (uint32_t)((b->max_pos + want - 1)/std::max<uint64_t>(want, 1));
+			a.segs = (uint32_t)((b->max_pos + a.seg_kmers - 1)/a.seg_kmers);
+		}
+		if((uint64_t)a.n_queries*a.segs*a.chunks/4 + 1 > 0x7FFFFFFFull){ return fail(KWAGE_ERR_ARG, "batch too large for one launch"); }
+		if(a.segs > 1){
+			if((rc = ctx->partial.reserve((uint64_t)a.n_queries*a.segs*planes*g->stride))){ return rc; }
+			a.partial = (uint32_t*)ctx->partial.p;
+		}
+		switch(planes){
+			case 7: launch_count_nh<7>(a, ctx->stream); break;
+			case 10: launch_count_nh<10>(a, ctx->stream); break;
+			case 14: launch_count_nh<14>(a, ctx->stream); break;
+			case 20: launch_count_nh<20>(a, ctx->stream); break;
+			default: launch_count_nh<32>(a, ctx->stream); break;
+		}
 	}
 	HIP_TRY(hipGetLastError());
 	return KWAGE_OK;
 }
 
+static const uint64_t SPEC_HITS = 8192;     // hit records copied back together with the counters
+
 struct SearchOutcome {
+	uint64_t staged_hits = 0;      // hit records already in ctx->h_stage
 	uint64_t n_hits = 0;
 	uint64_t total_kmers = 0;
 	float kmer_ms = 0, search_ms = 0;
@@ -352,6 +432,8 @@ int run_search(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
 
 	volatile uint64_t *hc = (volatile uint64_t*)ctx->h_counters.p;
 	out->launches = 0;
+	const uint64_t nq_bytes = (uint64_t)b->n*sizeof(uint32_t);
+	if(own_hits && (rc = ctx->h_stage.reserve(2*nq_bytes + SPEC_HITS*sizeof(kwage_hit)))){ return rc; }
 	while(true){
 		if(b->n && g->num_columns){
 			if(timing){ HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream)); }
@@ -360,6 +442,17 @@ int run_search(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
 			++out->launches;
 		}
 		HIP_TRY(hipMemcpyAsync(ctx->h_counters.p, ctx->counters.p, 2*sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+		if(own_hits){
+			// per-query counts and the first SPEC_HITS records ride along, so the common case
+			// (few hits) needs a single stream synchronisation per search
+			char *hs = (char*)ctx->h_stage.p;
+			if(b->n){
+				HIP_TRY(hipMemcpyAsync(hs, ctx->nkmer.p, nq_bytes, hipMemcpyDeviceToHost, ctx->stream));
+				HIP_TRY(hipMemcpyAsync(hs + nq_bytes, ctx->qthr.p, nq_bytes, hipMemcpyDeviceToHost, ctx->stream));
+			}
+			out->staged_hits = std::min<uint64_t>(SPEC_HITS, cap);
+			HIP_TRY(hipMemcpyAsync(hs + 2*nq_bytes, d_hits, out->staged_hits*sizeof(kwage_hit), hipMemcpyDeviceToHost, ctx->stream));
+		}
 		HIP_TRY(hipStreamSynchronize(ctx->stream));
 		out->n_hits = hc[0];
 		out->total_kmers = hc[1];
@@ -422,7 +515,7 @@ extern "C" void kwage_shutdown(kwage_ctx *ctx)
 	(void)hipSetDevice(ctx->device);
 	if(ctx->stream){ (void)hipStreamSynchronize(ctx->stream); }
 	ctx->rows.release(); ctx->nkmer.release(); ctx->qthr.release(); ctx->tables.release();
-	ctx->hits.release(); ctx->counters.release(); ctx->kmers.release(); ctx->h_counters.release();
+	ctx->hits.release(); ctx->partial.release(); ctx->counters.release(); ctx->kmers.release(); ctx->h_counters.release(); ctx->h_stage.release();
 	for(int i = 0; i < 4; ++i){ if(ctx->ev[i]){ (void)hipEventDestroy(ctx->ev[i]); } }
 	if(ctx->stream){ (void)hipStreamDestroy(ctx->stream); }
 	delete ctx;
@@ -819,12 +912,20 @@ extern "C" int kwage_search(kwage_group *g, kwage_batch *b, float threshold, uin
 	rs->hits.resize(so.n_hits);
 	rs->nkmer.resize(b->n);
 	rs->qthr.resize(b->n);
-	hipError_t e = hipSuccess;
-	if(so.n_hits){ e = hipMemcpyAsync(rs->hits.data(), ctx->hits.p, so.n_hits*sizeof(kwage_hit), hipMemcpyDeviceToHost, ctx->stream); }
-	if(e == hipSuccess && b->n){ e = hipMemcpyAsync(rs->nkmer.data(), ctx->nkmer.p, (size_t)b->n*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream); }
-	if(e == hipSuccess && b->n){ e = hipMemcpyAsync(rs->qthr.data(), ctx->qthr.p, (size_t)b->n*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream); }
-	if(e == hipSuccess){ e = hipStreamSynchronize(ctx->stream); }
-	if(e != hipSuccess){ delete rs; return fail(KWAGE_ERR_DEVICE, "kwage_search: copying results failed: %s", hipGetErrorString(e)); }
+	const uint64_t nq_bytes = (uint64_t)b->n*sizeof(uint32_t);
+	const char *hs = (const char*)ctx->h_stage.p;
+	if(b->n){
+		memcpy(rs->nkmer.data(), hs, nq_bytes);
+		memcpy(rs->qthr.data(), hs + nq_bytes, nq_bytes);
+	}
+	const uint64_t have = std::min(so.n_hits, so.staged_hits);
+	if(have){ memcpy(rs->hits.data(), hs + 2*nq_bytes, have*sizeof(kwage_hit)); }
+	if(so.n_hits > have){      // the rare large hit list: fetch the remainder
+		hipError_t e = hipMemcpyAsync(rs->hits.data() + have, (const kwage_hit*)ctx->hits.p + have,
+		                              (so.n_hits - have)*sizeof(kwage_hit), hipMemcpyDeviceToHost, ctx->stream);
+		if(e == hipSuccess){ e = hipStreamSynchronize(ctx->stream); }
+		if(e != hipSuccess){ delete rs; return fail(KWAGE_ERR_DEVICE, "kwage_search: copying results failed: %s", hipGetErrorString(e)); }
+	}
 
 	// deterministic order; the reference's own order among ties is unspecified (sort.h:22-27)
 	std::sort(rs->hits.begin(), rs->hits.end(), [](const kwage_hit &x, const kwage_hit &y){

@@ -256,29 +256,19 @@ struct SearchArgs {
 	const uint32_t *nkmer;
 	const uint32_t *qthr;
 	uint32_t num_hash;
-	uint32_t chunks;                // tiles per query = ceil(units_per_row / (64*VEC))
+	uint32_t chunks;                // tiles per (query, segment) = ceil(units_per_row / (64*VEC))
 	uint32_t n_queries;
 	kwage_hit *hits;
 	unsigned long long cap;
 	unsigned long long *hit_count;
 	int early_exit;
+	// long queries: the k-mer list of a query is cut into `segs` segments of `seg_kmers` k-mers, one
+	// wave per (query, segment, tile); partial results meet in `partial` and a combine kernel
+	// extracts the hits.  segs == 1: everything happens in one kernel, `partial` is unused.
+	uint32_t segs;
+	uint32_t seg_kmers;
+	uint32_t *partial;              // AND: u32 [query][units*4] masks; count: u32x4 [query][seg][plane][unit]
 };
-
-__device__ __forceinline__ uint4 and4(uint4 a, uint4 b)
-{
-	return make_uint4(a.x & b.x, a.y & b.y, a.z & b.z, a.w & b.w);
-}
-
-__device__ __forceinline__ bool nonzero4(uint4 a) { return (a.x | a.y | a.z | a.w) != 0; }
-
-__device__ __forceinline__ void emit_hit(const SearchArgs &a, uint32_t q, uint32_t col, uint32_t nm)
-{
-	const unsigned long long slot = atomicAdd(a.hit_count, 1ull);
-	if(slot < a.cap){
-		kwage_hit h; h.query = q; h.column = col; h.num_match = nm;
-		a.hits[slot] = h;
-	}
-}
 
 // 16 bytes of columns as a clang vector: bitwise operators apply lane-wise, and the nontemporal
 // load builtin accepts it.
@@ -291,24 +281,65 @@ __device__ __forceinline__ u32x4 load16(const u32x4 *p)
 	return *p;
 }
 
+__device__ __forceinline__ void emit_hit(const SearchArgs &a, uint32_t q, uint32_t col, uint32_t nm)
+{
+	const unsigned long long slot = atomicAdd(a.hit_count, 1ull);
+	if(slot < a.cap){
+		kwage_hit h; h.query = q; h.column = col; h.num_match = nm;
+		a.hits[slot] = h;
+	}
+}
+
+// hit extraction at threshold == 1 (kwage.cpp:489-499,517-518), restricted to real columns
+__device__ __forceinline__ void emit_mask_hits(const SearchArgs &a, uint32_t q, uint32_t unit, u32x4 acc, uint32_t n)
+{
+	const u32x4 m = acc & reinterpret_cast<const u32x4*>(a.valid)[unit];
+#pragma unroll
+	for(int d = 0; d < 4; ++d){
+		uint32_t bits = m[d];
+		while(bits){
+			const uint32_t b = __ffs(bits) - 1;
+			bits &= bits - 1;
+			emit_hit(a, q, unit*128u + d*32u + b, n);       // num_match = num_query_kmer
+		}
+	}
+}
+
+// Decompose a tile id into (query, segment, column tile); all wave-uniform.
+__device__ __forceinline__ void tile_coords(const SearchArgs &a, uint64_t tile, uint32_t &q, uint32_t &sg, uint32_t &c)
+{
+	const uint32_t per_q = a.segs*a.chunks;
+	q = __builtin_amdgcn_readfirstlane((uint32_t)(tile / per_q));
+	const uint32_t rem = __builtin_amdgcn_readfirstlane((uint32_t)(tile % per_q));
+	sg = rem / a.chunks;      // adjacent waves = adjacent column tiles of the SAME rows
+	c = rem % a.chunks;
+}
+
 // threshold == 1.0f: AND of every addressed row (kwage.cpp:404-470).
 //   VEC    16-byte vectors per lane per row (tile = 64*VEC*16 bytes of each row per wave)
 //   UNROLL rows in flight per wave
 //   NT     nontemporal loads: every row byte is used exactly once per (query, tile)
-template <int VEC, int UNROLL, bool NT>
+//   SEG    the query's row list is split over several waves (see SearchArgs::segs)
+template <int VEC, int UNROLL, bool NT, bool SEG>
 __global__ __launch_bounds__(SEARCH_THREADS) void and_kernel(SearchArgs a)
 {
 	const uint32_t lane = threadIdx.x & (WAVE - 1);
 	const uint64_t tile = (uint64_t)blockIdx.x*(SEARCH_THREADS/WAVE) + (threadIdx.x >> 6);
-	if(tile >= (uint64_t)a.n_queries*a.chunks){ return; }
+	if(tile >= (uint64_t)a.n_queries*a.segs*a.chunks){ return; }
 
 	// wave-uniform values -> SGPRs, so row indices come through the scalar cache
-	const uint32_t q = __builtin_amdgcn_readfirstlane((uint32_t)(tile / a.chunks));
-	const uint32_t c = __builtin_amdgcn_readfirstlane((uint32_t)(tile % a.chunks));
+	uint32_t q, sg, c;
+	tile_coords(a, tile, q, sg, c);
 	const uint32_t n = a.nkmer[q];
 	if(n == 0){ return; }
-	const uint32_t nrows = n*a.num_hash;
-	const uint32_t *rq = a.rows + a.pos_off[q]*a.num_hash;
+	uint32_t k0 = 0, k1 = n;
+	if(SEG){
+		k0 = sg*a.seg_kmers;
+		k1 = min(n, k0 + a.seg_kmers);
+		if(k0 >= k1){ return; }
+	}
+	const uint32_t nrows = (k1 - k0)*a.num_hash;
+	const uint32_t *rq = a.rows + (a.pos_off[q] + k0)*a.num_hash;
 
 	uint32_t unit[VEC];     // this lane's 16-byte units within a row (clamped in range: no divergence)
 	bool live[VEC];
@@ -322,6 +353,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void and_kernel(SearchArgs a)
 	}
 
 	uint32_t i = 0;
+	bool dead = false;        // early exit taken: the accumulator is all zero and stays so
 	for(; i + UNROLL <= nrows; i += UNROLL){
 		u32x4 x[UNROLL][VEC];
 #pragma unroll
@@ -340,32 +372,43 @@ __global__ __launch_bounds__(SEARCH_THREADS) void and_kernel(SearchArgs a)
 			bool nz = false;
 #pragma unroll
 			for(int v = 0; v < VEC; ++v){ nz |= ((acc[v].x | acc[v].y | acc[v].z | acc[v].w) != 0); }
-			if(!__any(nz)){ return; }
+			if(!__any(nz)){ dead = true; break; }
 		}
 	}
-	for(; i < nrows; ++i){
+	for(; !dead && i < nrows; ++i){
 		const uint32_t r = rq[i];
 		const u32x4 *p = reinterpret_cast<const u32x4*>(a.db + (uint64_t)r*a.stride);
 #pragma unroll
 		for(int v = 0; v < VEC; ++v){ acc[v] &= load16<NT>(p + unit[v]); }
 	}
 
-	// hit extraction (kwage.cpp:489-499), restricted to real columns
 #pragma unroll
 	for(int v = 0; v < VEC; ++v){
 		if(!live[v]){ continue; }
-		const u32x4 m = acc[v] & reinterpret_cast<const u32x4*>(a.valid)[unit[v]];
-		const uint32_t w[4] = {m.x, m.y, m.z, m.w};
+		if(SEG){
+			// meet the other segments of this (query, tile) in the mask buffer (pre-set to all ones)
+			uint32_t *m = a.partial + ((uint64_t)q*a.units_per_row + unit[v])*4;
 #pragma unroll
-		for(int d = 0; d < 4; ++d){
-			uint32_t bits = w[d];
-			while(bits){
-				const uint32_t b = __ffs(bits) - 1;
-				bits &= bits - 1;
-				emit_hit(a, q, unit[v]*128u + d*32u + b, n);    // num_match = num_query_kmer, kwage.cpp:517-518
+			for(int d = 0; d < 4; ++d){
+				if(acc[v][d] != ~0u){ atomicAnd(m + d, acc[v][d]); }
 			}
 		}
+		else{
+			emit_mask_hits(a, q, unit[v], acc[v], n);
+		}
 	}
+}
+
+// Second pass of the segmented AND: one thread per (query, 16-byte unit).
+__global__ __launch_bounds__(256) void and_combine_kernel(SearchArgs a)
+{
+	const uint32_t unit = blockIdx.x*blockDim.x + threadIdx.x;
+	const uint32_t q = blockIdx.y;
+	if(unit >= a.units_per_row){ return; }
+	const uint32_t n = a.nkmer[q];
+	if(n == 0){ return; }
+	const u32x4 acc = reinterpret_cast<const u32x4*>(a.partial)[(uint64_t)q*a.units_per_row + unit];
+	emit_mask_hits(a, q, unit, acc, n);
 }
 
 // threshold < 1: count, per column, the k-mers whose every hash row has the bit set
@@ -391,19 +434,56 @@ __device__ __forceinline__ void csa(u32x4 &sum, u32x4 &carry, u32x4 a, u32x4 b, 
 	sum = u ^ c;
 }
 
-template <int PLANES, int NH>
+// columns with count >= thr (kwage.cpp:497), compared plane by plane from the top; then the
+// count of every surviving column is re-assembled from the planes (num_match = match_count[i]).
+template <int PLANES>
+__device__ __forceinline__ void emit_count_hits(const SearchArgs &a, uint32_t q, uint32_t unit,
+                                                const u32x4 (&plane)[PLANES], uint32_t thr)
+{
+	u32x4 gt = (u32x4)(0u);
+	u32x4 eq = ~(u32x4)(0u);
+#pragma unroll
+	for(int p = PLANES - 1; p >= 0; --p){
+		const u32x4 t4 = (u32x4)(((thr >> p) & 1u) ? ~0u : 0u);
+		gt |= eq & plane[p] & ~t4;
+		eq &= ~(plane[p] ^ t4);
+	}
+	u32x4 ge = gt | eq;
+	if(PLANES < 32 && (thr >> PLANES) != 0){ ge = (u32x4)(0u); }   // unreachable: thr <= n < 2^PLANES
+	ge &= reinterpret_cast<const u32x4*>(a.valid)[unit];
+#pragma unroll
+	for(int d = 0; d < 4; ++d){
+		uint32_t bits = ge[d];
+		while(bits){
+			const uint32_t b = __ffs(bits) - 1;
+			bits &= bits - 1;
+			uint32_t cnt = 0;
+#pragma unroll
+			for(int p = 0; p < PLANES; ++p){ cnt |= ((plane[p][d] >> b) & 1u) << p; }
+			emit_hit(a, q, unit*128u + d*32u + b, cnt);
+		}
+	}
+}
+
+template <int PLANES, int NH, bool SEG>
 __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 {
 	const uint32_t lane = threadIdx.x & (WAVE - 1);
 	const uint64_t tile = (uint64_t)blockIdx.x*(SEARCH_THREADS/WAVE) + (threadIdx.x >> 6);
-	if(tile >= (uint64_t)a.n_queries*a.chunks){ return; }
+	if(tile >= (uint64_t)a.n_queries*a.segs*a.chunks){ return; }
 
-	const uint32_t q = __builtin_amdgcn_readfirstlane((uint32_t)(tile / a.chunks));
-	const uint32_t c = __builtin_amdgcn_readfirstlane((uint32_t)(tile % a.chunks));
+	uint32_t q, sg, c;
+	tile_coords(a, tile, q, sg, c);
 	const uint32_t n = a.nkmer[q];
 	if(n == 0){ return; }
-	const uint32_t thr = a.qthr[q];
-	const uint32_t *rq = a.rows + a.pos_off[q]*NH;
+	uint32_t k0 = 0, k1 = n;
+	if(SEG){
+		k0 = sg*a.seg_kmers;
+		k1 = min(n, k0 + a.seg_kmers);
+		if(k0 >= k1){ return; }
+	}
+	const uint32_t nk = k1 - k0;
+	const uint32_t *rq = a.rows + (a.pos_off[q] + k0)*NH;
 
 	const uint32_t u0 = c*WAVE + lane;
 	const bool live = (u0 < a.units_per_row);
@@ -416,7 +496,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 	// four k-mers per step: 4*NH row loads in flight, then a carry-save tree so that the ripple
 	// through the upper planes happens once per four k-mers (planes 0,1 are the CSA residues).
 	uint32_t i = 0;
-	for(; i + 4 <= n; i += 4){
+	for(; i + 4 <= nk; i += 4){
 		u32x4 m[4];
 #pragma unroll
 		for(int u = 0; u < 4; ++u){
@@ -442,7 +522,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 			for(int u = 0; u < 4; ++u){ planes_add<PLANES>(plane, m[u], 0); }
 		}
 	}
-	for(; i < n; ++i){
+	for(; i < nk; ++i){
 		u32x4 mm = ~(u32x4)(0u);
 #pragma unroll
 		for(int h = 0; h < NH; ++h){
@@ -453,35 +533,45 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 	}
 
 	if(!live){ return; }
-
-	// columns with count >= thr (kwage.cpp:497), compared plane by plane from the top
-	u32x4 gt = (u32x4)(0u);
-	u32x4 eq = ~(u32x4)(0u);
+	if(SEG){
+		// partial counters of this segment -> slab [query][segment][plane][unit]
+		u32x4 *slab = reinterpret_cast<u32x4*>(a.partial) + ((uint64_t)q*a.segs + sg)*PLANES*a.units_per_row + unit;
 #pragma unroll
-	for(int p = PLANES - 1; p >= 0; --p){
-		const u32x4 t4 = (u32x4)(((thr >> p) & 1u) ? ~0u : 0u);
-		gt |= eq & plane[p] & ~t4;
-		eq &= ~(plane[p] ^ t4);
+		for(int p = 0; p < PLANES; ++p){ slab[(uint64_t)p*a.units_per_row] = plane[p]; }
 	}
-	u32x4 ge = gt | eq;
-	if(PLANES < 32 && (thr >> PLANES) != 0){ ge = (u32x4)(0u); }   // unreachable: thr <= n < 2^PLANES
-	ge &= reinterpret_cast<const u32x4*>(a.valid)[unit];
+	else{
+		emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q]);
+	}
+}
 
-	const uint32_t w[4] = {ge.x, ge.y, ge.z, ge.w};
+// Second pass of the segmented count: add the per-segment bit-sliced counters (a ripple-carry
+// adder across planes, bit-parallel over columns), then threshold + emit.
+template <int PLANES>
+__global__ __launch_bounds__(256) void count_combine_kernel(SearchArgs a)
+{
+	const uint32_t unit = blockIdx.x*blockDim.x + threadIdx.x;
+	const uint32_t q = blockIdx.y;
+	if(unit >= a.units_per_row){ return; }
+	const uint32_t n = a.nkmer[q];
+	if(n == 0){ return; }
+	const uint32_t nseg = (n + a.seg_kmers - 1)/a.seg_kmers;
+	const u32x4 *slab = reinterpret_cast<const u32x4*>(a.partial) + (uint64_t)q*a.segs*PLANES*a.units_per_row + unit;
+	u32x4 plane[PLANES];
 #pragma unroll
-	for(int d = 0; d < 4; ++d){
-		uint32_t bits = w[d];
-		while(bits){
-			const uint32_t b = __ffs(bits) - 1;
-			bits &= bits - 1;
-			uint32_t cnt = 0;
+	for(int p = 0; p < PLANES; ++p){ plane[p] = slab[(uint64_t)p*a.units_per_row]; }
+	for(uint32_t sg = 1; sg < nseg; ++sg){
+		const u32x4 *s2 = slab + (uint64_t)sg*PLANES*a.units_per_row;
+		u32x4 carry = (u32x4)(0u);
 #pragma unroll
-			for(int p = 0; p < PLANES; ++p){
-				cnt |= ((plane[p][d] >> b) & 1u) << p;
-			}
-			emit_hit(a, q, unit*128u + d*32u + b, cnt);      // num_match = match_count[i], kwage.cpp:517-518
+		for(int p = 0; p < PLANES; ++p){
+			const u32x4 b = s2[(uint64_t)p*a.units_per_row];
+			const u32x4 x = plane[p] ^ b;
+			const u32x4 cnext = (plane[p] & b) | (carry & x);
+			plane[p] = x ^ carry;
+			carry = cnext;
 		}
 	}
+	emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q]);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -253,3 +253,41 @@ def test_cli_matches_reference_output(ka, oracle, case):
         assert score(got) == score(exp)
     if len(case["db"]) == 1 and case["name"] != "multi":
         assert got == exp                               # single file: byte-identical
+
+
+# ---------------------------------------------------------------------------------------------
+# long queries: the k-mer list is cut into segments handled by different waves and recombined
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("num_hash", [1, 3])
+def test_long_queries_are_segmented(ka, ctx, oracle, num_hash, monkeypatch):
+    rng = np.random.default_rng(77 + num_hash)
+    k, L, n_cols = 31, 12, 3000
+    image = _make_random_db(rng, L, n_cols, 0.93)
+    genome = rand_seq(rng, 20000)
+    seqs = [genome, genome[:9000] + "N" + rand_seq(rng, 7000), rand_seq(rng, 100), "", genome[5000:5300]]
+    # make column 5 and 2999 contain the whole genome
+    for col in (5, 2999):
+        for r in oracle.row_indices(oracle.unique_kmers(genome, k), k, num_hash, L).reshape(-1):
+            image[r, col // 8] |= np.uint8(1 << (col % 8))
+    g = ka.Group(ctx, k, num_hash, L, n_cols)
+    g.add_columns(image, n_cols)
+    g.finalize()
+    b = ka.Batch(ctx, seqs)
+    for force in (None, "1", "7", "64"):
+        if force is None:
+            monkeypatch.delenv("KWAGE_FORCE_SEGS", raising=False)     # natural choice: few tiles -> segments
+        else:
+            monkeypatch.setenv("KWAGE_FORCE_SEGS", force)
+        for threshold in (1.0, 0.97, 0.5):
+            thr32 = float(np.float32(threshold))
+            for flags in (0, ka.SEARCH_EARLY_EXIT):
+                r = g.search(b, threshold, flags)
+                per_q = r.per_query()
+                for i, s in enumerate(seqs):
+                    kmers = oracle.unique_kmers(s, k)
+                    exp, _ = oracle.search_image(image, image.shape[1], k, num_hash, L, n_cols, kmers, thr32)
+                    assert per_q[i] == exp, (force, threshold, flags, i, len(per_q[i]), len(exp))
+                if threshold == 1.0:
+                    assert {5, 2999} <= {c for c, _ in per_q[0]}
+    b.close()
+    g.close()
