@@ -10,6 +10,7 @@
 // Results are order-independent, so the inversion is invisible in the
 // output.  Extra knobs are environment variables only, to keep the option surface verbatim:
 //   KWAGE_DEVICE      HIP device index (default 0)
+//   KWAGE_DEVICES     "all" or "0,1,...": shard the database files over several GPUs
 //   KWAGE_EARLY_EXIT  1 = enable the reference's early-exit shortcut on the device (default 1)
 //   KWAGE_BATCH_BASES max bases per query batch (default 256 Mi)
 #include <algorithm>
@@ -23,6 +24,8 @@
 #include <iomanip>
 #include <iostream>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <sstream>
 #include <string>
 #include <unordered_map>
@@ -343,10 +346,26 @@ int main(int argc, char *argv[])
 			if(r < 0){ throw err; }
 		}
 
-		// ---- device --------------------------------------------------------------------------
-		const char *dev_env = getenv("KWAGE_DEVICE");
-		kwage_ctx *ctx = NULL;
-		check(kwage_init(dev_env ? atoi(dev_env) : 0, &ctx));
+		// ---- devices --------------------------------------------------------------------------
+		// KWAGE_DEVICES="all" | "0,1,..." shards every group's files (whole files, contiguous, balanced
+		// by column count) over several GPUs, one host thread + one kwage_ctx per GPU -- the
+		// reference's only parallel axis is the same one (OpenMP over files, kwage.cpp:76-87).
+		vector<int> devices;
+		if(const char *dl = getenv("KWAGE_DEVICES")){
+			if(string(dl) == "all"){
+				for(int d = 0; d < kwage_device_count(); ++d){ devices.push_back(d); }
+			}
+			else{
+				stringstream ss(dl);
+				string tok;
+				while(getline(ss, tok, ',')){ if(!tok.empty()){ devices.push_back(atoi(tok.c_str())); } }
+			}
+		}
+		if(devices.empty()){
+			const char *dev_env = getenv("KWAGE_DEVICE");
+			devices.push_back(dev_env ? atoi(dev_env) : 0);
+		}
+		const size_t ndev = devices.size();
 		const char *ee = getenv("KWAGE_EARLY_EXIT");
 		const uint32_t flags = (ee && atoi(ee) == 0) ? 0u : KWAGE_SEARCH_EARLY_EXIT;
 		const char *bb = getenv("KWAGE_BATCH_BASES");
@@ -362,36 +381,82 @@ int main(int argc, char *argv[])
 			groups[Key(make_pair(h.kmer_len, h.num_hash), make_pair(h.log_2_filter_len, h.hash_func))].push_back((uint32_t)i);
 		}
 
-		for(map<Key, vector<uint32_t> >::const_iterator gi = groups.begin(); gi != groups.end(); ++gi){
-			const vector<uint32_t> &members = gi->second;
-			kwage_params p;
-			p.kmer_len = gi->first.first.first;
-			p.num_hash = gi->first.first.second;
-			p.log_2_filter_len = gi->first.second.first;
-			p.hash_func = gi->first.second.second;
-			uint64_t span_bytes = 0;
-			for(size_t m = 0; m < members.size(); ++m){
-				span_bytes = (span_bytes + 15)/16*16 + ((uint64_t)files[members[m]].header.num_filter + 7)/8;
-			}
-			kwage_group *grp = NULL;
-			check(kwage_group_create(ctx, &p, span_bytes*8, &grp));
-			vector<DbFileEntry*> gfiles;
-			for(size_t m = 0; m < members.size(); ++m){
-				DbFileEntry &f = files[members[m]];
-				uint32_t nf = 0;
-				int rc = kwage_group_add_db_file(grp, f.path.c_str(), &f.first_column, &nf);
-				if(rc != KWAGE_OK){ kwage_group_destroy(grp); check(rc); }
-				gfiles.push_back(&f);
-			}
-			check(kwage_group_finalize(grp));
+		mutex merge_lock;
+		vector<string> worker_error(ndev);
 
-			search_queries(ctx, grp, gfiles, members, cmdline_queries, opt.threshold, flags, max_batch_bases,
-			               command_line_search_results);
-			search_queries(ctx, grp, gfiles, members, file_queries, opt.threshold, flags, max_batch_bases,
-			               file_search_results);
-			kwage_group_destroy(grp);
+		auto worker = [&](size_t di) {
+			try{
+				kwage_ctx *ctx = NULL;
+				check(kwage_init(devices[di], &ctx));
+				ResultMap local_file_results, local_cmdline_results;
+				for(map<Key, vector<uint32_t> >::const_iterator gi = groups.begin(); gi != groups.end(); ++gi){
+					// this device's share: a file belongs to the device that owns its middle column
+					uint64_t total = 0;
+					for(size_t m = 0; m < gi->second.size(); ++m){ total += files[gi->second[m]].header.num_filter; }
+					vector<uint32_t> members;
+					uint64_t prefix = 0;
+					for(size_t m = 0; m < gi->second.size(); ++m){
+						const uint64_t nf = files[gi->second[m]].header.num_filter;
+						const size_t owner = min<size_t>(ndev - 1, (size_t)(((long double)prefix + nf/2.0L)*ndev/max<uint64_t>(total, 1)));
+						if(owner == di){ members.push_back(gi->second[m]); }
+						prefix += nf;
+					}
+					if(members.empty()){ continue; }
+					kwage_params p;
+					p.kmer_len = gi->first.first.first;
+					p.num_hash = gi->first.first.second;
+					p.log_2_filter_len = gi->first.second.first;
+					p.hash_func = gi->first.second.second;
+					uint64_t span_bytes = 0;
+					for(size_t m = 0; m < members.size(); ++m){
+						span_bytes = (span_bytes + 15)/16*16 + ((uint64_t)files[members[m]].header.num_filter + 7)/8;
+					}
+					kwage_group *grp = NULL;
+					check(kwage_group_create(ctx, &p, span_bytes*8, &grp));
+					vector<DbFileEntry*> gfiles;
+					for(size_t m = 0; m < members.size(); ++m){
+						DbFileEntry &f = files[members[m]];       // each file is touched by exactly one worker
+						uint32_t nf = 0;
+						int rc = kwage_group_add_db_file(grp, f.path.c_str(), &f.first_column, &nf);
+						if(rc != KWAGE_OK){ kwage_group_destroy(grp); check(rc); }
+						gfiles.push_back(&f);
+					}
+					check(kwage_group_finalize(grp));
+					search_queries(ctx, grp, gfiles, members, cmdline_queries, opt.threshold, flags, max_batch_bases,
+					               local_cmdline_results);
+					search_queries(ctx, grp, gfiles, members, file_queries, opt.threshold, flags, max_batch_bases,
+					               local_file_results);
+					kwage_group_destroy(grp);
+				}
+				kwage_shutdown(ctx);
+				// merge, as the reference's `omp critical` section does (kwage.cpp:154-177)
+				lock_guard<mutex> lk(merge_lock);
+				for(ResultMap::const_iterator i = local_file_results.begin(); i != local_file_results.end(); ++i){
+					deque<Match> &ref = file_search_results[i->first];
+					ref.insert(ref.end(), i->second.begin(), i->second.end());
+				}
+				for(ResultMap::const_iterator i = local_cmdline_results.begin(); i != local_cmdline_results.end(); ++i){
+					deque<Match> &ref = command_line_search_results[i->first];
+					ref.insert(ref.end(), i->second.begin(), i->second.end());
+				}
+			}
+			catch(const char *error){ worker_error[di] = error; }
+			catch(const string &error){ worker_error[di] = error; }
+			catch(...){ worker_error[di] = "Unhandled search error"; }
+		};
+
+		if(ndev == 1){ worker(0); }
+		else{
+			vector<thread> pool;
+			for(size_t di = 0; di < ndev; ++di){ pool.push_back(thread(worker, di)); }
+			for(size_t di = 0; di < ndev; ++di){ pool[di].join(); }
 		}
-		kwage_shutdown(ctx);
+		for(size_t di = 0; di < ndev; ++di){
+			if(!worker_error[di].empty()){
+				cerr << "Caught the search error: " << worker_error[di] << endl;
+				throw worker_error[di];
+			}
+		}
 
 		// ---- order: as the single-threaded reference builds each deque (file order, then column),
 		// then its unstable descending sort by hits (kwage.cpp:191-201) --------------------------

@@ -291,3 +291,20 @@ def test_long_queries_are_segmented(ka, ctx, oracle, num_hash, monkeypatch):
                     assert {5, 2999} <= {c for c, _ in per_q[0]}
     b.close()
     g.close()
+
+
+def test_cli_sharded_over_two_contexts(ka, oracle):
+    """KWAGE_DEVICES shards whole files over devices, one host thread + ctx each.  With one GPU on
+    the box both contexts sit on device 0, which still exercises the sharding, threading and merge."""
+    from kwage_amd import native
+    cdir = os.path.join(GOLDEN, "multi")
+    for fmt in ("csv", "json"):
+        for thr in ("1.0", "0.7"):
+            args = [native.KWAGE_BIN, "-d", "dbs", "-i", "reads.fastq", "-i", "contigs.fa.gz", "-t", thr, "--o." + fmt]
+            one = subprocess.run(args, cwd=cdir, capture_output=True, env=dict(os.environ, KWAGE_DEVICES="0"))
+            two = subprocess.run(args, cwd=cdir, capture_output=True, env=dict(os.environ, KWAGE_DEVICES="0,0"))
+            three = subprocess.run(args, cwd=cdir, capture_output=True, env=dict(os.environ, KWAGE_DEVICES="0,0,0"))
+            assert one.returncode == 0 and two.returncode == 0 and three.returncode == 0, two.stderr.decode()
+            assert one.stdout == two.stdout == three.stdout      # deterministic, independent of the sharding
+            exp = open(os.path.join(cdir, "expected_t%s.%s" % (thr, fmt)), encoding="latin-1").read()
+            assert sorted(two.stdout.decode("latin-1").splitlines()) == sorted(exp.splitlines())
