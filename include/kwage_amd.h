@@ -185,6 +185,20 @@ int kwage_hash_batch(kwage_ctx *ctx, const kwage_params *params, kwage_batch *b,
 int kwage_stream_read_gbps(kwage_group *g, uint64_t bytes, uint32_t iters, double *gbps);
 
 /* ------------------------------------------------------------------------------------
+ * Database construction (the format's only writer): replaces build_db() (build_db.cpp:24-456;
+ * declared maestro.h:121) -- `.bloom` files in, one `.db` file out, byte-identical to the
+ * reference's output; the bit transpose (build_db.cpp:259-304) runs on the device.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+	uint64_t bits_transposed;      /* 2^L * n                               */
+	float transpose_kernel_ms;     /* sum over chunks, HIP events           */
+	uint64_t db_bytes;             /* size of the file written              */
+} kwage_build_stats;
+
+int kwage_build_db(kwage_ctx *ctx, const char *out_path, const kwage_params *params,
+                   const char *const *bloom_paths, uint32_t n, kwage_build_stats *stats);
+
+/* ------------------------------------------------------------------------------------
  * Host-side helpers that mirror the reference's host code for this path (no device needed).
  * ---------------------------------------------------------------------------------- */
 

@@ -1,0 +1,291 @@
+// kwage_amd/csrc/builder.hip -- database construction on the device:
+// the bit transpose at the heart of the reference's build_db() (build_db.cpp:24-456, loop
+// :259-315: for every set bit k of filter j, set bit j of slice k -- one get_bit/set_bit pair per
+// bit, single threaded) done as a wave-ballot transpose on the GPU, writing a `.db` file that is
+// byte-identical to the reference's for the same `.bloom` inputs.
+//
+// `.bloom` file = binary_write<BloomFilter> (binary_io.cpp:182-208): 1 magic byte (0xFF complete),
+// BloomParam {u32 kmer_len, u32 log_2_filter_len, u32 num_hash, i32 hash_func} (bloom.h:546-556),
+// u32 crc32 of the bit array, FilterInfo (binary_io.cpp:154-163), then 2^L/8 bytes of bits.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include "host.hpp"
+#include "internal.h"
+
+using namespace kwage;
+
+namespace {
+
+// One workgroup = 16 waves = 1024 filters x 128 slices.  Lane j of wave w holds 16 bytes (128
+// consecutive bits) of filter f0 + 64w + j; bit b of all 64 lanes is gathered with one ballot into
+// the 8 output bytes that slice (row0 + b) needs for those 64 filters.  The 128 x 128-byte tile is
+// assembled in LDS and written out as full 128-byte row segments.
+static constexpr int TB_WAVES = 16;
+static constexpr int TB_ROWS = 128;
+
+__global__ __launch_bounds__(TB_WAVES*64) void transpose_bits_kernel(
+	const uint8_t *__restrict__ in, uint64_t in_stride,   // [n_filters][in_stride bytes]: this chunk's bits
+	uint32_t n_filters, uint64_t chunk_rows,              // rows in this chunk (multiple of 8)
+	uint8_t *__restrict__ out, uint64_t slice_size)       // [chunk_rows][slice_size]
+{
+	__shared__ unsigned long long tile[TB_ROWS][TB_WAVES];
+
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = threadIdx.x >> 6;
+	const uint64_t row0 = (uint64_t)blockIdx.x*TB_ROWS;
+	const uint32_t f0 = blockIdx.y*(TB_WAVES*64);
+	const uint32_t f = f0 + wave*64 + lane;
+
+	uint32_t w[4] = {0, 0, 0, 0};
+	if(f < n_filters){
+		const uint8_t *src = in + (uint64_t)f*in_stride + row0/8;
+		const uint64_t avail = (chunk_rows - row0 + 7)/8;           // bytes of this filter left in the chunk
+		if(avail >= 16 && ((((uintptr_t)src) & 3) == 0)){
+			const uint32_t *s32 = reinterpret_cast<const uint32_t*>(src);
+			w[0] = s32[0]; w[1] = s32[1]; w[2] = s32[2]; w[3] = s32[3];
+		}
+		else{
+			for(uint32_t b = 0; b < 16 && b < avail; ++b){ w[b >> 2] |= (uint32_t)src[b] << (8*(b & 3)); }
+		}
+	}
+
+	// lane (b & 63) keeps the ballot of bit b; two ballots per lane
+	unsigned long long keep0 = 0, keep1 = 0;
+#pragma unroll
+	for(int b = 0; b < 128; ++b){
+		const unsigned long long m = __ballot((w[b >> 5] >> (b & 31)) & 1u);
+		if(b < 64){ if(lane == (uint32_t)b){ keep0 = m; } }
+		else{ if(lane == (uint32_t)(b - 64)){ keep1 = m; } }
+	}
+	tile[lane][wave] = keep0;
+	tile[64 + lane][wave] = keep1;
+	__syncthreads();
+
+	// write the tile: 128 rows x up to 128 bytes; thread t moves 16 bytes
+	const uint64_t col0 = f0/8;                                   // first output byte of this filter block
+	const uint8_t *t8 = reinterpret_cast<const uint8_t*>(&tile[0][0]);
+	for(uint32_t i = threadIdx.x; i < TB_ROWS*8; i += blockDim.x){
+		const uint32_t r = i >> 3, seg = i & 7;                   // 8 segments of 16 bytes per row
+		const uint64_t row = row0 + r;
+		if(row >= chunk_rows){ continue; }
+		const uint64_t cb = col0 + seg*16;
+		if(cb >= slice_size){ continue; }
+		const uint64_t nb = std::min<uint64_t>(16, slice_size - cb);
+		uint8_t *dst = out + row*slice_size + cb;
+		const uint8_t *srcb = t8 + r*(TB_WAVES*8) + seg*16;
+		if(nb == 16 && ((((uintptr_t)dst) & 15) == 0)){
+			*reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(srcb);
+		}
+		else{
+			for(uint64_t b = 0; b < nb; ++b){ dst[b] = srcb[b]; }
+		}
+	}
+}
+
+struct BloomFile {
+	int fd = -1;
+	const unsigned char *map = nullptr;
+	size_t size = 0;
+	uint32_t crc = 0;
+	FilterInfo info;
+	size_t bits_off = 0;
+	void close_file()
+	{
+		if(map){ munmap((void*)map, size); map = nullptr; }
+		if(fd >= 0){ close(fd); fd = -1; }
+	}
+};
+
+// crc32 of a large buffer continued from `crc`: parts in parallel, stitched with crc32_combine
+// (the result is identical to one sequential crc32_z call).
+uint32_t crc32_parallel(uint32_t crc, const unsigned char *buf, uint64_t len)
+{
+	const unsigned nthread = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+	if(len < (8u << 20) || nthread == 1){ return (uint32_t)crc32_z(crc, buf, len); }
+	const uint64_t part = (len + nthread - 1)/nthread;
+	std::vector<uint32_t> pc(nthread, 0);
+	std::vector<uint64_t> pl(nthread, 0);
+	std::vector<std::thread> pool;
+	for(unsigned t = 0; t < nthread; ++t){
+		const uint64_t b = (uint64_t)t*part;
+		if(b >= len){ break; }
+		pl[t] = std::min(part, len - b);
+		pool.emplace_back([&, t, b]() { pc[t] = (uint32_t)crc32_z(crc32_z(0L, Z_NULL, 0), buf + b, pl[t]); });
+	}
+	for(auto &th : pool){ th.join(); }
+	uint64_t out = crc;
+	for(unsigned t = 0; t < nthread && pl[t]; ++t){ out = crc32_combine(out, pc[t], (z_off_t)pl[t]); }
+	return (uint32_t)out;
+}
+
+inline uint32_t rd32(const unsigned char *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+}  // namespace
+
+// The device context internals this file needs (defined in engine.hip).
+namespace kwage { hipStream_t ctx_stream(kwage_ctx *ctx); int ctx_device(kwage_ctx *ctx); }
+
+extern "C" int kwage_build_db(kwage_ctx *ctx, const char *out_path, const kwage_params *params,
+                              const char *const *bloom_paths, uint32_t n, kwage_build_stats *stats)
+{
+	if(!ctx || !out_path || !params || !bloom_paths){ return fail(KWAGE_ERR_ARG, "kwage_build_db: NULL argument"); }
+	if(n == 0){ return fail(KWAGE_ERR_ARG, "build_db: Empty Bloom filter inventory file"); }      // build_db.cpp:30-32
+	int rc = check_params(params);
+	if(rc){ return rc; }
+	if(hipSetDevice(ctx_device(ctx)) != hipSuccess){ return fail(KWAGE_ERR_DEVICE, "hipSetDevice failed"); }
+	hipStream_t stream = ctx_stream(ctx);
+
+	const uint64_t filter_len = 1ull << params->log_2_filter_len;
+	const uint64_t filter_bytes = (filter_len + 7)/8;
+	const uint64_t slice_size = ((uint64_t)n + 7)/8;
+
+	std::vector<BloomFile> files(n);
+	auto cleanup = [&]() { for(auto &f : files){ f.close_file(); } };
+
+	// ---- open + validate every .bloom file (build_db.cpp:48-181) ------------------------------
+	for(uint32_t i = 0; i < n; ++i){
+		BloomFile &f = files[i];
+		f.fd = open(bloom_paths[i], O_RDONLY);
+		struct stat st;
+		if(f.fd < 0 || fstat(f.fd, &st) != 0){ cleanup(); return fail(KWAGE_ERR_IO, "build_db: Unable to open Bloom filter file %s", bloom_paths[i]); }
+		f.size = (size_t)st.st_size;
+		if(f.size < 21){ cleanup(); return fail(KWAGE_ERR_FORMAT, "build_db: %s is truncated", bloom_paths[i]); }
+		f.map = (const unsigned char*)mmap(nullptr, f.size, PROT_READ, MAP_PRIVATE, f.fd, 0);
+		if(f.map == MAP_FAILED){ f.map = nullptr; cleanup(); return fail(KWAGE_ERR_IO, "build_db: mmap(%s) failed", bloom_paths[i]); }
+		if(f.map[0] != 0xFF){ cleanup(); return fail(KWAGE_ERR_FORMAT, "build_db: Incomplete Bloom filter %s", bloom_paths[i]); }
+		const uint32_t k = rd32(f.map + 1), lg = rd32(f.map + 5), nh = rd32(f.map + 9);
+		const int32_t hf = (int32_t)rd32(f.map + 13);
+		if(k != params->kmer_len || lg != params->log_2_filter_len || nh != params->num_hash || hf != params->hash_func){
+			cleanup();
+			return fail(KWAGE_ERR_ARG, "build_db: Inconsistent Bloom parameters in %s", bloom_paths[i]);
+		}
+		f.crc = rd32(f.map + 17);
+		size_t used = 0;
+		if(!parse_filter_info(f.map + 21, f.size - 21, f.info, &used)){ cleanup(); return fail(KWAGE_ERR_FORMAT, "build_db: Error reading Bloom filter info from %s", bloom_paths[i]); }
+		f.bits_off = 21 + used;
+		if(f.size - f.bits_off < filter_bytes){ cleanup(); return fail(KWAGE_ERR_FORMAT, "build_db: Error reading filter bytes from %s", bloom_paths[i]); }
+	}
+
+	// ---- per-filter CRC32 (build_db.cpp:343-362), host threads; checked BEFORE anything is written
+	{
+		const unsigned nthread = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+		std::atomic<uint32_t> next(0), bad(0xFFFFFFFFu);
+		std::vector<std::thread> pool;
+		for(unsigned t = 0; t < nthread; ++t){
+			pool.emplace_back([&]() {
+				for(uint32_t i = next++; i < n; i = next++){
+					uint64_t crc = crc32_z(0L, Z_NULL, 0);
+					crc = crc32_z(crc, files[i].map + files[i].bits_off, filter_bytes);
+					if((uint32_t)crc != files[i].crc){ bad = i; }
+				}
+			});
+		}
+		for(auto &t : pool){ t.join(); }
+		if(bad != 0xFFFFFFFFu){
+			const uint32_t i = bad;
+			cleanup();
+			return fail(KWAGE_ERR_FORMAT, "build_db: One or more invalid Bloom filter CRC32 values (%s)", bloom_paths[i]);
+		}
+	}
+
+	FILE *fout = fopen(out_path, "wb");
+	if(!fout){ cleanup(); return fail(KWAGE_ERR_IO, "build_db: Unable to open output file for writing"); }
+
+	// header placeholder (rewritten at the end with crc32 + info_start), kwage.h:36-46
+	unsigned char hdr[DB_HEADER_BYTES];
+	auto put32 = [](unsigned char *p, uint32_t v) { for(int i = 0; i < 4; ++i){ p[i] = (unsigned char)(v >> (8*i)); } };
+	auto put64 = [](unsigned char *p, uint64_t v) { for(int i = 0; i < 8; ++i){ p[i] = (unsigned char)(v >> (8*i)); } };
+	memset(hdr, 0, sizeof(hdr));
+	put32(hdr, KWAGE_MAGIC_NUMBER); put32(hdr + 4, 2 /* CURRENT_DBFILE_VERSION */);
+	put32(hdr + 12, params->kmer_len); put32(hdr + 16, params->num_hash); put32(hdr + 20, params->log_2_filter_len);
+	put32(hdr + 24, n);   // hash_func stays 0 and compression NO_COMPRESSION, as build_db.cpp:189-199 leaves them
+	bool ok = fwrite(hdr, 1, sizeof(hdr), fout) == sizeof(hdr);
+
+	// ---- transpose, chunk by chunk --------------------------------------------------------------
+	// chunk rows: bounded so that the input (n x rows/8) and the output (rows x slice) both stay <= 512 MiB
+	uint64_t chunk_rows = filter_len;
+	while(chunk_rows > 1024 && (chunk_rows/8*n > (512ull << 20) || chunk_rows*slice_size > (512ull << 20))){ chunk_rows /= 2; }
+	const uint64_t in_stride = (chunk_rows + 7)/8;
+	void *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
+	hipError_t e = hipMalloc(&d_in, in_stride*n);
+	if(e == hipSuccess){ e = hipMalloc(&d_out, chunk_rows*slice_size); }
+	if(e == hipSuccess){ e = hipHostMalloc(&h_in, in_stride*n, hipHostMallocDefault); }
+	if(e == hipSuccess){ e = hipHostMalloc(&h_out, chunk_rows*slice_size, hipHostMallocDefault); }
+	uint32_t db_crc = 0;            // output_header.crc32 starts at 0 (build_db.cpp:192,307)
+	double t_kernel_ms = 0;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	if(e == hipSuccess){ e = hipEventCreate(&ev0); }
+	if(e == hipSuccess){ e = hipEventCreate(&ev1); }
+	for(uint64_t r0 = 0; r0 < filter_len && ok && e == hipSuccess; r0 += chunk_rows){
+		const uint64_t nr = std::min(chunk_rows, filter_len - r0);
+		const uint64_t nb = (nr + 7)/8;
+		for(uint32_t i = 0; i < n; ++i){
+			memcpy((char*)h_in + (uint64_t)i*in_stride, files[i].map + files[i].bits_off + r0/8, nb);
+		}
+		e = hipMemcpyAsync(d_in, h_in, in_stride*n, hipMemcpyHostToDevice, stream);
+		if(e != hipSuccess){ break; }
+		const dim3 grid((uint32_t)((nr + TB_ROWS - 1)/TB_ROWS), (n + TB_WAVES*64 - 1)/(TB_WAVES*64));
+		(void)hipEventRecord(ev0, stream);
+		hipLaunchKernelGGL(transpose_bits_kernel, grid, dim3(TB_WAVES*64), 0, stream,
+		                   (const uint8_t*)d_in, in_stride, n, nr, (uint8_t*)d_out, slice_size);
+		(void)hipEventRecord(ev1, stream);
+		e = hipGetLastError();
+		if(e == hipSuccess){ e = hipMemcpyAsync(h_out, d_out, nr*slice_size, hipMemcpyDeviceToHost, stream); }
+		if(e == hipSuccess){ e = hipStreamSynchronize(stream); }
+		if(e != hipSuccess){ break; }
+		float ms = 0;
+		(void)hipEventElapsedTime(&ms, ev0, ev1);
+		t_kernel_ms += ms;
+		db_crc = crc32_parallel(db_crc, (const unsigned char*)h_out, nr*slice_size);
+		ok = fwrite(h_out, 1, nr*slice_size, fout) == nr*slice_size;
+	}
+	if(d_in){ (void)hipFree(d_in); }
+	if(d_out){ (void)hipFree(d_out); }
+	if(h_in){ (void)hipHostFree(h_in); }
+	if(h_out){ (void)hipHostFree(h_out); }
+	if(ev0){ (void)hipEventDestroy(ev0); }
+	if(ev1){ (void)hipEventDestroy(ev1); }
+	if(e != hipSuccess){ fclose(fout); cleanup(); return fail(KWAGE_ERR_DEVICE, "kwage_build_db: %s", hipGetErrorString(e)); }
+
+	// ---- metadata index + records (build_db.cpp:371-416), then the final header (:421-427) -------
+	const uint64_t info_start = DB_HEADER_BYTES + filter_len*slice_size;
+	std::vector<unsigned char> recs;
+	std::vector<uint64_t> loc(n);
+	uint64_t pos = info_start + 8ull*n;
+	for(uint32_t i = 0; i < n; ++i){
+		loc[i] = pos;
+		const size_t before = recs.size();
+		pack_filter_info(files[i].info, recs);
+		pos += recs.size() - before;
+	}
+	std::vector<unsigned char> locb(8ull*n);
+	for(uint32_t i = 0; i < n; ++i){ put64(locb.data() + 8ull*i, loc[i]); }
+	ok = ok && fwrite(locb.data(), 1, locb.size(), fout) == locb.size();
+	ok = ok && (recs.empty() || fwrite(recs.data(), 1, recs.size(), fout) == recs.size());
+	put32(hdr + 8, db_crc);
+	put64(hdr + 36, info_start);
+	ok = ok && fseek(fout, 0, SEEK_SET) == 0 && fwrite(hdr, 1, sizeof(hdr), fout) == sizeof(hdr);
+	ok = (fclose(fout) == 0) && ok;
+	cleanup();
+	if(!ok){ return fail(KWAGE_ERR_IO, "build_db: Error writing database file %s", out_path); }
+	if(stats){
+		stats->bits_transposed = filter_len*n;
+		stats->transpose_kernel_ms = (float)t_kernel_ms;
+		stats->db_bytes = pos;
+	}
+	return KWAGE_OK;
+}

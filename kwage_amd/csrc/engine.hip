@@ -472,6 +472,11 @@ int run_search(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
 
 }  // namespace
 
+namespace kwage {
+hipStream_t ctx_stream(kwage_ctx *ctx) { return ctx->stream; }
+int ctx_device(kwage_ctx *ctx) { return ctx->device; }
+}
+
 // ------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------

@@ -166,7 +166,7 @@ struct Cursor {
 
 }  // namespace
 
-bool parse_filter_info(const unsigned char *buf, size_t len, FilterInfo &fi)
+bool parse_filter_info(const unsigned char *buf, size_t len, FilterInfo &fi, size_t *consumed)
 {
 	Cursor c{buf, buf + len};
 	fi = FilterInfo();
@@ -195,7 +195,27 @@ bool parse_filter_info(const unsigned char *buf, size_t len, FilterInfo &fi)
 	fi.number_of_spots = c.u64();
 	fi.number_of_bases = c.u64();
 	fi.day = c.u32(); fi.month = c.u32(); fi.year = c.u32();     // date.h:17-20 member order
+	if(consumed){ *consumed = (size_t)(c.p - buf); }
 	return c.ok;
+}
+
+void pack_filter_info(const FilterInfo &fi, std::vector<unsigned char> &out)
+{
+	auto u64 = [&](uint64_t v) { for(int i = 0; i < 8; ++i){ out.push_back((unsigned char)(v >> (8*i))); } };
+	auto u32 = [&](uint32_t v) { for(int i = 0; i < 4; ++i){ out.push_back((unsigned char)(v >> (8*i))); } };
+	auto str = [&](const std::string &s) { out.insert(out.end(), s.begin(), s.end()); out.push_back(0); };
+	u64(fi.run_accession); u64(fi.experiment_accession);
+	str(fi.experiment_title); str(fi.experiment_design_description); str(fi.experiment_library_name);
+	str(fi.experiment_library_strategy); str(fi.experiment_library_source); str(fi.experiment_library_selection);
+	str(fi.experiment_instrument_model);
+	u64(fi.sample_accession);
+	str(fi.sample_taxa);
+	u64(fi.sample_attributes.size());
+	for(const auto &kv : fi.sample_attributes){ str(kv.first); str(kv.second); }
+	u64(fi.study_accession);
+	str(fi.study_title); str(fi.study_abstract);
+	u64(fi.number_of_spots); u64(fi.number_of_bases);
+	u32(fi.day); u32(fi.month); u32(fi.year);
 }
 
 // ---- database metadata ----------------------------------------------------------------------

@@ -30,7 +30,10 @@ struct FilterInfo {
 	std::string json_string(const std::string &prefix) const;
 };
 
-bool parse_filter_info(const unsigned char *buf, size_t len, FilterInfo &fi);
+bool parse_filter_info(const unsigned char *buf, size_t len, FilterInfo &fi, size_t *consumed = nullptr);
+// binary_write<FilterInfo> (binary_io.cpp:154-163): members in order, strings NUL-terminated, the
+// attribute map as size_t count + pairs in the container's iteration order.
+void pack_filter_info(const FilterInfo &fi, std::vector<unsigned char> &out);
 bool str_to_accession(const std::string &s, uint64_t &out);
 std::string accession_to_str(uint64_t acc);
 bool find_file_extension(const std::string &path, const char *ext);

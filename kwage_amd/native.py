@@ -47,6 +47,10 @@ class Result(C.Structure):
                 ("search_kernel_launches", C.c_uint32)]
 
 
+class BuildStats(C.Structure):
+    _fields_ = [("bits_transposed", C.c_uint64), ("transpose_kernel_ms", C.c_float), ("db_bytes", C.c_uint64)]
+
+
 class DbHeader(C.Structure):
     _fields_ = [("magic", C.c_uint32), ("version", C.c_uint32), ("crc32", C.c_uint32),
                 ("kmer_len", C.c_uint32), ("num_hash", C.c_uint32), ("log_2_filter_len", C.c_uint32),
@@ -86,6 +90,7 @@ _SIGNATURES = [
     ("kwage_search_device", C.c_int, [_P, _P, C.c_float, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64), _P]),
     ("kwage_hash_batch", C.c_int, [_P, C.POINTER(Params), _P, _P, _P, _P, _P]),
     ("kwage_stream_read_gbps", C.c_int, [_P, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
+    ("kwage_build_db", C.c_int, [_P, C.c_char_p, C.POINTER(Params), C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(BuildStats)]),
     ("kwage_db_read_header", C.c_int, [C.c_char_p, C.POINTER(DbHeader)]),
     ("kwage_dbinfo_open", C.c_int, [C.c_char_p, C.POINTER(_P)]),
     ("kwage_dbinfo_close", None, [_P]),

@@ -10,6 +10,9 @@
 //   ref_tool kmers <k> <nhash> <seq> print, for every valid k-mer position, the reference's
 //                                   CanonicalWord (word.h:165) and bigsi_hash (hash.cpp:79)
 //   ref_tool accession <str>        print str_to_accession / accession_to_str round trip
+//   ref_tool build <out.db> <k> <L> <nhash> <list>   run the reference's build_db() on existing
+//                                   .bloom files (one path per line in <list>): CPU baseline of
+//                                   the device builder
 //
 // Spec format for mkdb (one record per line, fields separated by single TABs):
 //   DB <out.db> <kmer_len> <log_2_filter_len> <num_hash> <tmp_dir>
@@ -19,6 +22,7 @@
 //   A  <tag> <value>                                 add a sample attribute
 //   N  <spots> <bases>                               number_of_spots / number_of_bases
 //   D  <YYYY-MM-DD...>                               date_received
+//   KEEP                                             leave the intermediate .bloom files in <tmp_dir>
 // The order of F records is the column order of the database.
 
 #include <iostream>
@@ -89,6 +93,7 @@ static int cmd_mkdb(const char *spec_path)
 	deque<string> bloom_files;
 	PendingFilter cur;
 	size_t filter_index = 0;
+	bool keep_bloom = false;
 
 	// Flush the current filter to a .bloom file via the reference serializer.
 	auto flush = [&]() {
@@ -119,6 +124,9 @@ static int cmd_mkdb(const char *spec_path)
 			param.num_hash = atoi(f[4].c_str());
 			param.hash_func = MURMUR_HASH_32;
 			tmp_dir = f[5];
+		}
+		else if(tag == "KEEP"){
+			keep_bloom = true;
 		}
 		else if(tag == "F"){
 			flush();
@@ -177,7 +185,7 @@ static int cmd_mkdb(const char *spec_path)
 		return 1;
 	}
 
-	for(deque<string>::const_iterator i = bloom_files.begin(); i != bloom_files.end(); ++i){
+	for(deque<string>::const_iterator i = bloom_files.begin(); !keep_bloom && i != bloom_files.end(); ++i){
 		remove(i->c_str());
 	}
 	return 0;
@@ -208,12 +216,24 @@ int main(int argc, char *argv[])
 		if(argc == 5 && string(argv[1]) == "kmers"){
 			return cmd_kmers(atoi(argv[2]), atoi(argv[3]), argv[4]);
 		}
+		if(argc == 7 && string(argv[1]) == "build"){
+			BloomParam param;
+			param.kmer_len = atoi(argv[3]);
+			param.log_2_filter_len = atoi(argv[4]);
+			param.num_hash = atoi(argv[5]);
+			param.hash_func = MURMUR_HASH_32;
+			deque<string> bloom_files;
+			ifstream fl(argv[6]);
+			string line;
+			while(getline(fl, line)){ if(!line.empty()){ bloom_files.push_back(line); } }
+			return build_db(argv[2], param, bloom_files) ? 0 : 1;
+		}
 		if(argc == 3 && string(argv[1]) == "accession"){
 			const SraAccession a = str_to_accession(argv[2]);
 			cout << a << '\t' << accession_to_str(a) << '\n';
 			return 0;
 		}
-		cerr << "usage: ref_tool mkdb <spec> | kmers <k> <nhash> <seq> | accession <str>" << endl;
+		cerr << "usage: ref_tool mkdb <spec> | kmers <k> <nhash> <seq> | accession <str> | build <out.db> <k> <L> <nhash> <list>" << endl;
 		return 2;
 	}
 	catch(const char *error){

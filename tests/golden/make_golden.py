@@ -34,13 +34,16 @@ def revcomp(s):
     return s[::-1].translate(str.maketrans("ACGTacgt", "TGCAtgca"))
 
 
-def mkdb(out_db, k, L, nhash, filters):
-    """filters: list of dicts {acc, seed, noise, seqs:[...], meta:{}, attrs:[(k,v)], n:(spots,bases), date}"""
+def mkdb(out_db, k, L, nhash, filters, keep_bloom_dir=None):
+    """filters: list of dicts {acc, seed, noise, seqs:[...], meta:{}, attrs:[(k,v)], n:(spots,bases), date}
+    keep_bloom_dir: also keep the reference-written .bloom files (inputs of the builder parity test)."""
     os.makedirs(os.path.dirname(out_db), exist_ok=True)
     tmp = tempfile.mkdtemp(prefix="kwgold_")
     spec = os.path.join(tmp, "spec.tsv")
     with open(spec, "w") as f:
         f.write("DB\t%s\t%d\t%d\t%d\t%s\n" % (out_db, k, L, nhash, tmp))
+        if keep_bloom_dir:
+            f.write("KEEP\n")
         for fl in filters:
             f.write("F\t%s\t%d\t%d\n" % (fl["acc"], fl.get("seed", 1), fl.get("noise", 0)))
             for s in fl.get("seqs", []):
@@ -54,6 +57,12 @@ def mkdb(out_db, k, L, nhash, filters):
             if "date" in fl:
                 f.write("D\t%s\n" % fl["date"])
     subprocess.check_call([REF_TOOL, "mkdb", spec])
+    if keep_bloom_dir:
+        shutil.rmtree(keep_bloom_dir, ignore_errors=True)
+        os.makedirs(keep_bloom_dir)
+        for fn in sorted(os.listdir(tmp)):
+            if fn.endswith(".bloom"):
+                shutil.move(os.path.join(tmp, fn), os.path.join(keep_bloom_dir, fn))
     shutil.rmtree(tmp)
 
 
@@ -123,7 +132,7 @@ def main():
         elif j % 9 == 1:
             fl["date"] = "2010-03-24"
         filters.append(fl)
-    mkdb(os.path.join(cdir, "db", "basic.db"), 31, 12, 3, filters)
+    mkdb(os.path.join(cdir, "db", "basic.db"), 31, 12, 3, filters, keep_bloom_dir=os.path.join(cdir, "bloom"))
 
     with open(os.path.join(cdir, "q.fa"), "w") as f:
         f.write(">g0 full genome 0\n")
@@ -167,8 +176,9 @@ def main():
         for i in range(6):
             s = g[i % 4][10 * i: 10 * i + 150] if i != 4 else rand_seq(rng, 150)
             f.write("@read%d some description\n%s\n+\n%s\n" % (i, s, "I" * len(s)))
-    with gzip.open(os.path.join(cdir, "contigs.fa.gz"), "wt") as f:
-        f.write(">c0\n" + g[0] + "\n>c1\n" + g[3][:200] + "\n")
+    with open(os.path.join(cdir, "contigs.fa.gz"), "wb") as raw:
+        with gzip.GzipFile(fileobj=raw, mode="wb", mtime=0) as f:     # mtime=0: reproducible bytes
+            f.write((">c0\n" + g[0] + "\n>c1\n" + g[3][:200] + "\n").encode())
     add_case(name, ["dbs"], ["reads.fastq", "contigs.fa.gz"], [], ["1.0", "0.7"])
     add_case(name, ["dbs/a", "dbs/k31_L12_h3.db"], ["contigs.fa.gz"], [g[3][20:90]], ["1.0"],
              formats=("csv",), tag="_subset")
@@ -183,7 +193,8 @@ def main():
     g32 = rand_seq(rng, 200)
     mkdb(os.path.join(cdir, "k32.db"), 32, 10, 5,
          [{"acc": "SRR%d" % (1 + j), "seed": j, "noise": 150,
-           "seqs": [g32] if j in (2, 5) else ([g32[:120]] if j == 7 else [])} for j in range(8)])
+           "seqs": [g32] if j in (2, 5) else ([g32[:120]] if j == 7 else [])} for j in range(8)],
+         keep_bloom_dir=os.path.join(cdir, "bloom"))
     with open(os.path.join(cdir, "q.fna"), "w") as f:
         f.write(">one\n" + g32[:150] + "\n")
     add_case(name, ["k32.db"], ["q.fna"], [], ["1.0", "0.6"])

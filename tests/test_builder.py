@@ -1,0 +1,94 @@
+"""Database construction: the device bit-transpose builder against the
+reference's own build_db() output (tests/golden/*/bloom/*.bloom -> *.db, both written by the
+reference through oracle/_ref/ref_tool) and against the numpy restatement on synthetic inputs."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+
+def _blooms(case):
+    return sorted(glob.glob(os.path.join(GOLDEN, case, "bloom", "*.bloom")))
+
+
+def test_oracle_build_db_slices_match_reference(oracle):
+    """numpy restatement of the transpose == the reference's file (slice block, header, index)."""
+    for case, db in (("basic", "basic/db/basic.db"), ("k32", "k32/k32.db")):
+        ref = open(os.path.join(GOLDEN, db), "rb").read()
+        got = oracle.build_db_bytes(_blooms(case))
+        hdr = oracle.DBHeader.unpack(ref)
+        assert got[: hdr.info_start + 8 * hdr.num_filter] == ref[: hdr.info_start + 8 * hdr.num_filter]
+        assert len(got) == len(ref)
+
+
+def _device_build(ka, ctx, paths, params, out):
+    from kwage_amd import native
+    arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+    st = native.BuildStats()
+    p = native.Params(*params)
+    native.check(native.lib().kwage_build_db(ctx._h, out.encode(), C.byref(p), arr, len(paths), C.byref(st)))
+    return st
+
+
+@pytest.mark.gpu
+def test_device_builder_is_byte_identical_to_reference(tmp_path):
+    import kwage_amd as ka
+    with ka.Context(0) as ctx:
+        for case, db, params in (("basic", "basic/db/basic.db", (31, 3, 12, 0)), ("k32", "k32/k32.db", (32, 5, 10, 0))):
+            out = str(tmp_path / (case + ".db"))
+            st = _device_build(ka, ctx, _blooms(case), params, out)
+            ref = open(os.path.join(GOLDEN, db), "rb").read()
+            assert open(out, "rb").read() == ref, case
+            assert st.db_bytes == len(ref) and st.bits_transposed == (1 << params[2]) * len(_blooms(case))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,L", [(1, 3), (3, 5), (64, 7), (65, 10), (1000, 12), (1024, 11), (1025, 11), (2048, 14), (2500, 13)])
+def test_device_builder_vs_oracle_random(oracle, tmp_path, n, L):
+    import kwage_amd as ka
+    rng = np.random.default_rng(n * 31 + L)
+    paths = []
+    for j in range(n):
+        bits = rng.integers(0, 256, size=((1 << L) + 7) // 8, dtype=np.uint8)
+        if L < 3:
+            bits &= (1 << (1 << L)) - 1
+        fi = oracle.FilterInfo(run_accession=oracle.str_to_accession("SRR%d" % (j + 1)),
+                               sample_attributes=[("k", "v%d" % j)] if j % 3 == 0 else [],
+                               experiment_title="t%d" % j if j % 5 == 0 else "")
+        p = str(tmp_path / ("f%05d.bloom" % j))
+        oracle.write_bloom(p, 21, L, 2, fi, bits)
+        paths.append(p)
+    out = str(tmp_path / "out.db")
+    with ka.Context(0) as ctx:
+        _device_build(ka, ctx, paths, (21, 2, L, 0), out)
+        assert open(out, "rb").read() == oracle.build_db_bytes(paths)
+        # and the engine can search what it built
+        g = ka.Group(ctx, 21, 2, L, n)
+        assert g.add_db_file(out) == (0, n)
+        g.close()
+
+
+@pytest.mark.gpu
+def test_device_builder_rejects_bad_input(oracle, tmp_path):
+    import kwage_amd as ka
+    paths = _blooms("k32")
+    bad = str(tmp_path / "bad.bloom")
+    raw = bytearray(open(paths[0], "rb").read())
+    raw[-1] ^= 0x10                                   # flip a filter bit: CRC32 mismatch (build_db.cpp:343-362)
+    open(bad, "wb").write(raw)
+    with ka.Context(0) as ctx:
+        with pytest.raises(ka.KwageError) as e:
+            _device_build(ka, ctx, [bad] + paths[1:], (32, 5, 10, 0), str(tmp_path / "o.db"))
+        assert "CRC32" in str(e.value)
+        assert not os.path.exists(tmp_path / "o.db")  # nothing is written before validation passes
+        with pytest.raises(ka.KwageError):
+            _device_build(ka, ctx, paths, (31, 5, 10, 0), str(tmp_path / "o.db"))    # inconsistent params
+        raw = bytearray(open(paths[0], "rb").read())
+        raw[0] = 0x00                                 # BLOOM_MAGIC_IN_PROGRESS
+        open(bad, "wb").write(raw)
+        with pytest.raises(ka.KwageError):
+            _device_build(ka, ctx, [bad], (32, 5, 10, 0), str(tmp_path / "o.db"))
