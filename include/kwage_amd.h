@@ -212,6 +212,16 @@ typedef struct {
 
 int kwage_db_read_header(const char *path, kwage_db_header *out);
 
+/* Compressed container (host only).  The reference ships a slice CODEC (slice_z.h: raw deflate,
+ * windowBits -9, level 9, memLevel 9, default strategy, "store raw unless smaller") but no file
+ * layout, and its kwage ignores header.compression.  This repo defines the layout:
+ * header.compression = 2, u64 offset[2^L+1], per-slice payloads, then the usual metadata.
+ * kwage_group_add_db_file reads both layouts (slices are inflated once, on the host, at load).
+ * Parity with the reference is UNPINNED for this container (it has none); it is validated by
+ * round trip: decompress(compress(x)) == x byte for byte, and identical search results. */
+int kwage_db_compress(const char *in_path, const char *out_path, uint32_t threads);
+int kwage_db_decompress(const char *in_path, const char *out_path);
+
 /* Database metadata reader: info_loc[] + FilterInfo records (kwage.cpp:505-515,
  * binary_io.cpp:154-176), loaded once per file instead of two seeks per hit. */
 typedef struct kwage_dbinfo kwage_dbinfo;

@@ -18,6 +18,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include "host.hpp"
 #include "internal.h"
 #include "kernels.hpp"
 
@@ -664,12 +665,10 @@ extern "C" int kwage_group_add_columns(kwage_group *g, const void *host_rows, ui
 extern "C" int kwage_group_add_db_file(kwage_group *g, const char *path, uint64_t *first_column, uint32_t *num_filter)
 {
 	if(!g || !path){ return fail(KWAGE_ERR_ARG, "kwage_group_add_db_file: NULL argument"); }
-	kwage_db_header h;
-	int rc = kwage_db_read_header(path, &h);
-	if(rc){ return rc; }
-	if(h.compression != 0){
-		return fail(KWAGE_ERR_FORMAT, "%s: compression %u is not supported (the reference defines no compressed container)", path, h.compression);
-	}
+	DbSliceSource src;       // raw layout or this repo's deflate container (inflated on the host)
+	std::string err;
+	if(!src.open(path, err)){ return fail(KWAGE_ERR_IO, "%s", err.c_str()); }
+	const kwage_db_header &h = src.header;
 	if(h.kmer_len != g->params.kmer_len || h.num_hash != g->params.num_hash ||
 	   h.log_2_filter_len != g->params.log_2_filter_len || h.hash_func != g->params.hash_func){
 		return fail(KWAGE_ERR_ARG, "%s: parameters (k=%u, hashes=%u, log2 len=%u, func=%d) differ from the group's",
@@ -677,21 +676,14 @@ extern "C" int kwage_group_add_db_file(kwage_group *g, const char *path, uint64_
 	}
 	if(h.num_filter == 0){ return fail(KWAGE_ERR_FORMAT, "%s: num_filter is 0", path); }
 	kwage_ctx *ctx = g->ctx;
-	if((rc = set_device(ctx))){ return rc; }
+	int rc = set_device(ctx);
+	if(rc){ return rc; }
 
-	const uint64_t width = ((uint64_t)h.num_filter + 7)/8;
-	const int fd = open(path, O_RDONLY);
-	if(fd < 0){ return fail(KWAGE_ERR_IO, "Unable to open database file %s for reading", path); }
-	struct stat st;
-	if(fstat(fd, &st) != 0 || (uint64_t)st.st_size < DB_HEADER_BYTES + width*g->nrows){
-		close(fd);
-		return fail(KWAGE_ERR_IO, "%s: file is shorter than header + 2^%u slices of %llu bytes", path,
-		            h.log_2_filter_len, (unsigned long long)width);
-	}
+	const uint64_t width = src.slice_size;
 	uint64_t byte0 = 0;
-	if((rc = group_reserve_columns(g, h.num_filter, &byte0))){ close(fd); return rc; }
+	if((rc = group_reserve_columns(g, h.num_filter, &byte0))){ return rc; }
 
-	// double-buffered: read() into pinned buffer A while buffer B is copied + scattered
+	// double-buffered: fill pinned buffer A (pread / inflate) while buffer B is copied + scattered
 	const uint64_t chunk_rows = std::max<uint64_t>(1, std::min<uint64_t>(g->nrows, (32ull << 20)/width));
 	const uint64_t chunk_bytes = chunk_rows*width;
 	PinBuf pin[2];
@@ -704,20 +696,12 @@ extern "C" int kwage_group_add_db_file(kwage_group *g, const char *path, uint64_
 		if(!rc){ rc = dev[i].reserve(chunk_bytes); }
 		if(!rc && hipEventCreate(&done[i]) != hipSuccess){ rc = fail(KWAGE_ERR_DEVICE, "hipEventCreate failed"); }
 	}
-	uint64_t file_off = DB_HEADER_BYTES;
 	int cur = 0;
 	for(uint64_t r0 = 0; r0 < g->nrows && rc == KWAGE_OK; r0 += chunk_rows, cur ^= 1){
 		const uint64_t nr = std::min(chunk_rows, g->nrows - r0);
 		const uint64_t nb = nr*width;
 		if(used[cur]){ e = hipEventSynchronize(done[cur]); if(e != hipSuccess){ rc = fail(KWAGE_ERR_DEVICE, "%s", hipGetErrorString(e)); break; } }
-		uint64_t got = 0;
-		while(got < nb){
-			const ssize_t k = pread(fd, (char*)pin[cur].p + got, nb - got, (off_t)(file_off + got));
-			if(k <= 0){ rc = fail(KWAGE_ERR_IO, "%s: Error reading slice from file", path); break; }
-			got += (uint64_t)k;
-		}
-		if(rc){ break; }
-		file_off += nb;
+		if(!src.read_rows(r0, nr, (unsigned char*)pin[cur].p, err)){ rc = fail(KWAGE_ERR_IO, "%s: %s", path, err.c_str()); break; }
 		e = hipMemcpyAsync(dev[cur].p, pin[cur].p, nb, hipMemcpyHostToDevice, ctx->stream);
 		if(e == hipSuccess){
 			hipLaunchKernelGGL(place_rows_kernel, dim3(grid_for(nb/4 + 1, 256)), dim3(256), 0, ctx->stream,
@@ -733,7 +717,6 @@ extern "C" int kwage_group_add_db_file(kwage_group *g, const char *path, uint64_
 		pin[i].release(); dev[i].release();
 		if(done[i]){ (void)hipEventDestroy(done[i]); }
 	}
-	close(fd);
 	if(rc){ return rc; }
 	if(first_column){ *first_column = byte0*8; }
 	if(num_filter){ *num_filter = h.num_filter; }

@@ -14,6 +14,12 @@
 #include <unordered_map>
 #include <vector>
 
+#include <atomic>
+#include <thread>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include "host.hpp"
@@ -252,6 +258,113 @@ bool DbInfo::info(uint32_t column, FilterInfo &fi) const
 	return parse_filter_info(tail.data() + (loc - tail_start), tail.size() - (loc - tail_start), fi);
 }
 
+// ---- slice block reader + the compressed container -----------------------------------------
+// Codec = the reference's slice_z.h (dead code there, never wired to a container): raw deflate,
+// windowBits -9 (slice_z.h:9), level 9, memLevel 9, Z_DEFAULT_STRATEGY (slice_z.h:169-196); a slice
+// is stored raw when deflate does not make it smaller (CompressSlice::compress, slice_z.h:231-251).
+// Container (this repo's definition; the reference has none):
+//   [44-byte header, compression = 2, crc32 = crc of the UNCOMPRESSED slice block]
+//   [u64 offset[2^L + 1]  absolute file offsets; slice i = bytes offset[i] .. offset[i+1])]
+//   [slice payloads: length == ceil(N/8) -> raw bytes, otherwise a raw-deflate stream]
+//   [u64 info_loc[N]] [FilterInfo records]                       (as in the uncompressed layout)
+static const int SLICE_Z_WINDOW_BITS = -9;
+
+static unsigned host_threads(unsigned want)
+{
+	const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+	return std::max(1u, std::min(want ? want : 16u, hw));
+}
+
+static bool pread_all(int fd, void *dst, uint64_t n, uint64_t off)
+{
+	uint64_t got = 0;
+	while(got < n){
+		const ssize_t k = pread(fd, (char*)dst + got, n - got, (off_t)(off + got));
+		if(k <= 0){ return false; }
+		got += (uint64_t)k;
+	}
+	return true;
+}
+
+bool DbSliceSource::open(const std::string &path, std::string &err)
+{
+	close();
+	fd = ::open(path.c_str(), O_RDONLY);
+	if(fd < 0){ err = "Unable to open database file " + path + " for reading"; return false; }
+	unsigned char hb[DB_HEADER_BYTES];
+	struct stat st;
+	if(fstat(fd, &st) != 0 || !pread_all(fd, hb, DB_HEADER_BYTES, 0)){ err = path + ": Unable to read header"; return false; }
+	unpack_db_header(hb, &header);
+	if(header.magic != KWAGE_MAGIC_NUMBER){ err = path + ": not a KWAGE database (bad magic)"; return false; }
+	if(header.log_2_filter_len > 32){ err = path + ": log_2_filter_len > 32"; return false; }
+	slice_size = ((uint64_t)header.num_filter + 7)/8;
+	nrows = 1ull << header.log_2_filter_len;
+	const uint64_t fsize = (uint64_t)st.st_size;
+	if(header.compression == KWAGE_COMPRESSION_NONE){
+		if(fsize < DB_HEADER_BYTES + nrows*slice_size){ err = path + ": file is shorter than header + slices"; return false; }
+		return true;
+	}
+	if(header.compression != KWAGE_COMPRESSION_DEFLATE){
+		err = path + ": unsupported compression code (only 0 = none and 2 = deflate container)";
+		return false;
+	}
+	offsets.resize(nrows + 1);
+	if(fsize < DB_HEADER_BYTES + 8*(nrows + 1) || !pread_all(fd, offsets.data(), 8*(nrows + 1), DB_HEADER_BYTES)){
+		err = path + ": truncated slice offset table";
+		return false;
+	}
+	for(uint64_t i = 0; i < nrows; ++i){
+		if(offsets[i + 1] < offsets[i] || offsets[i + 1] > fsize || offsets[i + 1] - offsets[i] > slice_size){
+			err = path + ": corrupt slice offset table";
+			return false;
+		}
+	}
+	return true;
+}
+
+void DbSliceSource::close()
+{
+	if(fd >= 0){ ::close(fd); fd = -1; }
+	offsets.clear();
+}
+
+bool DbSliceSource::read_rows(uint64_t r0, uint64_t nr, unsigned char *dst, std::string &err)
+{
+	if(header.compression == KWAGE_COMPRESSION_NONE){
+		if(!pread_all(fd, dst, nr*slice_size, DB_HEADER_BYTES + r0*slice_size)){ err = "Error reading slice from file"; return false; }
+		return true;
+	}
+	const uint64_t c0 = offsets[r0], c1 = offsets[r0 + nr];
+	std::vector<unsigned char> comp(c1 - c0);
+	if(!pread_all(fd, comp.data(), c1 - c0, c0)){ err = "Error reading compressed slice from file"; return false; }
+	const unsigned nt = host_threads(16);
+	std::atomic<uint64_t> next(0);
+	std::atomic<bool> bad(false);
+	auto work = [&]() {
+		z_stream z;
+		memset(&z, 0, sizeof(z));
+		if(inflateInit2(&z, SLICE_Z_WINDOW_BITS) != Z_OK){ bad = true; return; }
+		const uint64_t grain = 1024;
+		for(uint64_t b = next.fetch_add(grain); b < nr && !bad; b = next.fetch_add(grain)){
+			for(uint64_t i = b; i < std::min(nr, b + grain); ++i){
+				const uint64_t o = offsets[r0 + i] - c0, len = offsets[r0 + i + 1] - offsets[r0 + i];
+				unsigned char *out = dst + i*slice_size;
+				if(len == slice_size){ memcpy(out, comp.data() + o, len); continue; }     // stored raw
+				z.next_in = comp.data() + o; z.avail_in = (uInt)len;
+				z.next_out = out; z.avail_out = (uInt)slice_size;
+				if(inflate(&z, Z_FINISH) != Z_STREAM_END || z.avail_out != 0 || inflateReset(&z) != Z_OK){ bad = true; break; }
+			}
+		}
+		inflateEnd(&z);
+	};
+	std::vector<std::thread> pool;
+	for(unsigned t = 1; t < nt; ++t){ pool.emplace_back(work); }
+	work();
+	for(auto &t : pool){ t.join(); }
+	if(bad){ err = "InflateSlice::inflate: Error in inflate"; return false; }
+	return true;
+}
+
 // ---- file_util.cpp:95-121 -------------------------------------------------------------------
 bool find_file_extension(const std::string &path, const char *ext)
 {
@@ -391,6 +504,146 @@ extern "C" int kwage_db_read_header(const char *path, kwage_db_header *out)
 	// The reference validates nothing here (kwage.cpp:99-105); a wrong magic would make it read
 	// garbage.  Refusing such a file is the only deliberate deviation.
 	if(out->magic != KWAGE_MAGIC_NUMBER){ return fail(KWAGE_ERR_FORMAT, "%s: not a KWAGE database (bad magic 0x%08x)", path, out->magic); }
+	return KWAGE_OK;
+}
+
+static int copy_tail(int in_fd, uint64_t in_off, uint64_t in_size, FILE *out)
+{
+	std::vector<unsigned char> buf(1 << 20);
+	while(in_off < in_size){
+		const uint64_t n = std::min<uint64_t>(buf.size(), in_size - in_off);
+		if(!pread_all(in_fd, buf.data(), n, in_off) || fwrite(buf.data(), 1, n, out) != n){ return -1; }
+		in_off += n;
+	}
+	return 0;
+}
+
+static void pack_db_header(const kwage_db_header &h, unsigned char *b)
+{
+	auto p32 = [](unsigned char *p, uint32_t v) { for(int i = 0; i < 4; ++i){ p[i] = (unsigned char)(v >> (8*i)); } };
+	p32(b, h.magic); p32(b + 4, h.version); p32(b + 8, h.crc32); p32(b + 12, h.kmer_len); p32(b + 16, h.num_hash);
+	p32(b + 20, h.log_2_filter_len); p32(b + 24, h.num_filter); p32(b + 28, (uint32_t)h.hash_func); p32(b + 32, h.compression);
+	p32(b + 36, (uint32_t)h.info_start); p32(b + 40, (uint32_t)(h.info_start >> 32));
+}
+
+extern "C" int kwage_db_compress(const char *in_path, const char *out_path, uint32_t threads)
+{
+	if(!in_path || !out_path){ return fail(KWAGE_ERR_ARG, "kwage_db_compress: NULL argument"); }
+	DbSliceSource src;
+	std::string err;
+	if(!src.open(in_path, err)){ return fail(KWAGE_ERR_IO, "%s", err.c_str()); }
+	if(src.header.compression != KWAGE_COMPRESSION_NONE){ return fail(KWAGE_ERR_FORMAT, "%s is already compressed", in_path); }
+	struct stat st;
+	fstat(src.fd, &st);
+	FILE *out = fopen(out_path, "wb");
+	if(!out){ return fail(KWAGE_ERR_IO, "Unable to open %s for writing", out_path); }
+
+	const uint64_t nrows = src.nrows, ss = src.slice_size;
+	std::vector<uint64_t> offsets(nrows + 1);
+	unsigned char hb[DB_HEADER_BYTES];
+	memset(hb, 0, sizeof(hb));
+	bool ok = fwrite(hb, 1, sizeof(hb), out) == sizeof(hb);
+	ok = ok && fwrite(offsets.data(), 8, nrows + 1, out) == nrows + 1;          // placeholders
+	uint64_t pos = DB_HEADER_BYTES + 8*(nrows + 1);
+	uint32_t crc = 0;
+
+	const uint64_t chunk_rows = std::max<uint64_t>(1, std::min<uint64_t>(nrows, (64ull << 20)/std::max<uint64_t>(ss, 1)));
+	std::vector<unsigned char> raw(chunk_rows*ss), comp(chunk_rows*ss);
+	std::vector<uint32_t> clen(chunk_rows);
+	const unsigned nt = host_threads(threads);
+	for(uint64_t r0 = 0; r0 < nrows && ok; r0 += chunk_rows){
+		const uint64_t nr = std::min(chunk_rows, nrows - r0);
+		if(!src.read_rows(r0, nr, raw.data(), err)){ ok = false; break; }
+		crc = (uint32_t)crc32_z(crc, raw.data(), nr*ss);
+		std::atomic<uint64_t> next(0);
+		std::atomic<bool> bad(false);
+		auto work = [&]() {
+			z_stream z;
+			memset(&z, 0, sizeof(z));
+			// slice_z.h:169-196: level 9, Z_DEFLATED, windowBits -9, memLevel 9, Z_DEFAULT_STRATEGY
+			if(deflateInit2(&z, 9, Z_DEFLATED, SLICE_Z_WINDOW_BITS, 9, Z_DEFAULT_STRATEGY) != Z_OK){ bad = true; return; }
+			const uint64_t grain = 512;
+			for(uint64_t b = next.fetch_add(grain); b < nr; b = next.fetch_add(grain)){
+				for(uint64_t i = b; i < std::min(nr, b + grain); ++i){
+					z.next_in = raw.data() + i*ss; z.avail_in = (uInt)ss;
+					z.next_out = comp.data() + i*ss; z.avail_out = (uInt)ss;      // "smaller than raw" or nothing
+					const int zr = deflate(&z, Z_FINISH);
+					const uint64_t produced = ss - z.avail_out;
+					deflateReset(&z);
+					if(zr == Z_STREAM_END && produced < ss){ clen[i] = (uint32_t)produced; }      // slice_z.h:250
+					else{ clen[i] = (uint32_t)ss; memcpy(comp.data() + i*ss, raw.data() + i*ss, ss); }
+				}
+			}
+			deflateEnd(&z);
+		};
+		std::vector<std::thread> pool;
+		for(unsigned t = 1; t < nt; ++t){ pool.emplace_back(work); }
+		work();
+		for(auto &t : pool){ t.join(); }
+		if(bad){ ok = false; break; }
+		for(uint64_t i = 0; i < nr && ok; ++i){
+			offsets[r0 + i] = pos;
+			ok = fwrite(comp.data() + i*ss, 1, clen[i], out) == clen[i];
+			pos += clen[i];
+		}
+	}
+	offsets[nrows] = pos;
+	// metadata: info_loc[] shifted by the size change, records verbatim
+	kwage_db_header h = src.header;
+	const uint64_t old_info = h.info_start;
+	const int64_t shift = (int64_t)pos - (int64_t)old_info;
+	std::vector<uint64_t> loc(h.num_filter);
+	ok = ok && pread_all(src.fd, loc.data(), 8ull*h.num_filter, old_info);
+	for(auto &l : loc){ l = (uint64_t)((int64_t)l + shift); }
+	ok = ok && fwrite(loc.data(), 8, h.num_filter, out) == h.num_filter;
+	ok = ok && copy_tail(src.fd, old_info + 8ull*h.num_filter, (uint64_t)st.st_size, out) == 0;
+	h.compression = KWAGE_COMPRESSION_DEFLATE;
+	h.info_start = pos;
+	h.crc32 = crc;
+	pack_db_header(h, hb);
+	ok = ok && fseek(out, 0, SEEK_SET) == 0 && fwrite(hb, 1, sizeof(hb), out) == sizeof(hb);
+	ok = ok && fwrite(offsets.data(), 8, nrows + 1, out) == nrows + 1;
+	ok = (fclose(out) == 0) && ok;
+	if(!ok){ return fail(KWAGE_ERR_IO, "kwage_db_compress: %s", err.empty() ? "I/O error" : err.c_str()); }
+	return KWAGE_OK;
+}
+
+extern "C" int kwage_db_decompress(const char *in_path, const char *out_path)
+{
+	if(!in_path || !out_path){ return fail(KWAGE_ERR_ARG, "kwage_db_decompress: NULL argument"); }
+	DbSliceSource src;
+	std::string err;
+	if(!src.open(in_path, err)){ return fail(KWAGE_ERR_IO, "%s", err.c_str()); }
+	struct stat st;
+	fstat(src.fd, &st);
+	FILE *out = fopen(out_path, "wb");
+	if(!out){ return fail(KWAGE_ERR_IO, "Unable to open %s for writing", out_path); }
+	const uint64_t nrows = src.nrows, ss = src.slice_size;
+	kwage_db_header h = src.header;
+	const uint64_t old_info = h.info_start;
+	h.compression = KWAGE_COMPRESSION_NONE;
+	h.info_start = DB_HEADER_BYTES + nrows*ss;
+	unsigned char hb[DB_HEADER_BYTES];
+	pack_db_header(h, hb);       // crc32 is already the crc of the uncompressed slice block
+	bool ok = fwrite(hb, 1, sizeof(hb), out) == sizeof(hb);
+	const uint64_t chunk_rows = std::max<uint64_t>(1, std::min<uint64_t>(nrows, (64ull << 20)/std::max<uint64_t>(ss, 1)));
+	std::vector<unsigned char> raw(chunk_rows*ss);
+	uint32_t crc = 0;
+	for(uint64_t r0 = 0; r0 < nrows && ok; r0 += chunk_rows){
+		const uint64_t nr = std::min(chunk_rows, nrows - r0);
+		if(!src.read_rows(r0, nr, raw.data(), err)){ ok = false; break; }
+		crc = (uint32_t)crc32_z(crc, raw.data(), nr*ss);
+		ok = fwrite(raw.data(), 1, nr*ss, out) == nr*ss;
+	}
+	if(ok && crc != h.crc32){ ok = false; err = "CRC32 of the inflated slice block does not match the header"; }
+	const int64_t shift = (int64_t)h.info_start - (int64_t)old_info;
+	std::vector<uint64_t> loc(h.num_filter);
+	ok = ok && pread_all(src.fd, loc.data(), 8ull*h.num_filter, old_info);
+	for(auto &l : loc){ l = (uint64_t)((int64_t)l + shift); }
+	ok = ok && fwrite(loc.data(), 8, h.num_filter, out) == h.num_filter;
+	ok = ok && copy_tail(src.fd, old_info + 8ull*h.num_filter, (uint64_t)st.st_size, out) == 0;
+	ok = (fclose(out) == 0) && ok;
+	if(!ok){ return fail(KWAGE_ERR_IO, "kwage_db_decompress: %s", err.empty() ? "I/O error" : err.c_str()); }
 	return KWAGE_OK;
 }
 

@@ -48,6 +48,23 @@ struct DbInfo {
 	bool info(uint32_t column, FilterInfo &fi) const;
 };
 
+// Reader of the bit-slice block of a `.db` file, raw (compression 0, the only layout the reference
+// writes: build_db.cpp:197-199) or this repo's compressed container (compression 2, see
+// kwage_db_compress in include/kwage_amd.h).  Compressed slices are inflated on the host.
+struct DbSliceSource {
+	int fd = -1;
+	kwage_db_header header{};
+	uint64_t slice_size = 0, nrows = 0;
+	std::vector<uint64_t> offsets;          // compressed only: nrows + 1 absolute file offsets
+	bool open(const std::string &path, std::string &err);
+	bool read_rows(uint64_t r0, uint64_t nr, unsigned char *dst, std::string &err);   // nr*slice_size bytes
+	void close();
+	~DbSliceSource() { close(); }
+};
+
+static const uint32_t KWAGE_COMPRESSION_NONE = 0;       // reference kwage.h:16-20 NO_COMPRESSION
+static const uint32_t KWAGE_COMPRESSION_DEFLATE = 2;    // reference enum slot RLE_HUFFMAN_COMPRESSION
+
 // FASTA / FASTQ record iterator with the reference SequenceIterator's exact behaviour.
 struct SeqFile {
 	void *fin;

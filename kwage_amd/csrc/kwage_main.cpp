@@ -55,6 +55,10 @@ struct SearchOptions {                       // reference options.h:16-41
 	bool quit = false;
 };
 
+// Database files: `.db` (options.cpp:30-33) and `.dbz`, which the reference's README.md:260 names but
+// its option parser never accepted (this repo's compressed container).
+static bool is_db_file(const string &p) { return find_file_extension(p, ".db") || find_file_extension(p, ".dbz"); }
+
 // Breadth-first walk in readdir order: regular files are reported as met, directories queued
 // (reference file_util.h:30-125).
 struct FindFiles {
@@ -68,7 +72,7 @@ struct FindFiles {
 			struct stat st;
 			if(stat(p.c_str(), &st) != 0){ throw "FindFiles::next: Unable to stat entry"; }
 			if(S_ISREG(st.st_mode)){
-				if(find_file_extension(p, ".db")){ out_db.push_back(p); }     // options.cpp:30-33
+				if(is_db_file(p)){ out_db.push_back(p); }
 				continue;
 			}
 			if(!S_ISDIR(st.st_mode)){ throw "FindFiles::next: Unknown filesystem object"; }
@@ -80,7 +84,7 @@ struct FindFiles {
 				struct stat ds;
 				if(stat(name.c_str(), &ds) != 0){ closedir(dp); throw "FindFiles::next: Unable to stat entry (2)"; }
 				if(S_ISDIR(ds.st_mode)){ targets.push_back(name); }
-				else if(S_ISREG(ds.st_mode) && find_file_extension(name, ".db")){ out_db.push_back(name); }
+				else if(S_ISREG(ds.st_mode) && is_db_file(name)){ out_db.push_back(name); }
 			}
 			closedir(dp);
 		}
