@@ -47,7 +47,8 @@ enum {
 /* search flags */
 #define KWAGE_SEARCH_EARLY_EXIT 1u /* kwage.cpp:437-483: stop a query tile once no column can
                                       still match. Never changes results, only work done.   */
-#define KWAGE_SEARCH_TIMING     2u /* record HIP-event durations of the kernels in the result */
+#define KWAGE_SEARCH_TIMING     2u /* record the HIP-event duration of the gather kernel in the result */
+#define KWAGE_SEARCH_TIMING_KMER 4u /* with TIMING: also time the k-mer stage (two more events)         */
 
 const char *kwage_last_error(void);
 uint32_t kwage_abi_version(void);

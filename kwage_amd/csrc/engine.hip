@@ -81,9 +81,15 @@ struct kwage_ctx {
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 	// scratch, grown on demand and reused
-	DevBuf rows, nkmer, qthr, tables, hits, counters, kmers, partial;
-	PinBuf h_counters;
-	PinBuf h_stage;        // [nkmer n][qthr n][hits ...] staged D2H with the counters: one sync per search
+	DevBuf rows, tables, kmers, partial;
+	// One contiguous result block per search, so that a single D2H copy returns everything:
+	//   [counters: 4 x u64 (hits, total k-mers, -, sink)] [nkmer: n x u32] [qthr: n x u32] [pad to 16] [hits: cap x 12 B]
+	DevBuf result;
+	uint64_t *d_counters = nullptr;
+	uint32_t *d_nkmer = nullptr, *d_qthr = nullptr;
+	kwage_hit *d_hits = nullptr;
+	uint64_t hit_cap = 0, head_bytes = 0;
+	PinBuf h_stage;        // host image of the head of the result block + the first SPEC_HITS records
 };
 
 struct kwage_group {
@@ -122,6 +128,41 @@ namespace {
 int set_device(kwage_ctx *ctx)
 {
 	HIP_TRY(hipSetDevice(ctx->device));
+	return KWAGE_OK;
+}
+
+// Lay the result block out for n queries and at least min_cap hit records. Growing the block keeps
+// its head (counters + per-query arrays) when keep_head is set (hit-buffer growth mid-search).
+int layout_result(kwage_ctx *ctx, uint32_t n, uint64_t min_cap, bool keep_head)
+{
+	const uint64_t head = (32 + 8ull*n + 15)/16*16;
+	uint64_t cap = std::max<uint64_t>(min_cap, 1u << 20);
+	if(ctx->result.cap >= head + sizeof(kwage_hit)){ cap = std::max(cap, (ctx->result.cap - head)/sizeof(kwage_hit)); }
+	const uint64_t need = head + cap*sizeof(kwage_hit);
+	if(need > ctx->result.cap){
+		if(keep_head && ctx->result.p && head == ctx->head_bytes){
+			void *np = nullptr;
+			const uint64_t want = need + need/4;
+			HIP_TRY(hipMalloc(&np, want));
+			HIP_TRY(hipMemcpyAsync(np, ctx->result.p, head, hipMemcpyDeviceToDevice, ctx->stream));
+			HIP_TRY(hipStreamSynchronize(ctx->stream));
+			(void)hipFree(ctx->result.p);
+			ctx->result.p = np;
+			ctx->result.cap = want;
+		}
+		else{
+			int rc = ctx->result.reserve(need);
+			if(rc){ return rc; }
+		}
+		cap = (ctx->result.cap - head)/sizeof(kwage_hit);
+	}
+	char *base = (char*)ctx->result.p;
+	ctx->d_counters = (uint64_t*)base;
+	ctx->d_nkmer = (uint32_t*)(base + 32);
+	ctx->d_qthr = (uint32_t*)(base + 32 + 4ull*n);
+	ctx->d_hits = (kwage_hit*)(base + head);
+	ctx->hit_cap = cap;
+	ctx->head_bytes = head;
 	return KWAGE_OK;
 }
 
@@ -181,14 +222,12 @@ int launch_kmer_stage(kwage_ctx *ctx, const kwage_params &p, kwage_batch *b, flo
 {
 	int rc = batch_prepare(b, p.kmer_len);
 	if(rc){ return rc; }
-	if((rc = ctx->nkmer.reserve(std::max<uint64_t>(b->n, 1)*sizeof(uint32_t)))){ return rc; }
-	if((rc = ctx->qthr.reserve(std::max<uint64_t>(b->n, 1)*sizeof(uint32_t)))){ return rc; }
-	if((rc = ctx->counters.reserve(4*sizeof(uint64_t)))){ return rc; }
+	if((rc = layout_result(ctx, b->n, 0, false))){ return rc; }
 	if(b->table_slots){
 		if((rc = ctx->tables.reserve(b->table_slots*sizeof(uint64_t)))){ return rc; }
 		HIP_TRY(hipMemsetAsync(ctx->tables.p, 0xFF, b->table_slots*sizeof(uint64_t), ctx->stream));
 	}
-	HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 4*sizeof(uint64_t), ctx->stream));
+	HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, 4*sizeof(uint64_t), ctx->stream));
 	if(b->n == 0){ return KWAGE_OK; }
 
 	KmerArgs a;
@@ -204,9 +243,9 @@ int launch_kmer_stage(kwage_ctx *ctx, const kwage_params &p, kwage_batch *b, flo
 	a.complete_match = (threshold == 1.0f) ? 1 : 0;      // kwage.cpp:349
 	a.rows = d_rows;
 	a.kmers_out = d_kmers;
-	a.nkmer = (uint32_t*)ctx->nkmer.p;
-	a.qthr = (uint32_t*)ctx->qthr.p;
-	a.total_kmers = (unsigned long long*)ctx->counters.p + 1;
+	a.nkmer = ctx->d_nkmer;
+	a.qthr = ctx->d_qthr;
+	a.total_kmers = (unsigned long long*)ctx->d_counters + 1;
 	hipLaunchKernelGGL(kmer_kernel, dim3(b->n), dim3(KM_THREADS), 0, ctx->stream, a);
 	HIP_TRY(hipGetLastError());
 	return KWAGE_OK;
@@ -332,13 +371,13 @@ int launch_search_stage(kwage_group *g, kwage_batch *b, float threshold, uint32_
 	a.valid = g->d_valid;
 	a.rows = (const uint32_t*)ctx->rows.p;
 	a.pos_off = b->d_pos_off;
-	a.nkmer = (const uint32_t*)ctx->nkmer.p;
-	a.qthr = (const uint32_t*)ctx->qthr.p;
+	a.nkmer = ctx->d_nkmer;
+	a.qthr = ctx->d_qthr;
 	a.num_hash = g->params.num_hash;
 	a.n_queries = b->n;
 	a.hits = d_hits;
 	a.cap = cap;
-	a.hit_count = (unsigned long long*)ctx->counters.p;
+	a.hit_count = (unsigned long long*)ctx->d_counters;
 	a.early_exit = (flags & KWAGE_SEARCH_EARLY_EXIT) ? 1 : 0;
 	a.partial = nullptr;
 	int rc;
@@ -401,7 +440,7 @@ struct SearchOutcome {
 	uint32_t launches = 0;
 };
 
-// Full device pipeline. If own_hits, results land in ctx->hits (grown as needed and the search
+// Full device pipeline. If own_hits, results land in the ctx result block (grown as needed and the search
 // kernel re-run on overflow); otherwise in the caller's buffer (no re-run: the caller grows).
 int run_search(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
                kwage_hit *ext_hits, uint64_t ext_cap, bool own_hits, SearchOutcome *out)
@@ -416,25 +455,16 @@ int run_search(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
 	if((rc = set_device(ctx))){ return rc; }
 	if((rc = batch_prepare(b, g->params.kmer_len))){ return rc; }
 	if((rc = ctx->rows.reserve(std::max<uint64_t>(b->total_pos*g->params.num_hash, 1)*sizeof(uint32_t)))){ return rc; }
-	if((rc = ctx->h_counters.reserve(4*sizeof(uint64_t)))){ return rc; }
-
 	const bool timing = (flags & KWAGE_SEARCH_TIMING) != 0;
-	if(timing){ HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream)); }
+	const bool timing_kmer = timing && (flags & KWAGE_SEARCH_TIMING_KMER) != 0;
+	if(timing_kmer){ HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream)); }
 	if((rc = launch_kmer_stage(ctx, g->params, b, threshold, (uint32_t*)ctx->rows.p, nullptr))){ return rc; }
-	if(timing){ HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream)); }
+	if(timing_kmer){ HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream)); }
 
-	uint64_t cap = ext_cap;
-	kwage_hit *d_hits = ext_hits;
-	if(own_hits){
-		if(ctx->hits.cap == 0 && (rc = ctx->hits.reserve((1u << 20)*sizeof(kwage_hit)))){ return rc; }
-		cap = ctx->hits.cap/sizeof(kwage_hit);
-		d_hits = (kwage_hit*)ctx->hits.p;
-	}
+	uint64_t cap = own_hits ? ctx->hit_cap : ext_cap;
+	kwage_hit *d_hits = own_hits ? ctx->d_hits : ext_hits;
 
-	volatile uint64_t *hc = (volatile uint64_t*)ctx->h_counters.p;
 	out->launches = 0;
-	const uint64_t nq_bytes = (uint64_t)b->n*sizeof(uint32_t);
-	if(own_hits && (rc = ctx->h_stage.reserve(2*nq_bytes + SPEC_HITS*sizeof(kwage_hit)))){ return rc; }
 	while(true){
 		if(b->n && g->num_columns){
 			if(timing){ HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream)); }
@@ -442,32 +472,25 @@ int run_search(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
 			if(timing){ HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream)); }
 			++out->launches;
 		}
-		HIP_TRY(hipMemcpyAsync(ctx->h_counters.p, ctx->counters.p, 2*sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-		if(own_hits){
-			// per-query counts and the first SPEC_HITS records ride along, so the common case
-			// (few hits) needs a single stream synchronisation per search
-			char *hs = (char*)ctx->h_stage.p;
-			if(b->n){
-				HIP_TRY(hipMemcpyAsync(hs, ctx->nkmer.p, nq_bytes, hipMemcpyDeviceToHost, ctx->stream));
-				HIP_TRY(hipMemcpyAsync(hs + nq_bytes, ctx->qthr.p, nq_bytes, hipMemcpyDeviceToHost, ctx->stream));
-			}
-			out->staged_hits = std::min<uint64_t>(SPEC_HITS, cap);
-			HIP_TRY(hipMemcpyAsync(hs + 2*nq_bytes, d_hits, out->staged_hits*sizeof(kwage_hit), hipMemcpyDeviceToHost, ctx->stream));
-		}
-		HIP_TRY(hipStreamSynchronize(ctx->stream));
+		// ONE copy brings back the counters, the per-query arrays and (own buffer) the first SPEC_HITS
+		// records: the common case -- few hits -- needs a single D2H + synchronisation per search
+		out->staged_hits = own_hits ? std::min<uint64_t>(SPEC_HITS, cap) : 0;
+		const uint64_t bytes = ctx->head_bytes + out->staged_hits*sizeof(kwage_hit);
+		if((rc = ctx->h_stage.reserve(bytes))){ return rc; }
+		HIP_TRY(hipMemcpyAsync(ctx->h_stage.p, ctx->result.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(hipStreamSynchronize(ctx->stream));     // (polling an event instead measured no faster)
+		const uint64_t *hc = (const uint64_t*)ctx->h_stage.p;
 		out->n_hits = hc[0];
 		out->total_kmers = hc[1];
 		if(!own_hits || out->n_hits <= cap){ break; }
 		// hit buffer too small (e.g. threshold truncated to 0: every column matches): grow, re-run
-		if((rc = ctx->hits.reserve(out->n_hits*sizeof(kwage_hit)))){ return rc; }
-		cap = ctx->hits.cap/sizeof(kwage_hit);
-		d_hits = (kwage_hit*)ctx->hits.p;
-		HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(uint64_t), ctx->stream));   // hit counter only
+		if((rc = layout_result(ctx, b->n, out->n_hits, true))){ return rc; }
+		cap = ctx->hit_cap;
+		d_hits = ctx->d_hits;
+		HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(uint64_t), ctx->stream));   // hit counter only
 	}
-	if(timing){
-		HIP_TRY(hipEventElapsedTime(&out->kmer_ms, ctx->ev[0], ctx->ev[1]));
-		if(out->launches){ HIP_TRY(hipEventElapsedTime(&out->search_ms, ctx->ev[2], ctx->ev[3])); }
-	}
+	if(timing_kmer){ HIP_TRY(hipEventElapsedTime(&out->kmer_ms, ctx->ev[0], ctx->ev[1])); }
+	if(timing && out->launches){ HIP_TRY(hipEventElapsedTime(&out->search_ms, ctx->ev[2], ctx->ev[3])); }
 	return KWAGE_OK;
 }
 
@@ -520,8 +543,8 @@ extern "C" void kwage_shutdown(kwage_ctx *ctx)
 	if(!ctx){ return; }
 	(void)hipSetDevice(ctx->device);
 	if(ctx->stream){ (void)hipStreamSynchronize(ctx->stream); }
-	ctx->rows.release(); ctx->nkmer.release(); ctx->qthr.release(); ctx->tables.release();
-	ctx->hits.release(); ctx->partial.release(); ctx->counters.release(); ctx->kmers.release(); ctx->h_counters.release(); ctx->h_stage.release();
+	ctx->rows.release(); ctx->tables.release(); ctx->result.release();
+	ctx->partial.release(); ctx->kmers.release(); ctx->h_stage.release();
 	for(int i = 0; i < 4; ++i){ if(ctx->ev[i]){ (void)hipEventDestroy(ctx->ev[i]); } }
 	if(ctx->stream){ (void)hipStreamDestroy(ctx->stream); }
 	delete ctx;
@@ -901,15 +924,15 @@ extern "C" int kwage_search(kwage_group *g, kwage_batch *b, float threshold, uin
 	rs->nkmer.resize(b->n);
 	rs->qthr.resize(b->n);
 	const uint64_t nq_bytes = (uint64_t)b->n*sizeof(uint32_t);
-	const char *hs = (const char*)ctx->h_stage.p;
+	const char *hs = (const char*)ctx->h_stage.p;        // host image of the result block's head
 	if(b->n){
-		memcpy(rs->nkmer.data(), hs, nq_bytes);
-		memcpy(rs->qthr.data(), hs + nq_bytes, nq_bytes);
+		memcpy(rs->nkmer.data(), hs + 32, nq_bytes);
+		memcpy(rs->qthr.data(), hs + 32 + nq_bytes, nq_bytes);
 	}
 	const uint64_t have = std::min(so.n_hits, so.staged_hits);
-	if(have){ memcpy(rs->hits.data(), hs + 2*nq_bytes, have*sizeof(kwage_hit)); }
+	if(have){ memcpy(rs->hits.data(), hs + ctx->head_bytes, have*sizeof(kwage_hit)); }
 	if(so.n_hits > have){      // the rare large hit list: fetch the remainder
-		hipError_t e = hipMemcpyAsync(rs->hits.data() + have, (const kwage_hit*)ctx->hits.p + have,
+		hipError_t e = hipMemcpyAsync(rs->hits.data() + have, ctx->d_hits + have,
 		                              (so.n_hits - have)*sizeof(kwage_hit), hipMemcpyDeviceToHost, ctx->stream);
 		if(e == hipSuccess){ e = hipStreamSynchronize(ctx->stream); }
 		if(e != hipSuccess){ delete rs; return fail(KWAGE_ERR_DEVICE, "kwage_search: copying results failed: %s", hipGetErrorString(e)); }
@@ -951,7 +974,7 @@ extern "C" int kwage_search_device(kwage_group *g, kwage_batch *b, float thresho
 	if(rc){ return rc; }
 	*n_hits = so.n_hits;
 	if(num_query_kmer_dev && b->n){
-		HIP_TRY(hipMemcpyAsync(num_query_kmer_dev, g->ctx->nkmer.p, (size_t)b->n*sizeof(uint32_t), hipMemcpyDeviceToDevice, g->ctx->stream));
+		HIP_TRY(hipMemcpyAsync(num_query_kmer_dev, g->ctx->d_nkmer, (size_t)b->n*sizeof(uint32_t), hipMemcpyDeviceToDevice, g->ctx->stream));
 		HIP_TRY(hipStreamSynchronize(g->ctx->stream));
 	}
 	return KWAGE_OK;
@@ -971,7 +994,7 @@ extern "C" int kwage_hash_batch(kwage_ctx *ctx, const kwage_params *params, kwag
 	if((rc = ctx->kmers.reserve(np*sizeof(uint64_t)))){ return rc; }
 	if((rc = launch_kmer_stage(ctx, *params, b, 1.0f, (uint32_t*)ctx->rows.p, (uint64_t*)ctx->kmers.p))){ return rc; }
 	memcpy(kmer_offsets, b->h_pos_off.data(), ((size_t)b->n + 1)*sizeof(uint64_t));
-	if(b->n){ HIP_TRY(hipMemcpyAsync(num_query_kmer, ctx->nkmer.p, (size_t)b->n*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
+	if(b->n){ HIP_TRY(hipMemcpyAsync(num_query_kmer, ctx->d_nkmer, (size_t)b->n*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
 	if(kmers && b->total_pos){ HIP_TRY(hipMemcpyAsync(kmers, ctx->kmers.p, b->total_pos*sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream)); }
 	if(rows && b->total_pos){ HIP_TRY(hipMemcpyAsync(rows, ctx->rows.p, b->total_pos*params->num_hash*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -986,8 +1009,8 @@ extern "C" int kwage_stream_read_gbps(kwage_group *g, uint64_t bytes, uint32_t i
 	if(rc){ return rc; }
 	bytes = std::min(bytes, g->alloc_bytes)/16*16;
 	if(bytes == 0){ return fail(KWAGE_ERR_ARG, "kwage_stream_read_gbps: nothing to read"); }
-	if((rc = ctx->counters.reserve(4*sizeof(uint64_t)))){ return rc; }
-	uint32_t *sink = (uint32_t*)((uint64_t*)ctx->counters.p + 3);
+	if((rc = layout_result(ctx, 0, 0, false))){ return rc; }
+	uint32_t *sink = (uint32_t*)(ctx->d_counters + 3);
 	const uint64_t n16 = bytes/16;
 	hipLaunchKernelGGL(stream_read_kernel, dim3(256*8), dim3(256), 0, ctx->stream, (const u32x4*)g->d_bits, n16, sink);   // warm-up
 	HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));

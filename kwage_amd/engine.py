@@ -18,6 +18,7 @@ from .native import Params, check, lib
 
 SEARCH_EARLY_EXIT = 1
 SEARCH_TIMING = 2
+SEARCH_TIMING_KMER = 4
 
 HIT_DTYPE = np.dtype([("query", "<u4"), ("column", "<u4"), ("num_match", "<u4")])
 
