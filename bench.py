@@ -143,7 +143,14 @@ def main():
     w = synth.WORKLOADS[args.workload]
     ctx = ka.Context(local_rank)
     t_build = time.perf_counter()
-    s = synth.build(ctx, w, seed=1, column_seed=rank)
+    multi = None
+    if args.workload == "c5":
+        # adaptive filter sizes: several groups searched back to back; everything below treats the first
+        # group as `s` for the shared query batch and sums work / kernel time over the groups
+        multi = synth.build_multi(ctx, synth.C5_GROUPS, w, seed=1, column_seed=rank)
+        s = multi[0]
+    else:
+        s = synth.build(ctx, w, seed=1, column_seed=rank)
     t_build = time.perf_counter() - t_build
     flags = ka.SEARCH_TIMING | (ka.SEARCH_EARLY_EXIT if args.early_exit else 0)
     threshold = w.threshold
@@ -152,17 +159,24 @@ def main():
     if world > 1:
         from kwage_amd.distributed import ShardedSearch, device_tensor_search_fn
         dev = "cuda:%d" % local_rank
-        ss = ShardedSearch(dist, rank, world, int(s.group.column_span),
-                           device_tensor_search_fn(s.group, flags, dev), device=dev if backend == "nccl" else "cpu")
+        ss = [ShardedSearch(dist, rank, world, int(m.group.column_span),
+                            device_tensor_search_fn(m.group, flags, dev), device=dev if backend == "nccl" else "cpu")
+              for m in (multi or [s])]
 
     def step():
         """One pass of the hot path; returns (result-or-None, search_kernel_ms, hits delivered to rank 0)."""
+        if world == 1 and multi is not None:
+            rs = [m.group.search(s.batch, threshold, flags) for m in multi]
+            return rs, sum(r.search_kernel_ms for r in rs), sum(len(r.hits) for r in rs)
         if world == 1:
             r = s.group.search(s.batch, threshold, flags)
             return r, r.search_kernel_ms, len(r.hits)
         # multi-GPU: hits stay in HBM, ONE gatherv over RCCL, rank 0 concatenates + sorts
-        merged, _ = ss.search(s.batch, threshold)
-        return None, 0.0, (len(merged) if merged is not None else 0)
+        total = 0
+        for one in ss:          # one group after the other; each ends in ONE gatherv of its hit list
+            merged, _ = one.search(s.batch, threshold)
+            total += len(merged) if merged is not None else 0
+        return None, 0.0, total
 
     def sync_all():
         ctx.sync()
@@ -189,13 +203,18 @@ def main():
         dt = float(tmax.item())
 
     # work per step (identical on every rank: same queries, same column count)
-    probe = last if last is not None else s.group.search(s.batch, threshold, flags)
-    bit_tests_rank = int(probe.bit_tests)
-    alg_bytes_rank = int(probe.algorithmic_bytes)
+    probe = last if last is not None else [m.group.search(s.batch, threshold, flags) for m in (multi or [s])]
+    if isinstance(probe, list):
+        bit_tests_rank = int(sum(r.bit_tests for r in probe))
+        alg_bytes_rank = int(sum(r.algorithmic_bytes for r in probe))
+        probe = probe[0]
+    else:
+        bit_tests_rank = int(probe.bit_tests)
+        alg_bytes_rank = int(probe.algorithmic_bytes)
     if world > 1:
         kernel_ms = []
         for _ in range(3):
-            kernel_ms.append(s.group.search(s.batch, threshold, flags).search_kernel_ms)
+            kernel_ms.append(sum(m.group.search(s.batch, threshold, flags).search_kernel_ms for m in (multi or [s])))
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -219,10 +238,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 (bitwise AND / bit-sliced integer counters)",
             "data": "synthetic",
-            "config": {"workload": w.name, "samples_per_gpu": w.num_samples, "log_2_filter_len": w.log_2_filter_len,
+            "config": {"workload": w.name, "samples_per_gpu": int(sum(ns for _, ns in synth.C5_GROUPS)) if multi else w.num_samples, "log_2_filter_len": w.log_2_filter_len,
                        "kmer_len": w.kmer_len, "num_hash": w.num_hash, "queries": w.num_queries, "query_len": w.query_len,
                        "threshold": w.threshold, "early_exit": bool(args.early_exit), "density": w.density_q8 / 256.0,
-                       "db_bytes_per_gpu": int(s.group.device_bytes), "sharding": "columns (samples) over %d GPU(s)" % world,
+                       "db_bytes_per_gpu": int(sum(m.group.device_bytes for m in multi)) if multi else int(s.group.device_bytes),
+                       "groups": [[lg, ns] for lg, ns in synth.C5_GROUPS] if multi else None, "sharding": "columns (samples) over %d GPU(s)" % world,
                        "total_kmers_per_step": int(probe.total_kmers), "hits_per_step": int(nhits),
                        "db_build_s": round(t_build, 2)},
             "hbm_gbps_algorithmic_whole_step": round(alg_bytes_rank * world * args.steps / dt / 1e9, 1),
@@ -241,8 +261,9 @@ def main():
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
 
-    s.batch.close()
-    s.group.close()
+    for m in (multi or [s]):
+        m.batch.close()
+        m.group.close()
     ctx.close()
     if dist is not None:
         dist.barrier()

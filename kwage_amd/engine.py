@@ -191,3 +191,29 @@ def hash_batch(ctx: Context, kmer_len: int, num_hash: int, log_2_filter_len: int
         out_k.append(kmers[o:o + n].copy())
         out_r.append(rows[o * num_hash:(o + n) * num_hash].reshape(n, num_hash).copy())
     return out_k, out_r
+
+
+class Database:
+    """Several Groups searched as one database -- what a KWAGE database directory is: `.db` files with
+    different (kmer_len, num_hash, log_2_filter_len) because maestro picks the Bloom parameters per
+    sample size (bloom.cpp:10-68 optimal_bloom_param), the adaptive / COBS-style layout of BASELINE
+    config C5.  Hits carry the group index; columns are local to the group."""
+
+    def __init__(self, groups: Sequence[Group]):
+        self.groups = list(groups)
+
+    @property
+    def num_columns(self) -> int:
+        return sum(g.num_columns for g in self.groups)
+
+    @property
+    def device_bytes(self) -> int:
+        return sum(g.device_bytes for g in self.groups)
+
+    def search(self, batch: Batch, threshold: float, flags: int = 0) -> List[SearchResult]:
+        # the k-mer stage is re-run per group: row indices depend on log_2_filter_len (kwage.cpp:411-412)
+        return [search(g, batch, threshold, flags) for g in self.groups]
+
+    def close(self) -> None:
+        for g in self.groups:
+            g.close()

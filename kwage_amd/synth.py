@@ -43,9 +43,19 @@ WORKLOADS: Dict[str, Workload] = {
     # count path (threshold < 1), 5 hashes: the C5 flavour on one filter size
     "c5s": Workload("C5-single-group: 200k samples x 2^22-bit filters, 5 hashes, 1k x 1 kb queries, t=0.8", 200_000, 22,
                     31, 5, 1000, 1000, 0.8, density_q8=194, num_genomes=32, genome_len=50_000),
+    # BASELINE.json configs[4], per-GPU share; the groups are C5_GROUPS (bench.py --workload c5)
+    "c5": Workload("C5: adaptive 2^18-2^25-bit filter groups (1.09M samples/GPU), 5 hashes, 1k x 1 kb queries, t=0.8", 0, 0, 31, 5,
+                   1000, 1000, 0.8, density_q8=194, num_genomes=32, genome_len=50_000),
     # small shapes for tests
     "tiny": Workload("tiny", 5000, 14, 31, 2, 64, 300, 1.0, density_q8=128, num_genomes=4, genome_len=1000),
 }
+
+
+# BASELINE.json configs[4] (C5), the share of ONE GPU: adaptive filter sizes 2^18..2^25, more samples in the
+# small filters (as optimal_bloom_param would assign them), 5 hash functions, threshold 0.8.
+# sum_g N(g) * 2^g / 8 = 189 GB per GPU; 1.09 M samples per GPU (8.7 M on 8 GPUs).
+C5_GROUPS = [(18, 400_000), (19, 300_000), (20, 200_000), (21, 100_000), (22, 50_000), (23, 25_000), (24, 12_500), (25, 6_000)]
+C5_TEST_GROUPS = [(10, 3000), (11, 2000), (12, 1000), (13, 500)]
 
 
 @dataclass
@@ -117,3 +127,13 @@ def build(ctx: Context, w: Workload, seed: int = 1, column_seed: int = 0) -> Syn
     s = Synth(w, g, genomes, planted, queries, qsrc)
     s.batch = Batch(ctx, queries)
     return s
+
+
+def build_multi(ctx: Context, groups: Sequence[Tuple[int, int]], base: Workload, seed: int = 1, column_seed: int = 0):
+    """One Synth per (log_2_filter_len, num_samples) group, all sharing genomes and queries (same seed)."""
+    from dataclasses import replace
+    out = []
+    for gi, (lg, ns) in enumerate(groups):
+        w = replace(base, name="%s/L%d" % (base.name, lg), log_2_filter_len=lg, num_samples=ns)
+        out.append(build(ctx, w, seed=seed, column_seed=column_seed * 1000 + gi))
+    return out

@@ -308,3 +308,31 @@ def test_cli_sharded_over_two_contexts(ka, oracle):
             assert one.stdout == two.stdout == three.stdout      # deterministic, independent of the sharding
             exp = open(os.path.join(cdir, "expected_t%s.%s" % (thr, fmt)), encoding="latin-1").read()
             assert sorted(two.stdout.decode("latin-1").splitlines()) == sorted(exp.splitlines())
+
+
+def test_mixed_filter_size_groups_five_hashes(ka, ctx, oracle):
+    """BASELINE config C5 at test scale: adaptive filter sizes (several log_2_filter_len groups), 5
+    hash functions, threshold 0.8 -- every group against the oracle on the bits resident in HBM."""
+    from kwage_amd import synth
+    base = synth.Workload("c5-test", 0, 0, 31, 5, 24, 400, 0.8, density_q8=194, num_genomes=4, genome_len=2000)
+    parts = synth.build_multi(ctx, synth.C5_TEST_GROUPS, base)
+    db = ka.Database([p.group for p in parts])
+    assert db.num_columns == sum(n for _, n in synth.C5_TEST_GROUPS)
+    for threshold in (0.8, 1.0):
+        results = db.search(parts[0].batch, threshold)
+        for p, r in zip(parts, results):
+            w = p.workload
+            image = p.group.read_rows(np.arange(1 << w.log_2_filter_len))
+            per_q = r.per_query()
+            for qi, q in enumerate(p.queries):
+                kmers = oracle.unique_kmers(q, w.kmer_len)
+                exp, _ = oracle.search_image(image, image.shape[1], w.kmer_len, w.num_hash, w.log_2_filter_len,
+                                             w.num_samples, kmers, float(np.float32(threshold)))
+                assert per_q[qi] == exp, (w.log_2_filter_len, threshold, qi)
+            # planted genomes are found in every group
+            for qi, gi in enumerate(p.query_genome):
+                if gi >= 0:
+                    assert set(p.planted[gi]) <= {c for c, _ in per_q[qi]}
+    for p in parts:
+        p.batch.close()
+    db.close()
