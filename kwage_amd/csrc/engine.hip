@@ -90,6 +90,10 @@ struct kwage_ctx {
 	kwage_hit *d_hits = nullptr;
 	uint64_t hit_cap = 0, head_bytes = 0;
 	PinBuf h_stage;        // host image of the head of the result block + the first SPEC_HITS records
+	// database loading: two pinned + two device staging buffers, kept across files
+	PinBuf load_pin[2];
+	DevBuf load_dev[2];
+	hipEvent_t load_done[2] = {nullptr, nullptr};
 };
 
 struct kwage_group {
@@ -545,6 +549,10 @@ extern "C" void kwage_shutdown(kwage_ctx *ctx)
 	if(ctx->stream){ (void)hipStreamSynchronize(ctx->stream); }
 	ctx->rows.release(); ctx->tables.release(); ctx->result.release();
 	ctx->partial.release(); ctx->kmers.release(); ctx->h_stage.release();
+	for(int i = 0; i < 2; ++i){
+		ctx->load_pin[i].release(); ctx->load_dev[i].release();
+		if(ctx->load_done[i]){ (void)hipEventDestroy(ctx->load_done[i]); }
+	}
 	for(int i = 0; i < 4; ++i){ if(ctx->ev[i]){ (void)hipEventDestroy(ctx->ev[i]); } }
 	if(ctx->stream){ (void)hipStreamDestroy(ctx->stream); }
 	delete ctx;
@@ -706,18 +714,18 @@ extern "C" int kwage_group_add_db_file(kwage_group *g, const char *path, uint64_
 	uint64_t byte0 = 0;
 	if((rc = group_reserve_columns(g, h.num_filter, &byte0))){ return rc; }
 
-	// double-buffered: fill pinned buffer A (pread / inflate) while buffer B is copied + scattered
-	const uint64_t chunk_rows = std::max<uint64_t>(1, std::min<uint64_t>(g->nrows, (32ull << 20)/width));
+	// double-buffered: fill pinned buffer A (parallel pread / inflate) while buffer B is copied + scattered
+	const uint64_t chunk_rows = std::max<uint64_t>(1, std::min<uint64_t>(g->nrows, (64ull << 20)/width));
 	const uint64_t chunk_bytes = chunk_rows*width;
-	PinBuf pin[2];
-	DevBuf dev[2];
-	hipEvent_t done[2] = {nullptr, nullptr};
+	PinBuf *pin = ctx->load_pin;
+	DevBuf *dev = ctx->load_dev;
+	hipEvent_t *done = ctx->load_done;
 	bool used[2] = {false, false};
 	hipError_t e = hipSuccess;
 	for(int i = 0; i < 2 && rc == KWAGE_OK; ++i){
 		rc = pin[i].reserve(chunk_bytes);
 		if(!rc){ rc = dev[i].reserve(chunk_bytes); }
-		if(!rc && hipEventCreate(&done[i]) != hipSuccess){ rc = fail(KWAGE_ERR_DEVICE, "hipEventCreate failed"); }
+		if(!rc && !done[i] && hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess){ rc = fail(KWAGE_ERR_DEVICE, "hipEventCreate failed"); }
 	}
 	int cur = 0;
 	for(uint64_t r0 = 0; r0 < g->nrows && rc == KWAGE_OK; r0 += chunk_rows, cur ^= 1){
@@ -736,10 +744,6 @@ extern "C" int kwage_group_add_db_file(kwage_group *g, const char *path, uint64_
 		used[cur] = true;
 	}
 	(void)hipStreamSynchronize(ctx->stream);
-	for(int i = 0; i < 2; ++i){
-		pin[i].release(); dev[i].release();
-		if(done[i]){ (void)hipEventDestroy(done[i]); }
-	}
 	if(rc){ return rc; }
 	if(first_column){ *first_column = byte0*8; }
 	if(num_filter){ *num_filter = h.num_filter; }

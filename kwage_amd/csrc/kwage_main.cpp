@@ -13,7 +13,9 @@
 //   KWAGE_DEVICES     "all" or "0,1,...": shard the database files over several GPUs
 //   KWAGE_EARLY_EXIT  1 = enable the reference's early-exit shortcut on the device (default 1)
 //   KWAGE_BATCH_BASES max bases per query batch (default 256 Mi)
+//   KWAGE_VERBOSE     1 = per-stage wall times on stderr
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -387,11 +389,16 @@ int main(int argc, char *argv[])
 
 		mutex merge_lock;
 		vector<string> worker_error(ndev);
+		const bool verbose = getenv("KWAGE_VERBOSE") && atoi(getenv("KWAGE_VERBOSE")) != 0;
+		auto now = []() { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); };
+		const double t_start = now();
 
 		auto worker = [&](size_t di) {
 			try{
 				kwage_ctx *ctx = NULL;
 				check(kwage_init(devices[di], &ctx));
+				double t_load = 0, t_search = 0, gb_loaded = 0;
+				const double t_init = now() - t_start;
 				ResultMap local_file_results, local_cmdline_results;
 				for(map<Key, vector<uint32_t> >::const_iterator gi = groups.begin(); gi != groups.end(); ++gi){
 					// this device's share: a file belongs to the device that owns its middle column
@@ -416,6 +423,7 @@ int main(int argc, char *argv[])
 						span_bytes = (span_bytes + 15)/16*16 + ((uint64_t)files[members[m]].header.num_filter + 7)/8;
 					}
 					kwage_group *grp = NULL;
+					double t0 = now();
 					check(kwage_group_create(ctx, &p, span_bytes*8, &grp));
 					vector<DbFileEntry*> gfiles;
 					for(size_t m = 0; m < members.size(); ++m){
@@ -426,13 +434,22 @@ int main(int argc, char *argv[])
 						gfiles.push_back(&f);
 					}
 					check(kwage_group_finalize(grp));
+					t_load += now() - t0;
+					gb_loaded += (double)kwage_group_row_bytes(grp)*(double)(1ull << p.log_2_filter_len)/1e9;
+					t0 = now();
 					search_queries(ctx, grp, gfiles, members, cmdline_queries, opt.threshold, flags, max_batch_bases,
 					               local_cmdline_results);
 					search_queries(ctx, grp, gfiles, members, file_queries, opt.threshold, flags, max_batch_bases,
 					               local_file_results);
+					t_search += now() - t0;
 					kwage_group_destroy(grp);
 				}
 				kwage_shutdown(ctx);
+				if(verbose){
+					lock_guard<mutex> lk(merge_lock);
+					cerr << "[kwage] device " << devices[di] << ": init " << t_init << " s, loaded " << gb_loaded << " GB in " << t_load
+						<< " s (" << (t_load > 0 ? gb_loaded/t_load : 0) << " GB/s), search " << t_search << " s" << endl;
+				}
 				// merge, as the reference's `omp critical` section does (kwage.cpp:154-177)
 				lock_guard<mutex> lk(merge_lock);
 				for(ResultMap::const_iterator i = local_file_results.begin(); i != local_file_results.end(); ++i){
