@@ -6,8 +6,11 @@ the addressed rows -- so every rank holds all rows of its
 block of columns, searches it independently (queries are replicated: kilobytes), and the only
 exchange is the variable-length gather of hit records to rank 0:
 
-    counts  <- all_gather(one int64 per rank)
-    hits    <- gatherv: one grouped send/recv (RCCL has no native gatherv), exact sizes, no padding
+    default ("padded"): ONE collective -- all_gather of fixed-capacity buffers [count | hits...];
+             if any rank's count exceeds the capacity every rank sees it, the capacity is doubled
+             and the exchange repeated (first steps only)
+    "p2p":   counts <- all_gather(one int64 per rank); hits <- one grouped send/recv with exact sizes
+             (RCCL has no native gatherv)
 
 Rank 0 concatenates; no merge is needed because column ranges are disjoint.  No row data ever
 crosses xGMI.  The reference has no counterpart (its only parallel axis is OpenMP over .db files,
@@ -94,20 +97,43 @@ def merge_hits(parts: Sequence[np.ndarray], column_base: Sequence[int]) -> np.nd
     return allh[order]
 
 
+def merge_hits_torch(parts, column_base):
+    """Device-side merge: records from all ranks -> global columns, sorted by (query, column) with
+    one torch.sort of 64-bit keys. parts: list of int32 [n_i, 3] tensors on one device."""
+    import torch
+    keys, vals = [], []
+    for r, p in enumerate(parts):
+        if p.shape[0] == 0:
+            continue
+        q = p[:, 0].to(torch.int64)
+        c = p[:, 1].to(torch.int64) + int(column_base[r])
+        keys.append((q << 32) | c)
+        vals.append(p[:, 2].to(torch.int64))
+    if not keys:
+        return np.zeros((0, 3), dtype=np.int64)
+    key = torch.cat(keys)
+    val = torch.cat(vals)
+    key, order = torch.sort(key)
+    out = torch.stack([key >> 32, key & 0xFFFFFFFF, val[order]], dim=1)
+    return out.cpu().numpy()
+
+
 @dataclass
 class ShardedSearch:
     """One rank's view of a column-sharded search.
 
-    search_fn(seqs, threshold) -> ([n,3] int array of (query, LOCAL column, num_match),
-                                   per-query num_query_kmer array)
-    is the rank-local searcher: on a GPU box the HIP engine (device_search_fn below); tests inject
-    a CPU stand-in to rehearse the exchange under gloo."""
+    search_fn(queries, threshold) -> ([n,3] int array or torch tensor of (query, LOCAL column,
+                                      num_match), per-query num_query_kmer array)
+    is the rank-local searcher: on a GPU box the HIP engine (device_tensor_search_fn below); tests
+    inject a CPU stand-in to rehearse the exchange under gloo."""
     dist: object
     rank: int
     world: int
     local_columns: int                 # column span of this rank's block
     search_fn: Callable
     device: str = "cpu"
+    exchange: str = "padded"           # "padded" (one all_gather) or "p2p" (count all_gather + grouped send/recv)
+    capacity: int = 4096               # records per rank in the padded exchange; grows on overflow
 
     def __post_init__(self):
         import torch
@@ -117,6 +143,27 @@ class ShardedSearch:
         spans = [int(s.item()) for s in spans]
         self.column_base = [int(sum(spans[:r])) for r in range(self.world)]
         self.total_columns = int(sum(spans))
+        self._send = None
+
+    def _exchange_padded(self, t):
+        """all_gather of [1 + capacity, 3] int32 buffers; row 0 carries the record count."""
+        import torch
+        n = int(t.shape[0])
+        while True:
+            cap = self.capacity
+            if self._send is None or self._send.shape[0] != cap + 1 or self._send.device != t.device:
+                self._send = torch.zeros((cap + 1, 3), dtype=torch.int32, device=t.device)
+                self._recv = torch.empty((self.world * (cap + 1), 3), dtype=torch.int32, device=t.device)
+            self._send[0, 0] = n
+            m = min(n, cap)
+            if m:
+                self._send[1:1 + m] = t[:m]
+            self.dist.all_gather_into_tensor(self._recv, self._send)
+            recv = self._recv.view(self.world, cap + 1, 3)
+            counts = recv[:, 0, 0].tolist()                       # one small D2H: every rank learns all counts
+            if max(counts) <= cap:
+                return [recv[r, 1:1 + counts[r]] for r in range(self.world)]
+            self.capacity = max(2 * max(counts), 2 * cap)         # same decision on every rank -> no deadlock
 
     def search(self, queries, threshold: float):
         """`queries` is handed to search_fn unchanged (a list of strings, or a resident Batch for the
@@ -132,11 +179,15 @@ class ShardedSearch:
             t = torch.as_tensor(np.ascontiguousarray(np.asarray(local, dtype=np.int32).reshape(-1, 3)))
             if self.device != "cpu":
                 t = t.to(self.device)
-        outs = gatherv_hits(t, self.dist, self.rank, self.world, 0, device=t.device)
+        if self.exchange == "p2p":
+            outs = gatherv_hits(t, self.dist, self.rank, self.world, 0, device=t.device)
+        else:
+            outs = self._exchange_padded(t)
         if self.rank != 0:
             return None, nk
-        parts = [o.cpu().numpy() for o in outs]
-        return merge_hits(parts, self.column_base), nk
+        if outs[0].is_cuda:
+            return merge_hits_torch(outs, self.column_base), nk
+        return merge_hits([o.numpy() for o in outs], self.column_base), nk
 
 
 def device_search_fn(group, ctx, flags: int = 0):

@@ -65,10 +65,13 @@ def _worker(rank, world, port, out_dir):
                 rows += [(qi, c, m) for c, m in hits]
             return np.array(rows, dtype=np.int64).reshape(-1, 3), np.array(nk, dtype=np.uint32)
 
-        ss = ShardedSearch(dist, rank, world, e - s, search_fn)
-        assert ss.total_columns == 100 and ss.column_base == [b[0] for b in bounds]
-        for threshold in (1.0, 0.5, 0.0001):
+        for exchange, threshold in (("padded", 1.0), ("padded", 0.5), ("padded", 0.0001), ("p2p", 1.0), ("p2p", 0.0001)):
+            # capacity 16 forces the grow-and-repeat path of the padded exchange at low thresholds
+            ss = ShardedSearch(dist, rank, world, e - s, search_fn, exchange=exchange, capacity=16)
+            assert ss.total_columns == 100 and ss.column_base == [b[0] for b in bounds]
             merged, nk = ss.search(seqs, threshold)
+            if exchange == "padded" and threshold == 0.0001:
+                assert ss.capacity > 16
             if rank == 0:
                 exp = []
                 for qi, q in enumerate(seqs):
@@ -76,7 +79,7 @@ def _worker(rank, world, port, out_dir):
                     hits, _ = oracle.search_image(db.rows, h.slice_size, h.kmer_len, h.num_hash, h.log_2_filter_len,
                                                   h.num_filter, kmers, float(np.float32(threshold)))
                     exp += [(qi, c, m) for c, m in hits]
-                assert merged.tolist() == [list(x) for x in exp], threshold
+                assert merged.tolist() == [list(x) for x in exp], (exchange, threshold)
         # an empty local hit list on one rank must not hang the gather
         ss2 = ShardedSearch(dist, rank, world, e - s,
                             lambda q, t: (np.zeros((0, 3), np.int64) if rank else np.array([[0, 1, 2]]), np.zeros(1, np.uint32)))
