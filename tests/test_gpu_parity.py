@@ -336,3 +336,35 @@ def test_mixed_filter_size_groups_five_hashes(ka, ctx, oracle):
     for p in parts:
         p.batch.close()
     db.close()
+
+
+def test_cli_error_and_empty_cases(ka, tmp_path):
+    """Failure behaviour of the drop-in: what the reference's `main` does when search() throws
+    (kwage.cpp:322-333: message on stderr, EXIT_FAILURE; its OpenMP build aborts instead because the
+    throw crosses the parallel region) and what it prints when nothing matches."""
+    from kwage_amd import native
+    good = os.path.join(GOLDEN, "k32", "k32.db")
+    q = os.path.join(GOLDEN, "k32", "q.fna")
+    raw = bytearray(open(good, "rb").read())
+    raw[28] = 1                                         # hash_func = 1: "Unknown hash function" (hash.cpp:92)
+    (tmp_path / "badhash.db").write_bytes(raw)
+    (tmp_path / "trunc.db").write_bytes(bytes(raw[:28]) + b"\0" + bytes(raw[29:300]))
+    (tmp_path / "empty.fa").write_text("")
+    (tmp_path / "onlydef.fa").write_text(">x\n")
+    run = lambda *a: subprocess.run([native.KWAGE_BIN] + list(a), capture_output=True, text=True)
+    r = run("-d", str(tmp_path / "badhash.db"), "-i", q, "--o.csv")
+    assert r.returncode == 1 and "Unknown hash function" in r.stderr and "Caught the" in r.stderr
+    r = run("-d", good, "-i", str(tmp_path / "missing.fa"), "--o.csv")
+    assert r.returncode == 1 and "Error opening: " in r.stderr
+    r = run("-d", str(tmp_path / "trunc.db"), "-i", q, "--o.csv")
+    assert r.returncode == 1 and r.stdout == ""
+    header = "query,num_kmers,num_kmers_found,percent_kmers_found,sample_metadata\n"
+    for qf in ("empty.fa", "onlydef.fa"):
+        r = run("-d", good, "-i", str(tmp_path / qf), "--o.csv")
+        assert r.returncode == 0 and r.stdout == header and "Search complete in" in r.stderr
+    r = run("-d", good, "--o.csv", "ACGT")              # too short for k: silently no result (kwage.cpp:369-371)
+    assert r.returncode == 0 and r.stdout == header
+    r = run("-d", good, "--o.json", "ACGT")
+    assert r.returncode == 0 and r.stdout == ""         # JSON: nothing at all when no query matched
+    r = run("-d", str(tmp_path / "nonexist.db"), "--o.csv", "ACGT")
+    assert r.returncode == 1 and "FindFiles::next: Unable to stat entry" in r.stderr
