@@ -40,6 +40,9 @@ WORKLOADS: Dict[str, Workload] = {
     # BASELINE.json configs[2]
     "c3": Workload("C3: 1M samples x 2^20-bit filters, 100k x 150 bp queries, 1 hash, t=1.0", 1_000_000, 20, 31, 1,
                    100_000, 150, 1.0, num_genomes=64, genome_len=150_000),
+    # BASELINE.json configs[3] (C4), the share of ONE GPU: 10M samples column-sharded over 8 GPUs
+    "c4": Workload("C4 per-GPU share: 1.25M samples x 2^20-bit filters, 10k x 1 kb queries, 1 hash, t=1.0", 1_250_000, 20, 31, 1,
+                   10_000, 1000, 1.0, num_genomes=64, genome_len=100_000),
     # count path (threshold < 1), 5 hashes: the C5 flavour on one filter size
     "c5s": Workload("C5-single-group: 200k samples x 2^22-bit filters, 5 hashes, 1k x 1 kb queries, t=0.8", 200_000, 22,
                     31, 5, 1000, 1000, 0.8, density_q8=194, num_genomes=32, genome_len=50_000),
