@@ -199,6 +199,12 @@ typedef struct {
 int kwage_build_db(kwage_ctx *ctx, const char *out_path, const kwage_params *params,
                    const char *const *bloom_paths, uint32_t n, kwage_build_stats *stats);
 
+/* Column-wise re-pack: the columns of several same-parameter `.db` files (raw or compressed) become
+ * ONE raw `.db` file with contiguous columns, in file order then column order -- the bit-level work of
+ * the reference's merge_db.cpp:268-820 (get_bit/set_bit per bit there; shift-and-OR on the device
+ * here), without its file naming / size policy.  The reference `kwage` reads the result. */
+int kwage_repack_db(kwage_ctx *ctx, const char *out_path, const char *const *in_paths, uint32_t n);
+
 /* ------------------------------------------------------------------------------------
  * Host-side helpers that mirror the reference's host code for this path (no device needed).
  * ---------------------------------------------------------------------------------- */

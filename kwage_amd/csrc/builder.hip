@@ -96,6 +96,34 @@ __global__ __launch_bounds__(TB_WAVES*64) void transpose_bits_kernel(
 	}
 }
 
+// Re-pack: OR `nbits` columns of a source block (rows of `src_width` bytes, column 0 at bit 0) into
+// the destination rows starting at destination column dst_bit0.  One thread per (row, destination dword).
+__global__ void pack_columns_kernel(uint32_t *dst, uint64_t dst_stride_words, uint64_t dst_bit0,
+                                    const uint8_t *src, uint64_t src_width, uint64_t nbits, uint64_t nrows)
+{
+	const uint64_t j0 = dst_bit0/32, j1 = (dst_bit0 + nbits + 31)/32;
+	const uint64_t per_row = j1 - j0;
+	const uint64_t total = nrows*per_row;
+	for(uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x*blockDim.x){
+		const uint64_t r = i / per_row, j = j0 + i % per_row;
+		const uint64_t lo = (j*32 > dst_bit0) ? j*32 : dst_bit0;
+		const uint64_t hi = ((j + 1)*32 < dst_bit0 + nbits) ? (j + 1)*32 : (dst_bit0 + nbits);
+		if(lo >= hi){ continue; }
+		const uint64_t sbit = lo - dst_bit0;                      // first source column of this dword
+		const uint32_t nb = (uint32_t)(hi - lo);
+		const uint8_t *row = src + r*src_width;
+		uint64_t v = 0;
+		const uint64_t byte0 = sbit/8;
+#pragma unroll
+		for(int b = 0; b < 5; ++b){
+			if(byte0 + b < src_width){ v |= (uint64_t)row[byte0 + b] << (8*b); }
+		}
+		v >>= (sbit % 8);
+		const uint32_t bits = (uint32_t)(v & ((nb == 32) ? 0xFFFFFFFFull : ((1ull << nb) - 1)));
+		if(bits){ atomicOr(dst + r*dst_stride_words + j, bits << (uint32_t)(lo - j*32)); }
+	}
+}
+
 struct BloomFile {
 	int fd = -1;
 	const unsigned char *map = nullptr;
@@ -287,5 +315,125 @@ extern "C" int kwage_build_db(kwage_ctx *ctx, const char *out_path, const kwage_
 		stats->transpose_kernel_ms = (float)t_kernel_ms;
 		stats->db_bytes = pos;
 	}
+	return KWAGE_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Column-wise re-pack of several same-parameter `.db` files into one (what the reference's
+// merge_db.cpp:268-820 does pairwise with get_bit/set_bit, without its file-size policy): columns keep
+// their order (file order, then column), FilterInfo records are copied verbatim, the slice block
+// CRC32 and the metadata index are recomputed.
+// ---------------------------------------------------------------------------------------------
+extern "C" int kwage_repack_db(kwage_ctx *ctx, const char *out_path, const char *const *in_paths, uint32_t n)
+{
+	if(!ctx || !out_path || !in_paths || n == 0){ return fail(KWAGE_ERR_ARG, "kwage_repack_db: bad argument"); }
+	if(hipSetDevice(ctx_device(ctx)) != hipSuccess){ return fail(KWAGE_ERR_DEVICE, "hipSetDevice failed"); }
+	hipStream_t stream = ctx_stream(ctx);
+
+	std::vector<DbSliceSource> src(n);
+	std::vector<DbInfo> info(n);
+	std::string err;
+	uint64_t total_cols = 0, max_width = 0;
+	for(uint32_t i = 0; i < n; ++i){
+		if(!src[i].open(in_paths[i], err) || !info[i].open(in_paths[i], err)){ return fail(KWAGE_ERR_IO, "%s", err.c_str()); }
+		const kwage_db_header &h = src[i].header, &h0 = src[0].header;
+		if(h.kmer_len != h0.kmer_len || h.num_hash != h0.num_hash || h.log_2_filter_len != h0.log_2_filter_len || h.hash_func != h0.hash_func){
+			return fail(KWAGE_ERR_ARG, "kwage_repack_db: %s has different Bloom parameters", in_paths[i]);   // merge_db.cpp condition 1
+		}
+		total_cols += h.num_filter;
+		max_width = std::max(max_width, src[i].slice_size);
+	}
+	if(total_cols == 0 || total_cols > 0xFFFFFFFFull){ return fail(KWAGE_ERR_ARG, "kwage_repack_db: bad total column count"); }
+	const uint64_t nrows = src[0].nrows;
+	const uint64_t out_slice = (total_cols + 7)/8;
+	const uint64_t dst_words = (out_slice + 3)/4;                 // device rows are padded to whole dwords
+
+	FILE *fout = fopen(out_path, "wb");
+	if(!fout){ return fail(KWAGE_ERR_IO, "Unable to open %s for writing", out_path); }
+	unsigned char hdr[DB_HEADER_BYTES];
+	memset(hdr, 0, sizeof(hdr));
+	bool ok = fwrite(hdr, 1, sizeof(hdr), fout) == sizeof(hdr);
+
+	uint64_t chunk_rows = nrows;
+	while(chunk_rows > 1 && (chunk_rows*dst_words*4 > (256ull << 20) || chunk_rows*max_width > (256ull << 20))){ chunk_rows /= 2; }
+	void *d_dst = nullptr, *d_src = nullptr, *h_buf = nullptr;
+	const uint64_t host_bytes = std::max(chunk_rows*dst_words*4, chunk_rows*max_width);
+	hipError_t e = hipMalloc(&d_dst, chunk_rows*dst_words*4);
+	if(e == hipSuccess){ e = hipMalloc(&d_src, chunk_rows*max_width); }
+	if(e == hipSuccess){ e = hipHostMalloc(&h_buf, host_bytes, hipHostMallocDefault); }
+	uint32_t crc = 0;
+	std::vector<unsigned char> packed;
+	for(uint64_t r0 = 0; r0 < nrows && ok && e == hipSuccess; r0 += chunk_rows){
+		const uint64_t nr = std::min(chunk_rows, nrows - r0);
+		e = hipMemsetAsync(d_dst, 0, nr*dst_words*4, stream);
+		uint64_t bit0 = 0;
+		for(uint32_t i = 0; i < n && e == hipSuccess; ++i){
+			if(!src[i].read_rows(r0, nr, (unsigned char*)h_buf, err)){ ok = false; break; }
+			e = hipMemcpyAsync(d_src, h_buf, nr*src[i].slice_size, hipMemcpyHostToDevice, stream);
+			if(e != hipSuccess){ break; }
+			const uint64_t nbits = src[i].header.num_filter;
+			const uint64_t work = nr*((bit0 + nbits + 31)/32 - bit0/32);
+			hipLaunchKernelGGL(pack_columns_kernel, dim3((uint32_t)std::min<uint64_t>((work + 255)/256, 8192)), dim3(256), 0, stream,
+			                   (uint32_t*)d_dst, dst_words, bit0, (const uint8_t*)d_src, src[i].slice_size, nbits, nr);
+			e = hipGetLastError();
+			if(e == hipSuccess){ e = hipStreamSynchronize(stream); }     // h_buf is reused for the next file
+			bit0 += nbits;
+		}
+		if(!ok || e != hipSuccess){ break; }
+		e = hipMemcpyAsync(h_buf, d_dst, nr*dst_words*4, hipMemcpyDeviceToHost, stream);
+		if(e == hipSuccess){ e = hipStreamSynchronize(stream); }
+		if(e != hipSuccess){ break; }
+		// strip the dword padding of the device rows
+		const unsigned char *hb = (const unsigned char*)h_buf;
+		if(dst_words*4 == out_slice){
+			crc = crc32_parallel(crc, hb, nr*out_slice);
+			ok = fwrite(hb, 1, nr*out_slice, fout) == nr*out_slice;
+		}
+		else{
+			packed.resize(nr*out_slice);
+			for(uint64_t r = 0; r < nr; ++r){ memcpy(packed.data() + r*out_slice, hb + r*dst_words*4, out_slice); }
+			crc = crc32_parallel(crc, packed.data(), packed.size());
+			ok = fwrite(packed.data(), 1, packed.size(), fout) == packed.size();
+		}
+	}
+	if(d_dst){ (void)hipFree(d_dst); }
+	if(d_src){ (void)hipFree(d_src); }
+	if(h_buf){ (void)hipHostFree(h_buf); }
+	if(e != hipSuccess){ fclose(fout); return fail(KWAGE_ERR_DEVICE, "kwage_repack_db: %s", hipGetErrorString(e)); }
+	if(!ok){ fclose(fout); return fail(KWAGE_ERR_IO, "kwage_repack_db: %s", err.empty() ? "I/O error" : err.c_str()); }
+
+	// metadata: records verbatim in column order, fresh index
+	const uint64_t info_start = DB_HEADER_BYTES + nrows*out_slice;
+	std::vector<uint64_t> loc;
+	std::vector<unsigned char> recs;
+	uint64_t pos = info_start + 8ull*total_cols;
+	for(uint32_t i = 0; i < n; ++i){
+		for(uint32_t j = 0; j < src[i].header.num_filter; ++j){
+			const uint64_t l = info[i].info_loc[j];
+			if(l < info[i].tail_start || l >= info[i].tail_start + info[i].tail.size()){ fclose(fout); return fail(KWAGE_ERR_FORMAT, "%s: bad metadata index", in_paths[i]); }
+			const unsigned char *p = info[i].tail.data() + (l - info[i].tail_start);
+			FilterInfo fi;
+			size_t used = 0;
+			if(!parse_filter_info(p, info[i].tail.size() - (l - info[i].tail_start), fi, &used)){ fclose(fout); return fail(KWAGE_ERR_FORMAT, "%s: bad FilterInfo record", in_paths[i]); }
+			loc.push_back(pos);
+			recs.insert(recs.end(), p, p + used);
+			pos += used;
+		}
+	}
+	auto put32 = [](unsigned char *p, uint32_t v) { for(int i = 0; i < 4; ++i){ p[i] = (unsigned char)(v >> (8*i)); } };
+	auto put64 = [](unsigned char *p, uint64_t v) { for(int i = 0; i < 8; ++i){ p[i] = (unsigned char)(v >> (8*i)); } };
+	std::vector<unsigned char> locb(8ull*total_cols);
+	for(uint64_t i = 0; i < total_cols; ++i){ put64(locb.data() + 8*i, loc[i]); }
+	ok = fwrite(locb.data(), 1, locb.size(), fout) == locb.size();
+	ok = ok && fwrite(recs.data(), 1, recs.size(), fout) == recs.size();
+	const kwage_db_header &h0 = src[0].header;
+	put32(hdr, KWAGE_MAGIC_NUMBER); put32(hdr + 4, h0.version); put32(hdr + 8, crc);
+	put32(hdr + 12, h0.kmer_len); put32(hdr + 16, h0.num_hash); put32(hdr + 20, h0.log_2_filter_len);
+	put32(hdr + 24, (uint32_t)total_cols); put32(hdr + 28, (uint32_t)h0.hash_func); put32(hdr + 32, 0);
+	put64(hdr + 36, info_start);
+	ok = ok && fseek(fout, 0, SEEK_SET) == 0 && fwrite(hdr, 1, sizeof(hdr), fout) == sizeof(hdr);
+	ok = (fclose(fout) == 0) && ok;
+	if(!ok){ return fail(KWAGE_ERR_IO, "kwage_repack_db: error writing %s", out_path); }
 	return KWAGE_OK;
 }

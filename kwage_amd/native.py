@@ -91,6 +91,7 @@ _SIGNATURES = [
     ("kwage_hash_batch", C.c_int, [_P, C.POINTER(Params), _P, _P, _P, _P, _P]),
     ("kwage_stream_read_gbps", C.c_int, [_P, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
     ("kwage_build_db", C.c_int, [_P, C.c_char_p, C.POINTER(Params), C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(BuildStats)]),
+    ("kwage_repack_db", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_char_p), C.c_uint32]),
     ("kwage_db_read_header", C.c_int, [C.c_char_p, C.POINTER(DbHeader)]),
     ("kwage_db_compress", C.c_int, [C.c_char_p, C.c_char_p, C.c_uint32]),
     ("kwage_db_decompress", C.c_int, [C.c_char_p, C.c_char_p]),

@@ -92,3 +92,66 @@ def test_device_builder_rejects_bad_input(oracle, tmp_path):
         open(bad, "wb").write(raw)
         with pytest.raises(ka.KwageError):
             _device_build(ka, ctx, [bad], (32, 5, 10, 0), str(tmp_path / "o.db"))
+
+
+# ---------------------------------------------------------------------------------------------
+# column-wise re-pack (the bit-level work of merge_db.cpp): several files -> one wide file
+# ---------------------------------------------------------------------------------------------
+def _repack(ctx, paths, out):
+    from kwage_amd import native
+    arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+    native.check(native.lib().kwage_repack_db(ctx._h, out.encode(), arr, len(paths)))
+
+
+@pytest.mark.gpu
+def test_repack_is_the_column_concatenation(oracle, tmp_path):
+    import subprocess
+    import zlib
+    import kwage_amd as ka
+    from kwage_amd import native
+    rng = np.random.default_rng(12)
+    paths, mats, names = [], [], []
+    for f, n in enumerate((13, 21, 1, 64, 7, 130)):       # ragged widths: every bit offset gets exercised
+        bits = rng.random((1 << 10, ((n + 7) // 8) * 8)) < 0.3
+        bits[:, n:] = False
+        rows = np.packbits(bits, axis=1, bitorder="little")
+        infos = [oracle.FilterInfo(run_accession=oracle.str_to_accession("ERR%d" % (100 * f + j + 1)),
+                                   experiment_title="file %d col %d" % (f, j) if j % 4 == 0 else "",
+                                   sample_attributes=[("a", "b"), ("c", "d")] if j % 5 == 0 else []) for j in range(n)]
+        p = str(tmp_path / ("part%d.db" % f))
+        oracle.write_db(p, 25, 2, 10, rows, n, infos)
+        paths.append(p); mats.append(bits[:, :n]); names += [i.csv_string() for i in infos]
+    z = str(tmp_path / "part1.dbz")                       # one input in the compressed container
+    native.check(native.lib().kwage_db_compress(paths[1].encode(), z.encode(), 2))
+    inputs = [paths[0], z] + paths[2:]
+    out = str(tmp_path / "wide.db")
+    with ka.Context(0) as ctx:
+        _repack(ctx, inputs, out)
+        with pytest.raises(ka.KwageError):
+            _repack(ctx, inputs + [os.path.join(GOLDEN, "k32", "k32.db")], str(tmp_path / "bad.db"))   # other parameters
+    wide = oracle.read_db(out)
+    total = sum(m.shape[1] for m in mats)
+    assert wide.header.num_filter == total and wide.header.compression == 0
+    exp = np.concatenate(mats, axis=1)
+    got = np.unpackbits(wide.rows, axis=1, bitorder="little")[:, :total].astype(bool)
+    assert np.array_equal(got, exp)
+    assert np.all(np.unpackbits(wide.rows, axis=1, bitorder="little")[:, total:] == 0)       # pad bits stay zero
+    assert zlib.crc32(wide.rows.tobytes()) & 0xFFFFFFFF == wide.header.crc32
+    assert [wide.info(j).csv_string() for j in range(total)] == names
+    assert wide.info(0).experiment_title == "file 0 col 0" and len(wide.info(13).sample_attributes) == 2
+    # the REFERENCE binary reads the wide file and reports what it reports on the parts
+    if os.access(oracle.REF_KWAGE, os.X_OK):
+        q = str(tmp_path / "q.fa")
+        acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+        with open(q, "w") as fh:
+            for i in range(6):
+                fh.write(">q%d\n%s\n" % (i, acgt[rng.integers(0, 4, size=60)].tobytes().decode()))
+        parts_dir = tmp_path / "parts"; parts_dir.mkdir()
+        for p in paths:
+            os.link(p, parts_dir / os.path.basename(p))
+        for thr in ("0.2", "0.05"):
+            run = lambda d: subprocess.run([oracle.REF_KWAGE, "-d", d, "-i", q, "-t", thr, "--o.csv"], capture_output=True, text=True,
+                                           env=dict(os.environ, OMP_NUM_THREADS="1"))
+            a, b = run(str(parts_dir)), run(out)
+            assert a.returncode == 0 and b.returncode == 0
+            assert sorted(a.stdout.splitlines()) == sorted(b.stdout.splitlines()) and len(a.stdout.splitlines()) > 1
