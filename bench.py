@@ -131,8 +131,17 @@ def main():
     backend = os.environ.get("KWAGE_BENCH_BACKEND", "nccl")
     if os.environ.get("KWAGE_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
+    # KWAGE_BENCH_FORCE_SHARDED=1: take the multi-GPU code path (device-resident hits + RCCL exchange)
+    # even with one rank, to measure its per-step overhead on a one-GPU box
+    force_sharded = os.environ.get("KWAGE_BENCH_FORCE_SHARDED") == "1"
+    if force_sharded and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    sharded = world > 1 or force_sharded
     dist = None
-    if world > 1:
+    if sharded:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
@@ -156,7 +165,7 @@ def main():
     threshold = w.threshold
 
     ss = None
-    if world > 1:
+    if sharded:
         from kwage_amd.distributed import ShardedSearch, device_tensor_search_fn
         dev = "cuda:%d" % local_rank
         ss = [ShardedSearch(dist, rank, world, int(m.group.column_span),
@@ -165,10 +174,10 @@ def main():
 
     def step():
         """One pass of the hot path; returns (result-or-None, search_kernel_ms, hits delivered to rank 0)."""
-        if world == 1 and multi is not None:
+        if not sharded and multi is not None:
             rs = [m.group.search(s.batch, threshold, flags) for m in multi]
             return rs, sum(r.search_kernel_ms for r in rs), sum(len(r.hits) for r in rs)
-        if world == 1:
+        if not sharded:
             r = s.group.search(s.batch, threshold, flags)
             return r, r.search_kernel_ms, len(r.hits)
         # multi-GPU: hits stay in HBM, ONE gatherv over RCCL, rank 0 concatenates + sorts
@@ -211,7 +220,7 @@ def main():
     else:
         bit_tests_rank = int(probe.bit_tests)
         alg_bytes_rank = int(probe.algorithmic_bytes)
-    if world > 1:
+    if sharded:
         kernel_ms = []
         for _ in range(3):
             kernel_ms.append(sum(m.group.search(s.batch, threshold, flags).search_kernel_ms for m in (multi or [s])))
@@ -253,6 +262,8 @@ def main():
                          "measured_stream_read_gbps": round(stream_gbps, 1),
                          "frac_of_measured_stream": round(achieved / stream_gbps, 4) if stream_gbps else None},
         }
+        if force_sharded:
+            out["config"]["note"] = "KWAGE_BENCH_FORCE_SHARDED: multi-GPU code path on one rank"
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(w, s.queries, args.cpu_files)
