@@ -239,13 +239,13 @@ def main():
         except Exception:
             pass
         out = {
-            "metric": "G k-mer*sample bit-tests/sec",
+            "metric": "G k-mer\u00b7sample bit-tests/sec (+ achieved HBM GB/s of the gather kernel in `roofline`)",
             "value": round(value, 3),
             "unit": "G bit-tests/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 (bitwise AND / bit-sliced integer counters)",
+            "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": w.name, "samples_per_gpu": int(sum(ns for _, ns in synth.C5_GROUPS)) if multi else w.num_samples, "log_2_filter_len": w.log_2_filter_len,
                        "kmer_len": w.kmer_len, "num_hash": w.num_hash, "queries": w.num_queries, "query_len": w.query_len,

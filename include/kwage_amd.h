@@ -199,6 +199,55 @@ typedef struct {
 int kwage_build_db(kwage_ctx *ctx, const char *out_path, const kwage_params *params,
                    const char *const *bloom_paths, uint32_t n, kwage_build_stats *stats);
 
+/* ------------------------------------------------------------------------------------
+ * Bloom filter construction from sequences -- the exact k-mer set, i.e. what the reference's
+ * make_bloom_filter() (make_bloom.cpp:76-504) yields at min_kmer_count == 1, where its counting
+ * Bloom pass (count_words, :506-621) degenerates to "every valid canonical k-mer sets bit
+ * hash_h & (2^L - 1) for h < num_hash" (fold :344-354).  min_kmer_count > 1 (read sets) is NOT
+ * provided: the reference's conservative-update counters are order dependent and its streaming
+ * front end needs the NCBI SDK.  Output: a `.bloom` file as binary_write<BloomFilter> writes it
+ * (binary_io.cpp:182-208), ready for kwage_build_db.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+	const char *run_accession;                /* required: 3 letters + 1..10 digits (sra_accession.cpp:27-64) */
+	const char *experiment_accession;         /* accessions and texts may be NULL or "" = absent */
+	const char *sample_accession;
+	const char *study_accession;
+	const char *experiment_title;
+	const char *experiment_design_description;
+	const char *experiment_library_name;
+	const char *experiment_library_strategy;
+	const char *experiment_library_source;
+	const char *experiment_library_selection;
+	const char *experiment_instrument_model;
+	const char *sample_taxa;
+	const char *study_title;
+	const char *study_abstract;
+	const char *const *attribute_tags;        /* num_attributes entries each */
+	const char *const *attribute_values;
+	uint32_t num_attributes;
+	uint64_t number_of_spots, number_of_bases;
+	uint32_t day, month, year;                /* date_received; 0,0,0 = absent */
+} kwage_sample_info;
+
+/* optimal_bloom_param (bloom.cpp:10-68): smallest log_2_filter_len in [min,max], then the num_hash in
+ * [1,5] with the lowest false-positive probability <= p for `num_kmer` distinct k-mers. */
+int kwage_optimal_bloom_param(uint32_t kmer_len, uint64_t num_kmer, float p, uint32_t min_log_2_filter_len,
+                              uint32_t max_log_2_filter_len, kwage_params *out);
+
+/* Distinct canonical k-mers over ALL sequences of the batch (one shared set). */
+int kwage_count_distinct_kmers(kwage_ctx *ctx, kwage_batch *b, uint32_t kmer_len, uint64_t *count);
+
+/* Bits of the sample's Bloom filter (2^L / 8 bytes, LSB first) computed on the device. */
+int kwage_bloom_bits_from_batch(kwage_ctx *ctx, const kwage_params *params, kwage_batch *b,
+                                void *bits_out, uint64_t *distinct);
+
+/* Sequences (concatenated + offsets, like kwage_batch_create) -> `.bloom` file. Long sequences are cut
+ * into overlapping pieces internally so that every k-mer is seen once by some workgroup. */
+int kwage_make_bloom(kwage_ctx *ctx, const kwage_params *params, const char *seqs, const uint64_t *offsets,
+                     uint32_t n_seqs, const kwage_sample_info *info, const char *out_path,
+                     uint64_t *num_distinct_kmers);
+
 /* Column-wise re-pack: the columns of several same-parameter `.db` files (raw or compressed) become
  * ONE raw `.db` file with contiguous columns, in file order then column order -- the bit-level work of
  * the reference's merge_db.cpp:268-820 (get_bit/set_bit per bit there; shift-and-OR on the device

@@ -250,6 +250,8 @@ int launch_kmer_stage(kwage_ctx *ctx, const kwage_params &p, kwage_batch *b, flo
 	a.nkmer = ctx->d_nkmer;
 	a.qthr = ctx->d_qthr;
 	a.total_kmers = (unsigned long long*)ctx->d_counters + 1;
+	a.shared_lg = 0;
+	a.bloom_bits = nullptr;
 	hipLaunchKernelGGL(kmer_kernel, dim3(b->n), dim3(KM_THREADS), 0, ctx->stream, a);
 	HIP_TRY(hipGetLastError());
 	return KWAGE_OK;
@@ -1003,6 +1005,81 @@ extern "C" int kwage_hash_batch(kwage_ctx *ctx, const kwage_params *params, kwag
 	if(rows && b->total_pos){ HIP_TRY(hipMemcpyAsync(rows, ctx->rows.p, b->total_pos*params->num_hash*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	return KWAGE_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Bloom filter construction from sequences (exact k-mer set)
+// ------------------------------------------------------------------------------------------
+namespace {
+
+// Run the k-mer stage over `b` with ONE shared distinct set; optionally set Bloom bits.
+int run_shared_kmer_pass(kwage_ctx *ctx, const kwage_params &p, kwage_batch *b, uint32_t *d_bloom_bits, uint64_t *distinct)
+{
+	int rc = batch_prepare(b, p.kmer_len);
+	if(rc){ return rc; }
+	if((rc = layout_result(ctx, b->n, 0, false))){ return rc; }
+	uint32_t lg = 10;
+	while((1ull << lg) < 2*std::max<uint64_t>(b->total_pos, 1)){ ++lg; }
+	if(lg > 36){ return fail(KWAGE_ERR_ARG, "too many k-mer positions for one sample"); }
+	if((rc = ctx->tables.reserve((1ull << lg)*sizeof(uint64_t)))){ return rc; }
+	HIP_TRY(hipMemsetAsync(ctx->tables.p, 0xFF, (1ull << lg)*sizeof(uint64_t), ctx->stream));
+	HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, 4*sizeof(uint64_t), ctx->stream));
+	if(b->n){
+		KmerArgs a;
+		a.seqs = b->d_seqs; a.seq_off = b->d_seq_off; a.pos_off = b->d_pos_off; a.tab_off = b->d_tab_off;
+		a.g_tables = (unsigned long long*)ctx->tables.p;
+		a.k = p.kmer_len; a.num_hash = p.num_hash;
+		a.row_mask = (p.log_2_filter_len >= 32) ? 0xFFFFFFFFu : ((1u << p.log_2_filter_len) - 1u);
+		a.threshold = 1.0f; a.complete_match = 1;
+		a.rows = nullptr; a.kmers_out = nullptr;
+		a.nkmer = ctx->d_nkmer; a.qthr = ctx->d_qthr;
+		a.total_kmers = (unsigned long long*)ctx->d_counters + 1;
+		a.shared_lg = lg;
+		a.bloom_bits = d_bloom_bits;
+		hipLaunchKernelGGL(kmer_kernel, dim3(b->n), dim3(KM_THREADS), 0, ctx->stream, a);
+		HIP_TRY(hipGetLastError());
+	}
+	uint64_t h[2] = {0, 0};
+	HIP_TRY(hipMemcpyAsync(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	if(distinct){ *distinct = h[1]; }
+	return KWAGE_OK;
+}
+
+}  // namespace
+
+extern "C" int kwage_count_distinct_kmers(kwage_ctx *ctx, kwage_batch *b, uint32_t kmer_len, uint64_t *count)
+{
+	if(!ctx || !b || !count){ return fail(KWAGE_ERR_ARG, "kwage_count_distinct_kmers: NULL argument"); }
+	if(b->ctx != ctx){ return fail(KWAGE_ERR_ARG, "kwage_count_distinct_kmers: batch belongs to another context"); }
+	kwage_params p = {kmer_len, 1, 0, KWAGE_HASH_MURMUR32};
+	int rc = check_params(&p);
+	if(rc){ return rc; }
+	if((rc = set_device(ctx))){ return rc; }
+	return run_shared_kmer_pass(ctx, p, b, nullptr, count);
+}
+
+extern "C" int kwage_bloom_bits_from_batch(kwage_ctx *ctx, const kwage_params *params, kwage_batch *b,
+                                           void *bits_out, uint64_t *distinct)
+{
+	if(!ctx || !params || !b || !bits_out){ return fail(KWAGE_ERR_ARG, "kwage_bloom_bits_from_batch: NULL argument"); }
+	if(b->ctx != ctx){ return fail(KWAGE_ERR_ARG, "kwage_bloom_bits_from_batch: batch belongs to another context"); }
+	int rc = check_params(params);
+	if(rc){ return rc; }
+	if((rc = set_device(ctx))){ return rc; }
+	const uint64_t nbytes = ((1ull << params->log_2_filter_len) + 7)/8;
+	const uint64_t alloc = (nbytes + 3)/4*4;
+	DevBuf bits;
+	if((rc = bits.reserve(alloc))){ return rc; }
+	hipError_t e = hipMemsetAsync(bits.p, 0, alloc, ctx->stream);
+	if(e != hipSuccess){ bits.release(); return fail(KWAGE_ERR_DEVICE, "%s", hipGetErrorString(e)); }
+	rc = run_shared_kmer_pass(ctx, *params, b, (uint32_t*)bits.p, distinct);
+	if(!rc){
+		e = hipMemcpy(bits_out, bits.p, nbytes, hipMemcpyDeviceToHost);
+		if(e != hipSuccess){ rc = fail(KWAGE_ERR_DEVICE, "%s", hipGetErrorString(e)); }
+	}
+	bits.release();
+	return rc;
 }
 
 extern "C" int kwage_stream_read_gbps(kwage_group *g, uint64_t bytes, uint32_t iters, double *gbps)

@@ -4,6 +4,7 @@
 // must reproduce (paths relative to the reference tree).
 #include <algorithm>
 #include <cctype>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -661,6 +662,110 @@ extern "C" int kwage_db_decompress(const char *in_path, const char *out_path)
 	ok = ok && copy_tail(src.fd, old_info + 8ull*h.num_filter, (uint64_t)st.st_size, out) == 0;
 	ok = (fclose(out) == 0) && ok;
 	if(!ok){ return fail(KWAGE_ERR_IO, "kwage_db_decompress: %s", err.empty() ? "I/O error" : err.c_str()); }
+	return KWAGE_OK;
+}
+
+// ---- Bloom construction (host side) ---------------------------------------------------------------
+extern "C" int kwage_optimal_bloom_param(uint32_t kmer_len, uint64_t num_kmer, float p_bound, uint32_t min_lg,
+                                         uint32_t max_lg, kwage_params *out)
+{
+	if(!out){ return fail(KWAGE_ERR_ARG, "kwage_optimal_bloom_param: NULL argument"); }
+	if(num_kmer == 0){ return fail(KWAGE_ERR_ARG, "optimal_bloom_param: No kmers found"); }      // bloom.cpp:16-18
+	out->kmer_len = kmer_len;
+	out->hash_func = KWAGE_HASH_MURMUR32;
+	out->num_hash = 0;
+	bool valid = false;
+	for(uint32_t lg = min_lg; lg <= max_lg && lg < 64; ++lg){          // bloom.cpp:36-64
+		float best_p = 10.0f;
+		for(uint32_t nh = KWAGE_MIN_NUM_HASH; nh <= KWAGE_MAX_NUM_HASH; ++nh){
+			const uint64_t len = 1ull << lg;
+			// per-filter, per-k-mer false positive probability; num_kmer*num_hash is integer arithmetic
+			const double p = pow(1.0 - pow(1.0 - 1.0/len, (double)(num_kmer*nh)), (double)nh);
+			if((p <= p_bound) && (p < best_p)){
+				best_p = (float)p;
+				out->num_hash = nh;
+				valid = true;
+			}
+		}
+		if(valid){ out->log_2_filter_len = lg; return KWAGE_OK; }
+	}
+	return fail(KWAGE_ERR_ARG, "optimal_bloom_param: Unable to satisfy Bloom filter probability bound");
+}
+
+static bool opt_accession(const char *s, uint64_t &out, bool required)
+{
+	out = 0;
+	if(!s || !*s){ return !required; }
+	return str_to_accession(s, out);
+}
+
+extern "C" int kwage_make_bloom(kwage_ctx *ctx, const kwage_params *params, const char *seqs, const uint64_t *offsets,
+                                uint32_t n_seqs, const kwage_sample_info *si, const char *out_path, uint64_t *num_distinct)
+{
+	if(!ctx || !params || !offsets || !si || !out_path){ return fail(KWAGE_ERR_ARG, "kwage_make_bloom: NULL argument"); }
+	int rc = check_params(params);
+	if(rc){ return rc; }
+	FilterInfo fi;
+	if(!opt_accession(si->run_accession, fi.run_accession, true) || !opt_accession(si->experiment_accession, fi.experiment_accession, false) ||
+	   !opt_accession(si->sample_accession, fi.sample_accession, false) || !opt_accession(si->study_accession, fi.study_accession, false)){
+		return fail(KWAGE_ERR_ARG, "str_to_accession: Unable to parse accession string");
+	}
+	auto txt = [](const char *s) { return std::string(s ? s : ""); };
+	fi.experiment_title = txt(si->experiment_title);
+	fi.experiment_design_description = txt(si->experiment_design_description);
+	fi.experiment_library_name = txt(si->experiment_library_name);
+	fi.experiment_library_strategy = txt(si->experiment_library_strategy);
+	fi.experiment_library_source = txt(si->experiment_library_source);
+	fi.experiment_library_selection = txt(si->experiment_library_selection);
+	fi.experiment_instrument_model = txt(si->experiment_instrument_model);
+	fi.sample_taxa = txt(si->sample_taxa);
+	fi.study_title = txt(si->study_title);
+	fi.study_abstract = txt(si->study_abstract);
+	for(uint32_t i = 0; i < si->num_attributes; ++i){
+		fi.sample_attributes.insert(std::make_pair(txt(si->attribute_tags[i]), txt(si->attribute_values[i])));
+	}
+	fi.number_of_spots = si->number_of_spots;
+	fi.number_of_bases = si->number_of_bases;
+	fi.day = si->day; fi.month = si->month; fi.year = si->year;
+
+	// cut long sequences into pieces overlapping by k-1 bases: one workgroup walks one piece
+	const uint64_t PIECE = 1u << 16;
+	const uint32_t k = params->kmer_len;
+	std::vector<uint64_t> po(1, 0);
+	std::string pieces;
+	for(uint32_t i = 0; i < n_seqs; ++i){
+		const uint64_t b = offsets[i], e = offsets[i + 1];
+		if(e < b){ return fail(KWAGE_ERR_ARG, "kwage_make_bloom: offsets must be non-decreasing"); }
+		for(uint64_t s0 = b; s0 < e; s0 += PIECE){
+			const uint64_t s1 = std::min(e, s0 + PIECE + (k - 1));
+			pieces.append(seqs + s0, s1 - s0);
+			po.push_back(pieces.size());
+			if(s1 == e){ break; }
+		}
+	}
+	if(po.size() - 1 > 0xFFFFFFFFull){ return fail(KWAGE_ERR_ARG, "kwage_make_bloom: too many sequence pieces"); }
+	kwage_batch *batch = nullptr;
+	if((rc = kwage_batch_create(ctx, pieces.data(), po.data(), (uint32_t)(po.size() - 1), &batch))){ return rc; }
+	const uint64_t nbytes = ((1ull << params->log_2_filter_len) + 7)/8;
+	std::vector<unsigned char> bits(nbytes);
+	uint64_t distinct = 0;
+	rc = kwage_bloom_bits_from_batch(ctx, params, batch, bits.data(), &distinct);
+	kwage_batch_destroy(batch);
+	if(rc){ return rc; }
+	if(num_distinct){ *num_distinct = distinct; }
+
+	// binary_write<BloomFilter> (binary_io.cpp:182-208)
+	std::vector<unsigned char> head;
+	head.push_back(0xFF);                                               // BLOOM_MAGIC_COMPLETE, bloom.h:28
+	auto u32 = [&](uint32_t v) { for(int i = 0; i < 4; ++i){ head.push_back((unsigned char)(v >> (8*i))); } };
+	u32(params->kmer_len); u32(params->log_2_filter_len); u32(params->num_hash); u32((uint32_t)params->hash_func);   // bloom.h:550-554
+	u32((uint32_t)crc32_z(crc32_z(0L, Z_NULL, 0), bits.data(), bits.size()));                                          // bloom.cpp:328-343
+	pack_filter_info(fi, head);
+	FILE *f = fopen(out_path, "wb");
+	if(!f){ return fail(KWAGE_ERR_IO, "Unable to open %s for writing", out_path); }
+	bool ok = fwrite(head.data(), 1, head.size(), f) == head.size() && fwrite(bits.data(), 1, bits.size(), f) == bits.size();
+	ok = (fclose(f) == 0) && ok;
+	if(!ok){ return fail(KWAGE_ERR_IO, "binary_write<BloomFilter>: Unable to write BloomFilter"); }
 	return KWAGE_OK;
 }
 

@@ -155,6 +155,10 @@ struct KmerArgs {
 	uint32_t *nkmer;                // per query
 	uint32_t *qthr;                 // per query threshold (kwage.cpp:388)
 	unsigned long long *total_kmers;
+	// Bloom construction: all sequences share ONE global set (distinct k-mers of the whole sample) and
+	// every new k-mer sets its num_hash bits in `bloom_bits` (bit index = hash & row_mask).
+	uint32_t shared_lg;             // 0 = one set per query (search); else log2 slots of the shared table
+	uint32_t *bloom_bits;           // may be null
 };
 
 template <bool LDS_TAB, typename TAB>
@@ -196,6 +200,14 @@ __device__ __forceinline__ void kmer_body(const KmerArgs &a, uint32_t q, uint64_
 				if(set_insert(tab, lg, canon)){                    // first time this k-mer is seen
 					const uint32_t idx = atomicAdd(count, 1u);
 					if(a.kmers_out){ a.kmers_out[base + idx] = canon; }
+					if(a.bloom_bits){
+						MurmurKeys mk;
+						murmur_keys(canon, k, mk);
+						for(uint32_t h = 0; h < a.num_hash; ++h){
+							const uint32_t bit = murmur_finish(mk, k, h) & a.row_mask;
+							atomicOr(a.bloom_bits + (bit >> 5), 1u << (bit & 31));      // LSB first, bloom.h:162
+						}
+					}
 					if(a.rows){
 						MurmurKeys mk;
 						murmur_keys(canon, k, mk);
@@ -234,6 +246,10 @@ __global__ __launch_bounds__(KM_THREADS) void kmer_kernel(KmerArgs a)
 		return;
 	}
 
+	if(a.shared_lg){
+		kmer_body<false>(a, q, s0, len, npos, a.g_tables, a.shared_lg, codes, &count);
+		return;
+	}
 	const uint32_t lg = table_log2(npos);
 	if((1ull << lg) <= KM_LDS_SLOTS){
 		kmer_body<true>(a, q, s0, len, npos, lds_tab, lg, codes, &count);

@@ -51,6 +51,17 @@ class BuildStats(C.Structure):
     _fields_ = [("bits_transposed", C.c_uint64), ("transpose_kernel_ms", C.c_float), ("db_bytes", C.c_uint64)]
 
 
+class SampleInfo(C.Structure):
+    _fields_ = [(n, C.c_char_p) for n in ("run_accession", "experiment_accession", "sample_accession", "study_accession",
+                                          "experiment_title", "experiment_design_description", "experiment_library_name",
+                                          "experiment_library_strategy", "experiment_library_source",
+                                          "experiment_library_selection", "experiment_instrument_model", "sample_taxa",
+                                          "study_title", "study_abstract")] + \
+               [("attribute_tags", C.POINTER(C.c_char_p)), ("attribute_values", C.POINTER(C.c_char_p)),
+                ("num_attributes", C.c_uint32), ("number_of_spots", C.c_uint64), ("number_of_bases", C.c_uint64),
+                ("day", C.c_uint32), ("month", C.c_uint32), ("year", C.c_uint32)]
+
+
 class DbHeader(C.Structure):
     _fields_ = [("magic", C.c_uint32), ("version", C.c_uint32), ("crc32", C.c_uint32),
                 ("kmer_len", C.c_uint32), ("num_hash", C.c_uint32), ("log_2_filter_len", C.c_uint32),
@@ -91,6 +102,10 @@ _SIGNATURES = [
     ("kwage_hash_batch", C.c_int, [_P, C.POINTER(Params), _P, _P, _P, _P, _P]),
     ("kwage_stream_read_gbps", C.c_int, [_P, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
     ("kwage_build_db", C.c_int, [_P, C.c_char_p, C.POINTER(Params), C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(BuildStats)]),
+    ("kwage_optimal_bloom_param", C.c_int, [C.c_uint32, C.c_uint64, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(Params)]),
+    ("kwage_count_distinct_kmers", C.c_int, [_P, _P, C.c_uint32, C.POINTER(C.c_uint64)]),
+    ("kwage_bloom_bits_from_batch", C.c_int, [_P, C.POINTER(Params), _P, _P, C.POINTER(C.c_uint64)]),
+    ("kwage_make_bloom", C.c_int, [_P, C.POINTER(Params), C.c_char_p, _P, C.c_uint32, C.POINTER(SampleInfo), C.c_char_p, C.POINTER(C.c_uint64)]),
     ("kwage_repack_db", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_char_p), C.c_uint32]),
     ("kwage_db_read_header", C.c_int, [C.c_char_p, C.POINTER(DbHeader)]),
     ("kwage_db_compress", C.c_int, [C.c_char_p, C.c_char_p, C.c_uint32]),

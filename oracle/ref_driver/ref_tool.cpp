@@ -10,6 +10,7 @@
 //   ref_tool kmers <k> <nhash> <seq> print, for every valid k-mer position, the reference's
 //                                   CanonicalWord (word.h:165) and bigsi_hash (hash.cpp:79)
 //   ref_tool accession <str>        print str_to_accession / accession_to_str round trip
+//   ref_tool param <k> <num_kmer> <p> <minL> <maxL>   the reference's optimal_bloom_param (bloom.cpp:10-68)
 //   ref_tool build <out.db> <k> <L> <nhash> <list>   run the reference's build_db() on existing
 //                                   .bloom files (one path per line in <list>): CPU baseline of
 //                                   the device builder
@@ -215,6 +216,17 @@ int main(int argc, char *argv[])
 		}
 		if(argc == 5 && string(argv[1]) == "kmers"){
 			return cmd_kmers(atoi(argv[2]), atoi(argv[3]), argv[4]);
+		}
+		if(argc == 7 && string(argv[1]) == "param"){
+			try{
+				const BloomParam p = optimal_bloom_param(atoi(argv[2]), strtoull(argv[3], NULL, 10), (float)atof(argv[4]),
+					MURMUR_HASH_32, atoi(argv[5]), atoi(argv[6]));
+				cout << p.log_2_filter_len << '\t' << p.num_hash << '\n';
+			}
+			catch(const char *error){
+				cout << "throw" << '\n';
+			}
+			return 0;
 		}
 		if(argc == 7 && string(argv[1]) == "build"){
 			BloomParam param;

@@ -226,6 +226,44 @@ def main():
     with open(os.path.join(HERE, "kat_accession.json"), "w") as f:
         json.dump(acc, f, indent=0)
 
+    # optimal_bloom_param (bloom.cpp:10-68) over a sweep of k-mer counts / bounds
+    opt = []
+    for p in ("0.25", "0.05", "0.5"):
+        for nk in [1, 2, 10, 1000, 75000, 75366, 100000, 150733, 301467, 1000000, 4800000, 5_000_000, 123456789,
+                   3_000_000_000, 10_000_000_000]:
+            for lo, hi in ((18, 32), (8, 20)):
+                out = subprocess.check_output([REF_TOOL, "param", "31", str(nk), p, str(lo), str(hi)]).decode().split()
+                opt.append({"num_kmer": nk, "p": p, "min": lo, "max": hi, "result": out})
+    with open(os.path.join(HERE, "kat_optimal_bloom_param.json"), "w") as f:
+        json.dump(opt, f, indent=0)
+
+    # ------------------------------------------------------------------------------
+    # case "bloomgen": filters that hold ONLY the k-mers of given sequences (no noise), kept as
+    # .bloom files: what make_bloom_filter yields at min_kmer_count == 1 -- inputs for the device
+    # Bloom-construction parity test
+    # ------------------------------------------------------------------------------
+    name = "bloomgen"
+    cdir = os.path.join(HERE, name)
+    shutil.rmtree(cdir, ignore_errors=True)
+    os.makedirs(cdir)
+    samples = []
+    for j in range(6):
+        seqs = [rand_seq(rng, int(n)) for n in ([40, 700, 31][: 1 + j % 3] + ([70000] if j == 4 else []))]
+        if j == 2:
+            seqs.append(seqs[0][:20] + "NNN" + seqs[0][20:].lower())
+        fl = {"acc": "ERR%07d" % (j + 1), "seed": 0, "noise": 0, "seqs": seqs}
+        if j % 2 == 0:
+            fl["meta"] = {"experiment_accession": "ERX%05d" % j, "sample_accession": "ERS%05d" % j,
+                          "study_accession": "ERP%04d" % j, "experiment_title": "bloomgen %d" % j,
+                          "sample_taxa": "Bacillus subtilis", "study_title": "study"}
+            fl["attrs"] = [("strain", "168"), ("host", "soil"), ("note", "x y z")][: 1 + j % 3]
+            fl["n"] = (10 + j, 1000 + j)
+            fl["date"] = "2021-0%d-1%d" % (1 + j, j)
+        samples.append(fl)
+    mkdb(os.path.join(cdir, "bloomgen.db"), 27, 16, 4, samples, keep_bloom_dir=os.path.join(cdir, "bloom"))
+    with open(os.path.join(cdir, "samples.json"), "w") as f:
+        json.dump({"kmer_len": 27, "log_2_filter_len": 16, "num_hash": 4, "samples": samples}, f, indent=0)
+
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     print("wrote", len(manifest["cases"]), "expected outputs")
