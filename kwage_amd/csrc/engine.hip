@@ -908,6 +908,45 @@ extern "C" uint32_t kwage_batch_num_queries(const kwage_batch *b) { return b ? b
 // search
 // ------------------------------------------------------------------------------------------
 namespace {
+
+// Order hits by (query, column): std::sort for short lists, otherwise an LSD radix sort on the
+// 64-bit key (11-bit digits; digits on which all keys agree are skipped).
+void sort_hits(std::vector<kwage_hit> &hits)
+{
+	const size_t n = hits.size();
+	if(n < 8192){
+		std::sort(hits.begin(), hits.end(), [](const kwage_hit &x, const kwage_hit &y){
+			return (x.query != y.query) ? (x.query < y.query) : (x.column < y.column);
+		});
+		return;
+	}
+	struct Rec { uint64_t key; uint32_t val; };
+	std::vector<Rec> a(n), b(n);
+	uint64_t all_or = 0, all_and = ~0ull;
+	for(size_t i = 0; i < n; ++i){
+		a[i].key = ((uint64_t)hits[i].query << 32) | hits[i].column;
+		a[i].val = hits[i].num_match;
+		all_or |= a[i].key; all_and &= a[i].key;
+	}
+	const uint64_t varying = all_or ^ all_and;
+	Rec *src = a.data(), *dst = b.data();
+	for(int shift = 0; shift < 64; shift += 11){
+		const uint64_t mask = 0x7FFull << shift;
+		if((varying & mask) == 0){ continue; }
+		size_t count[2049];
+		memset(count, 0, sizeof(count));
+		for(size_t i = 0; i < n; ++i){ ++count[((src[i].key >> shift) & 0x7FF) + 1]; }
+		for(int d = 0; d < 2048; ++d){ count[d + 1] += count[d]; }
+		for(size_t i = 0; i < n; ++i){ dst[count[(src[i].key >> shift) & 0x7FF]++] = src[i]; }
+		std::swap(src, dst);
+	}
+	for(size_t i = 0; i < n; ++i){
+		hits[i].query = (uint32_t)(src[i].key >> 32);
+		hits[i].column = (uint32_t)src[i].key;
+		hits[i].num_match = src[i].val;
+	}
+}
+
 struct ResultStorage {
 	kwage_result pub;
 	std::vector<kwage_hit> hits;
@@ -937,17 +976,18 @@ extern "C" int kwage_search(kwage_group *g, kwage_batch *b, float threshold, uin
 	}
 	const uint64_t have = std::min(so.n_hits, so.staged_hits);
 	if(have){ memcpy(rs->hits.data(), hs + ctx->head_bytes, have*sizeof(kwage_hit)); }
-	if(so.n_hits > have){      // the rare large hit list: fetch the remainder
-		hipError_t e = hipMemcpyAsync(rs->hits.data() + have, ctx->d_hits + have,
-		                              (so.n_hits - have)*sizeof(kwage_hit), hipMemcpyDeviceToHost, ctx->stream);
+	if(so.n_hits > have){      // a large hit list: fetch the remainder through pinned memory
+		const uint64_t rem_bytes = (so.n_hits - have)*sizeof(kwage_hit);
+		int rc2 = ctx->h_stage.reserve(rem_bytes);      // the staged head has been consumed above
+		if(rc2){ delete rs; return rc2; }
+		hipError_t e = hipMemcpyAsync(ctx->h_stage.p, ctx->d_hits + have, rem_bytes, hipMemcpyDeviceToHost, ctx->stream);
 		if(e == hipSuccess){ e = hipStreamSynchronize(ctx->stream); }
 		if(e != hipSuccess){ delete rs; return fail(KWAGE_ERR_DEVICE, "kwage_search: copying results failed: %s", hipGetErrorString(e)); }
+		memcpy(rs->hits.data() + have, ctx->h_stage.p, rem_bytes);
 	}
 
 	// deterministic order; the reference's own order among ties is unspecified (sort.h:22-27)
-	std::sort(rs->hits.begin(), rs->hits.end(), [](const kwage_hit &x, const kwage_hit &y){
-		return (x.query != y.query) ? (x.query < y.query) : (x.column < y.column);
-	});
+	sort_hits(rs->hits);
 
 	kwage_result &r = rs->pub;
 	r.n_hits = so.n_hits;
