@@ -368,3 +368,25 @@ def test_cli_error_and_empty_cases(ka, tmp_path):
     assert r.returncode == 0 and r.stdout == ""         # JSON: nothing at all when no query matched
     r = run("-d", str(tmp_path / "nonexist.db"), "--o.csv", "ACGT")
     assert r.returncode == 1 and "FindFiles::next: Unable to stat entry" in r.stderr
+
+
+def test_search_device_leaves_the_same_hits_in_hbm(ka, ctx):
+    """kwage_search_device (the multi-GPU entry point: hits stay in a caller-owned device buffer for
+    RCCL) returns the same records as kwage_search, including when the buffer must grow."""
+    import torch
+    from kwage_amd import synth
+    from kwage_amd.distributed import device_tensor_search_fn
+    s = synth.build(ctx, synth.WORKLOADS["tiny"])
+    for thr in (1.0, 0.6, 0.001):
+        ref = s.group.search(s.batch, thr)
+        fn = device_tensor_search_fn(s.group, 0, "cuda:0", initial_capacity=16)      # forces the grow-and-retry path
+        t, nk = fn(s.batch, thr)
+        got = t.cpu().numpy().astype(np.uint32)
+        order = np.lexsort((got[:, 1], got[:, 0]))
+        got = got[order]
+        assert len(got) == len(ref.hits)
+        assert np.array_equal(got[:, 0], ref.hits["query"]) and np.array_equal(got[:, 1], ref.hits["column"])
+        assert np.array_equal(got[:, 2], ref.hits["num_match"])
+        assert np.array_equal(nk.cpu().numpy().astype(np.uint32), ref.num_query_kmer)
+    s.batch.close()
+    s.group.close()
