@@ -128,10 +128,31 @@ EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
 _lib = None
 
 
+def _preload_torch_hip_runtime() -> None:
+    """One process must hold ONE HIP runtime.  PyTorch-ROCm bundles its own libamdhip64.so (same soname
+    as /opt/rocm's); if this library pulled in the system copy first, a later `import torch` would mix
+    the two and find no GPUs.  So when torch is installed, load its copy first (without importing torch):
+    the soname is then already resolved when libkwage_amd.so is opened.  The `kwage` CLI never loads
+    torch and uses the system runtime."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            try:
+                C.CDLL(p, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def lib() -> C.CDLL:
     """The loaded C-ABI library. Raises (loudly) if it has not been built: no fallback."""
     global _lib
     if _lib is None:
+        _preload_torch_hip_runtime()
         if not os.path.exists(_LIB):
             raise KwageError(-2, "%s is missing: build it with `make -C kwage_amd/csrc` "
                                  "(or __graft_entry__.build()); there is no CPU fallback" % _LIB)
