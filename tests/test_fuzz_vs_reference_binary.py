@@ -43,22 +43,54 @@ def _make_case(oracle, rng, root, n_files):
         infos = [oracle.FilterInfo(run_accession=oracle.str_to_accession("SRR%d" % (1000 * f + j + 1))) for j in range(n)]
         sub = "sub" if f % 3 == 2 else ""
         oracle.write_db(os.path.join(root, "db", sub, "f%02d.db" % f), k, nh, L, rows, n, infos)
-    fasta = os.path.join(root, "q.fa")
-    with open(fasta, "w") as fh:
-        for i in range(int(rng.integers(3, 9))):
-            kind = rng.integers(4)
-            g = genomes[int(rng.integers(len(genomes)))]
-            if kind == 0:
-                s = g
-            elif kind == 1:
-                a = int(rng.integers(0, len(g) // 2)); s = g[a:a + int(rng.integers(20, len(g)))]
-            elif kind == 2:
-                s = g[: len(g) // 2] + "N" + _seq(rng, 40)
-            else:
-                s = _seq(rng, int(rng.integers(5, 200)))
-            if rng.random() < 0.3:
-                s = s.lower()
-            fh.write(">q%d some text\n%s\n" % (i, s))
+    # query file: FASTA (sometimes gzip'd, CRLF, wrapped lines, blank lines, over-long deflines, '>' inside a
+    # line, odd leading characters) or FASTQ (sometimes with >2047-character sequence lines)
+    recs = []
+    for i in range(int(rng.integers(3, 9))):
+        kind = rng.integers(4)
+        g = genomes[int(rng.integers(len(genomes)))]
+        if kind == 0:
+            s = g
+        elif kind == 1:
+            a = int(rng.integers(0, len(g) // 2)); s = g[a:a + int(rng.integers(20, len(g)))]
+        elif kind == 2:
+            s = g[: len(g) // 2] + "N" + _seq(rng, 40)
+        else:
+            s = _seq(rng, int(rng.integers(5, 200)))
+        if rng.random() < 0.3:
+            s = s.lower()
+        recs.append(("q%d some text" % i, s))
+    style = int(rng.integers(5))
+    eol = "\r\n" if rng.random() < 0.3 else "\n"
+    if style == 4:                                           # FASTQ
+        fasta = os.path.join(root, "q.fastq")
+        with open(fasta, "w", newline="") as fh:
+            for i, (d, s) in enumerate(recs):
+                if i == 1:
+                    s = s * (2500 // max(len(s), 1) + 1)     # one gzgets chunk is not enough for this line
+                fh.write("@%s%s%s%s+%s%s%s" % (d, eol, s, eol, eol, "I" * len(s), eol))
+    else:
+        fasta = os.path.join(root, "q.fa.gz" if style == 3 else "q.fasta")
+        out = []
+        for i, (d, s) in enumerate(recs):
+            if i == 0 and style == 1:
+                d = "  > " + d + " " + "x" * 2600           # longer than the 2048-byte gzgets buffer
+            if i == 2 and style == 2:
+                d = d + " a>b, \"quoted\""
+            out.append(">" + d + eol)
+            w = int(rng.choice([60, 70, 1000000]))
+            for o in range(0, len(s), w):
+                out.append(s[o:o + w] + (" " if rng.random() < 0.1 else "") + eol)
+            if rng.random() < 0.2:
+                out.append(eol)
+        text = "".join(out)
+        if style == 3:
+            import gzip
+            with gzip.open(fasta, "wt", newline="") as fh:
+                fh.write(text)
+        else:
+            with open(fasta, "w", newline="") as fh:
+                fh.write(text)
     cmd = [genomes[0][:50]] if rng.random() < 0.5 else []
     return os.path.join(root, "db"), fasta, cmd
 
@@ -71,7 +103,7 @@ def _run(exe, db, fasta, cmd, thr, fmt="csv"):
 
 
 @needs_ref
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(30))
 def test_oracle_equals_reference_binary(oracle, tmp_path, seed):
     rng = np.random.default_rng(4242 + seed)
     db, fasta, cmd = _make_case(oracle, rng, str(tmp_path), int(rng.integers(1, 5)))
@@ -88,7 +120,7 @@ def test_oracle_equals_reference_binary(oracle, tmp_path, seed):
 
 @needs_ref
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(20))
 def test_cli_equals_reference_binary(oracle, tmp_path, seed):
     from kwage_amd import native
     rng = np.random.default_rng(777 + seed)
