@@ -125,7 +125,9 @@ def main():
 
     import torch
     import kwage_amd as ka
-    from kwage_amd import synth
+    from kwage_amd import native, synth
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        native.ensure_built()          # artefacts are git-ignored; normally they travel with the snapshot
 
     # KWAGE_BENCH_BACKEND=gloo + KWAGE_BENCH_ONE_DEVICE=1 rehearse the N>1 code path on a one-GPU box
     backend = os.environ.get("KWAGE_BENCH_BACKEND", "nccl")

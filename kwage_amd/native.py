@@ -30,6 +30,14 @@ def build_native(force: bool = False) -> str:
     return _LIB
 
 
+def ensure_built() -> str:
+    """Build the native library + CLI if (and only if) they are missing.  Used by bench.py / smoke();
+    compiling the HIP extension is not a fallback -- nothing runs without it."""
+    if not (os.path.exists(_LIB) and os.path.exists(KWAGE_BIN)):
+        build_native()
+    return _LIB
+
+
 class Hit(C.Structure):
     _fields_ = [("query", C.c_uint32), ("column", C.c_uint32), ("num_match", C.c_uint32)]
 
