@@ -128,6 +128,11 @@ def main():
     from kwage_amd import native, synth
     if int(os.environ.get("LOCAL_RANK", "0")) == 0:
         native.ensure_built()          # artefacts are git-ignored; normally they travel with the snapshot
+    else:
+        for _ in range(600):           # other ranks wait for rank 0's build instead of racing it
+            if os.path.exists(native.lib_path()) and os.path.exists(native.KWAGE_BIN):
+                break
+            time.sleep(0.5)
 
     # KWAGE_BENCH_BACKEND=gloo + KWAGE_BENCH_ONE_DEVICE=1 rehearse the N>1 code path on a one-GPU box
     backend = os.environ.get("KWAGE_BENCH_BACKEND", "nccl")
