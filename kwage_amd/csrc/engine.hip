@@ -351,6 +351,7 @@ void choose_segments(SearchArgs &a, uint64_t max_kmers, uint64_t max_segs)
 	const uint64_t MAX_SEGS = max_segs;
 	a.segs = 1;
 	a.seg_kmers = (uint32_t)std::max<uint64_t>(max_kmers, 1);
+	if(a.n_queries > 65535){ return; }      // the combine kernels index queries with gridDim.y
 	uint64_t want = 1;
 	const char *f = getenv("KWAGE_FORCE_SEGS");
 	if(f && atoi(f) > 0){ want = (uint64_t)atoi(f); }
@@ -866,6 +867,7 @@ extern "C" int kwage_batch_create(kwage_ctx *ctx, const char *seqs, const uint64
 		if(offsets[i + 1] < offsets[i]){ return fail(KWAGE_ERR_ARG, "kwage_batch_create: offsets must be non-decreasing"); }
 		if(offsets[i + 1] - offsets[i] >= (1ull << 31)){ return fail(KWAGE_ERR_ARG, "kwage_batch_create: query %u is longer than 2^31-1 bases", i); }
 	}
+	if(n_queries > 0x7FFFFFFFu){ return fail(KWAGE_ERR_ARG, "kwage_batch_create: at most 2^31-1 queries per batch"); }
 	const uint64_t total = offsets[n_queries] - offsets[0];
 	if(total && !seqs){ return fail(KWAGE_ERR_ARG, "kwage_batch_create: seqs is NULL"); }
 	int rc = set_device(ctx);

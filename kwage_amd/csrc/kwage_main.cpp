@@ -13,6 +13,8 @@
 //   KWAGE_DEVICES     "all" or "0,1,...": shard the database files over several GPUs
 //   KWAGE_EARLY_EXIT  1 = enable the reference's early-exit shortcut on the device (default 1)
 //   KWAGE_BATCH_BASES max bases per query batch (default 256 Mi)
+//   KWAGE_MAX_GROUP_BYTES  cap on the HBM bit matrix of one pass (default: 7/8 of the free device memory);
+//                     larger parameter groups are searched in several passes over whole files
 //   KWAGE_VERBOSE     1 = per-stage wall times on stderr
 #include <algorithm>
 #include <chrono>
@@ -376,6 +378,8 @@ int main(int argc, char *argv[])
 		const uint32_t flags = (ee && atoi(ee) == 0) ? 0u : KWAGE_SEARCH_EARLY_EXIT;
 		const char *bb = getenv("KWAGE_BATCH_BASES");
 		const uint64_t max_batch_bases = bb ? strtoull(bb, NULL, 10) : (256ull << 20);
+		const char *mg = getenv("KWAGE_MAX_GROUP_BYTES");
+		const uint64_t max_group_bytes = mg ? strtoull(mg, NULL, 10) : 0;       // 0 = what is free on the device
 
 		ResultMap file_search_results, command_line_search_results;
 
@@ -418,31 +422,49 @@ int main(int argc, char *argv[])
 					p.num_hash = gi->first.first.second;
 					p.log_2_filter_len = gi->first.second.first;
 					p.hash_func = gi->first.second.second;
-					uint64_t span_bytes = 0;
-					for(size_t m = 0; m < members.size(); ++m){
-						span_bytes = (span_bytes + 15)/16*16 + ((uint64_t)files[members[m]].header.num_filter + 7)/8;
+					// A group larger than the HBM that is free is searched in several passes over
+					// sub-groups of whole files (queries are re-run per pass; results are additive).
+					uint64_t budget = max_group_bytes;
+					if(budget == 0){
+						uint64_t free_b = 0, total_b = 0;
+						check(kwage_mem_info(ctx, &free_b, &total_b));
+						budget = free_b - free_b/8;          // leave room for staging buffers, row indices, hits
 					}
-					kwage_group *grp = NULL;
-					double t0 = now();
-					check(kwage_group_create(ctx, &p, span_bytes*8, &grp));
-					vector<DbFileEntry*> gfiles;
-					for(size_t m = 0; m < members.size(); ++m){
-						DbFileEntry &f = files[members[m]];       // each file is touched by exactly one worker
-						uint32_t nf = 0;
-						int rc = kwage_group_add_db_file(grp, f.path.c_str(), &f.first_column, &nf);
-						if(rc != KWAGE_OK){ kwage_group_destroy(grp); check(rc); }
-						gfiles.push_back(&f);
+					const uint64_t nrows = 1ull << p.log_2_filter_len;
+					size_t m0 = 0;
+					while(m0 < members.size()){
+						uint64_t span_bytes = 0;
+						size_t m1 = m0;
+						while(m1 < members.size()){
+							const uint64_t next = (span_bytes + 15)/16*16 + ((uint64_t)files[members[m1]].header.num_filter + 7)/8;
+							if(m1 > m0 && ((next + 127)/128*128)*nrows > budget){ break; }
+							span_bytes = next;
+							++m1;
+						}
+						const vector<uint32_t> part(members.begin() + m0, members.begin() + m1);
+						kwage_group *grp = NULL;
+						double t0 = now();
+						check(kwage_group_create(ctx, &p, span_bytes*8, &grp));
+						vector<DbFileEntry*> gfiles;
+						for(size_t m = 0; m < part.size(); ++m){
+							DbFileEntry &f = files[part[m]];       // each file is touched by exactly one worker
+							uint32_t nf = 0;
+							int rc = kwage_group_add_db_file(grp, f.path.c_str(), &f.first_column, &nf);
+							if(rc != KWAGE_OK){ kwage_group_destroy(grp); check(rc); }
+							gfiles.push_back(&f);
+						}
+						check(kwage_group_finalize(grp));
+						t_load += now() - t0;
+						gb_loaded += (double)kwage_group_row_bytes(grp)*(double)nrows/1e9;
+						t0 = now();
+						search_queries(ctx, grp, gfiles, part, cmdline_queries, opt.threshold, flags, max_batch_bases,
+						               local_cmdline_results);
+						search_queries(ctx, grp, gfiles, part, file_queries, opt.threshold, flags, max_batch_bases,
+						               local_file_results);
+						t_search += now() - t0;
+						kwage_group_destroy(grp);
+						m0 = m1;
 					}
-					check(kwage_group_finalize(grp));
-					t_load += now() - t0;
-					gb_loaded += (double)kwage_group_row_bytes(grp)*(double)(1ull << p.log_2_filter_len)/1e9;
-					t0 = now();
-					search_queries(ctx, grp, gfiles, members, cmdline_queries, opt.threshold, flags, max_batch_bases,
-					               local_cmdline_results);
-					search_queries(ctx, grp, gfiles, members, file_queries, opt.threshold, flags, max_batch_bases,
-					               local_file_results);
-					t_search += now() - t0;
-					kwage_group_destroy(grp);
 				}
 				kwage_shutdown(ctx);
 				if(verbose){

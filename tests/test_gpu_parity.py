@@ -306,6 +306,9 @@ def test_cli_sharded_over_two_contexts(ka, oracle):
             three = subprocess.run(args, cwd=cdir, capture_output=True, env=dict(os.environ, KWAGE_DEVICES="0,0,0"))
             assert one.returncode == 0 and two.returncode == 0 and three.returncode == 0, two.stderr.decode()
             assert one.stdout == two.stdout == three.stdout      # deterministic, independent of the sharding
+            # a database larger than HBM is searched in several passes over whole files: force one file per pass
+            passes = subprocess.run(args, cwd=cdir, capture_output=True, env=dict(os.environ, KWAGE_MAX_GROUP_BYTES="1"))
+            assert passes.returncode == 0 and passes.stdout == one.stdout
             exp = open(os.path.join(cdir, "expected_t%s.%s" % (thr, fmt)), encoding="latin-1").read()
             assert sorted(two.stdout.decode("latin-1").splitlines()) == sorted(exp.splitlines())
 
