@@ -217,3 +217,92 @@ class Database:
     def close(self) -> None:
         for g in self.groups:
             g.close()
+
+
+@dataclass
+class DatabaseHit:
+    query: int
+    path: str            # `.db` file the sample lives in
+    column: int          # column within that file
+    accession: str       # FilterInfo::csv_string() (run accession)
+    num_kmers_found: int
+    num_query_kmer: int
+
+
+class FileDatabase(Database):
+    """A directory tree / list of `.db` (`.dbz`) files loaded the way the `kwage` CLI loads it: files
+    grouped by (kmer_len, num_hash, log_2_filter_len, hash_func), each group one HBM matrix; hits are
+    mapped back to (file, column) and carry the sample's run accession."""
+
+    def __init__(self, ctx: Context, paths: Sequence[str]):
+        import os
+        files: List[str] = []
+        todo = list(paths)
+        while todo:                                   # breadth first, like FindFiles (file_util.h:30-125)
+            p = todo.pop(0)
+            if os.path.isdir(p):
+                for name in os.listdir(p):
+                    full = p + "/" + name
+                    if os.path.isdir(full):
+                        todo.append(full)
+                    elif full.lower().endswith((".db", ".dbz")):
+                        files.append(full)
+            elif os.path.isfile(p):
+                files.append(p)
+            else:
+                raise native.KwageError(-3, "FindFiles::next: Unable to stat entry " + p)
+        by_param = {}
+        for f in files:
+            h = native.DbHeader()
+            check(lib().kwage_db_read_header(f.encode(), C.byref(h)))
+            by_param.setdefault((h.kmer_len, h.num_hash, h.log_2_filter_len, h.hash_func), []).append((f, h.num_filter))
+        groups, self._layout, self._info = [], [], {}
+        for (k, nh, lg, hf), members in sorted(by_param.items()):
+            span = 0
+            for _, nf in members:
+                span = (span + 15) // 16 * 16 + (nf + 7) // 8
+            g = Group(ctx, k, nh, lg, span * 8, hf)
+            firsts = []
+            for f, _ in members:
+                first, nf = g.add_db_file(f)
+                firsts.append((first, nf, f))
+            g.finalize()
+            groups.append(g)
+            self._layout.append(firsts)
+        super().__init__(groups)
+        self.ctx = ctx
+        self.files = files
+
+    def _accession(self, path: str, column: int) -> str:
+        d = self._info.get(path)
+        if d is None:
+            d = C.c_void_p()
+            check(lib().kwage_dbinfo_open(path.encode(), C.byref(d)))
+            self._info[path] = d
+        buf = C.create_string_buffer(64)
+        check(lib().kwage_dbinfo_csv_string(d, column, buf, 64))
+        return buf.value.decode()
+
+    def search_sequences(self, seqs: Sequence[bytes | str], threshold: float = 1.0, flags: int = SEARCH_EARLY_EXIT) -> List[DatabaseHit]:
+        """What `kwage -d ... <seqs>` reports, as records: sorted by query, then descending hits."""
+        import bisect
+        b = Batch(self.ctx, seqs)
+        out: List[DatabaseHit] = []
+        try:
+            for g, layout in zip(self.groups, self._layout):
+                r = search(g, b, threshold, flags)
+                starts = [f[0] for f in layout]
+                for q, c, m in r.hits.tolist():
+                    i = bisect.bisect_right(starts, c) - 1
+                    first, _, path = layout[i]
+                    out.append(DatabaseHit(q, path, c - first, self._accession(path, c - first), m, int(r.num_query_kmer[q])))
+        finally:
+            b.close()
+        out.sort(key=lambda h: (h.query, -h.num_kmers_found, h.path, h.column))
+        return out
+
+    def close(self) -> None:
+        for d in self._info.values():
+            lib().kwage_dbinfo_close(d)
+        self._info = {}
+        super().close()

@@ -393,3 +393,23 @@ def test_search_device_leaves_the_same_hits_in_hbm(ka, ctx):
         assert np.array_equal(nk.cpu().numpy().astype(np.uint32), ref.num_query_kmer)
     s.batch.close()
     s.group.close()
+
+
+def test_python_file_database_matches_reference_report(ka, ctx, oracle):
+    """kwage_amd.FileDatabase (directory -> groups -> hits with accessions) == the reference's CSV."""
+    cdir = os.path.join(GOLDEN, "multi")
+    db = ka.FileDatabase(ctx, [os.path.join(cdir, "dbs")])
+    assert len(db.files) == 4 and len(db.groups) == 3
+    seqs = [s for _, s in oracle.read_sequences(os.path.join(cdir, "reads.fastq"))]
+    seqs += [s for _, s in oracle.read_sequences(os.path.join(cdir, "contigs.fa.gz"))]
+    names = [d for d, _ in oracle.read_sequences(os.path.join(cdir, "reads.fastq"))] + \
+            [d for d, _ in oracle.read_sequences(os.path.join(cdir, "contigs.fa.gz"))]
+    for thr, fn in ((1.0, "expected_t1.0.csv"), (0.7, "expected_t0.7.csv")):
+        exp = oracle.parse_csv(open(os.path.join(cdir, fn), encoding="latin-1").read())
+        got = {}
+        for h in db.search_sequences(seqs, thr):
+            got.setdefault(names[h.query], []).append((h.accession, h.num_query_kmer, h.num_kmers_found))
+        assert set(got) == set(exp)
+        for q in exp:
+            assert sorted(got[q]) == sorted((a, nk, nf) for a, nk, nf, _ in exp[q])
+    db.close()
