@@ -450,11 +450,10 @@ __device__ __forceinline__ void csa(u32x4 &sum, u32x4 &carry, u32x4 a, u32x4 b, 
 	sum = u ^ c;
 }
 
-// columns with count >= thr (kwage.cpp:497), compared plane by plane from the top; then the
-// count of every surviving column is re-assembled from the planes (num_match = match_count[i]).
+// Bit-parallel comparator: mask of the columns whose bit-sliced counter is >= thr, evaluated plane by
+// plane from the top.
 template <int PLANES>
-__device__ __forceinline__ void emit_count_hits(const SearchArgs &a, uint32_t q, uint32_t unit,
-                                                const u32x4 (&plane)[PLANES], uint32_t thr)
+__device__ __forceinline__ u32x4 planes_ge(const u32x4 (&plane)[PLANES], uint32_t thr)
 {
 	u32x4 gt = (u32x4)(0u);
 	u32x4 eq = ~(u32x4)(0u);
@@ -465,7 +464,17 @@ __device__ __forceinline__ void emit_count_hits(const SearchArgs &a, uint32_t q,
 		eq &= ~(plane[p] ^ t4);
 	}
 	u32x4 ge = gt | eq;
-	if(PLANES < 32 && (thr >> PLANES) != 0){ ge = (u32x4)(0u); }   // unreachable: thr <= n < 2^PLANES
+	if(PLANES < 32 && (thr >> PLANES) != 0){ ge = (u32x4)(0u); }   // a counter of PLANES bits cannot reach thr
+	return ge;
+}
+
+// columns with count >= thr (kwage.cpp:497); then the count of every surviving column is
+// re-assembled from the planes (num_match = match_count[i]).
+template <int PLANES>
+__device__ __forceinline__ void emit_count_hits(const SearchArgs &a, uint32_t q, uint32_t unit,
+                                                const u32x4 (&plane)[PLANES], uint32_t thr)
+{
+	u32x4 ge = planes_ge<PLANES>(plane, thr);
 	ge &= reinterpret_cast<const u32x4*>(a.valid)[unit];
 #pragma unroll
 	for(int d = 0; d < 4; ++d){
@@ -536,6 +545,16 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 		else{
 #pragma unroll
 			for(int u = 0; u < 4; ++u){ planes_add<PLANES>(plane, m[u], 0); }
+		}
+		// kwage.cpp:478-481 per tile: stop once no column of the tile can still reach the threshold
+		// even if every remaining k-mer matched (max count + remaining < threshold)
+		if(!SEG && a.early_exit && ((i + 4) & 63u) == 0){
+			const uint32_t remaining = nk - (i + 4);
+			const uint32_t thr = a.qthr[q];
+			if(thr > remaining){
+				const u32x4 can = planes_ge<PLANES>(plane, thr - remaining);
+				if(!__any((can.x | can.y | can.z | can.w) != 0)){ return; }
+			}
 		}
 	}
 	for(; i < nk; ++i){
