@@ -96,3 +96,29 @@ def test_wide_rows_and_five_hashes(ka, oracle):
             _check_sampled(ka, oracle, s, r3, hitq[:1] + missq[:1], other)
             s.batch.close()
             s.group.close()
+
+
+@pytest.mark.timeout(600)
+def test_two_to_the_thirty_rows(ka, oracle):
+    """log_2_filter_len = 30 (the reference allows up to 32, options.h:153): row indices beyond 2^24 and
+    64-bit row offsets (2^30 rows x 128 B = 137 GB)."""
+    from kwage_amd import synth
+    w = synth.Workload("L30", 1000, 30, 31, 3, 40, 500, 1.0, density_q8=200, num_genomes=2, genome_len=4000)
+    with ka.Context(0) as ctx:
+        free, _ = ctx.mem_info()
+        if free < 150e9:
+            pytest.skip("needs ~138 GB of free HBM")
+        s = synth.build(ctx, w)
+        assert s.group.device_bytes == (1 << 30) * 128
+        for thr in (1.0, 0.95):
+            r = s.group.search(s.batch, thr)
+            if thr == 1.0:
+                _check_planted(s, r)
+            hitq = [i for i, g in enumerate(s.query_genome) if g >= 0][:2]
+            missq = [i for i, g in enumerate(s.query_genome) if g < 0][:2]
+            _check_sampled(ka, oracle, s, r, hitq + missq, thr)
+        # the row indices really use the upper bits
+        k, rows = ka.hash_batch(ctx, 31, 3, 30, s.batch)
+        assert max(int(x.max()) for x in rows if x.size) > (1 << 29)
+        s.batch.close()
+        s.group.close()
