@@ -258,6 +258,7 @@ int launch_kmer_stage(kwage_ctx *ctx, const kwage_params &p, kwage_batch *b, flo
 }
 
 static int g_and_lds_bytes = 0;     // tuning only: dynamic LDS per workgroup caps waves per CU
+static int g_and_block_waves = SEARCH_THREADS/WAVE;   // tuning only: waves per workgroup of and_kernel
 
 uint32_t search_blocks(const SearchArgs &a)
 {
@@ -268,11 +269,14 @@ uint32_t search_blocks(const SearchArgs &a)
 template <int VEC, int UNROLL, bool NT>
 void launch_and(const SearchArgs &a, hipStream_t s)
 {
+	const uint64_t tiles = (uint64_t)a.n_queries*a.segs*a.chunks;
+	const uint32_t bw = (uint32_t)g_and_block_waves;
+	const dim3 grid((uint32_t)((tiles + bw - 1)/bw)), block(bw*WAVE);
 	if(a.segs > 1){
-		hipLaunchKernelGGL((and_kernel<VEC, UNROLL, NT, true>), dim3(search_blocks(a)), dim3(SEARCH_THREADS), (size_t)g_and_lds_bytes, s, a);
+		hipLaunchKernelGGL((and_kernel<VEC, UNROLL, NT, true>), grid, block, (size_t)g_and_lds_bytes, s, a);
 	}
 	else{
-		hipLaunchKernelGGL((and_kernel<VEC, UNROLL, NT, false>), dim3(search_blocks(a)), dim3(SEARCH_THREADS), (size_t)g_and_lds_bytes, s, a);
+		hipLaunchKernelGGL((and_kernel<VEC, UNROLL, NT, false>), grid, block, (size_t)g_and_lds_bytes, s, a);
 	}
 }
 
@@ -315,11 +319,12 @@ AndCfg and_config(uint32_t units_per_row)
 	c.nt = 1;      // +4-10 % on MI355X: each row byte is consumed once per (query, tile)
 	const char *e = getenv("KWAGE_AND_CFG");
 	if(e){
-		int v = 0, u = 0, n = 0, l = 0;
-		const int got = sscanf(e, "%d,%d,%d,%d", &v, &u, &n, &l);
+		int v = 0, u = 0, n = 0, l = 0, w = 0;
+		const int got = sscanf(e, "%d,%d,%d,%d,%d", &v, &u, &n, &l, &w);
 		if(got >= 3 && (v == 1 || v == 2 || v == 4) && (u == 4 || u == 8 || u == 16 || u == 32)){
 			c.vec = v; c.unroll = u; c.nt = n ? 1 : 0;
-			g_and_lds_bytes = (got == 4 && l > 0 && l <= 160) ? l*1024 : 0;
+			g_and_lds_bytes = (got >= 4 && l > 0 && l <= 160) ? l*1024 : 0;
+			g_and_block_waves = (got >= 5 && (w == 1 || w == 2 || w == 4)) ? w : SEARCH_THREADS/WAVE;
 		}
 	}
 	return c;

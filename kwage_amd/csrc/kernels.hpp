@@ -340,7 +340,7 @@ template <int VEC, int UNROLL, bool NT, bool SEG>
 __global__ __launch_bounds__(SEARCH_THREADS) void and_kernel(SearchArgs a)
 {
 	const uint32_t lane = threadIdx.x & (WAVE - 1);
-	const uint64_t tile = (uint64_t)blockIdx.x*(SEARCH_THREADS/WAVE) + (threadIdx.x >> 6);
+	const uint64_t tile = (uint64_t)blockIdx.x*(blockDim.x/WAVE) + (threadIdx.x >> 6);
 	if(tile >= (uint64_t)a.n_queries*a.segs*a.chunks){ return; }
 
 	// wave-uniform values -> SGPRs, so row indices come through the scalar cache

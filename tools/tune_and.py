@@ -13,16 +13,15 @@ from kwage_amd import synth
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 7
-variants = [(1, 8, 1, 0), (1, 16, 1, 0), (1, 32, 1, 0), (2, 8, 1, 0), (2, 16, 1, 0), (4, 8, 1, 0),
-            (1, 16, 1, 20), (1, 16, 1, 40), (1, 32, 1, 20), (1, 32, 1, 40), (2, 16, 1, 20), (2, 16, 1, 40),
-            (2, 8, 1, 10), (2, 8, 1, 20), (1, 8, 1, 10), (2, 8, 0, 0)]
+variants = [(2, 8, 1, 0, 4), (2, 8, 1, 0, 2), (2, 8, 1, 0, 1), (1, 8, 1, 0, 4), (1, 8, 1, 0, 1), (1, 16, 1, 0, 1),
+            (2, 16, 1, 0, 4), (2, 16, 1, 0, 1), (4, 8, 1, 0, 4), (4, 8, 1, 0, 1), (2, 8, 0, 0, 4)]
 ctx = ka.Context(0)
 s = synth.build(ctx, synth.WORKLOADS[wl])
 ms = {v: [] for v in variants}
 ref = None
 for r in range(rounds):
     for v in variants:
-        os.environ["KWAGE_AND_CFG"] = "%d,%d,%d,%d" % v
+        os.environ["KWAGE_AND_CFG"] = "%d,%d,%d,%d,%d" % v
         res = s.group.search(s.batch, s.workload.threshold, ka.SEARCH_TIMING)
         key = (len(res.hits), int(res.hits["column"].astype(np.uint64).sum()), int(res.hits["query"].astype(np.uint64).sum()))
         ref = ref or key
@@ -32,4 +31,4 @@ ab = res.algorithmic_bytes
 print("workload %s  algorithmic bytes/launch %.3f GB" % (wl, ab / 1e9))
 for v in sorted(variants, key=lambda v: np.median(ms[v])):
     m = np.array(ms[v][1:])
-    print("vec=%d unroll=%2d nt=%d ldsKB=%3d  median %.4f ms  min %.4f ms  -> %.0f GB/s (median)" % (v + (np.median(m), m.min(), ab / np.median(m) / 1e6)))
+    print("vec=%d unroll=%2d nt=%d ldsKB=%3d waves/block=%d  median %.4f ms  min %.4f ms  -> %.0f GB/s (median)" % (v + (np.median(m), m.min(), ab / np.median(m) / 1e6)))
