@@ -86,7 +86,7 @@ def cpu_baseline(w, queries, n_files):
                 fh.write(">q%d\n%s\n" % (i, q))
         bit_tests = total_kmers * nh * ncol * n_files
         if os.access(oracle.REF_KWAGE, os.X_OK):
-            env = dict(os.environ, OMP_NUM_THREADS=str(cores))
+            env = dict(os.environ, OMP_NUM_THREADS=str(min(cores, n_files)))   # its only parallel axis is files
             best = None
             for _ in range(2):     # first run warms the page cache
                 t0 = time.perf_counter()
