@@ -1,0 +1,76 @@
+"""Randomised GPU-vs-oracle sweep: random column counts (1 ... 300k), filter sizes, k, hash counts,
+thresholds, batch compositions (empty / duplicate / very long queries -> 14-, 20- and 32-plane counters),
+early exit on/off and forced segment counts.  Every case downloads the device-resident bit matrix and
+reduces it with the CPU oracle; hit lists must be identical."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def _seq(rng, n):
+    return ACGT[rng.integers(0, 4, size=n)].tobytes().decode()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configuration(oracle, seed, monkeypatch):
+    import kwage_amd as ka
+    rng = np.random.default_rng(9000 + seed)
+    k = int(rng.choice([5, 11, 16, 21, 27, 31, 32]))
+    nh = int(rng.integers(1, 6))
+    L = int(rng.integers(6, 15))
+    n_cols = int(rng.choice([1, 3, 8, 100, 1000, 8191, 8192, 8193, 20000, 100000, 300000]))
+    if n_cols >= 100000:
+        L = min(L, 10)
+    dens = int(rng.choice([64, 128, 200, 240]))
+    genome = _seq(rng, int(rng.choice([200, 3000, 40000])))
+    lens = [0, k - 1, k, k + 1, 50, 150, 1000] + ([20000] if seed % 3 == 0 else []) + ([70000] if seed % 8 == 0 else [])
+    seqs = []
+    for n in lens:
+        kind = rng.integers(3)
+        if kind == 0 and len(genome) >= n:
+            a = int(rng.integers(0, len(genome) - n + 1)); s = genome[a:a + n]
+        elif kind == 1:
+            s = _seq(rng, n)
+        else:
+            s = (genome[: max(n // 2, 0)] + "N" + _seq(rng, n))[:n]
+        seqs.append(s.lower() if rng.random() < 0.2 else s)
+    seqs.append(seqs[-1])                       # duplicate query
+    with ka.Context(0) as ctx:
+        g = ka.Group(ctx, k, nh, L, n_cols)
+        g.add_random_columns(n_cols, 100 + seed, dens)
+        gb = ka.Batch(ctx, [genome])
+        _, rows = ka.hash_batch(ctx, k, nh, L, gb)
+        gb.close()
+        planted = sorted(set(int(c) for c in rng.integers(0, n_cols, size=3)))
+        if rows[0].size:
+            for c in planted:
+                r = rows[0].reshape(-1)
+                g.set_bits(r, np.full(r.shape, c, dtype=np.uint64))
+        g.finalize()
+        image = g.read_rows(np.arange(1 << L))
+        b = ka.Batch(ctx, seqs)
+        thresholds = [1.0, float(rng.choice([0.99, 0.9, 0.75, 0.5])), float(rng.choice([0.3, 0.05, 0.0001])) if n_cols <= 20000 else 0.6]
+        for thr in thresholds:
+            thr32 = float(np.float32(thr))
+            exp = []
+            for s in seqs:
+                kmers = oracle.unique_kmers(s, k)
+                e, _ = oracle.search_image(image, image.shape[1], k, nh, L, n_cols, kmers, thr32)
+                exp.append((len(kmers), e))
+            for flags, force in ((0, None), (ka.SEARCH_EARLY_EXIT, None), (0, str(int(rng.choice([2, 5, 33])))), (ka.SEARCH_EARLY_EXIT, "3")):
+                if force is None:
+                    monkeypatch.delenv("KWAGE_FORCE_SEGS", raising=False)
+                else:
+                    monkeypatch.setenv("KWAGE_FORCE_SEGS", force)
+                r = g.search(b, thr, flags)
+                per_q = r.per_query()
+                for i, (nk, e) in enumerate(exp):
+                    assert r.num_query_kmer[i] == nk, (seed, thr, i)
+                    assert per_q[i] == e, (seed, k, nh, L, n_cols, thr, flags, force, i, len(per_q[i]), len(e))
+        b.close()
+        g.close()
