@@ -37,6 +37,9 @@ WORKLOADS: Dict[str, Workload] = {
     # BASELINE.json configs[1]: the configuration the metric is quoted on
     "c2": Workload("C2: 100k samples x 2^23-bit filters, 1k x 1 kb queries, 1 hash, t=1.0", 100_000, 23, 31, 1,
                    1000, 1000, 1.0, num_genomes=32, genome_len=50_000),
+    # C2 through the count path (threshold < 1, one hash): fewest loads in flight per wave
+    "c2t": Workload("C2 at t=0.8 (count path, 1 hash): 100k samples x 2^23-bit filters, 1k x 1 kb queries", 100_000, 23, 31, 1,
+                    1000, 1000, 0.8, num_genomes=32, genome_len=50_000),
     # BASELINE.json configs[2]
     "c3": Workload("C3: 1M samples x 2^20-bit filters, 100k x 150 bp queries, 1 hash, t=1.0", 1_000_000, 20, 31, 1,
                    100_000, 150, 1.0, num_genomes=64, genome_len=150_000),

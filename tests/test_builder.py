@@ -155,3 +155,34 @@ def test_repack_is_the_column_concatenation(oracle, tmp_path):
             a, b = run(str(parts_dir)), run(out)
             assert a.returncode == 0 and b.returncode == 0
             assert sorted(a.stdout.splitlines()) == sorted(b.stdout.splitlines()) and len(a.stdout.splitlines()) > 1
+
+
+@pytest.mark.gpu
+def test_dbtool_front_end(tmp_path):
+    """kwage_dbtool drives the same C-ABI entry points from the shell."""
+    import subprocess
+    from kwage_amd import native
+    tool = os.path.join(os.path.dirname(native.KWAGE_BIN), "kwage_dbtool")
+    run = lambda *a: subprocess.run([tool] + list(a), capture_output=True, text=True)
+    out = str(tmp_path / "k32.db")
+    r = run("build", out, "32", "10", "5", *_blooms("k32"))
+    assert r.returncode == 0, r.stderr
+    assert open(out, "rb").read() == open(os.path.join(GOLDEN, "k32", "k32.db"), "rb").read()
+    r = run("info", out)
+    assert "kmer_len\t32" in r.stdout and "num_filter\t8" in r.stdout
+    assert run("accessions", out).stdout.splitlines()[2] == "2\tSRR3"
+    z = str(tmp_path / "k32.dbz")
+    assert run("compress", out, z, "2").returncode == 0 and run("decompress", z, str(tmp_path / "b.db")).returncode == 0
+    assert open(tmp_path / "b.db", "rb").read() == open(out, "rb").read()
+    a, b = os.path.join(GOLDEN, "multi/dbs/a/k31_L10_h1.db"), os.path.join(GOLDEN, "multi/dbs/a/deeper/k31_L10_h1_b.db")
+    wide = str(tmp_path / "wide.db")
+    assert run("repack", wide, a, b).returncode == 0
+    assert "num_filter\t34" in run("info", wide).stdout
+    fa = tmp_path / "g.fasta"
+    fa.write_text(">c\n" + "ACGTTGCAAGGCTTAACCGGATATCGCGAT" * 20 + "\n")
+    bl = str(tmp_path / "g.bloom")
+    r = run("mkbloom", bl, "SRR424242", "21", "0", "0", str(fa))
+    assert r.returncode == 0 and "distinct k-mers -> log_2_filter_len 18" in r.stderr, r.stderr
+    assert run("build", str(tmp_path / "g.db"), "21", "18", r.stderr.split("num_hash ")[1].split()[0], bl).returncode == 0
+    assert run("repack", wide, a, os.path.join(GOLDEN, "k32", "k32.db")).returncode == 1      # different parameters
+    assert run("nonsense", "x").returncode == 2
