@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _LIB = os.path.join(_HERE, "lib", "libkwage_amd.so")
 KWAGE_BIN = os.path.join(_HERE, "bin", "kwage")
+KWAGE_DBTOOL_BIN = os.path.join(_HERE, "bin", "kwage_dbtool")
 
 
 class KwageError(RuntimeError):
@@ -33,7 +34,7 @@ def build_native(force: bool = False) -> str:
 def ensure_built() -> str:
     """Build the native library + CLI if (and only if) they are missing.  Used by bench.py / smoke();
     compiling the HIP extension is not a fallback -- nothing runs without it."""
-    if not (os.path.exists(_LIB) and os.path.exists(KWAGE_BIN)):
+    if not (os.path.exists(_LIB) and os.path.exists(KWAGE_BIN) and os.path.exists(KWAGE_DBTOOL_BIN)):
         build_native()
     return _LIB
 
