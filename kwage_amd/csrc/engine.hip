@@ -291,6 +291,20 @@ void launch_count(const SearchArgs &a, hipStream_t s)
 	}
 }
 
+template <int PLANES, int G>
+void launch_count_narrow(const SearchArgs &a, hipStream_t s)
+{
+	const uint64_t waves = ((uint64_t)a.n_queries + G - 1)/G;
+	const dim3 grid((uint32_t)((waves + 3)/4)), block(SEARCH_THREADS);
+	switch(a.num_hash){
+		case 1: hipLaunchKernelGGL((count_narrow_kernel<PLANES, 1, G>), grid, block, 0, s, a); break;
+		case 2: hipLaunchKernelGGL((count_narrow_kernel<PLANES, 2, G>), grid, block, 0, s, a); break;
+		case 3: hipLaunchKernelGGL((count_narrow_kernel<PLANES, 3, G>), grid, block, 0, s, a); break;
+		case 4: hipLaunchKernelGGL((count_narrow_kernel<PLANES, 4, G>), grid, block, 0, s, a); break;
+		default: hipLaunchKernelGGL((count_narrow_kernel<PLANES, 5, G>), grid, block, 0, s, a); break;
+	}
+}
+
 template <int PLANES>
 void launch_count_nh(const SearchArgs &a, hipStream_t s)
 {
@@ -399,6 +413,21 @@ int launch_search_stage(kwage_group *g, kwage_batch *b, float threshold, uint32_
 		a.chunks = (a.units_per_row + WAVE*cfg.vec - 1)/(WAVE*cfg.vec);
 		choose_segments(a, b->max_pos, 4096);
 		if((uint64_t)a.n_queries*a.segs*a.chunks/4 + 1 > 0x7FFFFFFFull){ return fail(KWAGE_ERR_ARG, "batch too large for one launch"); }
+		// narrow rows: several queries per wave (tools/bench_narrow.py); KWAGE_NARROW=0 disables it
+		static const bool narrow_ok = []() { const char *e = getenv("KWAGE_NARROW"); return !(e && atoi(e) == 0); }();
+		if(narrow_ok && a.segs == 1 && a.units_per_row <= 32 && a.n_queries >= 64){
+			const uint32_t G = (a.units_per_row <= 4) ? 16 : (a.units_per_row <= 8) ? 8 : (a.units_per_row <= 16) ? 4 : 2;
+			const uint64_t waves = ((uint64_t)a.n_queries + G - 1)/G;
+			const dim3 grid((uint32_t)((waves + 3)/4)), block(SEARCH_THREADS);
+			switch(G){
+				case 16: hipLaunchKernelGGL((and_narrow_kernel<16, 8>), grid, block, 0, ctx->stream, a); break;
+				case 8: hipLaunchKernelGGL((and_narrow_kernel<8, 8>), grid, block, 0, ctx->stream, a); break;
+				case 4: hipLaunchKernelGGL((and_narrow_kernel<4, 8>), grid, block, 0, ctx->stream, a); break;
+				default: hipLaunchKernelGGL((and_narrow_kernel<2, 8>), grid, block, 0, ctx->stream, a); break;
+			}
+			HIP_TRY(hipGetLastError());
+			return KWAGE_OK;
+		}
 		if(a.segs > 1){
 			const uint64_t bytes = (uint64_t)a.n_queries*g->stride;
 			if((rc = ctx->partial.reserve(bytes))){ return rc; }
@@ -429,6 +458,22 @@ int launch_search_stage(kwage_group *g, kwage_batch *b, float threshold, uint32_
 		if(a.segs > 1){
 			if((rc = ctx->partial.reserve((uint64_t)a.n_queries*a.segs*planes*g->stride))){ return rc; }
 			a.partial = (uint32_t*)ctx->partial.p;
+		}
+		static const bool narrow_ok = []() { const char *e = getenv("KWAGE_NARROW"); return !(e && atoi(e) == 0); }();
+		if(narrow_ok && a.segs == 1 && a.units_per_row <= 32 && a.units_per_row > 8 && a.n_queries >= 64 && planes <= 14){
+			// one reference file (<= 2048 columns = 16 units) or two: 4 resp. 2 queries per wave
+			if(a.units_per_row <= 16){
+				if(planes == 7){ launch_count_narrow<7, 4>(a, ctx->stream); }
+				else if(planes == 10){ launch_count_narrow<10, 4>(a, ctx->stream); }
+				else{ launch_count_narrow<14, 4>(a, ctx->stream); }
+			}
+			else{
+				if(planes == 7){ launch_count_narrow<7, 2>(a, ctx->stream); }
+				else if(planes == 10){ launch_count_narrow<10, 2>(a, ctx->stream); }
+				else{ launch_count_narrow<14, 2>(a, ctx->stream); }
+			}
+			HIP_TRY(hipGetLastError());
+			return KWAGE_OK;
 		}
 		switch(planes){
 			case 7: launch_count_nh<7>(a, ctx->stream); break;

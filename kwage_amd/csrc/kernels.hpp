@@ -415,6 +415,44 @@ __global__ __launch_bounds__(SEARCH_THREADS) void and_kernel(SearchArgs a)
 	}
 }
 
+// Narrow databases (a row is at most 64/G 16-byte units, e.g. one 2048-column file = 16 units): G queries
+// share a wave, 64/G lanes each, so a wave-load still moves up to 1 KiB.  Row indices are per lane group
+// (vector loads, broadcast within the group).  Shorter row lists are padded by re-reading their last row
+// (AND is idempotent), so there is no divergence inside the loop.
+template <int G, int UNROLL>
+__global__ __launch_bounds__(SEARCH_THREADS) void and_narrow_kernel(SearchArgs a)
+{
+	constexpr uint32_t LG = WAVE/G;
+	const uint32_t lane = threadIdx.x & (WAVE - 1);
+	const uint32_t l = lane % LG;
+	const uint64_t tile = (uint64_t)blockIdx.x*(blockDim.x/WAVE) + (threadIdx.x >> 6);
+	const uint64_t q64 = tile*G + lane/LG;
+	const bool has_q = (q64 < a.n_queries);
+	const uint32_t q = has_q ? (uint32_t)q64 : 0;
+	const uint32_t n = has_q ? a.nkmer[q] : 0;
+	const uint32_t nrows = n*a.num_hash;
+	const bool active = (nrows != 0) && (l < a.units_per_row);
+	const uint32_t *rq = a.rows + a.pos_off[q]*a.num_hash;
+	const uint32_t unit = (l < a.units_per_row) ? l : 0;
+
+	u32x4 acc = ~(u32x4)(0u);
+	if(active){
+		for(uint32_t i = 0; __any(i < nrows); i += UNROLL){
+			u32x4 x[UNROLL];
+#pragma unroll
+			for(int u = 0; u < UNROLL; ++u){
+				const uint32_t idx = min(i + u, nrows - 1);
+				const uint32_t r = rq[idx];
+				x[u] = load16<true>(reinterpret_cast<const u32x4*>(a.db + (uint64_t)r*a.stride) + unit);
+			}
+#pragma unroll
+			for(int u = 0; u < UNROLL; ++u){ acc &= x[u]; }
+			if(a.early_exit && !__any((acc.x | acc.y | acc.z | acc.w) != 0)){ break; }
+		}
+		emit_mask_hits(a, q, unit, acc, n);
+	}
+}
+
 // Second pass of the segmented AND: one thread per (query, 16-byte unit).
 __global__ __launch_bounds__(256) void and_combine_kernel(SearchArgs a)
 {
@@ -577,6 +615,50 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 	else{
 		emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q]);
 	}
+}
+
+// Narrow databases, count path: G queries per wave (see and_narrow_kernel).  A shorter k-mer list is padded
+// with all-zero matches (counting is not idempotent, so padded steps must add nothing).
+template <int PLANES, int NH, int G>
+__global__ __launch_bounds__(SEARCH_THREADS) void count_narrow_kernel(SearchArgs a)
+{
+	constexpr uint32_t LG = WAVE/G;
+	const uint32_t lane = threadIdx.x & (WAVE - 1);
+	const uint32_t l = lane % LG;
+	const uint64_t tile = (uint64_t)blockIdx.x*(blockDim.x/WAVE) + (threadIdx.x >> 6);
+	const uint64_t q64 = tile*G + lane/LG;
+	const bool has_q = (q64 < a.n_queries);
+	const uint32_t q = has_q ? (uint32_t)q64 : 0;
+	const uint32_t nk = has_q ? a.nkmer[q] : 0;
+	const bool active = (nk != 0) && (l < a.units_per_row);
+	if(!active){ return; }
+	const uint32_t *rq = a.rows + a.pos_off[q]*NH;
+	const uint32_t unit = l;
+
+	u32x4 plane[PLANES];
+#pragma unroll
+	for(int p = 0; p < PLANES; ++p){ plane[p] = (u32x4)(0u); }
+
+	for(uint32_t i = 0; __any(i < nk); i += 4){
+		u32x4 m[4];
+#pragma unroll
+		for(int u = 0; u < 4; ++u){
+			const bool real = (i + u < nk);
+			const uint32_t kk = real ? (i + u) : (nk - 1);
+			u32x4 x = load16<true>(reinterpret_cast<const u32x4*>(a.db + (uint64_t)rq[kk*NH]*a.stride) + unit);
+#pragma unroll
+			for(int h = 1; h < NH; ++h){
+				x &= load16<true>(reinterpret_cast<const u32x4*>(a.db + (uint64_t)rq[kk*NH + h]*a.stride) + unit);
+			}
+			m[u] = real ? x : (u32x4)(0u);
+		}
+		u32x4 twoA, twoB, four, s;
+		csa(s, twoA, plane[0], m[0], m[1]);
+		csa(plane[0], twoB, s, m[2], m[3]);
+		csa(plane[1], four, plane[1], twoA, twoB);
+		planes_add<PLANES>(plane, four, 2);
+	}
+	emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q]);
 }
 
 // Second pass of the segmented count: add the per-segment bit-sliced counters (a ripple-carry

@@ -413,3 +413,37 @@ def test_python_file_database_matches_reference_report(ka, ctx, oracle):
         for q in exp:
             assert sorted(got[q]) == sorted((a, nk, nf) for a, nk, nf, _ in exp[q])
     db.close()
+
+
+@pytest.mark.parametrize("n_cols", [1, 100, 300, 512, 600, 1024, 2048, 2049, 4096])
+def test_narrow_rows_many_queries(ka, ctx, oracle, n_cols):
+    """Rows narrower than a wave-load are searched with several queries per wave (and_narrow_kernel):
+    ragged query lengths (including empty / too short / all-N), >= 64 queries so that path is taken."""
+    rng = np.random.default_rng(n_cols + 5)
+    k, nh, L = 31, 2, 10
+    image = _make_random_db(rng, L, n_cols, 0.8)
+    genome = rand_seq(rng, 3000)
+    for col in {0, n_cols // 2, n_cols - 1}:
+        for r in oracle.row_indices(oracle.unique_kmers(genome, k), k, nh, L).reshape(-1):
+            image[r, col // 8] |= np.uint8(1 << (col % 8))
+    seqs = []
+    for i in range(150):
+        n = int(rng.choice([0, 10, 31, 32, 60, 150, 400, 1500]))
+        if i % 3 == 0 and n >= 31:
+            a = int(rng.integers(0, len(genome) - n + 1)); seqs.append(genome[a:a + n])
+        elif i % 7 == 0:
+            seqs.append("N" * n)
+        else:
+            seqs.append(rand_seq(rng, n))
+    g = ka.Group(ctx, k, nh, L, n_cols)
+    g.add_columns(image, n_cols)
+    g.finalize()
+    b = ka.Batch(ctx, seqs)
+    for thr in (1.0, 0.9):
+        exp = [oracle.search_image(image, image.shape[1], k, nh, L, n_cols, oracle.unique_kmers(s, k), float(np.float32(thr)))[0] for s in seqs]
+        for flags in (0, ka.SEARCH_EARLY_EXIT):
+            r = g.search(b, thr, flags)
+            assert r.per_query() == exp, (n_cols, thr, flags)
+    assert sum(len(e) for e in exp) > 0
+    b.close()
+    g.close()
