@@ -103,7 +103,7 @@ def _run(exe, db, fasta, cmd, thr, fmt="csv"):
 
 
 @needs_ref
-@pytest.mark.parametrize("seed", range(30))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KWAGE_FUZZ_SEEDS_CPU", "30"))))
 def test_oracle_equals_reference_binary(oracle, tmp_path, seed):
     rng = np.random.default_rng(4242 + seed)
     db, fasta, cmd = _make_case(oracle, rng, str(tmp_path), int(rng.integers(1, 5)))
@@ -120,7 +120,7 @@ def test_oracle_equals_reference_binary(oracle, tmp_path, seed):
 
 @needs_ref
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KWAGE_FUZZ_SEEDS", "20"))))
 def test_cli_equals_reference_binary(oracle, tmp_path, seed):
     from kwage_amd import native
     rng = np.random.default_rng(777 + seed)

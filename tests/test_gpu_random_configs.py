@@ -16,7 +16,7 @@ def _seq(rng, n):
     return ACGT[rng.integers(0, 4, size=n)].tobytes().decode()
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KWAGE_SWEEP_SEEDS", "24"))))
 def test_random_configuration(oracle, seed, monkeypatch):
     import kwage_amd as ka
     rng = np.random.default_rng(9000 + seed)
