@@ -447,3 +447,31 @@ def test_narrow_rows_many_queries(ka, ctx, oracle, n_cols):
     assert sum(len(e) for e in exp) > 0
     b.close()
     g.close()
+
+
+def test_c_example_program(ka, oracle, tmp_path):
+    """examples/search_example.c (plain C99 against the ABI) finds what the oracle finds."""
+    import shutil
+    from conftest import ROOT
+    from kwage_amd import native
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    exe = str(tmp_path / "search_example")
+    libdir = os.path.dirname(native.lib_path())
+    subprocess.check_call([gcc, "-std=c99", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "search_example.c"),
+                           "-L", libdir, "-lkwage_amd", "-Wl,-rpath," + libdir, "-o", exe])
+    pa = os.path.join(GOLDEN, "multi/dbs/a/k31_L10_h1.db")
+    pb = os.path.join(GOLDEN, "multi/dbs/a/deeper/k31_L10_h1_b.db")
+    seqs = [s for _, s in oracle.read_sequences(os.path.join(GOLDEN, "multi/contigs.fa.gz"))]
+    r = subprocess.run([exe, "1.0", pa, pb, "--"] + seqs, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = [(int(ln.split()[1]), int(ln.split()[3])) for ln in r.stdout.splitlines() if ln.startswith("query")]
+    exp = []
+    for qi, s in enumerate(seqs):
+        km = oracle.unique_kmers(s, 31)
+        for base, p in ((0, pa), (128, pb)):
+            db = oracle.read_db(p)
+            hits, _ = oracle.search_image(db.rows, db.header.slice_size, 31, 1, 10, db.header.num_filter, km, 1.0)
+            exp += [(qi, base + c) for c, _ in hits]
+    assert got == exp and len(got) > 0

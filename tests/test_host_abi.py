@@ -161,3 +161,14 @@ def test_cli_usage_and_validation_without_gpu():
     assert "Please provide: 0.0 < search threshold <= 1.0" in r.stderr
     r = subprocess.run([exe, "-d", db, "-t", "0", "ACGT"], capture_output=True, text=True)
     assert "Please provide: 0.0 < search threshold <= 1.0" in r.stderr
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/kwage_amd.h must be consumable from C (the FFI boundary): compile the C example strictly."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           "-c", os.path.join(ROOT, "examples", "search_example.c"), "-o", str(tmp_path / "ex.o")])
