@@ -72,11 +72,13 @@ def cpu_baseline(w, queries, n_files):
             if total_kmers else np.zeros(0, np.uint32)
         infos = [oracle.FilterInfo(run_accession=oracle.str_to_accession("SRR%07d" % j)) for j in range(ncol)]
         image = None
+        a = rng.integers(0, 1 << 63, size=(1 << L, ncol // 64), dtype=np.uint64)
+        b = rng.integers(0, 1 << 63, size=(1 << L, ncol // 64), dtype=np.uint64)
+        base = (a & b).view(np.uint8).reshape(1 << L, ncol // 8)               # density ~0.25
+        del a, b
         for f in range(n_files):
-            a = rng.integers(0, 1 << 63, size=(1 << L, ncol // 64), dtype=np.uint64)
-            b = rng.integers(0, 1 << 63, size=(1 << L, ncol // 64), dtype=np.uint64)
-            rows = (a & b).view(np.uint8).reshape(1 << L, ncol // 8).copy()    # density ~0.25
-            rows[addressed, 0] |= 1                                           # column 0 matches the first 200 queries
+            rows = np.roll(base, 7919 * f, axis=0)                               # a different matrix per file, same density
+            rows[addressed, 0] |= 1                                              # column 0 matches the first 200 queries
             oracle.write_db(os.path.join(tmp, "s%02d.db" % f), k, nh, L, rows, ncol, infos)
             if f == 0:
                 image = rows
