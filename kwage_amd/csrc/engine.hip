@@ -249,10 +249,16 @@ int launch_kmer_stage(kwage_ctx *ctx, const kwage_params &p, kwage_batch *b, flo
 	a.kmers_out = d_kmers;
 	a.nkmer = ctx->d_nkmer;
 	a.qthr = ctx->d_qthr;
-	a.total_kmers = (unsigned long long*)ctx->d_counters + 1;
+	a.total_kmers = nullptr;           // summed on the host from nkmer[] (a per-workgroup atomic serialises)
 	a.shared_lg = 0;
 	a.bloom_bits = nullptr;
-	hipLaunchKernelGGL(kmer_kernel, dim3(b->n), dim3(KM_THREADS), 0, ctx->stream, a);
+	// workgroup and LDS table sized for the longest query of the batch: queries whose table would not fit
+	// KM_LDS_SLOTS use the global tables laid out by batch_prepare (same rule there)
+	uint32_t slots = 64;
+	while(slots < KM_LDS_SLOTS && slots < 2*b->max_pos){ slots *= 2; }
+	a.lds_slots = slots;
+	const uint32_t threads = (b->max_pos <= 192) ? 64 : (b->max_pos <= 768) ? 128 : KM_THREADS;
+	hipLaunchKernelGGL(kmer_kernel, dim3(b->n), dim3(threads), (size_t)slots*sizeof(uint64_t), ctx->stream, a);
 	HIP_TRY(hipGetLastError());
 	return KWAGE_OK;
 }
@@ -538,7 +544,9 @@ int run_search(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
 		HIP_TRY(hipStreamSynchronize(ctx->stream));     // (polling an event instead measured no faster)
 		const uint64_t *hc = (const uint64_t*)ctx->h_stage.p;
 		out->n_hits = hc[0];
-		out->total_kmers = hc[1];
+		out->total_kmers = 0;
+		const uint32_t *hn = (const uint32_t*)((const char*)ctx->h_stage.p + 32);      // staged nkmer[]
+		for(uint32_t i = 0; i < b->n; ++i){ out->total_kmers += hn[i]; }
 		if(!own_hits || out->n_hits <= cap){ break; }
 		// hit buffer too small (e.g. threshold truncated to 0: every column matches): grow, re-run
 		if((rc = layout_result(ctx, b->n, out->n_hits, true))){ return rc; }
@@ -1128,6 +1136,7 @@ int run_shared_kmer_pass(kwage_ctx *ctx, const kwage_params &p, kwage_batch *b, 
 		a.total_kmers = (unsigned long long*)ctx->d_counters + 1;
 		a.shared_lg = lg;
 		a.bloom_bits = d_bloom_bits;
+		a.lds_slots = 0;                 // the shared global table is used for every sequence
 		hipLaunchKernelGGL(kmer_kernel, dim3(b->n), dim3(KM_THREADS), 0, ctx->stream, a);
 		HIP_TRY(hipGetLastError());
 	}

@@ -25,7 +25,7 @@
 namespace kwage {
 
 static constexpr int WAVE = 64;
-static constexpr int KM_THREADS = 256;
+static constexpr int KM_THREADS = 256;               // largest k-mer workgroup; short queries use 64 or 128
 static constexpr uint32_t KM_LDS_SLOTS = 4096;      // 32 KiB of u64 slots: queries up to 2048 positions
 static constexpr uint64_t KM_EMPTY = ~0ull;         // never a canonical word: min(w, rc) < all-ones
 static constexpr int SEARCH_THREADS = 256;          // 4 waves, one tile each
@@ -157,6 +157,7 @@ struct KmerArgs {
 	unsigned long long *total_kmers;
 	// Bloom construction: all sequences share ONE global set (distinct k-mers of the whole sample) and
 	// every new k-mer sets its num_hash bits in `bloom_bits` (bit index = hash & row_mask).
+	uint32_t lds_slots;             // capacity of the dynamic-LDS table (a power of two <= KM_LDS_SLOTS)
 	uint32_t shared_lg;             // 0 = one set per query (search); else log2 slots of the shared table
 	uint32_t *bloom_bits;           // may be null
 };
@@ -171,15 +172,15 @@ __device__ __forceinline__ void kmer_body(const KmerArgs &a, uint32_t q, uint64_
 	const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2*k)) - 1ull);
 
 	if(LDS_TAB){
-		for(uint32_t i = threadIdx.x; i < (1u << lg); i += KM_THREADS){ tab[i] = KM_EMPTY; }
+		for(uint32_t i = threadIdx.x; i < (1u << lg); i += blockDim.x){ tab[i] = KM_EMPTY; }
 	}
 	if(threadIdx.x == 0){ *count = 0; }
 	__syncthreads();
 
-	for(uint64_t t0 = 0; t0 < npos; t0 += KM_THREADS){
-		// stage the 2-bit codes of characters [t0, t0 + KM_THREADS + k - 1)
-		const uint32_t nchar = (uint32_t)min((uint64_t)(KM_THREADS + k - 1), len - t0);
-		for(uint32_t i = threadIdx.x; i < nchar; i += KM_THREADS){
+	for(uint64_t t0 = 0; t0 < npos; t0 += blockDim.x){
+		// stage the 2-bit codes of characters [t0, t0 + blockDim.x + k - 1)
+		const uint32_t nchar = (uint32_t)min((uint64_t)(blockDim.x + k - 1), len - t0);
+		for(uint32_t i = threadIdx.x; i < nchar; i += blockDim.x){
 			codes[i] = (uint8_t)base_code(a.seqs[s0 + t0 + i]);
 		}
 		__syncthreads();
@@ -226,13 +227,17 @@ __device__ __forceinline__ void kmer_body(const KmerArgs &a, uint32_t q, uint64_
 		a.nkmer[q] = n;
 		// kwage.cpp:388: unsigned = float * unsigned  ->  float32 product, truncation
 		a.qthr[q] = a.complete_match ? 0u : (uint32_t)__fmul_rn(a.threshold, (float)n);
-		if(n){ atomicAdd(a.total_kmers, (unsigned long long)n); }
+		// one same-address atomic per workgroup costs ~12 ns at the memory side (100k reads = 1.2 ms): the
+		// search path sums nkmer[] on the host instead and passes no counter
+		if(n && a.total_kmers){ atomicAdd(a.total_kmers, (unsigned long long)n); }
 	}
 }
 
+// Launched with 64, 128 or 256 threads and lds_slots*8 bytes of dynamic LDS (the distinct-set table): short
+// reads get small workgroups and small tables, so many of them are resident per CU.
 __global__ __launch_bounds__(KM_THREADS) void kmer_kernel(KmerArgs a)
 {
-	__shared__ unsigned long long lds_tab[KM_LDS_SLOTS];
+	extern __shared__ __attribute__((aligned(16))) unsigned long long lds_tab[];
 	__shared__ uint8_t codes[KM_THREADS + KWAGE_MAX_WORD_LEN];
 	__shared__ uint32_t count;
 
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(KM_THREADS) void kmer_kernel(KmerArgs a)
 		return;
 	}
 	const uint32_t lg = table_log2(npos);
-	if((1ull << lg) <= KM_LDS_SLOTS){
+	if((1ull << lg) <= a.lds_slots){
 		kmer_body<true>(a, q, s0, len, npos, lds_tab, lg, codes, &count);
 	}
 	else{
@@ -297,26 +302,49 @@ __device__ __forceinline__ u32x4 load16(const u32x4 *p)
 	return *p;
 }
 
-__device__ __forceinline__ void emit_hit(const SearchArgs &a, uint32_t q, uint32_t col, uint32_t nm)
+// Reserve room for `cnt` hit records of this lane: ONE atomic per wave (an inclusive scan over the lanes
+// gives each lane its offset), instead of one same-address atomic per hit.  Must be called by every
+// active lane of the wave the same number of times (lanes without hits pass 0).
+__device__ __forceinline__ unsigned long long reserve_hits(const SearchArgs &a, uint32_t cnt)
 {
-	const unsigned long long slot = atomicAdd(a.hit_count, 1ull);
+	uint32_t incl = cnt;
+#pragma unroll
+	for(int d = 1; d < WAVE; d <<= 1){
+		const uint32_t up = __shfl_up(incl, d);
+		if((int)(threadIdx.x & (WAVE - 1)) >= d){ incl += up; }
+	}
+	const uint32_t total = __shfl(incl, WAVE - 1);
+	unsigned long long base = 0;
+	if(total){
+		if((threadIdx.x & (WAVE - 1)) == WAVE - 1){ base = atomicAdd(a.hit_count, (unsigned long long)total); }
+		base = __shfl(base, WAVE - 1);
+	}
+	return base + (incl - cnt);
+}
+
+__device__ __forceinline__ void store_hit(const SearchArgs &a, unsigned long long slot, uint32_t q, uint32_t col, uint32_t nm)
+{
 	if(slot < a.cap){
 		kwage_hit h; h.query = q; h.column = col; h.num_match = nm;
 		a.hits[slot] = h;
 	}
 }
 
-// hit extraction at threshold == 1 (kwage.cpp:489-499,517-518), restricted to real columns
-__device__ __forceinline__ void emit_mask_hits(const SearchArgs &a, uint32_t q, uint32_t unit, u32x4 acc, uint32_t n)
+// hit extraction at threshold == 1 (kwage.cpp:489-499,517-518), restricted to real columns.
+// `on` = this lane holds a real tile position; every lane of the wave must call it.
+__device__ __forceinline__ void emit_mask_hits(const SearchArgs &a, uint32_t q, uint32_t unit, u32x4 acc, uint32_t n, bool on = true)
 {
-	const u32x4 m = acc & reinterpret_cast<const u32x4*>(a.valid)[unit];
+	u32x4 m = (u32x4)(0u);
+	if(on){ m = acc & reinterpret_cast<const u32x4*>(a.valid)[unit]; }
+	const uint32_t cnt = __popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w);
+	unsigned long long slot = reserve_hits(a, cnt);
 #pragma unroll
 	for(int d = 0; d < 4; ++d){
 		uint32_t bits = m[d];
 		while(bits){
 			const uint32_t b = __ffs(bits) - 1;
 			bits &= bits - 1;
-			emit_hit(a, q, unit*128u + d*32u + b, n);       // num_match = num_query_kmer
+			store_hit(a, slot++, q, unit*128u + d*32u + b, n);       // num_match = num_query_kmer
 		}
 	}
 }
@@ -400,17 +428,18 @@ __global__ __launch_bounds__(SEARCH_THREADS) void and_kernel(SearchArgs a)
 
 #pragma unroll
 	for(int v = 0; v < VEC; ++v){
-		if(!live[v]){ continue; }
 		if(SEG){
 			// meet the other segments of this (query, tile) in the mask buffer (pre-set to all ones)
-			uint32_t *m = a.partial + ((uint64_t)q*a.units_per_row + unit[v])*4;
+			if(live[v]){
+				uint32_t *m = a.partial + ((uint64_t)q*a.units_per_row + unit[v])*4;
 #pragma unroll
-			for(int d = 0; d < 4; ++d){
-				if(acc[v][d] != ~0u){ atomicAnd(m + d, acc[v][d]); }
+				for(int d = 0; d < 4; ++d){
+					if(acc[v][d] != ~0u){ atomicAnd(m + d, acc[v][d]); }
+				}
 			}
 		}
 		else{
-			emit_mask_hits(a, q, unit[v], acc[v], n);
+			emit_mask_hits(a, q, unit[v], acc[v], n, live[v]);     // every lane takes part in the wave scan
 		}
 	}
 }
@@ -449,20 +478,21 @@ __global__ __launch_bounds__(SEARCH_THREADS) void and_narrow_kernel(SearchArgs a
 			for(int u = 0; u < UNROLL; ++u){ acc &= x[u]; }
 			if(a.early_exit && !__any((acc.x | acc.y | acc.z | acc.w) != 0)){ break; }
 		}
-		emit_mask_hits(a, q, unit, acc, n);
 	}
+	emit_mask_hits(a, q, unit, acc, n, active);
 }
 
 // Second pass of the segmented AND: one thread per (query, 16-byte unit).
 __global__ __launch_bounds__(256) void and_combine_kernel(SearchArgs a)
 {
-	const uint32_t unit = blockIdx.x*blockDim.x + threadIdx.x;
+	const uint32_t u0 = blockIdx.x*blockDim.x + threadIdx.x;
 	const uint32_t q = blockIdx.y;
-	if(unit >= a.units_per_row){ return; }
 	const uint32_t n = a.nkmer[q];
-	if(n == 0){ return; }
+	if(n == 0){ return; }                                  // uniform per workgroup
+	const bool on = (u0 < a.units_per_row);
+	const uint32_t unit = on ? u0 : 0;
 	const u32x4 acc = reinterpret_cast<const u32x4*>(a.partial)[(uint64_t)q*a.units_per_row + unit];
-	emit_mask_hits(a, q, unit, acc, n);
+	emit_mask_hits(a, q, unit, acc, n, on);
 }
 
 // threshold < 1: count, per column, the k-mers whose every hash row has the bit set
@@ -507,13 +537,15 @@ __device__ __forceinline__ u32x4 planes_ge(const u32x4 (&plane)[PLANES], uint32_
 }
 
 // columns with count >= thr (kwage.cpp:497); then the count of every surviving column is
-// re-assembled from the planes (num_match = match_count[i]).
+// re-assembled from the planes (num_match = match_count[i]).  Every lane of the wave must call it
+// (`on` = the lane holds a real tile position): the records are placed with one atomic per wave.
 template <int PLANES>
 __device__ __forceinline__ void emit_count_hits(const SearchArgs &a, uint32_t q, uint32_t unit,
-                                                const u32x4 (&plane)[PLANES], uint32_t thr)
+                                                const u32x4 (&plane)[PLANES], uint32_t thr, bool on)
 {
-	u32x4 ge = planes_ge<PLANES>(plane, thr);
-	ge &= reinterpret_cast<const u32x4*>(a.valid)[unit];
+	u32x4 ge = (u32x4)(0u);
+	if(on){ ge = planes_ge<PLANES>(plane, thr) & reinterpret_cast<const u32x4*>(a.valid)[unit]; }
+	unsigned long long slot = reserve_hits(a, __popc(ge.x) + __popc(ge.y) + __popc(ge.z) + __popc(ge.w));
 #pragma unroll
 	for(int d = 0; d < 4; ++d){
 		uint32_t bits = ge[d];
@@ -523,7 +555,7 @@ __device__ __forceinline__ void emit_count_hits(const SearchArgs &a, uint32_t q,
 			uint32_t cnt = 0;
 #pragma unroll
 			for(int p = 0; p < PLANES; ++p){ cnt |= ((plane[p][d] >> b) & 1u) << p; }
-			emit_hit(a, q, unit*128u + d*32u + b, cnt);
+			store_hit(a, slot++, q, unit*128u + d*32u + b, cnt);
 		}
 	}
 }
@@ -605,15 +637,16 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 		planes_add<PLANES>(plane, mm, 0);
 	}
 
-	if(!live){ return; }
 	if(SEG){
 		// partial counters of this segment -> slab [query][segment][plane][unit]
-		u32x4 *slab = reinterpret_cast<u32x4*>(a.partial) + ((uint64_t)q*a.segs + sg)*PLANES*a.units_per_row + unit;
+		if(live){
+			u32x4 *slab = reinterpret_cast<u32x4*>(a.partial) + ((uint64_t)q*a.segs + sg)*PLANES*a.units_per_row + unit;
 #pragma unroll
-		for(int p = 0; p < PLANES; ++p){ slab[(uint64_t)p*a.units_per_row] = plane[p]; }
+			for(int p = 0; p < PLANES; ++p){ slab[(uint64_t)p*a.units_per_row] = plane[p]; }
+		}
 	}
 	else{
-		emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q]);
+		emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q], live);
 	}
 }
 
@@ -631,15 +664,14 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_narrow_kernel(SearchArgs
 	const uint32_t q = has_q ? (uint32_t)q64 : 0;
 	const uint32_t nk = has_q ? a.nkmer[q] : 0;
 	const bool active = (nk != 0) && (l < a.units_per_row);
-	if(!active){ return; }
 	const uint32_t *rq = a.rows + a.pos_off[q]*NH;
-	const uint32_t unit = l;
+	const uint32_t unit = (l < a.units_per_row) ? l : 0;
 
 	u32x4 plane[PLANES];
 #pragma unroll
 	for(int p = 0; p < PLANES; ++p){ plane[p] = (u32x4)(0u); }
 
-	for(uint32_t i = 0; __any(i < nk); i += 4){
+	for(uint32_t i = 0; active && __any(i < nk); i += 4){
 		u32x4 m[4];
 #pragma unroll
 		for(int u = 0; u < 4; ++u){
@@ -658,7 +690,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_narrow_kernel(SearchArgs
 		csa(plane[1], four, plane[1], twoA, twoB);
 		planes_add<PLANES>(plane, four, 2);
 	}
-	emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q]);
+	emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q], active);
 }
 
 // Second pass of the segmented count: add the per-segment bit-sliced counters (a ripple-carry
@@ -666,11 +698,12 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_narrow_kernel(SearchArgs
 template <int PLANES>
 __global__ __launch_bounds__(256) void count_combine_kernel(SearchArgs a)
 {
-	const uint32_t unit = blockIdx.x*blockDim.x + threadIdx.x;
+	const uint32_t u0 = blockIdx.x*blockDim.x + threadIdx.x;
 	const uint32_t q = blockIdx.y;
-	if(unit >= a.units_per_row){ return; }
 	const uint32_t n = a.nkmer[q];
-	if(n == 0){ return; }
+	if(n == 0){ return; }                                  // uniform per workgroup
+	const bool on = (u0 < a.units_per_row);
+	const uint32_t unit = on ? u0 : 0;
 	const uint32_t nseg = (n + a.seg_kmers - 1)/a.seg_kmers;
 	const u32x4 *slab = reinterpret_cast<const u32x4*>(a.partial) + (uint64_t)q*a.segs*PLANES*a.units_per_row + unit;
 	u32x4 plane[PLANES];
@@ -688,7 +721,7 @@ __global__ __launch_bounds__(256) void count_combine_kernel(SearchArgs a)
 			carry = cnext;
 		}
 	}
-	emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q]);
+	emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q], on);
 }
 
 // ------------------------------------------------------------------------------------------
