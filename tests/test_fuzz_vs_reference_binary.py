@@ -24,7 +24,7 @@ def _make_case(oracle, rng, root, n_files):
     """Random database directory + FASTA; returns (db_dir, fasta, cmdline_seqs)."""
     os.makedirs(os.path.join(root, "db", "sub"), exist_ok=True)
     genomes = [_seq(rng, int(rng.integers(60, 400))) for _ in range(3)]
-    param_pool = [(int(rng.integers(8, 33)), int(rng.integers(1, 6)), int(rng.integers(8, 12))) for _ in range(2)]
+    param_pool = [(int(rng.integers(1, 33)), int(rng.integers(1, 6)), int(rng.integers(8, 12))) for _ in range(2)]
     for f in range(n_files):
         k, nh, L = param_pool[f % len(param_pool)]
         n = int(rng.choice([1, 7, 8, 9, 31, 64, 65, 130]))
@@ -107,7 +107,7 @@ def _run(exe, db, fasta, cmd, thr, fmt="csv"):
 def test_oracle_equals_reference_binary(oracle, tmp_path, seed):
     rng = np.random.default_rng(4242 + seed)
     db, fasta, cmd = _make_case(oracle, rng, str(tmp_path), int(rng.integers(1, 5)))
-    for thr in ("1.0", "%.3f" % rng.uniform(0.05, 0.99), "0.0001"):
+    for thr in ("1.0", "%.3f" % rng.uniform(0.05, 0.99), str(rng.choice(["0.0001", "0.999999", "1e-9", "0.5", "0.33333334"]))):
         exp = oracle.parse_csv(_run(REF, db, fasta, cmd, thr))
         got = oracle.run_search([db], [fasta], cmd, float(thr))
         by_name = {}
@@ -125,7 +125,7 @@ def test_cli_equals_reference_binary(oracle, tmp_path, seed):
     from kwage_amd import native
     rng = np.random.default_rng(777 + seed)
     db, fasta, cmd = _make_case(oracle, rng, str(tmp_path), int(rng.integers(1, 7)))
-    for thr in ("1.0", "%.3f" % rng.uniform(0.05, 0.99), "0.0001"):
+    for thr in ("1.0", "%.3f" % rng.uniform(0.05, 0.99), str(rng.choice(["0.0001", "0.999999", "1e-9", "0.5", "0.33333334"]))):
         for fmt in ("csv", "json"):
             exp = _run(REF, db, fasta, cmd, thr, fmt)
             got = _run(native.KWAGE_BIN, db, fasta, cmd, thr, fmt)
