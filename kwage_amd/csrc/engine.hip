@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -974,7 +975,7 @@ namespace {
 void sort_hits(std::vector<kwage_hit> &hits)
 {
 	const size_t n = hits.size();
-	if(n < 8192){
+	if(n < 256){
 		std::sort(hits.begin(), hits.end(), [](const kwage_hit &x, const kwage_hit &y){
 			return (x.query != y.query) ? (x.query < y.query) : (x.column < y.column);
 		});
@@ -1018,9 +1019,12 @@ extern "C" int kwage_search(kwage_group *g, kwage_batch *b, float threshold, uin
 {
 	if(!g || !b || !out){ return fail(KWAGE_ERR_ARG, "kwage_search: NULL argument"); }
 	*out = nullptr;
+	static const bool prof = getenv("KWAGE_PROFILE_HOST") != nullptr;
+	const auto tp0 = std::chrono::steady_clock::now();
 	SearchOutcome so;
 	int rc = run_search(g, b, threshold, flags, nullptr, 0, true, &so);
 	if(rc){ return rc; }
+	const auto tp1 = std::chrono::steady_clock::now();
 	kwage_ctx *ctx = g->ctx;
 
 	ResultStorage *rs = new (std::nothrow) ResultStorage();
@@ -1062,6 +1066,12 @@ extern "C" int kwage_search(kwage_group *g, kwage_batch *b, float threshold, uin
 	r.search_kernel_ms = so.search_ms;
 	r.search_kernel_launches = so.launches;
 	*out = &rs->pub;
+	if(prof){
+		const auto tp2 = std::chrono::steady_clock::now();
+		fprintf(stderr, "[kwage_search] device pipeline + sync %.1f us, host result assembly + sort %.1f us (%llu hits)\n",
+		        std::chrono::duration<double, std::micro>(tp1 - tp0).count(),
+		        std::chrono::duration<double, std::micro>(tp2 - tp1).count(), (unsigned long long)so.n_hits);
+	}
 	return KWAGE_OK;
 }
 
