@@ -164,6 +164,14 @@ int kwage_search(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags
                  kwage_result **out);
 void kwage_result_free(kwage_result *r);
 
+/* The same search in two halves, for hosts that stream many batches: submit enqueues the whole device
+ * pipeline and returns at once; collect waits for it and builds the result.  A context holds at most TWO
+ * pending searches (each on its own HIP stream), so the k-mer stage, copy-back and host post-processing
+ * of one batch overlap with the gather kernel of the other.  kwage_search == submit + collect. */
+typedef struct kwage_pending kwage_pending;
+int kwage_search_submit(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags, kwage_pending **out);
+int kwage_search_collect(kwage_pending *p, kwage_result **out);   /* consumes p, also on error */
+
 /* Device-side variant for multi-GPU hosts that exchange hit lists themselves (RCCL): hits are
  * left UNSORTED in the caller's device buffer of `capacity` records; *n_hits receives the total
  * found (which may exceed capacity: grow and call again).  num_query_kmer_dev may be NULL or a

@@ -6,8 +6,8 @@ tests, bench.py and multi-GPU hosts.  There is no CPU fallback: importing works 
 every compute entry point raises if the HIP library or a gfx950 device is missing.
 """
 from .native import KwageError, lib, lib_path, build_native   # noqa: F401
-from .engine import (Context, Group, Batch, Database, FileDatabase, DatabaseHit, SearchResult, Params, hash_batch,   # noqa: F401
+from .engine import (Context, Group, Batch, Database, FileDatabase, DatabaseHit, SearchResult, PendingSearch, Params, hash_batch,   # noqa: F401
                      SEARCH_EARLY_EXIT, SEARCH_TIMING, SEARCH_TIMING_KMER)
 
 __all__ = ["KwageError", "lib", "lib_path", "build_native", "Context", "Group", "Batch", "Database", "FileDatabase", "DatabaseHit",
-           "SearchResult", "Params", "hash_batch", "SEARCH_EARLY_EXIT", "SEARCH_TIMING", "SEARCH_TIMING_KMER"]
+           "SearchResult", "PendingSearch", "Params", "hash_batch", "SEARCH_EARLY_EXIT", "SEARCH_TIMING", "SEARCH_TIMING_KMER"]

@@ -77,20 +77,40 @@ struct PinBuf {
 
 }  // namespace
 
-struct kwage_ctx {
-	int device = -1;
+// Everything one in-flight search owns.  A context has two slots so that a second search can be
+// submitted (and its k-mer stage run) while the first one's results are still being collected.
+struct Slot {
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t search_done = nullptr;   // recorded behind the slot's gather kernel(s)
+	bool search_done_valid = false;
 	// scratch, grown on demand and reused
-	DevBuf rows, tables, kmers, partial;
+	DevBuf rows, tables, partial;
 	// One contiguous result block per search, so that a single D2H copy returns everything:
-	//   [counters: 4 x u64 (hits, total k-mers, -, sink)] [nkmer: n x u32] [qthr: n x u32] [pad to 16] [hits: cap x 12 B]
+	//   [counters: 4 x u64 (hits, -, -, sink)] [nkmer: n x u32] [qthr: n x u32] [pad to 16] [hits: cap x 12 B]
 	DevBuf result;
 	uint64_t *d_counters = nullptr;
 	uint32_t *d_nkmer = nullptr, *d_qthr = nullptr;
 	kwage_hit *d_hits = nullptr;
 	uint64_t hit_cap = 0, head_bytes = 0;
 	PinBuf h_stage;        // host image of the head of the result block + the first SPEC_HITS records
+	// the submission occupying the slot
+	bool busy = false;
+	kwage_group *g = nullptr;
+	kwage_batch *b = nullptr;
+	float threshold = 1.0f;
+	uint32_t flags = 0;
+	uint32_t launches = 0;
+	uint64_t staged_hits = 0;
+	kwage_hit *ext_hits = nullptr;      // caller-owned device buffer (kwage_search_device) or null
+	uint64_t ext_cap = 0;
+};
+
+struct kwage_ctx {
+	int device = -1;
+	hipStream_t stream = nullptr;       // == slot[0].stream; loading, building and the synchronous calls use it
+	Slot slot[2];
+	DevBuf kmers;                       // kwage_hash_batch output
 	// database loading: two pinned + two device staging buffers, kept across files
 	PinBuf load_pin[2];
 	DevBuf load_dev[2];
@@ -138,36 +158,36 @@ int set_device(kwage_ctx *ctx)
 
 // Lay the result block out for n queries and at least min_cap hit records. Growing the block keeps
 // its head (counters + per-query arrays) when keep_head is set (hit-buffer growth mid-search).
-int layout_result(kwage_ctx *ctx, uint32_t n, uint64_t min_cap, bool keep_head)
+int layout_result(Slot *sl, uint32_t n, uint64_t min_cap, bool keep_head)
 {
 	const uint64_t head = (32 + 8ull*n + 15)/16*16;
 	uint64_t cap = std::max<uint64_t>(min_cap, 1u << 20);
-	if(ctx->result.cap >= head + sizeof(kwage_hit)){ cap = std::max(cap, (ctx->result.cap - head)/sizeof(kwage_hit)); }
+	if(sl->result.cap >= head + sizeof(kwage_hit)){ cap = std::max(cap, (sl->result.cap - head)/sizeof(kwage_hit)); }
 	const uint64_t need = head + cap*sizeof(kwage_hit);
-	if(need > ctx->result.cap){
-		if(keep_head && ctx->result.p && head == ctx->head_bytes){
+	if(need > sl->result.cap){
+		if(keep_head && sl->result.p && head == sl->head_bytes){
 			void *np = nullptr;
 			const uint64_t want = need + need/4;
 			HIP_TRY(hipMalloc(&np, want));
-			HIP_TRY(hipMemcpyAsync(np, ctx->result.p, head, hipMemcpyDeviceToDevice, ctx->stream));
-			HIP_TRY(hipStreamSynchronize(ctx->stream));
-			(void)hipFree(ctx->result.p);
-			ctx->result.p = np;
-			ctx->result.cap = want;
+			HIP_TRY(hipMemcpyAsync(np, sl->result.p, head, hipMemcpyDeviceToDevice, sl->stream));
+			HIP_TRY(hipStreamSynchronize(sl->stream));
+			(void)hipFree(sl->result.p);
+			sl->result.p = np;
+			sl->result.cap = want;
 		}
 		else{
-			int rc = ctx->result.reserve(need);
+			int rc = sl->result.reserve(need);
 			if(rc){ return rc; }
 		}
-		cap = (ctx->result.cap - head)/sizeof(kwage_hit);
+		cap = (sl->result.cap - head)/sizeof(kwage_hit);
 	}
-	char *base = (char*)ctx->result.p;
-	ctx->d_counters = (uint64_t*)base;
-	ctx->d_nkmer = (uint32_t*)(base + 32);
-	ctx->d_qthr = (uint32_t*)(base + 32 + 4ull*n);
-	ctx->d_hits = (kwage_hit*)(base + head);
-	ctx->hit_cap = cap;
-	ctx->head_bytes = head;
+	char *base = (char*)sl->result.p;
+	sl->d_counters = (uint64_t*)base;
+	sl->d_nkmer = (uint32_t*)(base + 32);
+	sl->d_qthr = (uint32_t*)(base + 32 + 4ull*n);
+	sl->d_hits = (kwage_hit*)(base + head);
+	sl->hit_cap = cap;
+	sl->head_bytes = head;
 	return KWAGE_OK;
 }
 
@@ -222,17 +242,17 @@ int batch_prepare(kwage_batch *b, uint32_t k)
 }
 
 // Launch the k-mer stage on the ctx stream. rows/kmers_out may be null.
-int launch_kmer_stage(kwage_ctx *ctx, const kwage_params &p, kwage_batch *b, float threshold,
+int launch_kmer_stage(Slot *sl, const kwage_params &p, kwage_batch *b, float threshold,
                       uint32_t *d_rows, uint64_t *d_kmers)
 {
 	int rc = batch_prepare(b, p.kmer_len);
 	if(rc){ return rc; }
-	if((rc = layout_result(ctx, b->n, 0, false))){ return rc; }
+	if((rc = layout_result(sl, b->n, 0, false))){ return rc; }
 	if(b->table_slots){
-		if((rc = ctx->tables.reserve(b->table_slots*sizeof(uint64_t)))){ return rc; }
-		HIP_TRY(hipMemsetAsync(ctx->tables.p, 0xFF, b->table_slots*sizeof(uint64_t), ctx->stream));
+		if((rc = sl->tables.reserve(b->table_slots*sizeof(uint64_t)))){ return rc; }
+		HIP_TRY(hipMemsetAsync(sl->tables.p, 0xFF, b->table_slots*sizeof(uint64_t), sl->stream));
 	}
-	HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, 4*sizeof(uint64_t), ctx->stream));
+	HIP_TRY(hipMemsetAsync(sl->d_counters, 0, 4*sizeof(uint64_t), sl->stream));
 	if(b->n == 0){ return KWAGE_OK; }
 
 	KmerArgs a;
@@ -240,7 +260,7 @@ int launch_kmer_stage(kwage_ctx *ctx, const kwage_params &p, kwage_batch *b, flo
 	a.seq_off = b->d_seq_off;
 	a.pos_off = b->d_pos_off;
 	a.tab_off = b->d_tab_off;
-	a.g_tables = (unsigned long long*)ctx->tables.p;
+	a.g_tables = (unsigned long long*)sl->tables.p;
 	a.k = p.kmer_len;
 	a.num_hash = p.num_hash;
 	a.row_mask = (p.log_2_filter_len >= 32) ? 0xFFFFFFFFu : ((1u << p.log_2_filter_len) - 1u);
@@ -248,8 +268,8 @@ int launch_kmer_stage(kwage_ctx *ctx, const kwage_params &p, kwage_batch *b, flo
 	a.complete_match = (threshold == 1.0f) ? 1 : 0;      // kwage.cpp:349
 	a.rows = d_rows;
 	a.kmers_out = d_kmers;
-	a.nkmer = ctx->d_nkmer;
-	a.qthr = ctx->d_qthr;
+	a.nkmer = sl->d_nkmer;
+	a.qthr = sl->d_qthr;
 	a.total_kmers = nullptr;           // summed on the host from nkmer[] (a per-workgroup atomic serialises)
 	a.shared_lg = 0;
 	a.bloom_bits = nullptr;
@@ -259,7 +279,7 @@ int launch_kmer_stage(kwage_ctx *ctx, const kwage_params &p, kwage_batch *b, flo
 	while(slots < KM_LDS_SLOTS && slots < 2*b->max_pos){ slots *= 2; }
 	a.lds_slots = slots;
 	const uint32_t threads = (b->max_pos <= 192) ? 64 : (b->max_pos <= 768) ? 128 : KM_THREADS;
-	hipLaunchKernelGGL(kmer_kernel, dim3(b->n), dim3(threads), (size_t)slots*sizeof(uint64_t), ctx->stream, a);
+	hipLaunchKernelGGL(kmer_kernel, dim3(b->n), dim3(threads), (size_t)slots*sizeof(uint64_t), sl->stream, a);
 	HIP_TRY(hipGetLastError());
 	return KWAGE_OK;
 }
@@ -393,24 +413,23 @@ void choose_segments(SearchArgs &a, uint64_t max_kmers, uint64_t max_segs)
 }
 
 // Launch the gather+reduce kernel(s) for the current batch.
-int launch_search_stage(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
+int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
                         kwage_hit *d_hits, uint64_t cap)
 {
-	kwage_ctx *ctx = g->ctx;
 	SearchArgs a;
 	a.db = g->d_bits;
 	a.stride = g->stride;
 	a.units_per_row = (uint32_t)(g->stride/16);
 	a.valid = g->d_valid;
-	a.rows = (const uint32_t*)ctx->rows.p;
+	a.rows = (const uint32_t*)sl->rows.p;
 	a.pos_off = b->d_pos_off;
-	a.nkmer = ctx->d_nkmer;
-	a.qthr = ctx->d_qthr;
+	a.nkmer = sl->d_nkmer;
+	a.qthr = sl->d_qthr;
 	a.num_hash = g->params.num_hash;
 	a.n_queries = b->n;
 	a.hits = d_hits;
 	a.cap = cap;
-	a.hit_count = (unsigned long long*)ctx->d_counters;
+	a.hit_count = (unsigned long long*)sl->d_counters;
 	a.early_exit = (flags & KWAGE_SEARCH_EARLY_EXIT) ? 1 : 0;
 	a.partial = nullptr;
 	int rc;
@@ -427,24 +446,24 @@ int launch_search_stage(kwage_group *g, kwage_batch *b, float threshold, uint32_
 			const uint64_t waves = ((uint64_t)a.n_queries + G - 1)/G;
 			const dim3 grid((uint32_t)((waves + 3)/4)), block(SEARCH_THREADS);
 			switch(G){
-				case 16: hipLaunchKernelGGL((and_narrow_kernel<16, 8>), grid, block, 0, ctx->stream, a); break;
-				case 8: hipLaunchKernelGGL((and_narrow_kernel<8, 8>), grid, block, 0, ctx->stream, a); break;
-				case 4: hipLaunchKernelGGL((and_narrow_kernel<4, 8>), grid, block, 0, ctx->stream, a); break;
-				default: hipLaunchKernelGGL((and_narrow_kernel<2, 8>), grid, block, 0, ctx->stream, a); break;
+				case 16: hipLaunchKernelGGL((and_narrow_kernel<16, 8>), grid, block, 0, sl->stream, a); break;
+				case 8: hipLaunchKernelGGL((and_narrow_kernel<8, 8>), grid, block, 0, sl->stream, a); break;
+				case 4: hipLaunchKernelGGL((and_narrow_kernel<4, 8>), grid, block, 0, sl->stream, a); break;
+				default: hipLaunchKernelGGL((and_narrow_kernel<2, 8>), grid, block, 0, sl->stream, a); break;
 			}
 			HIP_TRY(hipGetLastError());
 			return KWAGE_OK;
 		}
 		if(a.segs > 1){
 			const uint64_t bytes = (uint64_t)a.n_queries*g->stride;
-			if((rc = ctx->partial.reserve(bytes))){ return rc; }
-			HIP_TRY(hipMemsetAsync(ctx->partial.p, 0xFF, bytes, ctx->stream));
-			a.partial = (uint32_t*)ctx->partial.p;
+			if((rc = sl->partial.reserve(bytes))){ return rc; }
+			HIP_TRY(hipMemsetAsync(sl->partial.p, 0xFF, bytes, sl->stream));
+			a.partial = (uint32_t*)sl->partial.p;
 		}
-		if(cfg.nt){ launch_and_v<true>(a, ctx->stream, cfg); }
-		else{ launch_and_v<false>(a, ctx->stream, cfg); }
+		if(cfg.nt){ launch_and_v<true>(a, sl->stream, cfg); }
+		else{ launch_and_v<false>(a, sl->stream, cfg); }
 		if(a.segs > 1){
-			hipLaunchKernelGGL(and_combine_kernel, dim3((a.units_per_row + 255)/256, a.n_queries), dim3(256), 0, ctx->stream, a);
+			hipLaunchKernelGGL(and_combine_kernel, dim3((a.units_per_row + 255)/256, a.n_queries), dim3(256), 0, sl->stream, a);
 		}
 	}
 	else{
@@ -463,31 +482,31 @@ int launch_search_stage(kwage_group *g, kwage_batch *b, float threshold, uint32_
 		}
 		if((uint64_t)a.n_queries*a.segs*a.chunks/4 + 1 > 0x7FFFFFFFull){ return fail(KWAGE_ERR_ARG, "batch too large for one launch"); }
 		if(a.segs > 1){
-			if((rc = ctx->partial.reserve((uint64_t)a.n_queries*a.segs*planes*g->stride))){ return rc; }
-			a.partial = (uint32_t*)ctx->partial.p;
+			if((rc = sl->partial.reserve((uint64_t)a.n_queries*a.segs*planes*g->stride))){ return rc; }
+			a.partial = (uint32_t*)sl->partial.p;
 		}
 		static const bool narrow_ok = []() { const char *e = getenv("KWAGE_NARROW"); return !(e && atoi(e) == 0); }();
 		if(narrow_ok && a.segs == 1 && a.units_per_row <= 32 && a.units_per_row > 8 && a.n_queries >= 64 && planes <= 14){
 			// one reference file (<= 2048 columns = 16 units) or two: 4 resp. 2 queries per wave
 			if(a.units_per_row <= 16){
-				if(planes == 7){ launch_count_narrow<7, 4>(a, ctx->stream); }
-				else if(planes == 10){ launch_count_narrow<10, 4>(a, ctx->stream); }
-				else{ launch_count_narrow<14, 4>(a, ctx->stream); }
+				if(planes == 7){ launch_count_narrow<7, 4>(a, sl->stream); }
+				else if(planes == 10){ launch_count_narrow<10, 4>(a, sl->stream); }
+				else{ launch_count_narrow<14, 4>(a, sl->stream); }
 			}
 			else{
-				if(planes == 7){ launch_count_narrow<7, 2>(a, ctx->stream); }
-				else if(planes == 10){ launch_count_narrow<10, 2>(a, ctx->stream); }
-				else{ launch_count_narrow<14, 2>(a, ctx->stream); }
+				if(planes == 7){ launch_count_narrow<7, 2>(a, sl->stream); }
+				else if(planes == 10){ launch_count_narrow<10, 2>(a, sl->stream); }
+				else{ launch_count_narrow<14, 2>(a, sl->stream); }
 			}
 			HIP_TRY(hipGetLastError());
 			return KWAGE_OK;
 		}
 		switch(planes){
-			case 7: launch_count_nh<7>(a, ctx->stream); break;
-			case 10: launch_count_nh<10>(a, ctx->stream); break;
-			case 14: launch_count_nh<14>(a, ctx->stream); break;
-			case 20: launch_count_nh<20>(a, ctx->stream); break;
-			default: launch_count_nh<32>(a, ctx->stream); break;
+			case 7: launch_count_nh<7>(a, sl->stream); break;
+			case 10: launch_count_nh<10>(a, sl->stream); break;
+			case 14: launch_count_nh<14>(a, sl->stream); break;
+			case 20: launch_count_nh<20>(a, sl->stream); break;
+			default: launch_count_nh<32>(a, sl->stream); break;
 		}
 	}
 	HIP_TRY(hipGetLastError());
@@ -497,67 +516,113 @@ int launch_search_stage(kwage_group *g, kwage_batch *b, float threshold, uint32_
 static const uint64_t SPEC_HITS = 8192;     // hit records copied back together with the counters
 
 struct SearchOutcome {
-	uint64_t staged_hits = 0;      // hit records already in ctx->h_stage
+	uint64_t staged_hits = 0;      // hit records already in the slot's h_stage
 	uint64_t n_hits = 0;
 	uint64_t total_kmers = 0;
 	float kmer_ms = 0, search_ms = 0;
 	uint32_t launches = 0;
 };
 
-// Full device pipeline. If own_hits, results land in the ctx result block (grown as needed and the search
-// kernel re-run on overflow); otherwise in the caller's buffer (no re-run: the caller grows).
-int run_search(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
-               kwage_hit *ext_hits, uint64_t ext_cap, bool own_hits, SearchOutcome *out)
+// Enqueue, on the slot's stream: search kernel(s) + ONE D2H copy that brings back the counters, the
+// per-query arrays and (own buffer) the first SPEC_HITS records.
+int enqueue_search_and_copy(Slot *sl)
+{
+	int rc;
+	kwage_group *g = sl->g;
+	kwage_batch *b = sl->b;
+	const bool timing = (sl->flags & KWAGE_SEARCH_TIMING) != 0;
+	const bool own = (sl->ext_hits == nullptr && sl->ext_cap == 0);
+	const uint64_t cap = own ? sl->hit_cap : sl->ext_cap;
+	kwage_hit *d_hits = own ? sl->d_hits : sl->ext_hits;
+	if(b->n && g->num_columns){
+		// The gather kernels of the two slots must not run side by side (they would only share the HBM
+		// bandwidth and stretch each other): this one starts when the other slot's has finished.  The
+		// k-mer stage enqueued before and the copy-back enqueued after are what overlaps.
+		Slot *other = (sl == &g->ctx->slot[0]) ? &g->ctx->slot[1] : &g->ctx->slot[0];
+		if(other->search_done_valid){ HIP_TRY(hipStreamWaitEvent(sl->stream, other->search_done, 0)); }
+		if(timing){ HIP_TRY(hipEventRecord(sl->ev[2], sl->stream)); }
+		if((rc = launch_search_stage(sl, g, b, sl->threshold, sl->flags, d_hits, cap))){ return rc; }
+		if(timing){ HIP_TRY(hipEventRecord(sl->ev[3], sl->stream)); }
+		HIP_TRY(hipEventRecord(sl->search_done, sl->stream));
+		sl->search_done_valid = true;
+		++sl->launches;
+	}
+	sl->staged_hits = own ? std::min<uint64_t>(SPEC_HITS, cap) : 0;
+	const uint64_t bytes = sl->head_bytes + sl->staged_hits*sizeof(kwage_hit);
+	if((rc = sl->h_stage.reserve(bytes))){ return rc; }
+	HIP_TRY(hipMemcpyAsync(sl->h_stage.p, sl->result.p, bytes, hipMemcpyDeviceToHost, sl->stream));
+	return KWAGE_OK;
+}
+
+// First half of a search: validate, lay out the slot, enqueue the whole device pipeline. Returns at once.
+int submit_search(Slot *sl, kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
+                  kwage_hit *ext_hits, uint64_t ext_cap)
 {
 	kwage_ctx *ctx = g->ctx;
 	int rc;
+	if(sl->busy){ return fail(KWAGE_ERR_STATE, "search slot is busy: collect the pending search first"); }
 	if(!g->finalized){ return fail(KWAGE_ERR_STATE, "kwage_group_finalize() must be called before searching"); }
 	if(b->ctx != ctx){ return fail(KWAGE_ERR_ARG, "batch and group belong to different contexts"); }
 	if(!(threshold > 0.0f) || threshold > 1.0f){      // options.cpp:186-191
 		return fail(KWAGE_ERR_ARG, "search threshold must satisfy 0 < t <= 1");
 	}
 	if((rc = set_device(ctx))){ return rc; }
+	if(b->cached_k != g->params.kmer_len){
+		// the batch's per-k layout is shared by every slot: re-laying it out needs the other slot idle
+		for(int i = 0; i < 2; ++i){ if(ctx->slot[i].busy && ctx->slot[i].b == b){ return fail(KWAGE_ERR_STATE, "batch is in use by a pending search with another k-mer length"); } }
+	}
 	if((rc = batch_prepare(b, g->params.kmer_len))){ return rc; }
-	if((rc = ctx->rows.reserve(std::max<uint64_t>(b->total_pos*g->params.num_hash, 1)*sizeof(uint32_t)))){ return rc; }
-	const bool timing = (flags & KWAGE_SEARCH_TIMING) != 0;
-	const bool timing_kmer = timing && (flags & KWAGE_SEARCH_TIMING_KMER) != 0;
-	if(timing_kmer){ HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream)); }
-	if((rc = launch_kmer_stage(ctx, g->params, b, threshold, (uint32_t*)ctx->rows.p, nullptr))){ return rc; }
-	if(timing_kmer){ HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream)); }
+	if((rc = sl->rows.reserve(std::max<uint64_t>(b->total_pos*g->params.num_hash, 1)*sizeof(uint32_t)))){ return rc; }
+	sl->g = g; sl->b = b; sl->threshold = threshold; sl->flags = flags;
+	sl->ext_hits = ext_hits; sl->ext_cap = ext_cap;
+	sl->launches = 0;
 
-	uint64_t cap = own_hits ? ctx->hit_cap : ext_cap;
-	kwage_hit *d_hits = own_hits ? ctx->d_hits : ext_hits;
+	const bool timing_kmer = (flags & KWAGE_SEARCH_TIMING) && (flags & KWAGE_SEARCH_TIMING_KMER);
+	if(timing_kmer){ HIP_TRY(hipEventRecord(sl->ev[0], sl->stream)); }
+	if((rc = launch_kmer_stage(sl, g->params, b, threshold, (uint32_t*)sl->rows.p, nullptr))){ return rc; }
+	if(timing_kmer){ HIP_TRY(hipEventRecord(sl->ev[1], sl->stream)); }
+	if((rc = enqueue_search_and_copy(sl))){ return rc; }
+	sl->busy = true;
+	return KWAGE_OK;
+}
 
-	out->launches = 0;
+// Second half: wait for the slot's stream, grow the hit buffer and re-run the search kernel if it
+// overflowed (own buffer only), report counts and timings. Frees the slot.
+int collect_search(Slot *sl, SearchOutcome *out)
+{
+	if(!sl->busy){ return fail(KWAGE_ERR_STATE, "no pending search in this slot"); }
+	kwage_ctx *ctx = sl->g->ctx;
+	int rc = set_device(ctx);
+	if(rc){ sl->busy = false; return rc; }
+	const bool own = (sl->ext_hits == nullptr && sl->ext_cap == 0);
+	const bool timing = (sl->flags & KWAGE_SEARCH_TIMING) != 0;
+	const bool timing_kmer = timing && (sl->flags & KWAGE_SEARCH_TIMING_KMER) != 0;
+	sl->busy = false;                       // whatever happens below, the slot is released
 	while(true){
-		if(b->n && g->num_columns){
-			if(timing){ HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream)); }
-			if((rc = launch_search_stage(g, b, threshold, flags, d_hits, cap))){ return rc; }
-			if(timing){ HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream)); }
-			++out->launches;
-		}
-		// ONE copy brings back the counters, the per-query arrays and (own buffer) the first SPEC_HITS
-		// records: the common case -- few hits -- needs a single D2H + synchronisation per search
-		out->staged_hits = own_hits ? std::min<uint64_t>(SPEC_HITS, cap) : 0;
-		const uint64_t bytes = ctx->head_bytes + out->staged_hits*sizeof(kwage_hit);
-		if((rc = ctx->h_stage.reserve(bytes))){ return rc; }
-		HIP_TRY(hipMemcpyAsync(ctx->h_stage.p, ctx->result.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
-		HIP_TRY(hipStreamSynchronize(ctx->stream));     // (polling an event instead measured no faster)
-		const uint64_t *hc = (const uint64_t*)ctx->h_stage.p;
+		HIP_TRY(hipStreamSynchronize(sl->stream));     // (polling an event instead measured no faster)
+		const uint64_t *hc = (const uint64_t*)sl->h_stage.p;
 		out->n_hits = hc[0];
 		out->total_kmers = 0;
-		const uint32_t *hn = (const uint32_t*)((const char*)ctx->h_stage.p + 32);      // staged nkmer[]
-		for(uint32_t i = 0; i < b->n; ++i){ out->total_kmers += hn[i]; }
-		if(!own_hits || out->n_hits <= cap){ break; }
+		const uint32_t *hn = (const uint32_t*)((const char*)sl->h_stage.p + 32);      // staged nkmer[]
+		for(uint32_t i = 0; i < sl->b->n; ++i){ out->total_kmers += hn[i]; }
+		const uint64_t cap = own ? sl->hit_cap : sl->ext_cap;
+		if(!own || out->n_hits <= cap){ break; }
 		// hit buffer too small (e.g. threshold truncated to 0: every column matches): grow, re-run
-		if((rc = layout_result(ctx, b->n, out->n_hits, true))){ return rc; }
-		cap = ctx->hit_cap;
-		d_hits = ctx->d_hits;
-		HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(uint64_t), ctx->stream));   // hit counter only
+		if((rc = layout_result(sl, sl->b->n, out->n_hits, true))){ return rc; }
+		HIP_TRY(hipMemsetAsync(sl->d_counters, 0, sizeof(uint64_t), sl->stream));   // hit counter only
+		if((rc = enqueue_search_and_copy(sl))){ return rc; }
 	}
-	if(timing_kmer){ HIP_TRY(hipEventElapsedTime(&out->kmer_ms, ctx->ev[0], ctx->ev[1])); }
-	if(timing && out->launches){ HIP_TRY(hipEventElapsedTime(&out->search_ms, ctx->ev[2], ctx->ev[3])); }
+	out->staged_hits = sl->staged_hits;
+	out->launches = sl->launches;
+	if(timing_kmer){ HIP_TRY(hipEventElapsedTime(&out->kmer_ms, sl->ev[0], sl->ev[1])); }
+	if(timing && sl->launches){ HIP_TRY(hipEventElapsedTime(&out->search_ms, sl->ev[2], sl->ev[3])); }
 	return KWAGE_OK;
+}
+
+Slot *free_slot(kwage_ctx *ctx)
+{
+	for(int i = 0; i < 2; ++i){ if(!ctx->slot[i].busy){ return &ctx->slot[i]; } }
+	return nullptr;
 }
 
 }  // namespace
@@ -598,8 +663,13 @@ extern "C" int kwage_init(int device, kwage_ctx **out)
 	kwage_ctx *ctx = new (std::nothrow) kwage_ctx();
 	if(!ctx){ return fail(KWAGE_ERR_DEVICE, "out of host memory"); }
 	ctx->device = device;
-	HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-	for(int i = 0; i < 4; ++i){ HIP_TRY(hipEventCreate(&ctx->ev[i])); }
+	for(int k = 0; k < 2; ++k){
+		Slot *sl = &ctx->slot[k];
+		HIP_TRY(hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking));
+		for(int i = 0; i < 4; ++i){ HIP_TRY(hipEventCreate(&sl->ev[i])); }
+		HIP_TRY(hipEventCreateWithFlags(&sl->search_done, hipEventDisableTiming));
+	}
+	ctx->stream = ctx->slot[0].stream;
 	*out = ctx;
 	return KWAGE_OK;
 }
@@ -608,15 +678,20 @@ extern "C" void kwage_shutdown(kwage_ctx *ctx)
 {
 	if(!ctx){ return; }
 	(void)hipSetDevice(ctx->device);
-	if(ctx->stream){ (void)hipStreamSynchronize(ctx->stream); }
-	ctx->rows.release(); ctx->tables.release(); ctx->result.release();
-	ctx->partial.release(); ctx->kmers.release(); ctx->h_stage.release();
+	for(int k = 0; k < 2; ++k){
+		Slot *sl = &ctx->slot[k];
+		if(sl->stream){ (void)hipStreamSynchronize(sl->stream); }
+		sl->rows.release(); sl->tables.release(); sl->result.release();
+		sl->partial.release(); sl->h_stage.release();
+		for(int i = 0; i < 4; ++i){ if(sl->ev[i]){ (void)hipEventDestroy(sl->ev[i]); } }
+		if(sl->search_done){ (void)hipEventDestroy(sl->search_done); }
+		if(sl->stream){ (void)hipStreamDestroy(sl->stream); }
+	}
+	ctx->kmers.release();
 	for(int i = 0; i < 2; ++i){
 		ctx->load_pin[i].release(); ctx->load_dev[i].release();
 		if(ctx->load_done[i]){ (void)hipEventDestroy(ctx->load_done[i]); }
 	}
-	for(int i = 0; i < 4; ++i){ if(ctx->ev[i]){ (void)hipEventDestroy(ctx->ev[i]); } }
-	if(ctx->stream){ (void)hipStreamDestroy(ctx->stream); }
 	delete ctx;
 }
 
@@ -637,7 +712,8 @@ extern "C" int kwage_sync(kwage_ctx *ctx)
 	if(!ctx){ return fail(KWAGE_ERR_ARG, "kwage_sync: ctx is NULL"); }
 	int rc = set_device(ctx);
 	if(rc){ return rc; }
-	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->slot[0].stream));
+	HIP_TRY(hipStreamSynchronize(ctx->slot[1].stream));
 	return KWAGE_OK;
 }
 
@@ -693,7 +769,8 @@ extern "C" void kwage_group_destroy(kwage_group *g)
 {
 	if(!g){ return; }
 	(void)hipSetDevice(g->ctx->device);
-	(void)hipStreamSynchronize(g->ctx->stream);
+	(void)hipStreamSynchronize(g->ctx->slot[0].stream);
+	(void)hipStreamSynchronize(g->ctx->slot[1].stream);
 	if(g->d_bits){ (void)hipFree(g->d_bits); }
 	if(g->d_valid){ (void)hipFree(g->d_valid); }
 	delete g;
@@ -955,7 +1032,8 @@ extern "C" void kwage_batch_destroy(kwage_batch *b)
 {
 	if(!b){ return; }
 	(void)hipSetDevice(b->ctx->device);
-	(void)hipStreamSynchronize(b->ctx->stream);
+	(void)hipStreamSynchronize(b->ctx->slot[0].stream);
+	(void)hipStreamSynchronize(b->ctx->slot[1].stream);
 	if(b->d_seqs){ (void)hipFree(b->d_seqs); }
 	if(b->d_seq_off){ (void)hipFree(b->d_seq_off); }
 	if(b->d_pos_off){ (void)hipFree(b->d_pos_off); }
@@ -1013,41 +1091,31 @@ struct ResultStorage {
 	std::vector<kwage_hit> hits;
 	std::vector<uint32_t> nkmer, qthr;
 };
-}
 
-extern "C" int kwage_search(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags, kwage_result **out)
+// Build the host result of a collected search from the slot's staging buffer.
+int build_result(Slot *sl, kwage_group *g, kwage_batch *b, const SearchOutcome &so, kwage_result **out)
 {
-	if(!g || !b || !out){ return fail(KWAGE_ERR_ARG, "kwage_search: NULL argument"); }
-	*out = nullptr;
-	static const bool prof = getenv("KWAGE_PROFILE_HOST") != nullptr;
-	const auto tp0 = std::chrono::steady_clock::now();
-	SearchOutcome so;
-	int rc = run_search(g, b, threshold, flags, nullptr, 0, true, &so);
-	if(rc){ return rc; }
-	const auto tp1 = std::chrono::steady_clock::now();
-	kwage_ctx *ctx = g->ctx;
-
 	ResultStorage *rs = new (std::nothrow) ResultStorage();
 	if(!rs){ return fail(KWAGE_ERR_DEVICE, "out of host memory"); }
 	rs->hits.resize(so.n_hits);
 	rs->nkmer.resize(b->n);
 	rs->qthr.resize(b->n);
 	const uint64_t nq_bytes = (uint64_t)b->n*sizeof(uint32_t);
-	const char *hs = (const char*)ctx->h_stage.p;        // host image of the result block's head
+	const char *hs = (const char*)sl->h_stage.p;        // host image of the result block's head
 	if(b->n){
 		memcpy(rs->nkmer.data(), hs + 32, nq_bytes);
 		memcpy(rs->qthr.data(), hs + 32 + nq_bytes, nq_bytes);
 	}
 	const uint64_t have = std::min(so.n_hits, so.staged_hits);
-	if(have){ memcpy(rs->hits.data(), hs + ctx->head_bytes, have*sizeof(kwage_hit)); }
+	if(have){ memcpy(rs->hits.data(), hs + sl->head_bytes, have*sizeof(kwage_hit)); }
 	if(so.n_hits > have){      // a large hit list: fetch the remainder through pinned memory
 		const uint64_t rem_bytes = (so.n_hits - have)*sizeof(kwage_hit);
-		int rc2 = ctx->h_stage.reserve(rem_bytes);      // the staged head has been consumed above
+		int rc2 = sl->h_stage.reserve(rem_bytes);      // the staged head has been consumed above
 		if(rc2){ delete rs; return rc2; }
-		hipError_t e = hipMemcpyAsync(ctx->h_stage.p, ctx->d_hits + have, rem_bytes, hipMemcpyDeviceToHost, ctx->stream);
-		if(e == hipSuccess){ e = hipStreamSynchronize(ctx->stream); }
+		hipError_t e = hipMemcpyAsync(sl->h_stage.p, sl->d_hits + have, rem_bytes, hipMemcpyDeviceToHost, sl->stream);
+		if(e == hipSuccess){ e = hipStreamSynchronize(sl->stream); }
 		if(e != hipSuccess){ delete rs; return fail(KWAGE_ERR_DEVICE, "kwage_search: copying results failed: %s", hipGetErrorString(e)); }
-		memcpy(rs->hits.data() + have, ctx->h_stage.p, rem_bytes);
+		memcpy(rs->hits.data() + have, sl->h_stage.p, rem_bytes);
 	}
 
 	// deterministic order; the reference's own order among ties is unspecified (sort.h:22-27)
@@ -1066,13 +1134,63 @@ extern "C" int kwage_search(kwage_group *g, kwage_batch *b, float threshold, uin
 	r.search_kernel_ms = so.search_ms;
 	r.search_kernel_launches = so.launches;
 	*out = &rs->pub;
-	if(prof){
+	return KWAGE_OK;
+}
+
+}  // namespace
+
+struct kwage_pending { Slot *sl; };
+
+extern "C" int kwage_search_submit(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags, kwage_pending **out)
+{
+	if(!g || !b || !out){ return fail(KWAGE_ERR_ARG, "kwage_search_submit: NULL argument"); }
+	*out = nullptr;
+	Slot *sl = free_slot(g->ctx);
+	if(!sl){ return fail(KWAGE_ERR_STATE, "kwage_search_submit: two searches are already pending on this context"); }
+	int rc = submit_search(sl, g, b, threshold, flags, nullptr, 0);
+	if(rc){ return rc; }
+	kwage_pending *p = new (std::nothrow) kwage_pending();
+	if(!p){ SearchOutcome so; (void)collect_search(sl, &so); return fail(KWAGE_ERR_DEVICE, "out of host memory"); }
+	p->sl = sl;
+	*out = p;
+	return KWAGE_OK;
+}
+
+extern "C" int kwage_search_collect(kwage_pending *p, kwage_result **out)
+{
+	if(!p || !out){ return fail(KWAGE_ERR_ARG, "kwage_search_collect: NULL argument"); }
+	*out = nullptr;
+	Slot *sl = p->sl;
+	delete p;
+	kwage_group *g = sl->g;
+	kwage_batch *b = sl->b;
+	SearchOutcome so;
+	int rc = collect_search(sl, &so);
+	if(rc){ return rc; }
+	return build_result(sl, g, b, so, out);
+}
+
+extern "C" int kwage_search(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags, kwage_result **out)
+{
+	if(!g || !b || !out){ return fail(KWAGE_ERR_ARG, "kwage_search: NULL argument"); }
+	*out = nullptr;
+	static const bool prof = getenv("KWAGE_PROFILE_HOST") != nullptr;
+	const auto tp0 = std::chrono::steady_clock::now();
+	Slot *sl = free_slot(g->ctx);
+	if(!sl){ return fail(KWAGE_ERR_STATE, "kwage_search: two searches are already pending on this context"); }
+	int rc = submit_search(sl, g, b, threshold, flags, nullptr, 0);
+	if(rc){ return rc; }
+	SearchOutcome so;
+	if((rc = collect_search(sl, &so))){ return rc; }
+	const auto tp1 = std::chrono::steady_clock::now();
+	rc = build_result(sl, g, b, so, out);
+	if(prof && !rc){
 		const auto tp2 = std::chrono::steady_clock::now();
 		fprintf(stderr, "[kwage_search] device pipeline + sync %.1f us, host result assembly + sort %.1f us (%llu hits)\n",
 		        std::chrono::duration<double, std::micro>(tp1 - tp0).count(),
 		        std::chrono::duration<double, std::micro>(tp2 - tp1).count(), (unsigned long long)so.n_hits);
 	}
-	return KWAGE_OK;
+	return rc;
 }
 
 extern "C" void kwage_result_free(kwage_result *r)
@@ -1085,13 +1203,18 @@ extern "C" int kwage_search_device(kwage_group *g, kwage_batch *b, float thresho
                                    void *hits_dev, uint64_t capacity, uint64_t *n_hits, void *num_query_kmer_dev)
 {
 	if(!g || !b || !n_hits || (capacity && !hits_dev)){ return fail(KWAGE_ERR_ARG, "kwage_search_device: NULL argument"); }
-	SearchOutcome so;
-	int rc = run_search(g, b, threshold, flags, (kwage_hit*)hits_dev, capacity, false, &so);
+	Slot *sl = free_slot(g->ctx);
+	if(!sl){ return fail(KWAGE_ERR_STATE, "kwage_search_device: two searches are already pending on this context"); }
+	// a zero-capacity call (size query) still needs a non-null marker for "caller-owned buffer"
+	static kwage_hit dummy;
+	int rc = submit_search(sl, g, b, threshold, flags, capacity ? (kwage_hit*)hits_dev : &dummy, capacity);
 	if(rc){ return rc; }
+	SearchOutcome so;
+	if((rc = collect_search(sl, &so))){ return rc; }
 	*n_hits = so.n_hits;
 	if(num_query_kmer_dev && b->n){
-		HIP_TRY(hipMemcpyAsync(num_query_kmer_dev, g->ctx->d_nkmer, (size_t)b->n*sizeof(uint32_t), hipMemcpyDeviceToDevice, g->ctx->stream));
-		HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+		HIP_TRY(hipMemcpyAsync(num_query_kmer_dev, sl->d_nkmer, (size_t)b->n*sizeof(uint32_t), hipMemcpyDeviceToDevice, sl->stream));
+		HIP_TRY(hipStreamSynchronize(sl->stream));
 	}
 	return KWAGE_OK;
 }
@@ -1104,15 +1227,17 @@ extern "C" int kwage_hash_batch(kwage_ctx *ctx, const kwage_params *params, kwag
 	if(rc){ return rc; }
 	if(b->ctx != ctx){ return fail(KWAGE_ERR_ARG, "kwage_hash_batch: batch belongs to another context"); }
 	if((rc = set_device(ctx))){ return rc; }
+	Slot *sl = &ctx->slot[0];
+	if(sl->busy){ return fail(KWAGE_ERR_STATE, "kwage_hash_batch: a search is pending on this context"); }
 	if((rc = batch_prepare(b, params->kmer_len))){ return rc; }
 	const uint64_t np = std::max<uint64_t>(b->total_pos, 1);
-	if((rc = ctx->rows.reserve(np*params->num_hash*sizeof(uint32_t)))){ return rc; }
+	if((rc = sl->rows.reserve(np*params->num_hash*sizeof(uint32_t)))){ return rc; }
 	if((rc = ctx->kmers.reserve(np*sizeof(uint64_t)))){ return rc; }
-	if((rc = launch_kmer_stage(ctx, *params, b, 1.0f, (uint32_t*)ctx->rows.p, (uint64_t*)ctx->kmers.p))){ return rc; }
+	if((rc = launch_kmer_stage(sl, *params, b, 1.0f, (uint32_t*)sl->rows.p, (uint64_t*)ctx->kmers.p))){ return rc; }
 	memcpy(kmer_offsets, b->h_pos_off.data(), ((size_t)b->n + 1)*sizeof(uint64_t));
-	if(b->n){ HIP_TRY(hipMemcpyAsync(num_query_kmer, ctx->d_nkmer, (size_t)b->n*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
+	if(b->n){ HIP_TRY(hipMemcpyAsync(num_query_kmer, sl->d_nkmer, (size_t)b->n*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
 	if(kmers && b->total_pos){ HIP_TRY(hipMemcpyAsync(kmers, ctx->kmers.p, b->total_pos*sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream)); }
-	if(rows && b->total_pos){ HIP_TRY(hipMemcpyAsync(rows, ctx->rows.p, b->total_pos*params->num_hash*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
+	if(rows && b->total_pos){ HIP_TRY(hipMemcpyAsync(rows, sl->rows.p, b->total_pos*params->num_hash*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	return KWAGE_OK;
 }
@@ -1125,25 +1250,27 @@ namespace {
 // Run the k-mer stage over `b` with ONE shared distinct set; optionally set Bloom bits.
 int run_shared_kmer_pass(kwage_ctx *ctx, const kwage_params &p, kwage_batch *b, uint32_t *d_bloom_bits, uint64_t *distinct)
 {
+	Slot *sl = &ctx->slot[0];
+	if(sl->busy){ return fail(KWAGE_ERR_STATE, "a search is pending on this context"); }
 	int rc = batch_prepare(b, p.kmer_len);
 	if(rc){ return rc; }
-	if((rc = layout_result(ctx, b->n, 0, false))){ return rc; }
+	if((rc = layout_result(sl, b->n, 0, false))){ return rc; }
 	uint32_t lg = 10;
 	while((1ull << lg) < 2*std::max<uint64_t>(b->total_pos, 1)){ ++lg; }
 	if(lg > 36){ return fail(KWAGE_ERR_ARG, "too many k-mer positions for one sample"); }
-	if((rc = ctx->tables.reserve((1ull << lg)*sizeof(uint64_t)))){ return rc; }
-	HIP_TRY(hipMemsetAsync(ctx->tables.p, 0xFF, (1ull << lg)*sizeof(uint64_t), ctx->stream));
-	HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, 4*sizeof(uint64_t), ctx->stream));
+	if((rc = sl->tables.reserve((1ull << lg)*sizeof(uint64_t)))){ return rc; }
+	HIP_TRY(hipMemsetAsync(sl->tables.p, 0xFF, (1ull << lg)*sizeof(uint64_t), ctx->stream));
+	HIP_TRY(hipMemsetAsync(sl->d_counters, 0, 4*sizeof(uint64_t), ctx->stream));
 	if(b->n){
 		KmerArgs a;
 		a.seqs = b->d_seqs; a.seq_off = b->d_seq_off; a.pos_off = b->d_pos_off; a.tab_off = b->d_tab_off;
-		a.g_tables = (unsigned long long*)ctx->tables.p;
+		a.g_tables = (unsigned long long*)sl->tables.p;
 		a.k = p.kmer_len; a.num_hash = p.num_hash;
 		a.row_mask = (p.log_2_filter_len >= 32) ? 0xFFFFFFFFu : ((1u << p.log_2_filter_len) - 1u);
 		a.threshold = 1.0f; a.complete_match = 1;
 		a.rows = nullptr; a.kmers_out = nullptr;
-		a.nkmer = ctx->d_nkmer; a.qthr = ctx->d_qthr;
-		a.total_kmers = (unsigned long long*)ctx->d_counters + 1;
+		a.nkmer = sl->d_nkmer; a.qthr = sl->d_qthr;
+		a.total_kmers = (unsigned long long*)sl->d_counters + 1;
 		a.shared_lg = lg;
 		a.bloom_bits = d_bloom_bits;
 		a.lds_slots = 0;                 // the shared global table is used for every sequence
@@ -1151,7 +1278,7 @@ int run_shared_kmer_pass(kwage_ctx *ctx, const kwage_params &p, kwage_batch *b, 
 		HIP_TRY(hipGetLastError());
 	}
 	uint64_t h[2] = {0, 0};
-	HIP_TRY(hipMemcpyAsync(h, ctx->d_counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(h, sl->d_counters, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	if(distinct){ *distinct = h[1]; }
 	return KWAGE_OK;
@@ -1201,19 +1328,21 @@ extern "C" int kwage_stream_read_gbps(kwage_group *g, uint64_t bytes, uint32_t i
 	if(rc){ return rc; }
 	bytes = std::min(bytes, g->alloc_bytes)/16*16;
 	if(bytes == 0){ return fail(KWAGE_ERR_ARG, "kwage_stream_read_gbps: nothing to read"); }
-	if((rc = layout_result(ctx, 0, 0, false))){ return rc; }
-	uint32_t *sink = (uint32_t*)(ctx->d_counters + 3);
+	Slot *sl = &ctx->slot[0];
+	if(sl->busy){ return fail(KWAGE_ERR_STATE, "kwage_stream_read_gbps: a search is pending on this context"); }
+	if((rc = layout_result(sl, 0, 0, false))){ return rc; }
+	uint32_t *sink = (uint32_t*)(sl->d_counters + 3);
 	const uint64_t n16 = bytes/16;
 	hipLaunchKernelGGL(stream_read_kernel, dim3(256*8), dim3(256), 0, ctx->stream, (const u32x4*)g->d_bits, n16, sink);   // warm-up
-	HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+	HIP_TRY(hipEventRecord(sl->ev[0], ctx->stream));
 	for(uint32_t i = 0; i < iters; ++i){
 		hipLaunchKernelGGL(stream_read_kernel, dim3(256*8), dim3(256), 0, ctx->stream, (const u32x4*)g->d_bits, n16, sink);
 	}
-	HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+	HIP_TRY(hipEventRecord(sl->ev[1], ctx->stream));
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	float ms = 0;
-	HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+	HIP_TRY(hipEventElapsedTime(&ms, sl->ev[0], sl->ev[1]));
 	*gbps = (double)bytes*iters/((double)ms*1e-3)/1e9;
 	return KWAGE_OK;
 }

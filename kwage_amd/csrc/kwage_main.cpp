@@ -204,29 +204,23 @@ void check(int rc)
 	if(rc != KWAGE_OK){ throw string(kwage_last_error()); }
 }
 
-// Search one set of queries against one loaded group; append matches.
+// Search one set of queries against one loaded group; append matches.  Batches are software-pipelined
+// through the context's two search slots: batch i+1 is submitted before batch i is collected, so the
+// host-side mapping of hits overlaps with the device work of the next batch.
 void search_queries(kwage_ctx *ctx, kwage_group *grp, const vector<DbFileEntry*> &files,
                     const vector<uint32_t> &file_index, const vector<Query> &queries, float threshold,
                     uint32_t flags, uint64_t max_batch_bases, ResultMap &results)
 {
-	size_t q0 = 0;
-	while(q0 < queries.size()){
-		// assemble one batch
-		string concat;
-		vector<uint64_t> offs(1, 0);
-		size_t q1 = q0;
-		while(q1 < queries.size() && (q1 == q0 || concat.size() + queries[q1].seq.size() <= max_batch_bases) &&
-		      (q1 - q0) < (1u << 24)){
-			concat += queries[q1].seq;
-			offs.push_back(concat.size());
-			++q1;
-		}
+	struct InFlight {
 		kwage_batch *batch = NULL;
-		check(kwage_batch_create(ctx, concat.data(), offs.data(), (uint32_t)(q1 - q0), &batch));
+		kwage_pending *pending = NULL;
+		size_t q0 = 0;
+	};
+	auto finish = [&](InFlight &f) {
 		kwage_result *res = NULL;
-		int rc = kwage_search(grp, batch, threshold, flags, &res);
-		if(rc != KWAGE_OK){ kwage_batch_destroy(batch); check(rc); }
-
+		const int rc = kwage_search_collect(f.pending, &res);
+		f.pending = NULL;
+		if(rc != KWAGE_OK){ kwage_batch_destroy(f.batch); f.batch = NULL; check(rc); }
 		for(uint64_t i = 0; i < res->n_hits; ++i){
 			const kwage_hit &h = res->hits[i];
 			// global column -> (file, local column): files are laid out in increasing first_column
@@ -240,11 +234,42 @@ void search_queries(kwage_ctx *ctx, kwage_group *grp, const vector<DbFileEntry*>
 			m.num_query_kmer = res->num_query_kmer[h.query];
 			m.file_index = file_index[lo];
 			m.column = (uint32_t)(h.column - files[lo]->first_column);
-			results[queries[q0 + h.query].id].push_back(m);
+			results[queries[f.q0 + h.query].id].push_back(m);
 		}
 		kwage_result_free(res);
-		kwage_batch_destroy(batch);
-		q0 = q1;
+		kwage_batch_destroy(f.batch);
+		f.batch = NULL;
+	};
+
+	InFlight prev;
+	size_t q0 = 0;
+	try{
+		while(q0 < queries.size()){
+			// assemble one batch
+			string concat;
+			vector<uint64_t> offs(1, 0);
+			size_t q1 = q0;
+			while(q1 < queries.size() && (q1 == q0 || concat.size() + queries[q1].seq.size() <= max_batch_bases) &&
+			      (q1 - q0) < (1u << 24)){
+				concat += queries[q1].seq;
+				offs.push_back(concat.size());
+				++q1;
+			}
+			InFlight cur;
+			cur.q0 = q0;
+			check(kwage_batch_create(ctx, concat.data(), offs.data(), (uint32_t)(q1 - q0), &cur.batch));
+			const int rc = kwage_search_submit(grp, cur.batch, threshold, flags, &cur.pending);
+			if(rc != KWAGE_OK){ kwage_batch_destroy(cur.batch); check(rc); }
+			if(prev.pending){ finish(prev); }
+			prev = cur;
+			q0 = q1;
+		}
+		if(prev.pending){ finish(prev); }
+	}
+	catch(...){
+		if(prev.pending){ kwage_result *r = NULL; if(kwage_search_collect(prev.pending, &r) == KWAGE_OK){ kwage_result_free(r); } }
+		if(prev.batch){ kwage_batch_destroy(prev.batch); }
+		throw;
 	}
 }
 

@@ -150,10 +150,7 @@ class SearchResult:
         return out
 
 
-def search(group: Group, batch: Batch, threshold: float, flags: int = 0) -> SearchResult:
-    """kwage_search(): every query of the batch against every column of the group."""
-    res = C.POINTER(native.Result)()
-    check(lib().kwage_search(group._h, batch._h, C.c_float(threshold), flags, C.byref(res)))
+def _unpack_result(res) -> SearchResult:
     try:
         r = res.contents
         n = r.n_hits
@@ -169,7 +166,38 @@ def search(group: Group, batch: Batch, threshold: float, flags: int = 0) -> Sear
         lib().kwage_result_free(res)
 
 
+def search(group: Group, batch: Batch, threshold: float, flags: int = 0) -> SearchResult:
+    """kwage_search(): every query of the batch against every column of the group."""
+    res = C.POINTER(native.Result)()
+    check(lib().kwage_search(group._h, batch._h, C.c_float(threshold), flags, C.byref(res)))
+    return _unpack_result(res)
+
+
+class PendingSearch:
+    """A submitted search (kwage_search_submit); collect() waits for it and returns the result."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def collect(self) -> SearchResult:
+        h, self._h = self._h, None
+        if h is None:
+            raise native.KwageError(-6, "search already collected")
+        res = C.POINTER(native.Result)()
+        check(lib().kwage_search_collect(h, C.byref(res)))
+        return _unpack_result(res)
+
+
+def submit(group: Group, batch: Batch, threshold: float, flags: int = 0) -> PendingSearch:
+    """First half of a search: the device pipeline is enqueued, the call returns at once.  At most two
+    searches may be pending per context."""
+    h = C.c_void_p()
+    check(lib().kwage_search_submit(group._h, batch._h, C.c_float(threshold), flags, C.byref(h)))
+    return PendingSearch(h)
+
+
 Group.search = lambda self, batch, threshold, flags=0: search(self, batch, threshold, flags)
+Group.submit = lambda self, batch, threshold, flags=0: submit(self, batch, threshold, flags)
 
 
 def hash_batch(ctx: Context, kmer_len: int, num_hash: int, log_2_filter_len: int, batch: Batch

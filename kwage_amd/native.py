@@ -107,6 +107,8 @@ _SIGNATURES = [
     ("kwage_batch_num_queries", C.c_uint32, [_P]),
     ("kwage_search", C.c_int, [_P, _P, C.c_float, C.c_uint32, C.POINTER(C.POINTER(Result))]),
     ("kwage_result_free", None, [C.POINTER(Result)]),
+    ("kwage_search_submit", C.c_int, [_P, _P, C.c_float, C.c_uint32, C.POINTER(_P)]),
+    ("kwage_search_collect", C.c_int, [_P, C.POINTER(C.POINTER(Result))]),
     ("kwage_search_device", C.c_int, [_P, _P, C.c_float, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64), _P]),
     ("kwage_hash_batch", C.c_int, [_P, C.POINTER(Params), _P, _P, _P, _P, _P]),
     ("kwage_stream_read_gbps", C.c_int, [_P, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),

@@ -309,6 +309,9 @@ def test_cli_sharded_over_two_contexts(ka, oracle):
             # a database larger than HBM is searched in several passes over whole files: force one file per pass
             passes = subprocess.run(args, cwd=cdir, capture_output=True, env=dict(os.environ, KWAGE_MAX_GROUP_BYTES="1"))
             assert passes.returncode == 0 and passes.stdout == one.stdout
+            # many small query batches, software-pipelined through the two search slots
+            small = subprocess.run(args, cwd=cdir, capture_output=True, env=dict(os.environ, KWAGE_BATCH_BASES="300"))
+            assert small.returncode == 0 and small.stdout == one.stdout
             exp = open(os.path.join(cdir, "expected_t%s.%s" % (thr, fmt)), encoding="latin-1").read()
             assert sorted(two.stdout.decode("latin-1").splitlines()) == sorted(exp.splitlines())
 
@@ -475,3 +478,41 @@ def test_c_example_program(ka, oracle, tmp_path):
             hits, _ = oracle.search_image(db.rows, db.header.slice_size, 31, 1, 10, db.header.num_filter, km, 1.0)
             exp += [(qi, base + c) for c, _ in hits]
     assert got == exp and len(got) > 0
+
+
+def test_submit_collect_pipelining(ka, ctx):
+    """kwage_search_submit / _collect: two searches in flight on one context give the same results as the
+    synchronous call, in any collect order, including hit-buffer growth inside collect; a third submit
+    is refused."""
+    from kwage_amd import synth
+    s = synth.build(ctx, synth.WORKLOADS["tiny"])
+    rng = np.random.default_rng(2)
+    other = ka.Batch(ctx, [rand_seq(rng, 200) for _ in range(30)] + s.queries[:10])
+    ref = {(id(b), t): s.group.search(b, t) for b in (s.batch, other) for t in (1.0, 0.7, 0.001)}
+    for t1, t2 in ((1.0, 0.7), (0.001, 1.0), (0.7, 0.001)):
+        p1 = s.group.submit(s.batch, t1, ka.SEARCH_TIMING)
+        p2 = s.group.submit(other, t2)
+        with pytest.raises(ka.KwageError):
+            s.group.submit(other, t1)                   # both slots busy
+        with pytest.raises(ka.KwageError):
+            ka.hash_batch(ctx, 31, 2, 14, other)        # slot 0 is busy
+        r2 = p2.collect()
+        r1 = p1.collect()
+        assert np.array_equal(r1.hits, ref[(id(s.batch), t1)].hits) and r1.search_kernel_ms > 0
+        assert np.array_equal(r2.hits, ref[(id(other), t2)].hits)
+        assert np.array_equal(r1.num_query_kmer, ref[(id(s.batch), t1)].num_query_kmer)
+        with pytest.raises(ka.KwageError):
+            p1.collect()
+    # a long pipelined stream of submissions
+    pend, got = None, []
+    for i in range(12):
+        nxt = s.group.submit(s.batch if i % 2 == 0 else other, 1.0)
+        if pend is not None:
+            got.append(pend.collect())
+        pend = nxt
+    got.append(pend.collect())
+    for i, r in enumerate(got):
+        assert np.array_equal(r.hits, ref[(id(s.batch if i % 2 == 0 else other), 1.0)].hits)
+    other.close()
+    s.batch.close()
+    s.group.close()
