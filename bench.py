@@ -175,7 +175,7 @@ def main():
 
     ss = None
     if sharded:
-        from kwage_amd.distributed import ShardedSearch, device_tensor_search_fn
+        from kwage_amd.distributed import PipelinedDeviceSearcher, ShardedSearch, device_tensor_search_fn
         dev = "cuda:%d" % local_rank
         ss = [ShardedSearch(dist, rank, world, int(m.group.column_span),
                             device_tensor_search_fn(m.group, flags, dev), device=dev if backend == "nccl" else "cpu")
@@ -205,18 +205,41 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    pipe = None
+
+    def exchange(pipe, tk):
+        buf, n = pipe.collect_counted(tk)
+        if backend != "nccl":                    # gloo rehearsal: the same exchange on host tensors
+            buf = buf[:max(n, ss[0].capacity) + 1].cpu()
+        return ss[0].exchange_counted(buf, n)
+
     if not sharded and multi is None:
         # untimed: let the second search slot allocate its scratch too (the timed loop uses both)
         p1 = s.group.submit(s.batch, threshold, flags)
         p2 = s.group.submit(s.batch, threshold, flags)
         p1.collect()
         p2.collect()
+    elif sharded and multi is None:
+        pipe = PipelinedDeviceSearcher(s.group, flags, "cuda:%d" % local_rank)
+        t1, t2 = pipe.submit(s.batch, threshold), pipe.submit(s.batch, threshold)      # untimed warm-up of both slots
+        for tk in (t1, t2):
+            exchange(pipe, tk)
     sync_all()
     t0 = time.perf_counter()
     kernel_ms = []
     last = None
     nhits = 0
-    if not sharded and multi is None:
+    if sharded and multi is None:
+        # multi-GPU: the same software pipeline per rank -- step i+1's search is submitted before step i's hits
+        # are exchanged (one all_gather over RCCL) and merged on rank 0
+        tk = pipe.submit(s.batch, threshold)
+        for _ in range(args.steps - 1):
+            nxt = pipe.submit(s.batch, threshold)
+            merged = exchange(pipe, tk)
+            tk = nxt
+        merged = exchange(pipe, tk)
+        nhits = len(merged) if merged is not None else 0
+    elif not sharded and multi is None:
         # K steps, software-pipelined through the two search slots of the context: step i+1 is submitted
         # (its k-mer stage runs) before step i is collected (copy-back, sort); the gather kernels themselves
         # run back to back, never side by side.  Every step is complete when the region ends.

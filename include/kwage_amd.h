@@ -180,6 +180,15 @@ int kwage_search_device(kwage_group *g, kwage_batch *b, float threshold, uint32_
                         void *hits_dev, uint64_t capacity, uint64_t *n_hits,
                         void *num_query_kmer_dev);
 
+/* The device-side search in two halves (see kwage_search_submit): the caller alternates between two hit
+ * buffers so that the exchange of one step's hits overlaps with the next step's gather kernel.
+ * count_dev may be NULL or a device uint64 that receives the total hit count in stream order behind
+ * the search kernels -- an exchange buffer can then carry its own record count (header word followed
+ * by the records) and go straight into an all-gather without any further device work. */
+int kwage_search_device_submit(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
+                               void *hits_dev, uint64_t capacity, void *count_dev, kwage_pending **out);
+int kwage_search_device_collect(kwage_pending *p, uint64_t *n_hits, void *num_query_kmer_dev);
+
 /* K-mer stage alone (word.h:73-104 + kwage.cpp:362-366 + hash.cpp:176-234 on the device):
  * for query i writes its distinct canonical k-mers to kmers[kmer_offsets[i] ...] (unordered)
  * and their row indices to rows[(kmer_offsets[i]+j)*num_hash + h].  kmer_offsets must hold

@@ -104,6 +104,7 @@ struct Slot {
 	uint64_t staged_hits = 0;
 	kwage_hit *ext_hits = nullptr;      // caller-owned device buffer (kwage_search_device) or null
 	uint64_t ext_cap = 0;
+	uint64_t *ext_count = nullptr;      // optional device word that receives the hit count in stream order
 };
 
 struct kwage_ctx {
@@ -547,6 +548,9 @@ int enqueue_search_and_copy(Slot *sl)
 		sl->search_done_valid = true;
 		++sl->launches;
 	}
+	if(sl->ext_count){      // the caller's exchange buffer carries its own record count (no host round trip)
+		HIP_TRY(hipMemcpyAsync(sl->ext_count, sl->d_counters, sizeof(uint64_t), hipMemcpyDeviceToDevice, sl->stream));
+	}
 	sl->staged_hits = own ? std::min<uint64_t>(SPEC_HITS, cap) : 0;
 	const uint64_t bytes = sl->head_bytes + sl->staged_hits*sizeof(kwage_hit);
 	if((rc = sl->h_stage.reserve(bytes))){ return rc; }
@@ -556,7 +560,7 @@ int enqueue_search_and_copy(Slot *sl)
 
 // First half of a search: validate, lay out the slot, enqueue the whole device pipeline. Returns at once.
 int submit_search(Slot *sl, kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
-                  kwage_hit *ext_hits, uint64_t ext_cap)
+                  kwage_hit *ext_hits, uint64_t ext_cap, uint64_t *ext_count = nullptr)
 {
 	kwage_ctx *ctx = g->ctx;
 	int rc;
@@ -574,7 +578,7 @@ int submit_search(Slot *sl, kwage_group *g, kwage_batch *b, float threshold, uin
 	if((rc = batch_prepare(b, g->params.kmer_len))){ return rc; }
 	if((rc = sl->rows.reserve(std::max<uint64_t>(b->total_pos*g->params.num_hash, 1)*sizeof(uint32_t)))){ return rc; }
 	sl->g = g; sl->b = b; sl->threshold = threshold; sl->flags = flags;
-	sl->ext_hits = ext_hits; sl->ext_cap = ext_cap;
+	sl->ext_hits = ext_hits; sl->ext_cap = ext_cap; sl->ext_count = ext_count;
 	sl->launches = 0;
 
 	const bool timing_kmer = (flags & KWAGE_SEARCH_TIMING) && (flags & KWAGE_SEARCH_TIMING_KMER);
@@ -663,9 +667,18 @@ extern "C" int kwage_init(int device, kwage_ctx **out)
 	kwage_ctx *ctx = new (std::nothrow) kwage_ctx();
 	if(!ctx){ return fail(KWAGE_ERR_DEVICE, "out of host memory"); }
 	ctx->device = device;
+	// Search streams take the LOWEST queue priority: the gather kernels fill every CU for milliseconds, and
+	// a caller's own small kernels (hit exchange over RCCL, merge sort on the torch stream) must be able
+	// to get workgroups in between instead of waiting for the whole grid to drain.  KWAGE_STREAM_PRIORITY=
+	// normal restores the default.
+	int prio_least = 0, prio_greatest = 0;
+	HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+	const char *pe = getenv("KWAGE_STREAM_PRIORITY");
+	const bool low = !(pe && strcmp(pe, "normal") == 0);
 	for(int k = 0; k < 2; ++k){
 		Slot *sl = &ctx->slot[k];
-		HIP_TRY(hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking));
+		if(low){ HIP_TRY(hipStreamCreateWithPriority(&sl->stream, hipStreamNonBlocking, prio_least)); }
+		else{ HIP_TRY(hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking)); }
 		for(int i = 0; i < 4; ++i){ HIP_TRY(hipEventCreate(&sl->ev[i])); }
 		HIP_TRY(hipEventCreateWithFlags(&sl->search_done, hipEventDisableTiming));
 	}
@@ -1197,6 +1210,40 @@ extern "C" void kwage_result_free(kwage_result *r)
 {
 	if(!r){ return; }
 	delete reinterpret_cast<ResultStorage*>(r);     // pub is the first member
+}
+
+extern "C" int kwage_search_device_submit(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
+                                          void *hits_dev, uint64_t capacity, void *count_dev, kwage_pending **out)
+{
+	if(!g || !b || !out || (capacity && !hits_dev)){ return fail(KWAGE_ERR_ARG, "kwage_search_device_submit: NULL argument"); }
+	*out = nullptr;
+	Slot *sl = free_slot(g->ctx);
+	if(!sl){ return fail(KWAGE_ERR_STATE, "kwage_search_device_submit: two searches are already pending on this context"); }
+	static kwage_hit dummy;          // non-null marker for "caller-owned buffer" when capacity is 0
+	int rc = submit_search(sl, g, b, threshold, flags, capacity ? (kwage_hit*)hits_dev : &dummy, capacity, (uint64_t*)count_dev);
+	if(rc){ return rc; }
+	kwage_pending *p = new (std::nothrow) kwage_pending();
+	if(!p){ SearchOutcome so; (void)collect_search(sl, &so); return fail(KWAGE_ERR_DEVICE, "out of host memory"); }
+	p->sl = sl;
+	*out = p;
+	return KWAGE_OK;
+}
+
+extern "C" int kwage_search_device_collect(kwage_pending *p, uint64_t *n_hits, void *num_query_kmer_dev)
+{
+	if(!p || !n_hits){ return fail(KWAGE_ERR_ARG, "kwage_search_device_collect: NULL argument"); }
+	Slot *sl = p->sl;
+	delete p;
+	kwage_batch *b = sl->b;
+	SearchOutcome so;
+	int rc = collect_search(sl, &so);
+	if(rc){ return rc; }
+	*n_hits = so.n_hits;
+	if(num_query_kmer_dev && b->n){
+		HIP_TRY(hipMemcpyAsync(num_query_kmer_dev, sl->d_nkmer, (size_t)b->n*sizeof(uint32_t), hipMemcpyDeviceToDevice, sl->stream));
+		HIP_TRY(hipStreamSynchronize(sl->stream));
+	}
+	return KWAGE_OK;
 }
 
 extern "C" int kwage_search_device(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,

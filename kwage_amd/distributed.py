@@ -144,6 +144,8 @@ class ShardedSearch:
         self.column_base = [int(sum(spans[:r])) for r in range(self.world)]
         self.total_columns = int(sum(spans))
         self._send = None
+        self._crecv = None
+        self._chost = None
 
     def _exchange_padded(self, t):
         """all_gather of [1 + capacity, 3] int32 buffers; row 0 carries the record count."""
@@ -179,15 +181,54 @@ class ShardedSearch:
             t = torch.as_tensor(np.ascontiguousarray(np.asarray(local, dtype=np.int32).reshape(-1, 3)))
             if self.device != "cpu":
                 t = t.to(self.device)
+        return self.exchange_and_merge(t), nk
+
+    def exchange_counted(self, buf, n: int):
+        """Exchange for a buffer that already has the padded layout (row 0 = u64 record count, rows 1.. =
+        records; PipelinedDeviceSearcher fills it on the device): one all_gather of the first 1+capacity
+        rows, one copy-back to pinned host memory, merge + sort on the host.  No other device work, so it
+        overlaps with a running gather kernel.  -> merged global hit list on rank 0, None elsewhere."""
+        import torch
+        if n > int(buf.shape[0]) - 1:
+            raise ValueError("exchange_counted: the buffer holds fewer records than its count says")
+        while True:
+            cap = self.capacity                            # the same on every rank, whatever the local buffer size
+            if int(buf.shape[0]) >= cap + 1:
+                send = buf[:cap + 1]
+            else:                                          # rare: another rank's count made the capacity outgrow this buffer
+                send = torch.zeros((cap + 1, 3), dtype=torch.int32, device=buf.device)
+                send[:buf.shape[0]] = buf
+            if self._crecv is None or self._crecv.shape[0] != self.world * (cap + 1) or self._crecv.device != buf.device:
+                self._crecv = torch.empty((self.world * (cap + 1), 3), dtype=torch.int32, device=buf.device)
+                self._chost = torch.empty((self.world * (cap + 1), 3), dtype=torch.int32, pin_memory=buf.is_cuda)
+            self.dist.all_gather_into_tensor(self._crecv, send)
+            if buf.is_cuda:
+                self._chost.copy_(self._crecv, non_blocking=True)
+                torch.cuda.current_stream(buf.device).synchronize()
+                host = self._chost.numpy().reshape(self.world, cap + 1, 3)
+            else:
+                host = self._crecv.numpy().reshape(self.world, cap + 1, 3)
+            head = host[:, 0, :2].astype(np.int64) & 0xFFFFFFFF
+            counts = [int(head[r, 0] | (head[r, 1] << 32)) for r in range(self.world)]
+            if max(counts) <= cap:
+                break
+            self.capacity = max(2 * max(counts), 2 * cap)     # same decision on every rank -> no deadlock
+        if self.rank != 0:
+            return None
+        return merge_hits([host[r, 1:1 + counts[r]] for r in range(self.world)], self.column_base)
+
+    def exchange_and_merge(self, t):
+        """The exchange step alone: this rank's [n,3] int32 hit tensor -> merged global hit list on rank 0
+        (None elsewhere).  Callers that pipeline searches (bench.py) call it while the next search runs."""
         if self.exchange == "p2p":
             outs = gatherv_hits(t, self.dist, self.rank, self.world, 0, device=t.device)
         else:
             outs = self._exchange_padded(t)
         if self.rank != 0:
-            return None, nk
+            return None
         if outs[0].is_cuda:
-            return merge_hits_torch(outs, self.column_base), nk
-        return merge_hits([o.numpy() for o in outs], self.column_base), nk
+            return merge_hits_torch(outs, self.column_base)
+        return merge_hits([o.numpy() for o in outs], self.column_base)
 
 
 def device_search_fn(group, ctx, flags: int = 0):
@@ -228,3 +269,50 @@ def device_tensor_search_fn(group, flags: int = 0, device: str = "cuda", initial
             state["buf"] = torch.empty((int(n.value * 1.25) + 1, 3), dtype=torch.int32, device=device)
         return state["buf"][: n.value], nk[: batch.n]
     return fn
+
+
+class PipelinedDeviceSearcher:
+    """submit()/collect() over kwage_search_device_submit/_collect with two alternating exchange buffers:
+    while step i's hits are exchanged over RCCL, step i+1's gather kernel is already running.
+
+    Each buffer is an int32 [1 + capacity, 3] tensor: row 0 holds the u64 record count (written by the
+    engine itself in stream order), rows 1.. the (query, local column, num_match) records -- the layout
+    ShardedSearch.exchange_counted() all-gathers as it stands.  Small torch kernels queued behind a
+    running gather kernel each wait 0.1-0.5 ms for wave slots (tools/concurrency_probe.py), so the
+    exchange must not need any device work besides the collective and one copy-back."""
+
+    def __init__(self, group, flags: int = 0, device: str = "cuda", initial_capacity: int = 1 << 18):
+        import torch
+        self.group, self.flags, self.device = group, flags, device
+        self.bufs = [torch.zeros((1 + initial_capacity, 3), dtype=torch.int32, device=device) for _ in range(2)]
+        self.turn = 0
+
+    def _submit_into(self, buf, batch, threshold):
+        import ctypes as C
+        from .native import check, lib
+        h = C.c_void_p()
+        check(lib().kwage_search_device_submit(self.group._h, batch._h, C.c_float(threshold), self.flags,
+                                               buf.data_ptr() + 12, buf.shape[0] - 1, buf.data_ptr(), C.byref(h)))
+        return h
+
+    def submit(self, batch, threshold):
+        i = self.turn
+        self.turn ^= 1
+        return (self._submit_into(self.bufs[i], batch, threshold), i, batch, threshold)
+
+    def collect_counted(self, ticket):
+        """-> (exchange buffer [1 + capacity, 3] with its count in row 0, n_hits)."""
+        import ctypes as C
+        import torch
+        from .native import check, lib
+        h, i, batch, threshold = ticket
+        n = C.c_uint64()
+        check(lib().kwage_search_device_collect(h, C.byref(n), None))
+        while n.value > self.bufs[i].shape[0] - 1:     # rare: grow this buffer and redo the search
+            self.bufs[i] = torch.zeros((int(n.value * 1.25) + 2, 3), dtype=torch.int32, device=self.device)
+            check(lib().kwage_search_device_collect(self._submit_into(self.bufs[i], batch, threshold), C.byref(n), None))
+        return self.bufs[i], int(n.value)
+
+    def collect(self, ticket):
+        buf, n = self.collect_counted(ticket)
+        return buf[1:1 + n]

@@ -86,6 +86,28 @@ def _worker(rank, world, port, out_dir):
         merged, _ = ss2.search(["A"], 1.0)
         if rank == 0:
             assert merged.tolist() == [[0, 1, 2]]
+        # exchange_counted: the buffer layout the pipelined device searcher fills (row 0 = u64 count, rows 1.. =
+        # records).  Ranks hold buffers of DIFFERENT sizes and the first capacity is too small on rank 1 only.
+        import torch
+        rng = np.random.default_rng(5 + rank)
+        for n_local in ((3, 40), (0, 7), (25, 0)):
+            n = n_local[rank]
+            rec = np.stack([rng.integers(0, 9, n), rng.permutation(e - s)[:n], rng.integers(1, 99, n)], axis=1).astype(np.int32)
+            buf = torch.zeros((1 + (64 if rank == 0 else 41), 3), dtype=torch.int32)
+            buf[0, 0] = n
+            buf[1:1 + n] = torch.from_numpy(rec)
+            ss3 = ShardedSearch(dist, rank, world, e - s, None, capacity=8)
+            merged = ss3.exchange_counted(buf, n)
+            assert ss3.capacity >= max(n_local) and (max(n_local) <= 8 or ss3.capacity > 8)
+            both = [None, None]
+            dist.all_gather_object(both, rec.tolist())
+            if rank == 0:
+                exp = sorted((q, c + bounds[r][0], m) for r in range(world) for q, c, m in both[r])
+                assert sorted(map(tuple, merged.tolist())) == exp and merged.tolist() == [list(x) for x in sorted(exp, key=lambda x: (x[0], x[1]))]
+            else:
+                assert merged is None
+        with pytest.raises(ValueError):
+            ShardedSearch(dist, rank, world, e - s, None).exchange_counted(torch.zeros((3, 3), dtype=torch.int32), 5)
         open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
     finally:
         dist.destroy_process_group()

@@ -516,3 +516,40 @@ def test_submit_collect_pipelining(ka, ctx):
     other.close()
     s.batch.close()
     s.group.close()
+
+
+def test_pipelined_device_search_and_counted_exchange(ka, ctx):
+    """kwage_search_device_submit/_collect through PipelinedDeviceSearcher: the exchange buffer carries its own
+    u64 count (written by the engine in stream order) followed by the records; two searches in flight, buffer
+    growth, and the world-1 RCCL exchange_counted() all reproduce kwage_search."""
+    import torch
+    import torch.distributed as dist
+    from kwage_amd import synth
+    from kwage_amd.distributed import PipelinedDeviceSearcher, ShardedSearch
+    s = synth.build(ctx, synth.WORKLOADS["tiny"])
+    ref = {t: s.group.search(s.batch, t) for t in (1.0, 0.6, 0.001)}
+    pipe = PipelinedDeviceSearcher(s.group, 0, "cuda:0", initial_capacity=64)       # 0.001 overflows -> grow + redo
+    own = not dist.is_initialized()
+    if own:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        ss = ShardedSearch(dist, 0, 1, s.group.num_columns, None, device="cuda:0", capacity=32)
+        seq = [1.0, 0.6, 0.001, 1.0, 0.001, 0.6]
+        tk = pipe.submit(s.batch, seq[0])
+        for i, t in enumerate(seq):
+            nxt = pipe.submit(s.batch, seq[i + 1]) if i + 1 < len(seq) else None
+            buf, n = pipe.collect_counted(tk)
+            head = buf[0].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+            assert n == len(ref[t].hits) == int(head[0] | (head[1] << 32))
+            merged = ss.exchange_counted(buf, n)
+            assert np.array_equal(merged[:, 0], ref[t].hits["query"]) and np.array_equal(merged[:, 1], ref[t].hits["column"])
+            assert np.array_equal(merged[:, 2], ref[t].hits["num_match"])
+            tk = nxt
+        assert ss.capacity >= len(ref[0.001].hits) > 64
+    finally:
+        if own:
+            dist.destroy_process_group()
+    s.batch.close()
+    s.group.close()
