@@ -667,18 +667,11 @@ extern "C" int kwage_init(int device, kwage_ctx **out)
 	kwage_ctx *ctx = new (std::nothrow) kwage_ctx();
 	if(!ctx){ return fail(KWAGE_ERR_DEVICE, "out of host memory"); }
 	ctx->device = device;
-	// Search streams take the LOWEST queue priority: the gather kernels fill every CU for milliseconds, and
-	// a caller's own small kernels (hit exchange over RCCL, merge sort on the torch stream) must be able
-	// to get workgroups in between instead of waiting for the whole grid to drain.  KWAGE_STREAM_PRIORITY=
-	// normal restores the default.
-	int prio_least = 0, prio_greatest = 0;
-	HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-	const char *pe = getenv("KWAGE_STREAM_PRIORITY");
-	const bool low = !(pe && strcmp(pe, "normal") == 0);
 	for(int k = 0; k < 2; ++k){
 		Slot *sl = &ctx->slot[k];
-		if(low){ HIP_TRY(hipStreamCreateWithPriority(&sl->stream, hipStreamNonBlocking, prio_least)); }
-		else{ HIP_TRY(hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking)); }
+		// (a lowest-priority stream was tried so that a caller's small kernels get in between the gather
+		// kernel's workgroups: no measurable difference on gfx950, tools/shard_pipe_probe.py)
+		HIP_TRY(hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking));
 		for(int i = 0; i < 4; ++i){ HIP_TRY(hipEventCreate(&sl->ev[i])); }
 		HIP_TRY(hipEventCreateWithFlags(&sl->search_done, hipEventDisableTiming));
 	}
