@@ -265,6 +265,63 @@ int kwage_make_bloom(kwage_ctx *ctx, const kwage_params *params, const char *seq
                      uint32_t n_seqs, const kwage_sample_info *info, const char *out_path,
                      uint64_t *num_distinct_kmers);
 
+/* ------------------------------------------------------------------------------------
+ * Bloom filter construction WITH a minimum k-mer count -- make_bloom_filter()'s counting pass
+ * (make_bloom.cpp:76-504, count_words :506-621) with the reference's order-dependent semantics: two
+ * 4-bit counting Bloom filters of 2^C elements with conservative update over the k-mer occurrences
+ * of the read stream IN ORDER; the occurrence that lifts a k-mer's minimum counter to
+ * min_kmer_count sets its five candidate bits in 2^M-bit vectors and counts as one k-mer; at the
+ * end optimal_bloom_param(num_kmer) picks (log_2_filter_len, num_hash) and the first num_hash
+ * vectors are OR-folded to that length (:336-354).  The device schedule commits occurrences that
+ * share a counter in their original order, so counters, bits and num_kmer equal the sequential
+ * loop's (kwage_amd/csrc/counter.hip).  Fragments are the sequences handed to _add, in call order
+ * (the reference's front end -- NCBI SDK read iterators -- is replaced by whatever reads the caller
+ * has, e.g. kwage_seqfile_*).  Note that even min_kmer_count == 1 differs from the exact k-mer set
+ * of kwage_make_bloom: a new k-mer whose four counters were already raised by others is skipped.
+ * PARITY UNPINNED against a running reference (make_bloom.cpp needs the NCBI SDK): checked against
+ * the line-by-line restatement in oracle/.
+ * ---------------------------------------------------------------------------------- */
+typedef struct kwage_bloom_counter kwage_bloom_counter;
+
+typedef struct {
+	uint64_t num_valid_kmer;          /* m_progress.num_kmer                                      */
+	uint64_t num_bp;                  /* m_progress.num_bp: bases of all fragments                */
+	uint64_t positions;               /* k-mer start positions examined                           */
+	uint64_t occurrences_committed;   /* occurrences that changed a counter                       */
+	uint64_t chunks, rounds;          /* device chunks processed, commit rounds over all chunks   */
+	uint32_t max_rounds;              /* longest commit chain in one chunk                        */
+	uint32_t reserved;
+	double add_ms;                    /* host wall time inside _add/_flush                        */
+} kwage_bloom_counter_stats;
+
+#define KWAGE_BLOOM_SUCCESS 0         /* STATUS_BLOOM_SUCCESS, maestro.h:25 */
+#define KWAGE_BLOOM_INVALID 1         /* STATUS_BLOOM_INVALID, maestro.h:27: bound not satisfiable / no k-mers */
+
+/* make_bloom.cpp:105-130: log2 length of the counting filters from the number of bases (0 = unknown -> 32). */
+uint32_t kwage_counting_filter_log2(uint64_t num_bp);
+/* bloom.cpp:72-121 approximate_max_kmers */
+uint64_t kwage_approximate_max_kmers(float false_positive_probability, uint32_t min_log_2_filter_len,
+                                     uint32_t max_log_2_filter_len);
+
+int kwage_bloom_counter_create(kwage_ctx *ctx, uint32_t kmer_len, int32_t hash_func, uint32_t min_kmer_count,
+                               uint32_t log_2_counting_filter_len, uint32_t max_log_2_filter_len,
+                               kwage_bloom_counter **out);
+void kwage_bloom_counter_destroy(kwage_bloom_counter *bc);
+/* Append fragments (concatenated + offsets, like kwage_batch_create) to the read stream. */
+int kwage_bloom_counter_add(kwage_bloom_counter *bc, const char *seqs, const uint64_t *offsets, uint32_t n_seqs);
+/* Process what is staged on the host so far (add() works in 16 M-position chunks). */
+int kwage_bloom_counter_flush(kwage_bloom_counter *bc);
+int kwage_bloom_counter_get_stats(kwage_bloom_counter *bc, kwage_bloom_counter_stats *out);
+/* Inspection (tests): CountingBloom elements [first, first+n) as bytes (low nibble `first`, high nibble
+ * `second`, make_bloom.cpp:59-66) and bytes of candidate bit vector `hash` (LSB first). */
+int kwage_bloom_counter_read_counts(kwage_bloom_counter *bc, uint64_t first, uint64_t n, void *out);
+int kwage_bloom_counter_read_valid_bits(kwage_bloom_counter *bc, uint32_t hash, uint64_t first_byte, uint64_t nbytes, void *out);
+/* make_bloom.cpp:210-216,309-450: *status = KWAGE_BLOOM_INVALID (nothing written) if num_kmer exceeds
+ * approximate_max_kmers or no parameters satisfy the bound; else fold, CRC and write the `.bloom` file
+ * (out_path may be NULL: parameters only).  `chosen` may be NULL. */
+int kwage_bloom_counter_finish(kwage_bloom_counter *bc, float false_positive_probability, uint32_t min_log_2_filter_len,
+                               const kwage_sample_info *info, const char *out_path, kwage_params *chosen, int *status);
+
 /* Column-wise re-pack: the columns of several same-parameter `.db` files (raw or compressed) become
  * ONE raw `.db` file with contiguous columns, in file order then column order -- the bit-level work of
  * the reference's merge_db.cpp:268-820 (get_bit/set_bit per bit there; shift-and-OR on the device

@@ -699,13 +699,10 @@ static bool opt_accession(const char *s, uint64_t &out, bool required)
 	return str_to_accession(s, out);
 }
 
-extern "C" int kwage_make_bloom(kwage_ctx *ctx, const kwage_params *params, const char *seqs, const uint64_t *offsets,
-                                uint32_t n_seqs, const kwage_sample_info *si, const char *out_path, uint64_t *num_distinct)
+namespace kwage {
+
+int sample_info_to_filter_info(const kwage_sample_info *si, FilterInfo &fi)
 {
-	if(!ctx || !params || !offsets || !si || !out_path){ return fail(KWAGE_ERR_ARG, "kwage_make_bloom: NULL argument"); }
-	int rc = check_params(params);
-	if(rc){ return rc; }
-	FilterInfo fi;
 	if(!opt_accession(si->run_accession, fi.run_accession, true) || !opt_accession(si->experiment_accession, fi.experiment_accession, false) ||
 	   !opt_accession(si->sample_accession, fi.sample_accession, false) || !opt_accession(si->study_accession, fi.study_accession, false)){
 		return fail(KWAGE_ERR_ARG, "str_to_accession: Unable to parse accession string");
@@ -727,6 +724,37 @@ extern "C" int kwage_make_bloom(kwage_ctx *ctx, const kwage_params *params, cons
 	fi.number_of_spots = si->number_of_spots;
 	fi.number_of_bases = si->number_of_bases;
 	fi.day = si->day; fi.month = si->month; fi.year = si->year;
+	return KWAGE_OK;
+}
+
+// binary_write<BloomFilter> (binary_io.cpp:182-208)
+int write_bloom_file(const char *out_path, const kwage_params *params, const FilterInfo &fi,
+                     const unsigned char *bits, uint64_t nbytes)
+{
+	std::vector<unsigned char> head;
+	head.push_back(0xFF);                                               // BLOOM_MAGIC_COMPLETE, bloom.h:28
+	auto u32 = [&](uint32_t v) { for(int i = 0; i < 4; ++i){ head.push_back((unsigned char)(v >> (8*i))); } };
+	u32(params->kmer_len); u32(params->log_2_filter_len); u32(params->num_hash); u32((uint32_t)params->hash_func);   // bloom.h:550-554
+	u32((uint32_t)crc32_z(crc32_z(0L, Z_NULL, 0), bits, nbytes));                                                      // bloom.cpp:328-343
+	pack_filter_info(fi, head);
+	FILE *f = fopen(out_path, "wb");
+	if(!f){ return fail(KWAGE_ERR_IO, "Unable to open %s for writing", out_path); }
+	bool ok = fwrite(head.data(), 1, head.size(), f) == head.size() && fwrite(bits, 1, nbytes, f) == nbytes;
+	ok = (fclose(f) == 0) && ok;
+	if(!ok){ return fail(KWAGE_ERR_IO, "binary_write<BloomFilter>: Unable to write BloomFilter"); }
+	return KWAGE_OK;
+}
+
+}  // namespace kwage
+
+extern "C" int kwage_make_bloom(kwage_ctx *ctx, const kwage_params *params, const char *seqs, const uint64_t *offsets,
+                                uint32_t n_seqs, const kwage_sample_info *si, const char *out_path, uint64_t *num_distinct)
+{
+	if(!ctx || !params || !offsets || !si || !out_path){ return fail(KWAGE_ERR_ARG, "kwage_make_bloom: NULL argument"); }
+	int rc = check_params(params);
+	if(rc){ return rc; }
+	FilterInfo fi;
+	if((rc = sample_info_to_filter_info(si, fi))){ return rc; }
 
 	// cut long sequences into pieces overlapping by k-1 bases: one workgroup walks one piece
 	const uint64_t PIECE = 1u << 16;
@@ -754,19 +782,7 @@ extern "C" int kwage_make_bloom(kwage_ctx *ctx, const kwage_params *params, cons
 	if(rc){ return rc; }
 	if(num_distinct){ *num_distinct = distinct; }
 
-	// binary_write<BloomFilter> (binary_io.cpp:182-208)
-	std::vector<unsigned char> head;
-	head.push_back(0xFF);                                               // BLOOM_MAGIC_COMPLETE, bloom.h:28
-	auto u32 = [&](uint32_t v) { for(int i = 0; i < 4; ++i){ head.push_back((unsigned char)(v >> (8*i))); } };
-	u32(params->kmer_len); u32(params->log_2_filter_len); u32(params->num_hash); u32((uint32_t)params->hash_func);   // bloom.h:550-554
-	u32((uint32_t)crc32_z(crc32_z(0L, Z_NULL, 0), bits.data(), bits.size()));                                          // bloom.cpp:328-343
-	pack_filter_info(fi, head);
-	FILE *f = fopen(out_path, "wb");
-	if(!f){ return fail(KWAGE_ERR_IO, "Unable to open %s for writing", out_path); }
-	bool ok = fwrite(head.data(), 1, head.size(), f) == head.size() && fwrite(bits.data(), 1, bits.size(), f) == bits.size();
-	ok = (fclose(f) == 0) && ok;
-	if(!ok){ return fail(KWAGE_ERR_IO, "binary_write<BloomFilter>: Unable to write BloomFilter"); }
-	return KWAGE_OK;
+	return write_bloom_file(out_path, params, fi, bits.data(), bits.size());
 }
 
 struct kwage_dbinfo { DbInfo d; };

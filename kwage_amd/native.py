@@ -60,6 +60,12 @@ class BuildStats(C.Structure):
     _fields_ = [("bits_transposed", C.c_uint64), ("transpose_kernel_ms", C.c_float), ("db_bytes", C.c_uint64)]
 
 
+class BloomCounterStats(C.Structure):
+    _fields_ = [("num_valid_kmer", C.c_uint64), ("num_bp", C.c_uint64), ("positions", C.c_uint64),
+                ("occurrences_committed", C.c_uint64), ("chunks", C.c_uint64), ("rounds", C.c_uint64),
+                ("max_rounds", C.c_uint32), ("reserved", C.c_uint32), ("add_ms", C.c_double)]
+
+
 class SampleInfo(C.Structure):
     _fields_ = [(n, C.c_char_p) for n in ("run_accession", "experiment_accession", "sample_accession", "study_accession",
                                           "experiment_title", "experiment_design_description", "experiment_library_name",
@@ -119,6 +125,16 @@ _SIGNATURES = [
     ("kwage_count_distinct_kmers", C.c_int, [_P, _P, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("kwage_bloom_bits_from_batch", C.c_int, [_P, C.POINTER(Params), _P, _P, C.POINTER(C.c_uint64)]),
     ("kwage_make_bloom", C.c_int, [_P, C.POINTER(Params), C.c_char_p, _P, C.c_uint32, C.POINTER(SampleInfo), C.c_char_p, C.POINTER(C.c_uint64)]),
+    ("kwage_counting_filter_log2", C.c_uint32, [C.c_uint64]),
+    ("kwage_approximate_max_kmers", C.c_uint64, [C.c_float, C.c_uint32, C.c_uint32]),
+    ("kwage_bloom_counter_create", C.c_int, [_P, C.c_uint32, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    ("kwage_bloom_counter_destroy", None, [_P]),
+    ("kwage_bloom_counter_add", C.c_int, [_P, C.c_char_p, _P, C.c_uint32]),
+    ("kwage_bloom_counter_flush", C.c_int, [_P]),
+    ("kwage_bloom_counter_get_stats", C.c_int, [_P, C.POINTER(BloomCounterStats)]),
+    ("kwage_bloom_counter_read_counts", C.c_int, [_P, C.c_uint64, C.c_uint64, _P]),
+    ("kwage_bloom_counter_read_valid_bits", C.c_int, [_P, C.c_uint32, C.c_uint64, C.c_uint64, _P]),
+    ("kwage_bloom_counter_finish", C.c_int, [_P, C.c_float, C.c_uint32, C.POINTER(SampleInfo), C.c_char_p, C.POINTER(Params), C.POINTER(C.c_int)]),
     ("kwage_repack_db", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_char_p), C.c_uint32]),
     ("kwage_db_read_header", C.c_int, [C.c_char_p, C.POINTER(DbHeader)]),
     ("kwage_db_compress", C.c_int, [C.c_char_p, C.c_char_p, C.c_uint32]),

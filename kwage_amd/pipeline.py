@@ -14,7 +14,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from .engine import Batch, Context
-from .native import BuildStats, Params, SampleInfo, check, lib
+from .native import BloomCounterStats, BuildStats, Params, SampleInfo, check, lib
 
 MAX_NUM_FILTER_CHUNK = 2048
 
@@ -38,15 +38,85 @@ def read_sequences(path: str) -> List[Tuple[str, bytes]]:
     return out
 
 
+class BloomCounter:
+    """make_bloom_filter()'s counting pass (make_bloom.cpp:76-504) on the device: add() fragments in read
+    order, finish() -> (status, Params) and optionally the `.bloom` file.  See include/kwage_amd.h."""
+
+    def __init__(self, ctx: Context, kmer_len: int = 31, min_kmer_count: int = 5, log_2_counting_filter_len: int = 0,
+                 max_log_2_filter_len: int = 32, num_bp: int = 0, hash_func: int = 0):
+        L = lib()
+        if not log_2_counting_filter_len:
+            log_2_counting_filter_len = L.kwage_counting_filter_log2(num_bp)          # make_bloom.cpp:105-130
+        self.log_2_counting_filter_len, self.max_log_2_filter_len = log_2_counting_filter_len, max_log_2_filter_len
+        self._h = C.c_void_p()
+        check(L.kwage_bloom_counter_create(ctx._h, kmer_len, hash_func, min_kmer_count, log_2_counting_filter_len,
+                                           max_log_2_filter_len, C.byref(self._h)))
+
+    def add(self, seqs: Sequence[bytes]):
+        offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        if seqs:
+            offs[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+        check(lib().kwage_bloom_counter_add(self._h, b"".join(seqs), offs.ctypes.data, len(seqs)))
+
+    def stats(self) -> BloomCounterStats:
+        st = BloomCounterStats()
+        check(lib().kwage_bloom_counter_get_stats(self._h, C.byref(st)))
+        return st
+
+    def counts(self, first: int = 0, n: int = None) -> np.ndarray:
+        n = (1 << self.log_2_counting_filter_len) - first if n is None else n
+        out = np.empty(n, dtype=np.uint8)
+        check(lib().kwage_bloom_counter_read_counts(self._h, first, n, out.ctypes.data))
+        return out
+
+    def valid_bits(self, h: int) -> np.ndarray:
+        out = np.empty((1 << self.max_log_2_filter_len) // 8, dtype=np.uint8)
+        check(lib().kwage_bloom_counter_read_valid_bits(self._h, h, 0, out.size, out.ctypes.data))
+        return out
+
+    def finish(self, false_positive: float = 0.25, min_log_2_filter_len: int = 18, info: SampleInfo = None,
+               out_path: str = None):
+        prm, status = Params(), C.c_int()
+        check(lib().kwage_bloom_counter_finish(self._h, C.c_float(false_positive), min_log_2_filter_len,
+                                               C.byref(info) if info is not None else None,
+                                               out_path.encode() if out_path else None, C.byref(prm), C.byref(status)))
+        return status.value, prm
+
+    def close(self):
+        if self._h:
+            lib().kwage_bloom_counter_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 def build_databases(ctx: Context, samples: Sequence[Tuple[str, str]], out_prefix: str, kmer_len: int = 31,
                     false_positive: float = 0.25, min_log_2_filter_len: int = 18, max_log_2_filter_len: int = 32,
-                    work_dir: Optional[str] = None) -> List[str]:
-    """samples: (run accession, sequence file).  Returns the `.db` files written."""
+                    work_dir: Optional[str] = None, min_kmer_count: int = 0) -> List[str]:
+    """samples: (run accession, sequence file).  Returns the `.db` files written.
+    min_kmer_count 0: exact k-mer set of each sample (assemblies / genomes); 1..15: the reference's counting
+    pass for read sets (make_bloom.cpp, its default is 5) -- samples it declares INVALID are left out."""
     L = lib()
     tmp = work_dir or tempfile.mkdtemp(prefix="kwage_bloom_")
     groups: Dict[Tuple[int, int], List[str]] = {}
     for acc, path in samples:
         seqs = [s for _, s in read_sequences(path)]
+        if min_kmer_count:
+            si = SampleInfo()
+            si.run_accession = acc.encode()
+            si.number_of_spots = len(seqs)
+            si.number_of_bases = sum(len(s) for s in seqs)
+            bloom = os.path.join(tmp, acc + ".bloom")
+            with BloomCounter(ctx, kmer_len, min_kmer_count, 0, max_log_2_filter_len, num_bp=si.number_of_bases) as bc:
+                bc.add(seqs)
+                status, prm = bc.finish(false_positive, min_log_2_filter_len, si, bloom)
+            if status == 0:
+                groups.setdefault((prm.log_2_filter_len, prm.num_hash), []).append(bloom)
+            continue
         b = Batch(ctx, seqs)
         n = C.c_uint64()
         check(L.kwage_count_distinct_kmers(ctx._h, b._h, kmer_len, C.byref(n)))

@@ -6,6 +6,7 @@
  */
 #include "kwage_oracle.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -305,4 +306,115 @@ size_t kwo_search_sequence(const uint8_t *rows, size_t row_stride,
 	                                    hits, cap, rows_read);
 	free(kmers);
 	return ret;
+}
+
+/* ======================================================================================
+ * Bloom filter construction with a minimum k-mer count -- make_bloom.cpp (PARITY UNPINNED,
+ * see kwage_oracle.h).
+ * ==================================================================================== */
+
+/* make_bloom.cpp:105-130 (MAX_LOG_COUNT_FILTER_LEN 32, MIN 18, COUNT_FILTER_FP 1e-2 :20-24) */
+uint32_t kwo_counting_filter_log2(uint64_t num_bp)
+{
+	uint64_t lg = 32;
+	if(num_bp > 0){
+		const double counting_length = 1.0/( 1.0 - pow( 1.0 - pow(1.0e-2, 1.0/4.0), 1.0/(2*num_bp) ) );
+		/* the reference assigns the double result of ceil() to a size_t member */
+		lg = (uint64_t)ceil( log(counting_length)/log(2.0) );
+		if(lg > 32){ lg = 32; }
+		if(lg < 18){ lg = 18; }
+	}
+	return (uint32_t)lg;
+}
+
+/* bloom.cpp:72-121 */
+uint64_t kwo_approximate_max_kmers(float m_p, uint32_t min_lg, uint32_t max_lg)
+{
+	for(uint64_t log_2_num_kmer = 1; log_2_num_kmer < 64; ++log_2_num_kmer){
+		const uint64_t num_kmer = UINT64_C(1) << log_2_num_kmer;
+		int valid = 0;
+		for(uint64_t lg = min_lg; (lg <= max_lg) && !valid; ++lg){
+			float best_p = 10.0f;
+			for(uint32_t num_hash = 1; (num_hash <= 5) && !valid; ++num_hash){
+				const uint64_t len = UINT64_C(1) << lg;
+				const double p = pow(1.0 - pow(1.0 - 1.0/len, num_kmer*num_hash), num_hash);
+				if( (p <= m_p) && (p < best_p) ){ valid = 1; }
+			}
+		}
+		if(!valid){ return num_kmer; }
+	}
+	return UINT64_C(0xFFFFFFFFFFFFFFFF);
+}
+
+kwo_counter *kwo_counter_new(uint32_t kmer_len, uint32_t min_kmer_count, uint32_t log2_count, uint32_t max_log2)
+{
+	kwo_counter *c = (kwo_counter*)calloc(1, sizeof(kwo_counter));
+	if(!c){ return NULL; }
+	c->kmer_len = kmer_len; c->min_kmer_count = min_kmer_count;
+	c->log2_count = log2_count; c->max_log2 = max_log2;
+	c->count = (uint8_t*)calloc((size_t)1 << log2_count, 1);                 /* :159 memset 0 */
+	size_t vb = (((size_t)1 << max_log2) + 7)/8;
+	for(int h = 0; h < 5; ++h){ c->valid[h] = (uint8_t*)calloc(vb, 1); }       /* :165-169 */
+	return c;
+}
+
+void kwo_counter_free(kwo_counter *c)
+{
+	if(!c){ return; }
+	free(c->count);
+	for(int h = 0; h < 5; ++h){ free(c->valid[h]); }
+	free(c);
+}
+
+/* make_bloom.cpp:506-621 */
+void kwo_counter_add(kwo_counter *c, const char *seq, size_t len)
+{
+	c->num_bp += len;
+	if(len == 0){ return; }
+	uint64_t *words = (uint64_t*)malloc(len*sizeof(uint64_t));
+	const size_t n = kwo_canonical_kmers(seq, len, c->kmer_len, words, NULL);
+	const uint64_t count_mask = (UINT64_C(1) << c->log2_count) - 1;     /* :138-148 */
+	const uint64_t seq_mask = (UINT64_C(1) << c->max_log2) - 1;
+	const uint32_t m = c->min_kmer_count;
+	for(size_t i = 0; i < n; ++i){
+		uint64_t hi[5];
+		for(uint32_t h = 0; h < 5; ++h){ hi[h] = kwo_murmur3_32_word(words[i], c->kmer_len, h); }   /* :530 */
+		uint8_t *c0 = &c->count[hi[0] & count_mask], *c1 = &c->count[hi[1] & count_mask];
+		uint8_t *c2 = &c->count[hi[2] & count_mask], *c3 = &c->count[hi[3] & count_mask];
+		const unsigned f0 = *c0 & 15u, f1 = *c1 & 15u;                    /* .first  :546-547 */
+		const unsigned s0 = *c2 >> 4, s1 = *c3 >> 4;                       /* .second :549-550 */
+		unsigned mn = f0;
+		if(f1 < mn){ mn = f1; }
+		if(s0 < mn){ mn = s0; }
+		if(s1 < mn){ mn = s1; }
+		if(mn < m){                                                        /* :560 */
+			if(mn == m - 1){                                               /* :562 */
+				++c->num_valid_kmer;
+				for(uint32_t h = 0; h < 5; ++h){
+					const uint64_t b = hi[h] & seq_mask;
+					c->valid[h][b >> 3] |= (uint8_t)(1u << (b & 7));       /* BitVector::set_bit, bloom.h:143 */
+				}
+			}
+			/* :587-602: four separate ++ on 4-bit fields (two hashes landing on the same element
+			 * increment it twice; a 4-bit field wraps) */
+			if(f0 == mn){ *c0 = (uint8_t)((*c0 & 0xF0u) | ((*c0 + 1u) & 15u)); }
+			if(f1 == mn){ *c1 = (uint8_t)((*c1 & 0xF0u) | ((*c1 + 1u) & 15u)); }
+			if(s0 == mn){ *c2 = (uint8_t)((*c2 & 0x0Fu) | ((((*c2 >> 4) + 1u) & 15u) << 4)); }
+			if(s1 == mn){ *c3 = (uint8_t)((*c3 & 0x0Fu) | ((((*c3 >> 4) + 1u) & 15u) << 4)); }
+		}
+	}
+	free(words);
+}
+
+/* make_bloom.cpp:336-354 */
+void kwo_counter_fold(const kwo_counter *c, uint32_t log_2_filter_len, uint32_t num_hash, uint8_t *out)
+{
+	const uint64_t num_dst_block = (UINT64_C(1) << log_2_filter_len)/8;
+	const uint64_t num_src_block = (UINT64_C(1) << c->max_log2)/8;
+	memset(out, 0, num_dst_block);
+	for(uint32_t h = 0; h < num_hash; ++h){
+		for(uint64_t i = 0; i < num_src_block; i += num_dst_block){
+			for(uint64_t j = 0; j < num_dst_block; ++j){ out[j] |= c->valid[h][i + j]; }
+		}
+	}
 }

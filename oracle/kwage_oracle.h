@@ -102,6 +102,42 @@ size_t kwo_search_sequence(const uint8_t *rows, size_t row_stride,
                            kwo_hit *hits, size_t cap,
                            uint32_t *num_query_kmer, uint64_t *rows_read);
 
+/* ---- Bloom filter construction with a minimum k-mer count (make_bloom.cpp) --------------------------
+ * PARITY UNPINNED for this block: make_bloom.cpp needs the NCBI SDK headers and cannot be compiled
+ * here, and the reference ships no vectors for it.  The functions below restate its source line by
+ * line (sequential, one fragment after the other); the pieces it shares with the pinned path
+ * (ForEachDuplexWord, bigsi_hash, optimal_bloom_param, binary_write<BloomFilter>) ARE pinned. */
+
+/* make_bloom.cpp:105-130: log2 length of the two 4-bit counting Bloom filters from the number of
+ * bases (0 = unknown -> the maximum, 32); clamped to [18, 32]. */
+uint32_t kwo_counting_filter_log2(uint64_t num_bp);
+
+/* bloom.cpp:72-121 approximate_max_kmers: the smallest power of two of k-mers for which no
+ * (filter length, num_hash) in range meets the false-positive bound. */
+uint64_t kwo_approximate_max_kmers(float p, uint32_t min_log_2_filter_len, uint32_t max_log_2_filter_len);
+
+/* State of make_bloom_filter() between fragments: CountingBloom[2^log2_count] (one byte each:
+ * low nibble `first`, high nibble `second`, make_bloom.cpp:59-66), MAX_NUM_HASH = 5 bit vectors of
+ * 2^max_log2 bits (`valid_bits`, :165-169) and the running num_kmer. */
+typedef struct {
+	uint32_t kmer_len, min_kmer_count, log2_count, max_log2;
+	uint8_t *count;
+	uint8_t *valid[5];
+	uint64_t num_valid_kmer;
+	uint64_t num_bp;
+} kwo_counter;
+
+kwo_counter *kwo_counter_new(uint32_t kmer_len, uint32_t min_kmer_count, uint32_t log2_count, uint32_t max_log2);
+void kwo_counter_free(kwo_counter *c);
+
+/* count_words (make_bloom.cpp:506-621) for one fragment, preceded by the num_bp bookkeeping of the
+ * calling loops (:202,:238,:290). */
+void kwo_counter_add(kwo_counter *c, const char *seq, size_t len);
+
+/* make_bloom.cpp:336-354: OR-fold of valid_bits[h], h < num_hash, into a filter of 2^log_2_filter_len
+ * bits (out: 2^log_2_filter_len / 8 bytes, log_2_filter_len >= 3). */
+void kwo_counter_fold(const kwo_counter *c, uint32_t log_2_filter_len, uint32_t num_hash, uint8_t *out);
+
 #ifdef __cplusplus
 }
 #endif
