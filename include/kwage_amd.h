@@ -217,12 +217,11 @@ int kwage_build_db(kwage_ctx *ctx, const char *out_path, const kwage_params *par
                    const char *const *bloom_paths, uint32_t n, kwage_build_stats *stats);
 
 /* ------------------------------------------------------------------------------------
- * Bloom filter construction from sequences -- the exact k-mer set, i.e. what the reference's
- * make_bloom_filter() (make_bloom.cpp:76-504) yields at min_kmer_count == 1, where its counting
- * Bloom pass (count_words, :506-621) degenerates to "every valid canonical k-mer sets bit
- * hash_h & (2^L - 1) for h < num_hash" (fold :344-354).  min_kmer_count > 1 (read sets) is NOT
- * provided: the reference's conservative-update counters are order dependent and its streaming
- * front end needs the NCBI SDK.  Output: a `.bloom` file as binary_write<BloomFilter> writes it
+ * Bloom filter construction from sequences -- the EXACT k-mer set (genomes / assemblies): every valid
+ * canonical k-mer sets bit hash_h & (2^L - 1) for h < num_hash.  (The reference's make_bloom_filter()
+ * always runs its counting-Bloom pass, which even at min_kmer_count == 1 may skip a k-mer whose counters
+ * were raised by others; that behaviour, for any min_kmer_count, is kwage_bloom_counter_* below.)
+ * Output: a `.bloom` file as binary_write<BloomFilter> writes it
  * (binary_io.cpp:182-208), ready for kwage_build_db.
  * ---------------------------------------------------------------------------------- */
 typedef struct {

@@ -1,7 +1,7 @@
 """FASTA/FASTQ per sample -> `.bloom` -> `.db`, entirely through the C ABI (device k-mer stage, device
-Bloom bits, device bit transpose).  This is the database-construction side of KWAGE for inputs whose
-every k-mer counts (assemblies / genomes: the reference's min_kmer_count == 1 case); like the
-reference's maestro it gives each sample the smallest Bloom parameters that meet the false-positive
+Bloom bits or device counting pass, device bit transpose).  This is the database-construction side of KWAGE:
+exact k-mer sets for assemblies / genomes, the reference's minimum-k-mer-count pass for read sets
+(BloomCounter); like the reference's maestro it gives each sample the smallest Bloom parameters that meet the false-positive
 bound (optimal_bloom_param, bloom.cpp:10-68) and writes one `.db` per distinct parameter set, at most
 2048 samples per file (options.h:137 MAX_NUM_FILTER_CHUNK)."""
 from __future__ import annotations
