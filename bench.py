@@ -206,9 +206,11 @@ def main():
     for _ in range(args.warmup):
         step()
     pipe = None
+    kernel_ms = []
 
     def exchange(pipe, tk):
         buf, n = pipe.collect_counted(tk)
+        kernel_ms.append(pipe.last_kernel_ms)
         if backend != "nccl":                    # gloo rehearsal: the same exchange on host tensors
             buf = buf[:max(n, ss[0].capacity) + 1].cpu()
         return ss[0].exchange_counted(buf, n)
@@ -272,7 +274,7 @@ def main():
     else:
         bit_tests_rank = int(probe.bit_tests)
         alg_bytes_rank = int(probe.algorithmic_bytes)
-    if sharded:
+    if sharded and multi is not None:
         kernel_ms = []
         for _ in range(3):
             kernel_ms.append(sum(m.group.search(s.batch, threshold, flags).search_kernel_ms for m in (multi or [s])))

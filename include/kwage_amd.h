@@ -187,7 +187,8 @@ int kwage_search_device(kwage_group *g, kwage_batch *b, float threshold, uint32_
  * by the records) and go straight into an all-gather without any further device work. */
 int kwage_search_device_submit(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
                                void *hits_dev, uint64_t capacity, void *count_dev, kwage_pending **out);
-int kwage_search_device_collect(kwage_pending *p, uint64_t *n_hits, void *num_query_kmer_dev);
+/* search_kernel_ms (may be NULL): HIP-event duration of the gather kernel(s) when KWAGE_SEARCH_TIMING was set. */
+int kwage_search_device_collect(kwage_pending *p, uint64_t *n_hits, void *num_query_kmer_dev, float *search_kernel_ms);
 
 /* K-mer stage alone (word.h:73-104 + kwage.cpp:362-366 + hash.cpp:176-234 on the device):
  * for query i writes its distinct canonical k-mers to kmers[kmer_offsets[i] ...] (unordered)

@@ -1222,7 +1222,7 @@ extern "C" int kwage_search_device_submit(kwage_group *g, kwage_batch *b, float 
 	return KWAGE_OK;
 }
 
-extern "C" int kwage_search_device_collect(kwage_pending *p, uint64_t *n_hits, void *num_query_kmer_dev)
+extern "C" int kwage_search_device_collect(kwage_pending *p, uint64_t *n_hits, void *num_query_kmer_dev, float *search_kernel_ms)
 {
 	if(!p || !n_hits){ return fail(KWAGE_ERR_ARG, "kwage_search_device_collect: NULL argument"); }
 	Slot *sl = p->sl;
@@ -1232,6 +1232,7 @@ extern "C" int kwage_search_device_collect(kwage_pending *p, uint64_t *n_hits, v
 	int rc = collect_search(sl, &so);
 	if(rc){ return rc; }
 	*n_hits = so.n_hits;
+	if(search_kernel_ms){ *search_kernel_ms = so.search_ms; }
 	if(num_query_kmer_dev && b->n){
 		HIP_TRY(hipMemcpyAsync(num_query_kmer_dev, sl->d_nkmer, (size_t)b->n*sizeof(uint32_t), hipMemcpyDeviceToDevice, sl->stream));
 		HIP_TRY(hipStreamSynchronize(sl->stream));

@@ -286,6 +286,7 @@ class PipelinedDeviceSearcher:
         self.group, self.flags, self.device = group, flags, device
         self.bufs = [torch.zeros((1 + initial_capacity, 3), dtype=torch.int32, device=device) for _ in range(2)]
         self.turn = 0
+        self.last_kernel_ms = 0.0          # HIP-event time of the last collected search (SEARCH_TIMING flag)
 
     def _submit_into(self, buf, batch, threshold):
         import ctypes as C
@@ -306,11 +307,12 @@ class PipelinedDeviceSearcher:
         import torch
         from .native import check, lib
         h, i, batch, threshold = ticket
-        n = C.c_uint64()
-        check(lib().kwage_search_device_collect(h, C.byref(n), None))
+        n, ms = C.c_uint64(), C.c_float()
+        check(lib().kwage_search_device_collect(h, C.byref(n), None, C.byref(ms)))
         while n.value > self.bufs[i].shape[0] - 1:     # rare: grow this buffer and redo the search
             self.bufs[i] = torch.zeros((int(n.value * 1.25) + 2, 3), dtype=torch.int32, device=self.device)
-            check(lib().kwage_search_device_collect(self._submit_into(self.bufs[i], batch, threshold), C.byref(n), None))
+            check(lib().kwage_search_device_collect(self._submit_into(self.bufs[i], batch, threshold), C.byref(n), None, C.byref(ms)))
+        self.last_kernel_ms = float(ms.value)
         return self.bufs[i], int(n.value)
 
     def collect(self, ticket):

@@ -117,7 +117,7 @@ _SIGNATURES = [
     ("kwage_search_collect", C.c_int, [_P, C.POINTER(C.POINTER(Result))]),
     ("kwage_search_device", C.c_int, [_P, _P, C.c_float, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64), _P]),
     ("kwage_search_device_submit", C.c_int, [_P, _P, C.c_float, C.c_uint32, _P, C.c_uint64, _P, C.POINTER(_P)]),
-    ("kwage_search_device_collect", C.c_int, [_P, C.POINTER(C.c_uint64), _P]),
+    ("kwage_search_device_collect", C.c_int, [_P, C.POINTER(C.c_uint64), _P, C.POINTER(C.c_float)]),
     ("kwage_hash_batch", C.c_int, [_P, C.POINTER(Params), _P, _P, _P, _P, _P]),
     ("kwage_stream_read_gbps", C.c_int, [_P, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
     ("kwage_build_db", C.c_int, [_P, C.c_char_p, C.POINTER(Params), C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(BuildStats)]),
