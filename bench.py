@@ -309,7 +309,7 @@ def main():
                        "total_kmers_per_step": int(probe.total_kmers), "hits_per_step": int(nhits),
                        "db_build_s": round(t_build, 2)},
             "hbm_gbps_algorithmic_whole_step": round(alg_bytes_rank * world * args.steps / dt / 1e9, 1),
-            "roofline": {"bound": "hbm", "kernel": "and_kernel" if threshold == 1.0 else "count_kernel",
+            "roofline": {"bound": "hbm", "kernel": getattr(probe, "search_kernel", "") or ("and_kernel" if threshold == 1.0 else "count_kernel"),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": alg_bytes_rank,

@@ -158,6 +158,8 @@ typedef struct {
 	float kmer_kernel_ms;           /* with KWAGE_SEARCH_TIMING, else 0                       */
 	float search_kernel_ms;         /* the gather + AND / count kernel                        */
 	uint32_t search_kernel_launches;/* >1 if the hit buffer had to grow and the kernel re-ran */
+	const char *search_kernel;      /* which gather kernel ran (static string): "and_kernel", "and_walk_kernel",
+	                                 * "and_narrow_kernel", "count_kernel", "count_narrow_kernel", "" if none */
 } kwage_result;
 
 int kwage_search(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,

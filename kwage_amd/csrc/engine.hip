@@ -101,6 +101,7 @@ struct Slot {
 	float threshold = 1.0f;
 	uint32_t flags = 0;
 	uint32_t launches = 0;
+	const char *kernel_name = "";       // the gather kernel launch_search_stage picked
 	uint64_t staged_hits = 0;
 	kwage_hit *ext_hits = nullptr;      // caller-owned device buffer (kwage_search_device) or null
 	uint64_t ext_cap = 0;
@@ -446,6 +447,7 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 			const uint32_t G = (a.units_per_row <= 4) ? 16 : (a.units_per_row <= 8) ? 8 : (a.units_per_row <= 16) ? 4 : 2;
 			const uint64_t waves = ((uint64_t)a.n_queries + G - 1)/G;
 			const dim3 grid((uint32_t)((waves + 3)/4)), block(SEARCH_THREADS);
+			sl->kernel_name = "and_narrow_kernel";
 			switch(G){
 				case 16: hipLaunchKernelGGL((and_narrow_kernel<16, 8>), grid, block, 0, sl->stream, a); break;
 				case 8: hipLaunchKernelGGL((and_narrow_kernel<8, 8>), grid, block, 0, sl->stream, a); break;
@@ -455,12 +457,45 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 			HIP_TRY(hipGetLastError());
 			return KWAGE_OK;
 		}
+		// rows of 3..16 KiB with enough queries to fill the chip: the walk form (one workgroup per (query, column
+		// tile), each wave walks a quarter of the rows over the tile's whole width; kernels.hpp and_walk_kernel).
+		// KWAGE_WALK=0 keeps the tiled kernel, KWAGE_WALK=2 selects two rows in flight instead of four.
+		// (read per call, like KWAGE_AND_CFG: tools/tune_walk.py switches them inside one process)
+		const char *we = getenv("KWAGE_WALK"), *wq = getenv("KWAGE_WALK_MIN_QUERIES");
+		const int walk_unroll = we ? atoi(we) : 4;
+		const uint32_t walk_min_q = wq ? (uint32_t)atoi(wq) : 900u;
+		const uint32_t kib = (a.units_per_row + WAVE - 1)/WAVE;
+		// (the kernel handles wider rows as several balanced column tiles -- KWAGE_WALK_MAX_KIB raises the limit --
+		// but 125 KB rows measured no gain over the tiled kernel)
+		const char *wk = getenv("KWAGE_WALK_MAX_KIB");
+		const uint32_t walk_max_kib = wk ? (uint32_t)atoi(wk) : 16u;
+		const uint32_t coltiles = (kib + 15)/16, walk_ch = (kib + coltiles - 1)/coltiles;     // balanced tiles of <= 16 KiB
+		if(walk_unroll && a.segs == 1 && kib >= 3 && kib <= walk_max_kib && (uint64_t)a.n_queries*coltiles >= walk_min_q &&
+		   (uint64_t)a.n_queries*coltiles <= 0x7FFFFFFFull){
+			SearchArgs wa = a;
+			wa.chunks = coltiles;                            // column tiles per row
+			sl->kernel_name = "and_walk_kernel";
+			const dim3 grid((uint32_t)((uint64_t)a.n_queries*coltiles)), block(SEARCH_THREADS);
+#define KWAGE_WALK_CASE(CH) case CH: \
+				if(walk_unroll == 2){ hipLaunchKernelGGL((and_walk_kernel<CH, 2>), grid, block, 0, sl->stream, wa); } \
+				else{ hipLaunchKernelGGL((and_walk_kernel<CH, 4>), grid, block, 0, sl->stream, wa); } break;
+			switch(walk_ch){
+				KWAGE_WALK_CASE(3) KWAGE_WALK_CASE(4) KWAGE_WALK_CASE(5) KWAGE_WALK_CASE(6) KWAGE_WALK_CASE(7)
+				KWAGE_WALK_CASE(8) KWAGE_WALK_CASE(9) KWAGE_WALK_CASE(10) KWAGE_WALK_CASE(11) KWAGE_WALK_CASE(12)
+				KWAGE_WALK_CASE(13) KWAGE_WALK_CASE(14) KWAGE_WALK_CASE(15)
+				default: KWAGE_WALK_CASE(16)
+			}
+#undef KWAGE_WALK_CASE
+			HIP_TRY(hipGetLastError());
+			return KWAGE_OK;
+		}
 		if(a.segs > 1){
 			const uint64_t bytes = (uint64_t)a.n_queries*g->stride;
 			if((rc = sl->partial.reserve(bytes))){ return rc; }
 			HIP_TRY(hipMemsetAsync(sl->partial.p, 0xFF, bytes, sl->stream));
 			a.partial = (uint32_t*)sl->partial.p;
 		}
+		sl->kernel_name = "and_kernel";
 		if(cfg.nt){ launch_and_v<true>(a, sl->stream, cfg); }
 		else{ launch_and_v<false>(a, sl->stream, cfg); }
 		if(a.segs > 1){
@@ -489,6 +524,7 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 		static const bool narrow_ok = []() { const char *e = getenv("KWAGE_NARROW"); return !(e && atoi(e) == 0); }();
 		if(narrow_ok && a.segs == 1 && a.units_per_row <= 32 && a.units_per_row > 8 && a.n_queries >= 64 && planes <= 14){
 			// one reference file (<= 2048 columns = 16 units) or two: 4 resp. 2 queries per wave
+			sl->kernel_name = "count_narrow_kernel";
 			if(a.units_per_row <= 16){
 				if(planes == 7){ launch_count_narrow<7, 4>(a, sl->stream); }
 				else if(planes == 10){ launch_count_narrow<10, 4>(a, sl->stream); }
@@ -502,6 +538,7 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 			HIP_TRY(hipGetLastError());
 			return KWAGE_OK;
 		}
+		sl->kernel_name = "count_kernel";
 		switch(planes){
 			case 7: launch_count_nh<7>(a, sl->stream); break;
 			case 10: launch_count_nh<10>(a, sl->stream); break;
@@ -522,6 +559,7 @@ struct SearchOutcome {
 	uint64_t total_kmers = 0;
 	float kmer_ms = 0, search_ms = 0;
 	uint32_t launches = 0;
+	const char *kernel_name = "";
 };
 
 // Enqueue, on the slot's stream: search kernel(s) + ONE D2H copy that brings back the counters, the
@@ -618,6 +656,7 @@ int collect_search(Slot *sl, SearchOutcome *out)
 	}
 	out->staged_hits = sl->staged_hits;
 	out->launches = sl->launches;
+	out->kernel_name = sl->kernel_name;
 	if(timing_kmer){ HIP_TRY(hipEventElapsedTime(&out->kmer_ms, sl->ev[0], sl->ev[1])); }
 	if(timing && sl->launches){ HIP_TRY(hipEventElapsedTime(&out->search_ms, sl->ev[2], sl->ev[3])); }
 	return KWAGE_OK;
@@ -1139,6 +1178,7 @@ int build_result(Slot *sl, kwage_group *g, kwage_batch *b, const SearchOutcome &
 	r.kmer_kernel_ms = so.kmer_ms;
 	r.search_kernel_ms = so.search_ms;
 	r.search_kernel_launches = so.launches;
+	r.search_kernel = so.kernel_name;
 	*out = &rs->pub;
 	return KWAGE_OK;
 }

@@ -358,6 +358,75 @@ __global__ __launch_bounds__(SEARCH_THREADS) void and_kernel(SearchArgs a)
 	}
 }
 
+// threshold == 1.0f, "walk" form of the gather + AND.
+// One 4-wave workgroup per (query, column tile of CH <= 16 KiB); wave w takes the w-th quarter of the query's
+// row list and walks each of its rows over the WHOLE tile width, UNROLL rows at a time, one KiB-chunk
+// after the other (CH accumulators per lane).  A row's consecutive KiB are then requested back to back by
+// one wave instead of by different waves at different times as in and_kernel's (query, 2 KiB tile) form.
+// Worth about 1 % on rows of 12.5 KB (C2: 1.878 vs 1.900 ms, tools/tune_walk.py; the isolated access
+// patterns differ by 2-4 %, tools/micro/stream_variants.hip), nothing on 125 KB rows, so the host uses it
+// for rows of 3..16 KiB only.  The four quarter results meet in LDS (no global pass), wave 0 extracts hits.
+template <int CH, int UNROLL>
+__global__ __launch_bounds__(SEARCH_THREADS, 4) void and_walk_kernel(SearchArgs a)
+{
+	__shared__ u32x4 red[3][CH][WAVE];
+	const uint32_t lane = threadIdx.x & (WAVE - 1);
+	const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t q = blockIdx.x / a.chunks;            // a.chunks = column tiles per row here
+	const uint32_t c = blockIdx.x % a.chunks;
+	const uint32_t n = a.nkmer[q];
+	if(n == 0){ return; }                                // the whole workgroup leaves
+	const uint32_t per = (n + 3)/4;
+	const uint32_t k0 = min(n, w*per), k1 = min(n, k0 + per);
+	const uint32_t nrows = (k1 - k0)*a.num_hash;
+	const uint32_t *rq = a.rows + (a.pos_off[q] + k0)*a.num_hash;
+
+	// Rows are read through buffer descriptors (base = the row, num_records = the row's bytes): the address of
+	// chunk j is "descriptor + lane offset + scalar j KiB" with no per-chunk vector arithmetic, and lanes past
+	// the row end (last chunk(s) of the last column tile) are bounds-checked by the hardware -- they return 0
+	// without touching memory, and are never reported.
+	const uint32_t u0 = c*CH*WAVE + lane;
+	const uint32_t row_bytes = a.units_per_row*16u;
+	u32x4 acc[CH];
+#pragma unroll
+	for(int j = 0; j < CH; ++j){ acc[j] = ~(u32x4)(0u); }
+	for(uint32_t i = 0; i < nrows; i += UNROLL){
+		__amdgpu_buffer_rsrc_t rs[UNROLL];
+#pragma unroll
+		for(int u = 0; u < UNROLL; ++u){
+			const uint32_t r = rq[min(i + u, nrows - 1)];        // past the end: the last row again (AND is idempotent)
+			rs[u] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.db + (uint64_t)r*a.stride), 0, row_bytes, 0x00020000);
+		}
+#pragma unroll
+		for(int j = 0; j < CH; ++j){
+			u32x4 x[UNROLL];
+#pragma unroll
+			for(int u = 0; u < UNROLL; ++u){ x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs[u], u0*16u, j*1024, 2 /* nt */); }
+#pragma unroll
+			for(int u = 0; u < UNROLL; ++u){ acc[j] &= x[u]; }
+		}
+		if(a.early_exit){     // kwage.cpp:466-470: this quarter alone already rules every column out
+			bool nz = false;
+#pragma unroll
+			for(int j = 0; j < CH; ++j){ nz |= ((acc[j].x | acc[j].y | acc[j].z | acc[j].w) != 0); }
+			if(!__any(nz)){ break; }
+		}
+	}
+	if(w){
+#pragma unroll
+		for(int j = 0; j < CH; ++j){ red[w - 1][j][lane] = acc[j]; }
+	}
+	__syncthreads();
+	if(w == 0){
+		const uint32_t umax = a.units_per_row - 1;
+#pragma unroll
+		for(int j = 0; j < CH; ++j){
+			acc[j] &= red[0][j][lane] & red[1][j][lane] & red[2][j][lane];
+			emit_mask_hits(a, q, min(u0 + (uint32_t)j*WAVE, umax), acc[j], n, u0 + (uint32_t)j*WAVE <= umax);
+		}
+	}
+}
+
 // Narrow databases (a row is at most 64/G 16-byte units, e.g. one 2048-column file = 16 units): G queries
 // share a wave, 64/G lanes each, so a wave-load still moves up to 1 KiB.  Row indices are per lane group
 // (vector loads, broadcast within the group).  Shorter row lists are padded by re-reading their last row

@@ -142,6 +142,7 @@ class SearchResult:
     kmer_kernel_ms: float
     search_kernel_ms: float
     search_kernel_launches: int
+    search_kernel: str = ""
 
     def per_query(self) -> List[List[Tuple[int, int]]]:
         out: List[List[Tuple[int, int]]] = [[] for _ in range(len(self.num_query_kmer))]
@@ -161,7 +162,8 @@ def _unpack_result(res) -> SearchResult:
         nk = np.ctypeslib.as_array(r.num_query_kmer, shape=(nq,)).copy() if nq else np.zeros(0, np.uint32)
         qt = np.ctypeslib.as_array(r.query_threshold, shape=(nq,)).copy() if nq else np.zeros(0, np.uint32)
         return SearchResult(hits, nk, qt, r.total_kmers, r.bit_tests, r.algorithmic_bytes,
-                            r.kmer_kernel_ms, r.search_kernel_ms, r.search_kernel_launches)
+                            r.kmer_kernel_ms, r.search_kernel_ms, r.search_kernel_launches,
+                            (r.search_kernel or b"").decode())
     finally:
         lib().kwage_result_free(res)
 

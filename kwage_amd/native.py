@@ -53,7 +53,7 @@ class Result(C.Structure):
                 ("num_query_kmer", C.POINTER(C.c_uint32)), ("query_threshold", C.POINTER(C.c_uint32)),
                 ("total_kmers", C.c_uint64), ("bit_tests", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
                 ("kmer_kernel_ms", C.c_float), ("search_kernel_ms", C.c_float),
-                ("search_kernel_launches", C.c_uint32)]
+                ("search_kernel_launches", C.c_uint32), ("search_kernel", C.c_char_p)]
 
 
 class BuildStats(C.Structure):

@@ -553,3 +553,46 @@ def test_pipelined_device_search_and_counted_exchange(ka, ctx):
             dist.destroy_process_group()
     s.batch.close()
     s.group.close()
+
+
+@pytest.mark.parametrize("n_cols", [16500, 24576, 40000, 65536, 100000, 131072, 131073, 300000])
+def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, monkeypatch):
+    """Rows of >= 3 KiB with >= 900 (query, column tile) pairs take and_walk_kernel (one workgroup per pair,
+    four waves each walking a quarter of the row list over the tile's whole width, LDS reduce): ragged query
+    lengths so that quarters are empty / one k-mer long / uneven, hits in the first, middle and last columns;
+    131073 columns (17 KiB) needs two column tiles whose last chunk lies wholly past the row end, 300000
+    columns three tiles (by default rows wider than 16 KiB stay with the tiled kernel: the limit is raised here)."""
+    monkeypatch.setenv("KWAGE_WALK_MAX_KIB", "64")
+    rng = np.random.default_rng(n_cols)
+    k, nh, L = 31, 2, 10
+    image = _make_random_db(rng, L, n_cols, 0.9)
+    genome = rand_seq(rng, 1200)
+    cols = sorted({0, 1, n_cols // 2, n_cols - 130, n_cols - 1})
+    for col in cols:
+        for r in oracle.row_indices(oracle.unique_kmers(genome, k), k, nh, L).reshape(-1):
+            image[r, col // 8] |= np.uint8(1 << (col % 8))
+    seqs = []
+    for i in range(960):
+        n = int(rng.choice([0, 30, 31, 32, 33, 34, 35, 40, 64, 150, 300]))
+        if i % 2 == 0 and n >= 31:
+            a = int(rng.integers(0, len(genome) - n + 1)); seqs.append(genome[a:a + n])
+        elif i % 11 == 0:
+            seqs.append("N" * n)
+        else:
+            seqs.append(rand_seq(rng, n))
+    g = ka.Group(ctx, k, nh, L, n_cols)
+    g.add_columns(image, n_cols)
+    g.finalize()
+    b = ka.Batch(ctx, seqs)
+    exp = [oracle.search_image(image, image.shape[1], k, nh, L, n_cols, oracle.unique_kmers(s, k), 1.0)[0] for s in seqs]
+    for flags in (0, ka.SEARCH_EARLY_EXIT):
+        r = g.search(b, 1.0, flags)
+        assert r.search_kernel == "and_walk_kernel"
+        assert r.per_query() == exp, (n_cols, flags)
+    monkeypatch.setenv("KWAGE_WALK", "0")
+    r = g.search(b, 1.0, 0)
+    assert r.search_kernel == "and_kernel" and r.per_query() == exp
+    planted = [e for s, e in zip(seqs, exp) if len(s) >= 31 and s in genome]
+    assert planted and all({c for c, _ in e} >= set(cols) for e in planted)
+    b.close()
+    g.close()

@@ -27,14 +27,29 @@ t0 = time.perf_counter()
 for _ in range(20): m = ss.exchange_counted(*t)
 print("hits", len(m), "exchange+merge unloaded %.3f ms" % ((time.perf_counter() - t0) / 20 * 1e3))
 # loaded
-ph = np.zeros(3); N = 50
+ph = np.zeros(3); N = 50; kms = []
 tk = pipe.submit(s.batch, thr)
 T0 = time.perf_counter()
 for _ in range(N):
     a = time.perf_counter(); nxt = pipe.submit(s.batch, thr)
-    b = time.perf_counter(); t = pipe.collect_counted(tk)
+    b = time.perf_counter(); t = pipe.collect_counted(tk); kms.append(pipe.last_kernel_ms)
     c = time.perf_counter(); m = ss.exchange_counted(*t)
     d = time.perf_counter(); ph += (b - a, c - b, d - c); tk = nxt
 pipe.collect_counted(tk); sync()
-print("per step %.3f ms: submit %.3f collect %.3f exchange %.3f" % ((time.perf_counter() - T0) / N * 1e3, *(ph / N * 1e3)))
+print("per step %.3f ms: submit %.3f collect %.3f exchange %.3f; gather kernel %.3f ms (HIP events)" % ((time.perf_counter() - T0) / N * 1e3, *(ph / N * 1e3), float(np.mean(kms))))
+# the same loop without the exchange (device search only)
+tk = pipe.submit(s.batch, thr); kms = []
+T0 = time.perf_counter()
+for _ in range(N):
+    nxt = pipe.submit(s.batch, thr); pipe.collect_counted(tk); kms.append(pipe.last_kernel_ms); tk = nxt
+pipe.collect_counted(tk); sync()
+print("no exchange: per step %.3f ms; gather kernel %.3f ms" % ((time.perf_counter() - T0) / N * 1e3, float(np.mean(kms))))
+# exchange only the collective
+tk = pipe.submit(s.batch, thr); kms = []
+T0 = time.perf_counter()
+for _ in range(N):
+    nxt = pipe.submit(s.batch, thr); buf, n = pipe.collect_counted(tk); kms.append(pipe.last_kernel_ms)
+    ss.dist.all_gather_into_tensor(ss._crecv, buf[:ss.capacity + 1]); tk = nxt
+pipe.collect_counted(tk); sync()
+print("all_gather only: per step %.3f ms; gather kernel %.3f ms" % ((time.perf_counter() - T0) / N * 1e3, float(np.mean(kms))))
 dist.destroy_process_group()
