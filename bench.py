@@ -150,6 +150,7 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
     sharded = world > 1 or force_sharded
     dist = None
+    ctx = ka.Context(local_rank)       # before torch.distributed creates its streams (hardware-queue assignment is first come, first served)
     if sharded:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -159,7 +160,6 @@ def main():
             dist.init_process_group(backend)
 
     w = synth.WORKLOADS[args.workload]
-    ctx = ka.Context(local_rank)
     t_build = time.perf_counter()
     multi = None
     if args.workload == "c5":
@@ -208,8 +208,13 @@ def main():
     pipe = None
     kernel_ms = []
 
+    trace = [] if os.environ.get("KWAGE_BENCH_TRACE") == "1" else None
+
     def exchange(pipe, tk):
+        t_a = time.perf_counter()
         buf, n = pipe.collect_counted(tk)
+        if trace is not None:
+            trace.append((time.perf_counter() - t_a, t_a))
         kernel_ms.append(pipe.last_kernel_ms)
         if backend != "nccl":                    # gloo rehearsal: the same exchange on host tensors
             buf = buf[:max(n, ss[0].capacity) + 1].cpu()
@@ -241,6 +246,10 @@ def main():
             tk = nxt
         merged = exchange(pipe, tk)
         nhits = len(merged) if merged is not None else 0
+        if trace:     # host view of the pipeline: time blocked in collect, and collect-to-collect period
+            per = np.diff([t for _, t in trace[-args.steps:]])
+            print("[trace] collect wait mean %.3f ms; collect-to-collect mean %.3f ms (min %.3f max %.3f)"
+                  % (np.mean([d for d, _ in trace[-args.steps:]]) * 1e3, per.mean() * 1e3, per.min() * 1e3, per.max() * 1e3), file=sys.stderr)
     elif not sharded and multi is None:
         # K steps, software-pipelined through the two search slots of the context: step i+1 is submitted
         # (its k-mer stage runs) before step i is collected (copy-back, sort); the gather kernels themselves

@@ -324,6 +324,9 @@ void write_json_footer(ostream &out, bool multiple) { if(multiple){ out << "\n]\
 
 int main(int argc, char *argv[])
 {
+	// two search streams per device context plus the loader's: keep them on hardware queues of their own
+	// (HIP's default is 4 queues per device for all streams of the process); an explicit setting wins
+	setenv("GPU_MAX_HW_QUEUES", "8", 0);
 	try{
 		time_t profile = time(NULL);
 

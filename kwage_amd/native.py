@@ -19,6 +19,14 @@ class KwageError(RuntimeError):
         self.message = msg
 
 
+# The engine pipelines searches over two HIP streams of its own while the host program (torch, RCCL) runs
+# several more.  HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); when a search
+# stream shares a queue with a torch/RCCL stream the pipeline serialises (measured: +0.2 ms on a 1.9 ms step,
+# DESIGN.md section 6).  The variable is read when the HIP runtime initialises, i.e. at the first device
+# call, so setting it at import time is early enough; an explicit setting by the user wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
 def lib_path() -> str:
     return _LIB
 
