@@ -470,7 +470,12 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 		const char *wk = getenv("KWAGE_WALK_MAX_KIB");
 		const uint32_t walk_max_kib = wk ? (uint32_t)atoi(wk) : 16u;
 		const uint32_t coltiles = (kib + 15)/16, walk_ch = (kib + coltiles - 1)/coltiles;     // balanced tiles of <= 16 KiB
-		if(walk_unroll && a.segs == 1 && kib >= 3 && kib <= walk_max_kib && (uint64_t)a.n_queries*coltiles >= walk_min_q &&
+		// With early exit the tiled kernel wins: a tile that holds no candidate column stops after a few rows even
+		// when another tile of the same query holds a hit, whereas a walking wave covers the hit column's whole row
+		// width and never stops (C2 with early exit: 0.64 ms tiled, 1.29 ms walk).  KWAGE_WALK_EARLY_EXIT=1 overrides.
+		const char *wx = getenv("KWAGE_WALK_EARLY_EXIT");
+		const bool walk_ee_ok = !a.early_exit || (wx && atoi(wx) != 0);
+		if(walk_unroll && walk_ee_ok && a.segs == 1 && kib >= 3 && kib <= walk_max_kib && (uint64_t)a.n_queries*coltiles >= walk_min_q &&
 		   (uint64_t)a.n_queries*coltiles <= 0x7FFFFFFFull){
 			SearchArgs wa = a;
 			wa.chunks = coltiles;                            // column tiles per row

@@ -585,9 +585,10 @@ def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, monkeypatch):
     g.finalize()
     b = ka.Batch(ctx, seqs)
     exp = [oracle.search_image(image, image.shape[1], k, nh, L, n_cols, oracle.unique_kmers(s, k), 1.0)[0] for s in seqs]
-    for flags in (0, ka.SEARCH_EARLY_EXIT):
+    for flags, ee in ((0, "0"), (ka.SEARCH_EARLY_EXIT, "1"), (ka.SEARCH_EARLY_EXIT, "0")):
+        monkeypatch.setenv("KWAGE_WALK_EARLY_EXIT", ee)      # with early exit the host prefers the tiled kernel unless told otherwise
         r = g.search(b, 1.0, flags)
-        assert r.search_kernel == "and_walk_kernel"
+        assert r.search_kernel == ("and_kernel" if (flags and ee == "0") else "and_walk_kernel")
         assert r.per_query() == exp, (n_cols, flags)
     monkeypatch.setenv("KWAGE_WALK", "0")
     r = g.search(b, 1.0, 0)

@@ -77,12 +77,13 @@ def test_random_configuration(oracle, seed, monkeypatch):
                 monkeypatch.delenv("KWAGE_FORCE_SEGS", raising=False)
                 monkeypatch.setenv("KWAGE_WALK_MIN_QUERIES", "1")
                 monkeypatch.setenv("KWAGE_WALK_MAX_KIB", "64")
+                monkeypatch.setenv("KWAGE_WALK_EARLY_EXIT", "1")
                 for unroll, flags in (("4", 0), ("2", ka.SEARCH_EARLY_EXIT)):
                     monkeypatch.setenv("KWAGE_WALK", unroll)
                     r = g.search(b, thr, flags)
                     assert r.search_kernel in ("and_walk_kernel", "and_kernel")      # long queries may still be segmented
                     assert [(int(n), e) for n, e in zip(r.num_query_kmer, r.per_query())] == exp, (seed, n_cols, unroll)
-                for v in ("KWAGE_WALK_MIN_QUERIES", "KWAGE_WALK_MAX_KIB", "KWAGE_WALK"):
+                for v in ("KWAGE_WALK_MIN_QUERIES", "KWAGE_WALK_MAX_KIB", "KWAGE_WALK", "KWAGE_WALK_EARLY_EXIT"):
                     monkeypatch.delenv(v, raising=False)
         b.close()
         g.close()
