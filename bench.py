@@ -68,7 +68,7 @@ def cpu_baseline(w, queries, n_files):
         # rows addressed by the queries' k-mers (so the planted column matches every query)
         uniq = [oracle.unique_kmers(q, k) for q in qs]
         total_kmers = int(sum(len(u) for u in uniq))
-        addressed = np.unique(np.concatenate([oracle.row_indices(u, k, nh, L).reshape(-1) for u in uniq[:200]])) \
+        addressed = np.unique(np.concatenate([oracle.row_indices(u, k, nh, L).reshape(-1) for u in uniq])) \
             if total_kmers else np.zeros(0, np.uint32)
         infos = [oracle.FilterInfo(run_accession=oracle.str_to_accession("SRR%07d" % j)) for j in range(ncol)]
         image = None
@@ -78,7 +78,7 @@ def cpu_baseline(w, queries, n_files):
         del a, b
         for f in range(n_files):
             rows = np.roll(base, 7919 * f, axis=0)                               # a different matrix per file, same density
-            rows[addressed, 0] |= 1                                              # column 0 matches the first 200 queries
+            rows[addressed, 0] |= 1                                              # column 0 matches EVERY query: no early exit anywhere
             oracle.write_db(os.path.join(tmp, "s%02d.db" % f), k, nh, L, rows, ncol, infos)
             if f == 0:
                 image = rows
@@ -100,7 +100,7 @@ def cpu_baseline(w, queries, n_files):
                 best = dt if best is None else min(best, dt)
             return {"value": bit_tests / best / 1e9, "unit": "G bit-tests/s", "cores": min(cores, 16, n_files), "kind": "reference",
                     "sample": "reference kwage (OpenMP over files), %d files x %d columns x 2^%d rows, %d queries x %d bp, "
-                              "page cache warm, best of 2, wall %.2f s; early exit mostly defeated by a planted column"
+                              "page cache warm, best of 2, wall %.2f s; a planted column matches every query, so the early exit never fires and every addressed row is read (as in the nominal GPU figure)"
                               % (n_files, ncol, L, len(qs), w.query_len, best)}
         # fallback: the repo's own C restatement, one thread, one file image in memory
         t0 = time.perf_counter()
