@@ -334,7 +334,8 @@ bool DbSliceSource::read_rows(uint64_t r0, uint64_t nr, unsigned char *dst, std:
 	if(header.compression == KWAGE_COMPRESSION_NONE){
 		// one thread moves ~4 GB/s out of the page cache; several in parallel keep up with PCIe
 		const uint64_t total = nr*slice_size, base = DB_HEADER_BYTES + r0*slice_size;
-		const unsigned nt = (total >= (8u << 20)) ? host_threads(8) : 1;
+		static const unsigned load_threads = []() { const char *e = getenv("KWAGE_LOAD_THREADS"); return (e && atoi(e) > 0) ? (unsigned)atoi(e) : 8u; }();
+		const unsigned nt = (total >= (8u << 20)) ? host_threads(load_threads) : 1;
 		if(nt == 1){
 			if(!pread_all(fd, dst, total, base)){ err = "Error reading slice from file"; return false; }
 			return true;
