@@ -11,6 +11,9 @@ exchange is the variable-length gather of hit records to rank 0:
              and the exchange repeated (first steps only)
     "p2p":   counts <- all_gather(one int64 per rank); hits <- one grouped send/recv with exact sizes
              (RCCL has no native gatherv)
+    pipelined (bench.py, PipelinedDeviceSearcher + ShardedSearch.exchange_counted): the engine writes
+             [u64 count | hits...] itself, so the buffer goes into the all_gather as it stands while the
+             next search's gather kernel is already running; merge + sort on the host
 
 Rank 0 concatenates; no merge is needed because column ranges are disjoint.  No row data ever
 crosses xGMI.  The reference has no counterpart (its only parallel axis is OpenMP over .db files,
