@@ -363,13 +363,13 @@ __global__ __launch_bounds__(SEARCH_THREADS) void and_kernel(SearchArgs a)
 // row list and walks each of its rows over the WHOLE tile width, UNROLL rows at a time, one KiB-chunk
 // after the other (CH accumulators per lane).  A row's consecutive KiB are then requested back to back by
 // one wave instead of by different waves at different times as in and_kernel's (query, 2 KiB tile) form.
-// Worth about 1 % on rows of 12.5 KB (C2: 1.878 vs 1.900 ms, tools/tune_walk.py; the isolated access
+// Worth 1-2.4 % on rows of 12.5 KB (C2: 1.831 vs 1.876 ms, tools/tune_walk.py; the isolated access
 // patterns differ by 2-4 %, tools/micro/stream_variants.hip), nothing on 125 KB rows, so the host uses it
 // for rows of 3..16 KiB only.  The four quarter results meet in LDS (no global pass), wave 0 extracts hits.
 template <int CH, int UNROLL>
 __global__ __launch_bounds__(SEARCH_THREADS, 4) void and_walk_kernel(SearchArgs a)
 {
-	__shared__ u32x4 red[3][CH][WAVE];
+	__shared__ uint32_t red[CH][4][WAVE];                // one CH-KiB mask: wave 0's result, ANDed into by waves 1..3
 	const uint32_t lane = threadIdx.x & (WAVE - 1);
 	const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t q = blockIdx.x / a.chunks;            // a.chunks = column tiles per row here
@@ -412,16 +412,31 @@ __global__ __launch_bounds__(SEARCH_THREADS, 4) void and_walk_kernel(SearchArgs 
 			if(!__any(nz)){ break; }
 		}
 	}
+	// the four quarters meet in LDS: wave 0 stores its mask, the others AND theirs in (ds_and_b32; CH KiB of LDS
+	// per workgroup instead of 3*CH, which leaves room for the next batch's k-mer workgroups beside four resident
+	// walk workgroups per CU), wave 0 reads the result back
+	if(w == 0){
+#pragma unroll
+		for(int j = 0; j < CH; ++j){
+#pragma unroll
+			for(int d = 0; d < 4; ++d){ red[j][d][lane] = acc[j][d]; }
+		}
+	}
+	__syncthreads();
 	if(w){
 #pragma unroll
-		for(int j = 0; j < CH; ++j){ red[w - 1][j][lane] = acc[j]; }
+		for(int j = 0; j < CH; ++j){
+#pragma unroll
+			for(int d = 0; d < 4; ++d){ if(acc[j][d] != ~0u){ atomicAnd(&red[j][d][lane], acc[j][d]); } }
+		}
 	}
 	__syncthreads();
 	if(w == 0){
 		const uint32_t umax = a.units_per_row - 1;
 #pragma unroll
 		for(int j = 0; j < CH; ++j){
-			acc[j] &= red[0][j][lane] & red[1][j][lane] & red[2][j][lane];
+#pragma unroll
+			for(int d = 0; d < 4; ++d){ acc[j][d] = red[j][d][lane]; }
 			emit_mask_hits(a, q, min(u0 + (uint32_t)j*WAVE, umax), acc[j], n, u0 + (uint32_t)j*WAVE <= umax);
 		}
 	}
