@@ -316,7 +316,8 @@ def main():
                        "db_bytes_per_gpu": int(sum(m.group.device_bytes for m in multi)) if multi else int(s.group.device_bytes),
                        "groups": [[lg, ns] for lg, ns in synth.C5_GROUPS] if multi else None, "sharding": "columns (samples) over %d GPU(s)" % world,
                        "total_kmers_per_step": int(probe.total_kmers), "hits_per_step": int(nhits),
-                       "db_build_s": round(t_build, 2)},
+                       "db_build_s": round(t_build, 2),
+                       "seeds": {"queries_and_planted_genomes": 1, "columns": "rank (splitmix64 keyed by seed, row, word; kwage_amd/synth.py)"}},
             "hbm_gbps_algorithmic_whole_step": round(alg_bytes_rank * world * args.steps / dt / 1e9, 1),
             "roofline": {"bound": "hbm", "kernel": getattr(probe, "search_kernel", "") or ("and_kernel" if threshold == 1.0 else "count_kernel"),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
