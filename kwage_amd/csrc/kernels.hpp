@@ -6,6 +6,9 @@
 //                 (row index) + kwage.cpp:388 (float32 threshold).
 //   and_kernel    kwage.cpp:404-470 at threshold == 1.0f: gather the addressed bit-slice rows,
 //                 AND them (bloom.h:245-262), extract hits (kwage.cpp:489-538).
+//   and_walk_kernel  the same reduction for rows of 3..16 KiB and >= 900 queries: one workgroup per query,
+//                 each wave walks a quarter of the rows over the whole row width through bounds-checked
+//                 buffer loads; the quarters meet in LDS.
 //   count_kernel  the threshold < 1 path: per k-mer AND over hashes, then bit-sliced (vertical)
 //                 per-column counters in registers instead of bloom.h:291-330's per-bit loop.
 //
