@@ -107,7 +107,8 @@ def _run(exe, db, fasta, cmd, thr, fmt="csv"):
 def test_oracle_equals_reference_binary(oracle, tmp_path, seed):
     rng = np.random.default_rng(4242 + seed)
     db, fasta, cmd = _make_case(oracle, rng, str(tmp_path), int(rng.integers(1, 5)))
-    for thr in ("1.0", "%.3f" % rng.uniform(0.05, 0.99), str(rng.choice(["0.0001", "0.999999", "1e-9", "0.5", "0.33333334"]))):
+    for thr in ("1.0", "%.3f" % rng.uniform(0.05, 0.99), str(rng.choice(["0.0001", "0.999999", "1e-9", "0.5", "0.33333334", "0.99999999", ".75", "1", "1.0e0", "9.9e-1"]))):
+        # ("0.99999999" rounds to 1.0f in the reference's `float threshold`: the AND path)
         exp = oracle.parse_csv(_run(REF, db, fasta, cmd, thr))
         got = oracle.run_search([db], [fasta], cmd, float(thr))
         by_name = {}
@@ -125,7 +126,8 @@ def test_cli_equals_reference_binary(oracle, tmp_path, seed):
     from kwage_amd import native
     rng = np.random.default_rng(777 + seed)
     db, fasta, cmd = _make_case(oracle, rng, str(tmp_path), int(rng.integers(1, 7)))
-    for thr in ("1.0", "%.3f" % rng.uniform(0.05, 0.99), str(rng.choice(["0.0001", "0.999999", "1e-9", "0.5", "0.33333334"]))):
+    for thr in ("1.0", "%.3f" % rng.uniform(0.05, 0.99), str(rng.choice(["0.0001", "0.999999", "1e-9", "0.5", "0.33333334", "0.99999999", ".75", "1", "1.0e0", "9.9e-1"]))):
+        # ("0.99999999" rounds to 1.0f in the reference's `float threshold`: the AND path)
         for fmt in ("csv", "json"):
             exp = _run(REF, db, fasta, cmd, thr, fmt)
             got = _run(native.KWAGE_BIN, db, fasta, cmd, thr, fmt)
