@@ -309,6 +309,9 @@ int kwage_bloom_counter_create(kwage_ctx *ctx, uint32_t kmer_len, int32_t hash_f
                                uint32_t log_2_counting_filter_len, uint32_t max_log_2_filter_len,
                                kwage_bloom_counter **out);
 void kwage_bloom_counter_destroy(kwage_bloom_counter *bc);
+/* Next sample in the same object (device allocations kept; a 2^32-element object costs ~20 GB to create):
+ * counters, candidate bits and totals are zeroed; the counting filters may be smaller than at creation. */
+int kwage_bloom_counter_reset(kwage_bloom_counter *bc, uint32_t min_kmer_count, uint32_t log_2_counting_filter_len);
 /* Append fragments (concatenated + offsets, like kwage_batch_create) to the read stream. */
 int kwage_bloom_counter_add(kwage_bloom_counter *bc, const char *seqs, const uint64_t *offsets, uint32_t n_seqs);
 /* Process what is staged on the host so far (add() works in 16 M-position chunks). */

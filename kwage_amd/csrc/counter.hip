@@ -253,6 +253,7 @@ struct kwage_bloom_counter {
 	kwage_ctx *ctx = nullptr;
 	hipStream_t stream = nullptr;
 	uint32_t k = 0, min_count = 0, logc = 0, max_log2 = 0;
+	uint32_t logc_cap = 0;                   // counting filters are allocated for 2^logc_cap elements
 	uint32_t *d_count = nullptr, *d_owner = nullptr, *d_valid = nullptr, *d_hash = nullptr;
 	uint32_t *d_pend[2] = { nullptr, nullptr };
 	unsigned long long *d_ctr = nullptr;
@@ -404,7 +405,7 @@ extern "C" int kwage_bloom_counter_create(kwage_ctx *ctx, uint32_t kmer_len, int
 	kwage_bloom_counter *bc = new (std::nothrow) kwage_bloom_counter();
 	if(!bc){ return fail(KWAGE_ERR_DEVICE, "out of host memory"); }
 	bc->ctx = ctx; bc->stream = ctx_stream(ctx);
-	bc->k = kmer_len; bc->min_count = min_kmer_count; bc->logc = log_2_counting_filter_len; bc->max_log2 = max_log_2_filter_len;
+	bc->k = kmer_len; bc->min_count = min_kmer_count; bc->logc = bc->logc_cap = log_2_counting_filter_len; bc->max_log2 = max_log_2_filter_len;
 	bc->valid_words = (1ull << max_log_2_filter_len)/32;
 	const uint64_t cells = 1ull << bc->logc;
 	hipError_t e = hipMalloc(&bc->d_count, cells);
@@ -428,6 +429,31 @@ extern "C" int kwage_bloom_counter_create(kwage_ctx *ctx, uint32_t kmer_len, int
 		            hipGetErrorString(e), log_2_counting_filter_len, max_log_2_filter_len);
 	}
 	*out = bc;
+	return KWAGE_OK;
+}
+
+// Start the next sample in the same object: everything is zeroed again (make_bloom.cpp:159,167-169), the
+// device allocations are kept.  The counting filters may shrink (a smaller read set), never grow.
+extern "C" int kwage_bloom_counter_reset(kwage_bloom_counter *bc, uint32_t min_kmer_count, uint32_t log_2_counting_filter_len)
+{
+	if(!bc){ return fail(KWAGE_ERR_ARG, "kwage_bloom_counter_reset: NULL argument"); }
+	if(min_kmer_count < 1 || min_kmer_count > 15){ return fail(KWAGE_ERR_ARG, "make_bloom_filter: min_kmer_count must be in [1, 15]"); }
+	if(log_2_counting_filter_len < 2 || log_2_counting_filter_len > bc->logc_cap){
+		return fail(KWAGE_ERR_ARG, "kwage_bloom_counter_reset: log_2_counting_filter_len must be in [2, %u] (the size the object was created with)", bc->logc_cap);
+	}
+	HIP_TRY(hipSetDevice(ctx_device(bc->ctx)));
+	HIP_TRY(hipStreamSynchronize(bc->stream));
+	bc->min_count = min_kmer_count;
+	bc->logc = log_2_counting_filter_len;
+	bc->staged = 0;
+	bc->started = false;
+	bc->st = kwage_bloom_counter_stats{};
+	// owner[] is all NO_OWNER again whenever a chunk has been processed to the end, so only the counters, the
+	// candidate bits and the running totals need clearing
+	HIP_TRY(hipMemsetAsync(bc->d_count, 0, 1ull << bc->logc, bc->stream));
+	HIP_TRY(hipMemsetAsync(bc->d_valid, 0, 5*bc->valid_words*sizeof(uint32_t), bc->stream));
+	HIP_TRY(hipMemsetAsync(bc->d_ctr, 0, 2*sizeof(unsigned long long), bc->stream));
+	HIP_TRY(hipStreamSynchronize(bc->stream));
 	return KWAGE_OK;
 }
 

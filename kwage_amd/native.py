@@ -137,6 +137,7 @@ _SIGNATURES = [
     ("kwage_approximate_max_kmers", C.c_uint64, [C.c_float, C.c_uint32, C.c_uint32]),
     ("kwage_bloom_counter_create", C.c_int, [_P, C.c_uint32, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     ("kwage_bloom_counter_destroy", None, [_P]),
+    ("kwage_bloom_counter_reset", C.c_int, [_P, C.c_uint32, C.c_uint32]),
     ("kwage_bloom_counter_add", C.c_int, [_P, C.c_char_p, _P, C.c_uint32]),
     ("kwage_bloom_counter_flush", C.c_int, [_P]),
     ("kwage_bloom_counter_get_stats", C.c_int, [_P, C.POINTER(BloomCounterStats)]),

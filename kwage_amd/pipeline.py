@@ -52,6 +52,13 @@ class BloomCounter:
         check(L.kwage_bloom_counter_create(ctx._h, kmer_len, hash_func, min_kmer_count, log_2_counting_filter_len,
                                            max_log_2_filter_len, C.byref(self._h)))
 
+    def reset(self, min_kmer_count: int, log_2_counting_filter_len: int = 0, num_bp: int = 0):
+        """Next sample in the same object (allocations kept); the counting filters may only shrink."""
+        if not log_2_counting_filter_len:
+            log_2_counting_filter_len = lib().kwage_counting_filter_log2(num_bp)
+        check(lib().kwage_bloom_counter_reset(self._h, min_kmer_count, log_2_counting_filter_len))
+        self.log_2_counting_filter_len = log_2_counting_filter_len
+
     def add(self, seqs: Sequence[bytes]):
         offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
         if seqs:
@@ -103,6 +110,7 @@ def build_databases(ctx: Context, samples: Sequence[Tuple[str, str]], out_prefix
     L = lib()
     tmp = work_dir or tempfile.mkdtemp(prefix="kwage_bloom_")
     groups: Dict[Tuple[int, int], List[str]] = {}
+    counter: Optional[BloomCounter] = None       # one object for all samples; re-created only when a sample needs larger counting filters
     for acc, path in samples:
         seqs = [s for _, s in read_sequences(path)]
         if min_kmer_count:
@@ -111,9 +119,16 @@ def build_databases(ctx: Context, samples: Sequence[Tuple[str, str]], out_prefix
             si.number_of_spots = len(seqs)
             si.number_of_bases = sum(len(s) for s in seqs)
             bloom = os.path.join(tmp, acc + ".bloom")
-            with BloomCounter(ctx, kmer_len, min_kmer_count, 0, max_log_2_filter_len, num_bp=si.number_of_bases) as bc:
-                bc.add(seqs)
-                status, prm = bc.finish(false_positive, min_log_2_filter_len, si, bloom)
+            logc = L.kwage_counting_filter_log2(si.number_of_bases)
+            if counter is not None and logc <= counter.capacity_log2:
+                counter.reset(min_kmer_count, logc)
+            else:
+                if counter is not None:
+                    counter.close()
+                counter = BloomCounter(ctx, kmer_len, min_kmer_count, logc, max_log_2_filter_len)
+                counter.capacity_log2 = logc
+            counter.add(seqs)
+            status, prm = counter.finish(false_positive, min_log_2_filter_len, si, bloom)
             if status == 0:
                 groups.setdefault((prm.log_2_filter_len, prm.num_hash), []).append(bloom)
             continue
@@ -134,6 +149,8 @@ def build_databases(ctx: Context, samples: Sequence[Tuple[str, str]], out_prefix
         check(L.kwage_make_bloom(ctx._h, C.byref(prm), b"".join(seqs), offs.ctypes.data, len(seqs), C.byref(si),
                                  bloom.encode(), None))
         groups.setdefault((prm.log_2_filter_len, prm.num_hash), []).append(bloom)
+    if counter is not None:
+        counter.close()
     written = []
     for (lg, nh), blooms in sorted(groups.items()):
         for part, i in enumerate(range(0, len(blooms), MAX_NUM_FILTER_CHUNK)):

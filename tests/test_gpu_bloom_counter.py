@@ -231,3 +231,26 @@ def test_read_sets_to_db_to_search(ka, oracle, tmp_path):
         refout = subprocess.run([oracle.REF_KWAGE, "-d", str(dbdir), "-i", str(q), "--o.csv", "-t", "0.9"], capture_output=True,
                                 text=True, env=dict(os.environ, OMP_NUM_THREADS="1"))
         assert refout.returncode == 0 and sorted(refout.stdout.splitlines()) == sorted(out.stdout.splitlines())
+
+
+def test_reset_reuses_the_object(ka, ctx, oracle):
+    """kwage_bloom_counter_reset: several samples through one object (smaller counting filters allowed, larger
+    refused) give what fresh objects give."""
+    from kwage_amd.pipeline import BloomCounter
+    rng = np.random.default_rng(77)
+    bc = BloomCounter(ctx, 31, 3, 20, 20)
+    for m, logc in ((3, 20), (2, 18), (5, 19), (1, 12)):
+        reads = read_set(rng, 8000, 400, 150)
+        bc.reset(m, logc)
+        bc.add([r.encode() for r in reads])
+        ref = oracle.CountingPass(31, m, logc, 20)
+        for r in reads:
+            ref.add(r)
+        assert_same_state(ref, bc)
+        exp = ref.finish(0.25, 14)
+        status, prm = bc.finish(0.25, 14)
+        assert (status == 1) == (exp is None) and (exp is None or (prm.log_2_filter_len, prm.num_hash) == exp[0])
+        ref.close()
+    with pytest.raises(ka.KwageError):
+        bc.reset(3, 21)
+    bc.close()
