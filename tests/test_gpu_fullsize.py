@@ -122,3 +122,50 @@ def test_two_to_the_thirty_rows(ka, oracle):
         assert max(int(x.max()) for x in rows if x.size) > (1 << 29)
         s.batch.close()
         s.group.close()
+
+
+@pytest.mark.timeout(600)
+def test_c1_reference_shape_cli_vs_reference_binary(ka, oracle, tmp_path):
+    """BASELINE.json configs[0] (C1), the reference's own CPU-runnable case at its exact shape: 1 k synthetic
+    Bloom filters of 2^20 bits, k = 31, 1 hash, one 10 kb FASTA query.  The same `.db` file and FASTA through the
+    REFERENCE binary, this repo's `kwage` CLI and the CPU oracle; three thresholds, CSV and JSON."""
+    import os
+    import subprocess
+    from kwage_amd import native
+    if not os.access(oracle.REF_KWAGE, os.X_OK):
+        pytest.skip("oracle/_ref/kwage not built")
+    rng = np.random.default_rng(2020)
+    k, nh, L, ncol = 31, 1, 20, 1000
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    genome = acgt[rng.integers(0, 4, size=30_000)].tobytes().decode()
+    query = genome[5_000:15_000]
+    a = rng.integers(0, 1 << 63, size=(1 << L, 16), dtype=np.uint64)
+    b = rng.integers(0, 1 << 63, size=(1 << L, 16), dtype=np.uint64)
+    rows = np.ascontiguousarray((a & b).view(np.uint8)[:, : (ncol + 7) // 8])          # density 0.25, as at the design point
+    rows[:, -1] &= np.uint8((1 << (ncol % 8)) - 1) if ncol % 8 else np.uint8(255)
+    grows = oracle.row_indices(oracle.unique_kmers(genome, k), k, nh, L).reshape(-1)
+    partial = oracle.row_indices(oracle.unique_kmers(genome[:12_000], k), k, nh, L).reshape(-1)
+    for col in (0, 499, 999):
+        rows[grows, col // 8] |= np.uint8(1 << (col % 8))
+    rows[partial, 77 // 8] |= np.uint8(1 << (77 % 8))                                  # a sample holding 70 % of the query
+    infos = [oracle.FilterInfo(run_accession=oracle.str_to_accession("SRR%07d" % j)) for j in range(ncol)]
+    db = tmp_path / "db"
+    db.mkdir()
+    oracle.write_db(str(db / "c1.db"), k, nh, L, rows, ncol, infos)
+    fa = tmp_path / "q.fa"
+    fa.write_text(">q10kb\n" + "\n".join(query[i:i + 70] for i in range(0, len(query), 70)) + "\n")
+    kmers = oracle.unique_kmers(query, k)
+    assert len(kmers) == 9970
+    for thr in ("1.0", "0.8", "0.6"):
+        exp_hits, _ = oracle.search_image(rows, rows.shape[1], k, nh, L, ncol, kmers, float(np.float32(float(thr))))
+        for fmt in ("--o.csv", "--o.json"):
+            args = ["-d", str(db), "-i", str(fa), "-t", thr, fmt]
+            ref = subprocess.run([oracle.REF_KWAGE] + args, capture_output=True, text=True, env=dict(os.environ, OMP_NUM_THREADS="1"))
+            got = subprocess.run([native.KWAGE_BIN] + args, capture_output=True, text=True)
+            assert ref.returncode == 0 and got.returncode == 0, (ref.stderr, got.stderr)
+            assert sorted(got.stdout.splitlines()) == sorted(ref.stdout.splitlines()), (thr, fmt)
+            if fmt == "--o.csv":
+                rep = oracle.parse_csv(got.stdout)["q10kb"]
+                assert sorted((a_, nf) for a_, nk, nf, _ in rep) == sorted(("SRR%07d" % c, m) for c, m in exp_hits)
+        cols = {c for c, _ in exp_hits}
+        assert {0, 499, 999} <= cols and ((77 in cols) == (float(thr) <= 0.7))
