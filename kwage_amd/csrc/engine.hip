@@ -475,7 +475,21 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 		// width and never stops (C2 with early exit: 0.64 ms tiled, 1.29 ms walk).  KWAGE_WALK_EARLY_EXIT=1 overrides.
 		const char *wx = getenv("KWAGE_WALK_EARLY_EXIT");
 		const bool walk_ee_ok = !a.early_exit || (wx && atoi(wx) != 0);
-		if(walk_unroll && walk_ee_ok && a.segs == 1 && kib >= 3 && kib <= walk_max_kib && (uint64_t)a.n_queries*coltiles >= walk_min_q &&
+		// The walk form has few, long workgroups (one per query and column tile, 4 resident per CU): a last round
+		// that fills only a fraction of the chip runs latency bound and costs almost a whole round (1030 queries:
+		// 2.71 ms vs 2.15 ms tiled; 2100: 4.70 vs 4.15; tools/walk_sizes.py).  Use it when the last round is at
+		// least 60 % full or the rounds are many.
+		bool walk_fill_ok = true;
+		{
+			int ncu = 0;
+			(void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, g->ctx->device);
+			const uint64_t cap = (uint64_t)std::max(ncu, 1)*4;                 // __launch_bounds__(256, 4)
+			const uint64_t wgs = (uint64_t)a.n_queries*coltiles;
+			const uint64_t rounds = (wgs + cap - 1)/cap, last = wgs - (rounds - 1)*cap;
+			const char *wf = getenv("KWAGE_WALK_ANY_FILL");
+			walk_fill_ok = (wf && atoi(wf) != 0) || rounds >= 8 || last*10 >= cap*6;
+		}
+		if(walk_unroll && walk_ee_ok && walk_fill_ok && a.segs == 1 && kib >= 3 && kib <= walk_max_kib && (uint64_t)a.n_queries*coltiles >= walk_min_q &&
 		   (uint64_t)a.n_queries*coltiles <= 0x7FFFFFFFull){
 			SearchArgs wa = a;
 			wa.chunks = coltiles;                            // column tiles per row

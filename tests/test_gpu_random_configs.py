@@ -74,16 +74,17 @@ def test_random_configuration(oracle, seed, monkeypatch):
                     assert per_q[i] == e, (seed, k, nh, L, n_cols, thr, flags, force, i, len(per_q[i]), len(e))
             if thr == 1.0 and n_cols > 16384:
                 # the walk form of the AND kernel (normally for >= 900 queries and rows <= 16 KiB), both unrolls
-                monkeypatch.delenv("KWAGE_FORCE_SEGS", raising=False)
+                monkeypatch.setenv("KWAGE_FORCE_SEGS", "1")           # no row-list segments, or the tiled kernel is the only choice
                 monkeypatch.setenv("KWAGE_WALK_MIN_QUERIES", "1")
                 monkeypatch.setenv("KWAGE_WALK_MAX_KIB", "64")
                 monkeypatch.setenv("KWAGE_WALK_EARLY_EXIT", "1")
+                monkeypatch.setenv("KWAGE_WALK_ANY_FILL", "1")
                 for unroll, flags in (("4", 0), ("2", ka.SEARCH_EARLY_EXIT)):
                     monkeypatch.setenv("KWAGE_WALK", unroll)
                     r = g.search(b, thr, flags)
-                    assert r.search_kernel in ("and_walk_kernel", "and_kernel")      # long queries may still be segmented
+                    assert r.search_kernel == "and_walk_kernel"
                     assert [(int(n), e) for n, e in zip(r.num_query_kmer, r.per_query())] == exp, (seed, n_cols, unroll)
-                for v in ("KWAGE_WALK_MIN_QUERIES", "KWAGE_WALK_MAX_KIB", "KWAGE_WALK", "KWAGE_WALK_EARLY_EXIT"):
+                for v in ("KWAGE_WALK_MIN_QUERIES", "KWAGE_WALK_MAX_KIB", "KWAGE_WALK", "KWAGE_WALK_EARLY_EXIT", "KWAGE_WALK_ANY_FILL", "KWAGE_FORCE_SEGS"):
                     monkeypatch.delenv(v, raising=False)
         b.close()
         g.close()
