@@ -597,3 +597,42 @@ def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, monkeypatch):
     assert planted and all({c for c, _ in e} >= set(cols) for e in planted)
     b.close()
     g.close()
+
+
+@pytest.mark.parametrize("env", [{}, {"KWAGE_LOAD_MMAP": "0"}, {"KWAGE_LOAD_CHUNK_KB": "8", "KWAGE_LOAD_WINDOW_KB": "20"},
+                                 {"KWAGE_LOAD_CHUNK_KB": "3", "KWAGE_LOAD_WINDOW_KB": "3"}])
+def test_loader_paths_give_the_same_matrix(ka, oracle, tmp_path, env):
+    """kwage_group_add_db_file: zero-copy path (file mapping pinned with hipHostRegister, copies left in flight
+    across files), the same with many small windows / chunks, and the pread path -- the resident matrix must be
+    the file's rows, for several files of odd widths in one group.  (The knobs are read once per process.)"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/oracle")
+import kwage_amd as ka, kwage_oracle as oracle
+rng = np.random.default_rng(8)
+files = []
+for j, ncol in enumerate((100, 2048, 13, 777)):
+    rows = rng.integers(0, 256, size=(1 << 12, (ncol + 7) // 8), dtype=np.uint8)
+    if ncol %% 8:
+        rows[:, -1] &= np.uint8((1 << (ncol %% 8)) - 1)
+    infos = [oracle.FilterInfo(run_accession=oracle.str_to_accession("SRR%%07d" %% (j * 10000 + i))) for i in range(ncol)]
+    p = %r + "/f%%d.db" %% j
+    oracle.write_db(p, 31, 2, 12, rows, ncol, infos)
+    files.append((p, ncol, rows))
+with ka.Context(0) as ctx:
+    g = ka.Group(ctx, 31, 2, 12, sum(((n + 127) // 128) * 128 for _, n, _ in files))
+    firsts = [g.add_db_file(p)[0] for p, _, _ in files]
+    g.finalize()
+    image = g.read_rows(np.arange(1 << 12))
+    for (p, ncol, rows), first in zip(files, firsts):
+        assert first %% 128 == 0
+        got = image[:, first // 8: first // 8 + rows.shape[1]]
+        assert np.array_equal(got, rows), p
+    g.close()
+print("ok")
+''' % (ROOT, ROOT, str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
