@@ -21,11 +21,13 @@ int main(int argc, char **argv)
 	}
 	void *dev; if(hipMalloc(&dev, n) != hipSuccess){ puts("hipMalloc failed"); return 1; }
 	int fd = open(path, O_RDONLY);
-	for(int flags_i = 0; flags_i < 3; ++flags_i){
+	for(int flags_i = 0; flags_i < 5; ++flags_i){
 		const int prot = (flags_i == 2) ? (PROT_READ | PROT_WRITE) : PROT_READ;
 		const int mflags = (flags_i == 0) ? MAP_SHARED : MAP_PRIVATE;
+		const int pop = (flags_i >= 3) ? 0 : MAP_POPULATE;          // variants 3, 4: no MAP_POPULATE (4: + MADV_HUGEPAGE/WILLNEED)
 		double t0 = now();
-		void *p = mmap(nullptr, n, prot, mflags | MAP_POPULATE, fd, 0);
+		void *p = mmap(nullptr, n, prot, mflags | pop, fd, 0);
+		if(flags_i == 4 && p != MAP_FAILED){ (void)madvise(p, n, MADV_WILLNEED); }
 		double t1 = now();
 		if(p == MAP_FAILED){ perror("mmap"); continue; }
 		hipError_t e = hipHostRegister(p, n, (flags_i == 2) ? hipHostRegisterDefault : hipHostRegisterReadOnly);
