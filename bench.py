@@ -206,6 +206,7 @@ def main():
     for _ in range(args.warmup):
         step()
     pipe = None
+    pipeline_note = "on" if not sharded else "n/a"
     kernel_ms = []
 
     trace = [] if os.environ.get("KWAGE_BENCH_TRACE") == "1" else None
@@ -227,16 +228,27 @@ def main():
         p1.collect()
         p2.collect()
     elif sharded and multi is None:
-        pipe = PipelinedDeviceSearcher(s.group, flags, "cuda:%d" % local_rank)
-        t1, t2 = pipe.submit(s.batch, threshold), pipe.submit(s.batch, threshold)      # untimed warm-up of both slots
-        for tk in (t1, t2):
-            exchange(pipe, tk)
+        pipeline_note = "on"
+        try:
+            pipe = PipelinedDeviceSearcher(s.group, flags, "cuda:%d" % local_rank)
+            t1, t2 = pipe.submit(s.batch, threshold), pipe.submit(s.batch, threshold)      # untimed warm-up of both slots
+            for tk in (t1, t2):
+                exchange(pipe, tk)
+            ok = 1
+        except Exception as exc:       # keep a number rather than none: fall back to the synchronous exchange
+            print("[bench] pipelined exchange failed on rank %d (%r): falling back to the synchronous path" % (rank, exc), file=sys.stderr)
+            ok = 0
+        agree = torch.tensor([ok], dtype=torch.int32, device=("cuda:%d" % local_rank) if backend == "nccl" else "cpu")
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        if int(agree.item()) == 0:
+            pipe, pipeline_note = None, "off (warm-up of the pipelined exchange failed on some rank)"
+            ctx.sync()
     sync_all()
     t0 = time.perf_counter()
     kernel_ms = []
     last = None
     nhits = 0
-    if sharded and multi is None:
+    if sharded and multi is None and pipe is not None:
         # multi-GPU: the same software pipeline per rank -- step i+1's search is submitted before step i's hits
         # are exchanged (one all_gather over RCCL) and merged on rank 0
         tk = pipe.submit(s.batch, threshold)
@@ -283,7 +295,7 @@ def main():
     else:
         bit_tests_rank = int(probe.bit_tests)
         alg_bytes_rank = int(probe.algorithmic_bytes)
-    if sharded and multi is not None:
+    if sharded and (multi is not None or pipe is None):
         kernel_ms = []
         for _ in range(3):
             kernel_ms.append(sum(m.group.search(s.batch, threshold, flags).search_kernel_ms for m in (multi or [s])))
@@ -314,7 +326,7 @@ def main():
                        "kmer_len": w.kmer_len, "num_hash": w.num_hash, "queries": w.num_queries, "query_len": w.query_len,
                        "threshold": w.threshold, "early_exit": bool(args.early_exit), "density": w.density_q8 / 256.0,
                        "db_bytes_per_gpu": int(sum(m.group.device_bytes for m in multi)) if multi else int(s.group.device_bytes),
-                       "groups": [[lg, ns] for lg, ns in synth.C5_GROUPS] if multi else None, "sharding": "columns (samples) over %d GPU(s)" % world,
+                       "groups": [[lg, ns] for lg, ns in synth.C5_GROUPS] if multi else None, "sharding": "columns (samples) over %d GPU(s)" % world, "step_pipeline": pipeline_note,
                        "total_kmers_per_step": int(probe.total_kmers), "hits_per_step": int(nhits),
                        "db_build_s": round(t_build, 2),
                        "seeds": {"queries_and_planted_genomes": 1, "columns": "rank (splitmix64 keyed by seed, row, word; kwage_amd/synth.py)"}},
