@@ -17,6 +17,9 @@ No row data ever crosses xGMI.
 The CPU baseline (rank 0, N=1 only) times the REFERENCE binary (oracle/_ref/kwage, OpenMP over
 <=2048-column .db files) when it travelled with the snapshot, else the repo's C restatement, on
 a bounded column subset of the same workload.  It is a reported baseline, not the target.
+
+Rank 0 prints the result as ONE JSON line, the last line of stdout (with NCCL_DEBUG=VERSION in the
+environment RCCL prints its version banner to stdout before it).
 """
 import argparse
 import json
