@@ -22,7 +22,7 @@ kwage.cpp:76-87); this is what replaces it at node scale.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Callable, List, Optional, Sequence, Tuple
+from typing import Callable, List, Sequence, Tuple
 
 import numpy as np
 

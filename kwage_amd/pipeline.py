@@ -14,7 +14,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from .engine import Batch, Context
-from .native import BloomCounterStats, BuildStats, Params, SampleInfo, check, lib
+from .native import BloomCounterStats, Params, SampleInfo, check, lib
 
 MAX_NUM_FILTER_CHUNK = 2048
 

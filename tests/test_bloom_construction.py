@@ -2,7 +2,6 @@
 parameter choice, pinned by files the REFERENCE wrote (tests/golden/bloomgen: its BloomFilter +
 binary_write through oracle/_ref/ref_tool) and by its optimal_bloom_param (kat_optimal_bloom_param.json)."""
 import ctypes as C
-import glob
 import json
 import os
 

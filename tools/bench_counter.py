@@ -31,7 +31,6 @@ L = ka.native.lib()
 logc = L.kwage_counting_filter_log2(num_bp)
 print("reads %d x %d = %.1f M bases, counting filters 2^%d, min_kmer_count %d" % (n_reads, args.read_len, num_bp / 1e6, logc, args.min_count))
 
-import ctypes as C
 with ka.Context(0) as ctx:
     for rep in range(2):
         bc = BloomCounter(ctx, 31, args.min_count, logc, 32)
