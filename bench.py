@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the kwage search path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5|c5s|c2t|c1]
 
 A "step" is one pass of the hot path over one batch of synthetic queries against the
 HBM-resident synthetic database (k-mer pack + MurmurHash3 + row gather + AND/count + hit
@@ -9,10 +9,15 @@ compaction + D2H of the sorted hit list).  Inputs (database and query strings) a
 HBM before the timed region.  Metric = BASELINE.json's: G k-mer.sample bit-tests/s, with the
 achieved HBM GB/s of the gather kernel against the 8 TB/s roofline beside it.
 
-N > 1: one process per GPU (launched by torch.distributed.run); the sample (column) axis is
-sharded -- every rank holds its own block of `num_samples` columns (weak scaling), searches it
-independently, and the per-rank hit lists are concatenated on rank 0 by one padded RCCL gather.
-No row data ever crosses xGMI.
+N > 1: one process per GPU.  Either the caller starts the ranks (`python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N`: RANK / LOCAL_RANK / WORLD_SIZE come from the environment), or
+plain `python bench.py --gpus N` starts them itself: the parent process -- which never touches the GPU --
+runs torch.distributed.run as a child and relays its output and exit code.  The sample (column) axis is
+sharded: every rank holds its own block of `num_samples` columns (weak scaling), searches it independently,
+and the per-rank hit lists are concatenated on rank 0 by one padded RCCL gather per step.  No row data ever
+crosses xGMI.  Every rank's gather-kernel time goes into the line (`aggregate`): the north-star figure is
+the fraction of the AGGREGATE HBM bandwidth, i.e. all ranks' algorithmic bytes over the slowest rank's
+kernel time.  `--workload c4` / `c5` are the per-GPU shares of BASELINE.json's 8-GPU configurations.
 
 The CPU baseline (rank 0, N=1 only) times the REFERENCE binary (oracle/_ref/kwage, OpenMP over
 <=2048-column .db files) when it travelled with the snapshot, else the repo's C restatement, on
@@ -25,6 +30,7 @@ import argparse
 import json
 import os
 import shutil
+import socket
 import subprocess
 import sys
 import tempfile
@@ -33,28 +39,72 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SUSTAINED_SECONDS = 2.0  # back-to-back steps after the timed region (DVFS: a 40 ms window could be a burst)
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=os.environ.get("KWAGE_BENCH_WORKLOAD", "c2"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the %.0f s sustained block after the timed steps" % SUSTAINED_SECONDS)
     ap.add_argument("--early-exit", action="store_true", help="enable the reference's early exit (not the nominal figure)")
     ap.add_argument("--cpu-files", type=int, default=0, help="number of 2048-column .db files of the CPU sample (default: host cores, max 16)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` without an external launcher
+# ------------------------------------------------------------------------------------------------------
+def launch_command(n_ranks, argv, port=None):
+    """The child command that starts one rank per GPU.  Pure function of its arguments (tested on CPU)."""
+    if port is None:
+        with socket.socket() as sk:        # a free port of this host
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(n_ranks, argv):
+    """Parent of a self-launched multi-GPU run: start the ranks as a CHILD process group, relay their stdout
+    (rank 0's JSON line comes last) and return the child's exit code.  Nothing here initialises HIP: a
+    process that has touched the GPU must never be replaced or re-used as a launcher on this pool."""
+    cmd = launch_command(n_ranks, argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print("[bench] starting %d ranks: %s" % (n_ranks, " ".join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    last_json = None
+    for line in proc.stdout:
+        if line.startswith("{") and '"metric"' in line:
+            last_json = line            # hold the result line back so that it is the LAST line of stdout
+        else:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    rc = proc.wait()
+    if last_json is not None:
+        sys.stdout.write(last_json)
+        sys.stdout.flush()
+    elif rc == 0:
+        print("[bench] the ranks exited without a result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------------
+# CPU baseline
+# ------------------------------------------------------------------------------------------------------
 def cpu_baseline(w, queries, n_files):
     """Time the reference CPU `kwage` (or the oracle port) on a bounded sample of workload w:
     n_files .db files x 2048 columns, 2^min(L,20) rows, SAME k / hashes / threshold / queries.
     Every file holds the planted genomes in one column so that the reference's early exit
     (kwage.cpp:466-470) never fires: it reads every addressed row, like the nominal GPU figure."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import kwage_oracle as oracle
     cores = os.cpu_count() or 1
@@ -67,6 +117,12 @@ def cpu_baseline(w, queries, n_files):
     # sample of the query set sized so the CPU leg stays ~10-30 s
     qs = [q for q in queries if len(q) >= k][:max(1, min(len(queries), 1000))]
     tmp = tempfile.mkdtemp(prefix="kwage_cpu_", dir="/tmp")
+    # The CPU leg runs on a column / row SUBSET with a matrix of its own (same density, same queries, same k,
+    # hashes and threshold): the GPU matrix (>= 100 GB) does not fit the host.  Cost is linear in columns
+    # per addressed row, so the rate carries over -- but it is an extrapolation and says so.
+    subset = {"columns": ncol * n_files, "of_columns": int(w.num_samples) if w.num_samples else None,
+              "log_2_rows": L, "of_log_2_rows": int(w.log_2_filter_len) if w.log_2_filter_len else None,
+              "queries": len(qs), "of_queries": len(queries), "matrix": "own random bits of the same density (seed 99), not the GPU matrix"}
     try:
         # rows addressed by the queries' k-mers (so the planted column matches every query)
         uniq = [oracle.unique_kmers(q, k) for q in qs]
@@ -102,6 +158,7 @@ def cpu_baseline(w, queries, n_files):
                     raise RuntimeError("reference kwage failed: " + r.stderr.decode())
                 best = dt if best is None else min(best, dt)
             return {"value": bit_tests / best / 1e9, "unit": "G bit-tests/s", "cores": min(cores, 16, n_files), "kind": "reference",
+                    "extrapolated": True, "subset": subset,
                     "sample": "reference kwage (OpenMP over files), %d files x %d columns x 2^%d rows, %d queries x %d bp, "
                               "page cache warm, best of 2, wall %.2f s; a planted column matches every query, so the early exit never fires and every addressed row is read (as in the nominal GPU figure)"
                               % (n_files, ncol, L, len(qs), w.query_len, best)}
@@ -111,27 +168,48 @@ def cpu_baseline(w, queries, n_files):
         for u in uniq:
             oracle.search_image(image, image.shape[1], k, nh, L, ncol, u, thr, early_exit=True)
         dt = time.perf_counter() - t0
+        subset["columns"] = ncol
         return {"value": total_kmers * nh * ncol / dt / 1e9, "unit": "G bit-tests/s", "cores": 1, "kind": "port",
+                "extrapolated": True, "subset": subset,
                 "sample": "oracle C restatement, 1 thread, 1 file x %d columns x 2^%d rows in memory, %d queries, wall %.2f s"
                           % (ncol, L, len(qs), dt)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def main():
-    args = parse_args()
+def measured_traffic(workload, kernel, early_exit):
+    """HBM bytes per launch from the PMC counters: they come from a SEPARATE rocprofv3 --pmc pass of this same
+    command (counters cannot be collected from inside the run), kept in profiles/pmc_traffic.json with the
+    kernel (name + template shape) and commit they were taken on.  The number is reported only when that
+    kernel is the one this run used; otherwise null, with the reason in traffic_source."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(workload)
+    except Exception as exc:
+        return None, {"file": "profiles/pmc_traffic.json", "status": "unreadable: %r" % (exc,)}
+    if not t:
+        return None, {"file": "profiles/pmc_traffic.json", "status": "no PMC pass recorded for workload %r" % workload}
+    src = {"file": "profiles/pmc_traffic.json", "pmc_pass": t.get("source"), "kernel": t.get("kernel"), "commit": t.get("commit")}
+    if early_exit:
+        src["status"] = "not applicable with --early-exit"
+        return None, src
+    if t.get("kernel") != kernel:
+        src["status"] = "stale: the PMC pass profiled %s, this run used %s" % (t.get("kernel"), kernel)
+        return None, src
+    src["status"] = "kernel matches"
+    return t["hbm_read_bytes_per_launch"], src
+
+
+def rank_main(args):
+    import numpy as np
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
 
     import torch
     import kwage_amd as ka
     from kwage_amd import native, synth
-    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+    if local_rank == 0:
         native.ensure_built()          # artefacts are git-ignored; normally they travel with the snapshot
     else:
         for _ in range(600):           # other ranks wait for rank 0's build instead of racing it
@@ -154,6 +232,7 @@ def main():
     sharded = world > 1 or force_sharded
     dist = None
     ctx = ka.Context(local_rank)       # before torch.distributed creates its streams (hardware-queue assignment is first come, first served)
+    cdev = ("cuda:%d" % local_rank) if backend == "nccl" else "cpu"       # where the collectives' tensors live
     if sharded:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -181,7 +260,7 @@ def main():
         from kwage_amd.distributed import PipelinedDeviceSearcher, ShardedSearch, device_tensor_search_fn
         dev = "cuda:%d" % local_rank
         ss = [ShardedSearch(dist, rank, world, int(m.group.column_span),
-                            device_tensor_search_fn(m.group, flags, dev), device=dev if backend == "nccl" else "cpu")
+                            device_tensor_search_fn(m.group, flags, dev), device=cdev)
               for m in (multi or [s])]
 
     def step():
@@ -214,7 +293,7 @@ def main():
 
     trace = [] if os.environ.get("KWAGE_BENCH_TRACE") == "1" else None
 
-    def exchange(pipe, tk):
+    def local_collect(pipe, tk):
         t_a = time.perf_counter()
         buf, n = pipe.collect_counted(tk)
         if trace is not None:
@@ -222,6 +301,10 @@ def main():
         kernel_ms.append(pipe.last_kernel_ms)
         if backend != "nccl":                    # gloo rehearsal: the same exchange on host tensors
             buf = buf[:max(n, ss[0].capacity) + 1].cpu()
+        return buf, n
+
+    def exchange(pipe, tk):
+        buf, n = local_collect(pipe, tk)
         return ss[0].exchange_counted(buf, n)
 
     if not sharded and multi is None:
@@ -231,63 +314,93 @@ def main():
         p1.collect()
         p2.collect()
     elif sharded and multi is None:
+        # untimed warm-up of both slots of the pipelined exchange.  Rank-LOCAL work first (submit + collect, may fail
+        # on one rank only, e.g. out of memory), then every rank learns whether all succeeded, and only then the
+        # first collective exchange: a rank that failed never leaves the others blocked inside an all_gather.
         pipeline_note = "on"
+        pending = []
         try:
             pipe = PipelinedDeviceSearcher(s.group, flags, "cuda:%d" % local_rank)
-            t1, t2 = pipe.submit(s.batch, threshold), pipe.submit(s.batch, threshold)      # untimed warm-up of both slots
-            for tk in (t1, t2):
-                exchange(pipe, tk)
+            t1, t2 = pipe.submit(s.batch, threshold), pipe.submit(s.batch, threshold)
+            pending = [local_collect(pipe, t1), local_collect(pipe, t2)]
             ok = 1
         except Exception as exc:       # keep a number rather than none: fall back to the synchronous exchange
-            print("[bench] pipelined exchange failed on rank %d (%r): falling back to the synchronous path" % (rank, exc), file=sys.stderr)
+            print("[bench] pipelined search failed on rank %d (%r): falling back to the synchronous path" % (rank, exc), file=sys.stderr)
             ok = 0
-        agree = torch.tensor([ok], dtype=torch.int32, device=("cuda:%d" % local_rank) if backend == "nccl" else "cpu")
+        agree = torch.tensor([ok], dtype=torch.int32, device=cdev)
         dist.all_reduce(agree, op=dist.ReduceOp.MIN)
         if int(agree.item()) == 0:
-            pipe, pipeline_note = None, "off (warm-up of the pipelined exchange failed on some rank)"
+            pipe, pipeline_note = None, "off (warm-up of the pipelined search failed on some rank)"
             ctx.sync()
-    sync_all()
-    t0 = time.perf_counter()
-    kernel_ms = []
-    last = None
-    nhits = 0
-    if sharded and multi is None and pipe is not None:
-        # multi-GPU: the same software pipeline per rank -- step i+1's search is submitted before step i's hits
-        # are exchanged (one all_gather over RCCL) and merged on rank 0
-        tk = pipe.submit(s.batch, threshold)
-        for _ in range(args.steps - 1):
-            nxt = pipe.submit(s.batch, threshold)
+        else:
+            for buf, n in pending:
+                ss[0].exchange_counted(buf, n)
+
+    def timed_steps(nsteps):
+        """nsteps passes, software-pipelined where the path allows; -> (last result or None, hits of the last step)."""
+        last, nhits = None, 0
+        if sharded and multi is None and pipe is not None:
+            # multi-GPU: the same software pipeline per rank -- step i+1's search is submitted before step i's hits
+            # are exchanged (one all_gather over RCCL) and merged on rank 0
+            tk = pipe.submit(s.batch, threshold)
+            for _ in range(nsteps - 1):
+                nxt = pipe.submit(s.batch, threshold)
+                merged = exchange(pipe, tk)
+                tk = nxt
             merged = exchange(pipe, tk)
-            tk = nxt
-        merged = exchange(pipe, tk)
-        nhits = len(merged) if merged is not None else 0
-        if trace:     # host view of the pipeline: time blocked in collect, and collect-to-collect period
-            per = np.diff([t for _, t in trace[-args.steps:]])
-            print("[trace] collect wait mean %.3f ms; collect-to-collect mean %.3f ms (min %.3f max %.3f)"
-                  % (np.mean([d for d, _ in trace[-args.steps:]]) * 1e3, per.mean() * 1e3, per.min() * 1e3, per.max() * 1e3), file=sys.stderr)
-    elif not sharded and multi is None:
-        # K steps, software-pipelined through the two search slots of the context: step i+1 is submitted
-        # (its k-mer stage runs) before step i is collected (copy-back, sort); the gather kernels themselves
-        # run back to back, never side by side.  Every step is complete when the region ends.
-        pend = s.group.submit(s.batch, threshold, flags)
-        for _ in range(args.steps - 1):
-            nxt = s.group.submit(s.batch, threshold, flags)
+            nhits = len(merged) if merged is not None else 0
+        elif not sharded and multi is None:
+            # K steps, software-pipelined through the two search slots of the context: step i+1 is submitted
+            # (its k-mer stage runs) before step i is collected (copy-back, sort); the gather kernels themselves
+            # run back to back, never side by side.  Every step is complete when the region ends.
+            pend = s.group.submit(s.batch, threshold, flags)
+            for _ in range(nsteps - 1):
+                nxt = s.group.submit(s.batch, threshold, flags)
+                last = pend.collect()
+                kernel_ms.append(last.search_kernel_ms)
+                pend = nxt
             last = pend.collect()
             kernel_ms.append(last.search_kernel_ms)
-            pend = nxt
-        last = pend.collect()
-        kernel_ms.append(last.search_kernel_ms)
-        nhits = len(last.hits)
-    else:
-        for _ in range(args.steps):
-            last, ms, nhits = step()
-            kernel_ms.append(ms)
+            nhits = len(last.hits)
+        else:
+            for _ in range(nsteps):
+                last, ms, nhits = step()
+                kernel_ms.append(ms)
+        return last, nhits
+
+    sync_all()
+    t0 = time.perf_counter()
+    kernel_ms.clear()
+    last, nhits = timed_steps(args.steps)
     sync_all()
     dt = time.perf_counter() - t0
+    if trace:     # host view of the pipeline: time blocked in collect, and collect-to-collect period
+        per = np.diff([t for _, t in trace[-args.steps:]])
+        print("[trace] collect wait mean %.3f ms; collect-to-collect mean %.3f ms (min %.3f max %.3f)"
+              % (np.mean([d for d, _ in trace[-args.steps:]]) * 1e3, per.mean() * 1e3, per.min() * 1e3, per.max() * 1e3), file=sys.stderr)
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    timed_kernel_ms = list(kernel_ms)
+
+    # ---- sustained block: the same steps back to back for >= SUSTAINED_SECONDS (the count is derived from the agreed
+    # max-over-ranks step time, so every rank runs the same number of steps and collectives) ------------------------
+    sustained = None
+    if not args.no_sustained:
+        n_sus = int(max(args.steps, min(20000, SUSTAINED_SECONDS / max(dt / args.steps, 1e-6)))) + 1
+        sync_all()
+        kernel_ms.clear()
+        t1 = time.perf_counter()
+        timed_steps(n_sus)
+        sync_all()
+        dts = time.perf_counter() - t1
+        if dist is not None:
+            tmax = torch.tensor([dts], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dts = float(tmax.item())
+        sus_kernel_ms = list(kernel_ms)
+        sustained = {"steps": n_sus, "seconds": round(dts, 3), "ms_per_step": round(dts / n_sus * 1e3, 4)}
 
     # work per step (identical on every rank: same queries, same column count)
     probe = last if last is not None else [m.group.search(s.batch, threshold, flags) for m in (multi or [s])]
@@ -299,25 +412,36 @@ def main():
         bit_tests_rank = int(probe.bit_tests)
         alg_bytes_rank = int(probe.algorithmic_bytes)
     if sharded and (multi is not None or pipe is None):
-        kernel_ms = []
-        for _ in range(3):
-            kernel_ms.append(sum(m.group.search(s.batch, threshold, flags).search_kernel_ms for m in (multi or [s])))
+        # the synchronous sharded path does not return kernel times: measure them with three local searches
+        timed_kernel_ms = [sum(m.group.search(s.batch, threshold, flags).search_kernel_ms for m in (multi or [s])) for _ in range(3)]
+        sus_kernel_ms = []
+
+    def stats(xs):
+        xs = [float(x) for x in xs if x > 0]
+        return [float(np.mean(xs)), float(np.min(xs)), float(np.max(xs))] if xs else [0.0, 0.0, 0.0]
+
+    # every rank's kernel time (timed region: mean/min/max; sustained block: mean/min/max), gathered on all ranks
+    mine = stats(timed_kernel_ms) + (stats(sus_kernel_ms) if sustained else [0.0, 0.0, 0.0])
+    per_rank = [mine]
+    if dist is not None:
+        t = torch.tensor(mine, dtype=torch.float64, device=cdev)
+        outs = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        per_rank = [[float(x) for x in o.tolist()] for o in outs]
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = bit_tests_rank * world * args.steps / dt / 1e9
-        k_ms = float(np.mean(kernel_ms)) if kernel_ms else 0.0
+        k_ms = per_rank[0][0]
         achieved = alg_bytes_rank / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         stream_gbps = s.group.stream_read_gbps(min(s.group.device_bytes, 8 << 30), 3)
-        traffic = None
-        try:     # PMC numbers come from a separate rocprofv3 --pmc pass of this same command (profiles/)
-            t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
-            if t and not args.early_exit:
-                traffic = t["hbm_read_bytes_per_launch"]
-        except Exception:
-            pass
+        kernel = getattr(probe, "search_kernel", "") or ("and_kernel" if threshold == 1.0 else "count_kernel")
+        traffic, traffic_source = measured_traffic(args.workload, kernel, args.early_exit)
+        k_means = [r[0] for r in per_rank]
+        k_max, k_mean = max(k_means), float(np.mean(k_means))
+        agg_achieved = alg_bytes_rank * world / (k_max * 1e-3) / 1e9 if k_max > 0 else 0.0
         out = {
-            "metric": "G k-mer\u00b7sample bit-tests/sec (+ achieved HBM GB/s of the gather kernel in `roofline`)",
+            "metric": "G k-mer·sample bit-tests/sec (+ achieved HBM GB/s of the gather kernel in `roofline`)",
             "value": round(value, 3),
             "unit": "G bit-tests/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -330,17 +454,39 @@ def main():
                        "threshold": w.threshold, "early_exit": bool(args.early_exit), "density": w.density_q8 / 256.0,
                        "db_bytes_per_gpu": int(sum(m.group.device_bytes for m in multi)) if multi else int(s.group.device_bytes),
                        "groups": [[lg, ns] for lg, ns in synth.C5_GROUPS] if multi else None, "sharding": "columns (samples) over %d GPU(s)" % world, "step_pipeline": pipeline_note,
-                       "total_kmers_per_step": int(probe.total_kmers), "hits_per_step": int(nhits),
+                       "total_kmers_per_step": int(probe.total_kmers) if not multi else None, "hits_per_step": int(nhits),
                        "db_build_s": round(t_build, 2),
                        "seeds": {"queries_and_planted_genomes": 1, "columns": "rank (splitmix64 keyed by seed, row, word; kwage_amd/synth.py)"}},
             "hbm_gbps_algorithmic_whole_step": round(alg_bytes_rank * world * args.steps / dt / 1e9, 1),
-            "roofline": {"bound": "hbm", "kernel": getattr(probe, "search_kernel", "") or ("and_kernel" if threshold == 1.0 else "count_kernel"),
+            "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": alg_bytes_rank,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel_ms": round(k_ms, 4), "kernel_ms_min": round(per_rank[0][1], 4), "kernel_ms_max": round(per_rank[0][2], 4),
+                         "algorithmic_bytes_per_launch": alg_bytes_rank,
                          "measured_stream_read_gbps": round(stream_gbps, 1),
                          "frac_of_measured_stream": round(achieved / stream_gbps, 4) if stream_gbps else None},
+            # all ranks: every GPU's algorithmic bytes over the SLOWEST rank's mean kernel time, against N x 8 TB/s
+            "aggregate": {"n_gpus": world, "kernel_ms_per_rank": [round(x, 4) for x in k_means],
+                          "kernel_ms_max": round(k_max, 4), "kernel_ms_mean": round(k_mean, 4),
+                          "achieved": round(agg_achieved, 1), "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
+                          "aggregate_frac": round(agg_achieved / (HBM_PEAK_GBPS * world), 4)},
         }
+        if sustained is not None:
+            sk = per_rank[0][3:6]
+            sustained.update({"kernel_ms_mean": round(sk[0], 4), "kernel_ms_min": round(sk[1], 4), "kernel_ms_max": round(sk[2], 4),
+                              "achieved": round(alg_bytes_rank / (sk[0] * 1e-3) / 1e9, 1) if sk[0] > 0 else None,
+                              "frac": round(alg_bytes_rank / (sk[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if sk[0] > 0 else None,
+                              "value": round(bit_tests_rank * world / (sustained["ms_per_step"] * 1e-3) / 1e9, 3),
+                              "kernel_ms_mean_per_rank": [round(r[3], 4) for r in per_rank]})
+            out["sustained"] = sustained
+        if sharded:
+            rv = None
+            try:
+                rv = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None
+            except Exception:
+                pass
+            out["rccl"] = {"world": world, "backend": backend, "version": rv,
+                           "exchange": "one all_gather of [count | records] buffers per step" if pipe is not None else "one padded all_gather per group and step"}
         if force_sharded:
             out["config"]["note"] = "KWAGE_BENCH_FORCE_SHARDED: multi-GPU code path on one rank"
         if world == 1 and not args.no_cpu_baseline:
@@ -358,6 +504,14 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher above us: start the ranks ourselves, from a process that never touches the GPU
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    rank_main(args)
 
 
 if __name__ == "__main__":

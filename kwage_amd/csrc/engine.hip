@@ -102,7 +102,9 @@ struct Slot {
 	float threshold = 1.0f;
 	uint32_t flags = 0;
 	uint32_t launches = 0;
-	const char *kernel_name = "";       // the gather kernel launch_search_stage picked
+	char kernel_name[64] = "";          // the gather kernel launch_search_stage picked, with its template shape
+	// and_walk_kernel's meeting place for (query, tile) pairs cut by a wave-share boundary: all zero between searches
+	DevBuf walk_or, walk_done;
 	uint64_t staged_hits = 0;
 	kwage_hit *ext_hits = nullptr;      // caller-owned device buffer (kwage_search_device) or null
 	uint64_t ext_cap = 0;
@@ -307,6 +309,8 @@ int launch_kmer_stage(Slot *sl, const kwage_params &p, kwage_batch *b, float thr
 	return KWAGE_OK;
 }
 
+static const uint32_t WALK_MIN_ROWS_PER_WAVE = 64;   // and_walk_kernel: below this share per wave the tiled kernel is used
+
 static int g_and_lds_bytes = 0;     // tuning only: dynamic LDS per workgroup caps waves per CU
 static int g_and_block_waves = SEARCH_THREADS/WAVE;   // tuning only: waves per workgroup of and_kernel
 
@@ -365,9 +369,36 @@ void launch_count_nh(const SearchArgs &a, hipStream_t s)
 		case 4: launch_count<PLANES, 4>(a, s); break;
 		default: launch_count<PLANES, 5>(a, s); break;
 	}
-	if(a.segs > 1){
-		hipLaunchKernelGGL((count_combine_kernel<PLANES>), dim3((a.units_per_row + 255)/256, a.n_queries), dim3(256), 0, s, a);
+}
+
+// counter planes for counts up to `max_count`: the smallest instantiated size whose bits hold it
+uint32_t planes_for(uint64_t max_count)
+{
+	uint32_t bits = 1;
+	while(bits < 32 && (max_count >> bits) != 0){ ++bits; }
+	return (bits <= 7) ? 7 : (bits <= 10) ? 10 : (bits <= 14) ? 14 : (bits <= 20) ? 20 : 32;
+}
+
+void launch_count_planes(uint32_t planes, const SearchArgs &a, hipStream_t s)
+{
+	switch(planes){
+		case 7: launch_count_nh<7>(a, s); break;
+		case 10: launch_count_nh<10>(a, s); break;
+		case 14: launch_count_nh<14>(a, s); break;
+		case 20: launch_count_nh<20>(a, s); break;
+		default: launch_count_nh<32>(a, s); break;
 	}
+}
+
+template <int PLANES>
+int launch_count_combine(const SearchArgs &a, uint32_t seg_planes, hipStream_t s)
+{
+	const size_t lds = (size_t)(COMBINE_WAVES/2)*PLANES*WAVE*16;
+	if(lds > 48*1024){      // 32 planes only (queries above 2^20 positions); the attribute is per device, so set it per launch
+		HIP_TRY(hipFuncSetAttribute((const void*)count_combine_kernel<PLANES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	}
+	hipLaunchKernelGGL((count_combine_kernel<PLANES>), dim3((a.units_per_row + WAVE - 1)/WAVE, a.n_queries), dim3(COMBINE_WAVES*WAVE), lds, s, a, seg_planes);
+	return KWAGE_OK;
 }
 
 // Shape of the AND kernel: VEC 16-byte vectors per lane, UNROLL rows in flight, nontemporal loads.
@@ -468,7 +499,7 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 			const uint32_t G = (a.units_per_row <= 4) ? 16 : (a.units_per_row <= 8) ? 8 : (a.units_per_row <= 16) ? 4 : 2;
 			const uint64_t waves = ((uint64_t)a.n_queries + G - 1)/G;
 			const dim3 grid((uint32_t)((waves + 3)/4)), block(SEARCH_THREADS);
-			sl->kernel_name = "and_narrow_kernel";
+			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_narrow_kernel<%u,8>", G);
 			switch(G){
 				case 16: hipLaunchKernelGGL((and_narrow_kernel<16, 8>), grid, block, 0, sl->stream, a); break;
 				case 8: hipLaunchKernelGGL((and_narrow_kernel<8, 8>), grid, block, 0, sl->stream, a); break;
@@ -478,13 +509,15 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 			HIP_TRY(hipGetLastError());
 			return KWAGE_OK;
 		}
-		// rows of 3..16 KiB with enough queries to fill the chip: the walk form (one workgroup per (query, column
-		// tile), each wave walks a quarter of the rows over the tile's whole width; kernels.hpp and_walk_kernel).
-		// KWAGE_WALK=0 keeps the tiled kernel, KWAGE_WALK=2 selects two rows in flight instead of four.
+		// rows of 3..16 KiB: the walk form (a persistent grid, every wave walks an equal share of the batch's row
+		// list over the whole width of a column tile; kernels.hpp and_walk_kernel).  Worth it once every wave of
+		// the chip gets a few dozen rows; smaller batches stay with the tiled kernel and its row-list segments.
+		// KWAGE_WALK=0 keeps the tiled kernel, KWAGE_WALK=2 selects two rows in flight instead of four;
+		// KWAGE_WALK_MIN_ROWS / KWAGE_WALK_MAX_KIB move the limits (tests force the walk form on tiny inputs).
 		// (read per call, like KWAGE_AND_CFG: tools/tune_walk.py switches them inside one process)
-		const char *we = getenv("KWAGE_WALK"), *wq = getenv("KWAGE_WALK_MIN_QUERIES");
+		const char *we = getenv("KWAGE_WALK"), *wr = getenv("KWAGE_WALK_MIN_ROWS");
 		const int walk_unroll = we ? atoi(we) : 4;
-		const uint32_t walk_min_q = wq ? (uint32_t)atoi(wq) : 900u;
+		const uint64_t walk_min_rows = wr ? strtoull(wr, nullptr, 10) : (uint64_t)WALK_MIN_ROWS_PER_WAVE*4096;
 		const uint32_t kib = (a.units_per_row + WAVE - 1)/WAVE;
 		// (the kernel handles wider rows as several balanced column tiles -- KWAGE_WALK_MAX_KIB raises the limit --
 		// but 125 KB rows measured no gain over the tiled kernel)
@@ -496,29 +529,44 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 		// width and never stops (C2 with early exit: 0.64 ms tiled, 1.29 ms walk).  KWAGE_WALK_EARLY_EXIT=1 overrides.
 		const char *wx = getenv("KWAGE_WALK_EARLY_EXIT");
 		const bool walk_ee_ok = !a.early_exit || (wx && atoi(wx) != 0);
-		// The walk form has few, long workgroups (one per query and column tile, 4 resident per CU): a last round
-		// that fills only a fraction of the chip runs latency bound and costs almost a whole round (1030 queries:
-		// 2.71 ms vs 2.15 ms tiled; 2100: 4.70 vs 4.15; tools/walk_sizes.py).  Use it when the last round is at
-		// least 60 % full or the rounds are many.
-		bool walk_fill_ok = true;
-		{
+		const uint64_t walk_slots = (uint64_t)coltiles*b->total_pos;
+		if(walk_unroll && walk_ee_ok && kib >= 3 && kib <= walk_max_kib && walk_slots*a.num_hash >= walk_min_rows && walk_slots > 0){
+			// as many waves as the chip holds at once (4 workgroups of 4 waves per CU: __launch_bounds__(256, 4)),
+			// fewer when the batch is small: a wave should have WALK_MIN_ROWS_PER_WAVE rows to walk
 			int ncu = 0;
 			(void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, g->ctx->device);
-			const uint64_t cap = (uint64_t)std::max(ncu, 1)*4;                 // __launch_bounds__(256, 4)
-			const uint64_t wgs = (uint64_t)a.n_queries*coltiles;
-			const uint64_t rounds = (wgs + cap - 1)/cap, last = wgs - (rounds - 1)*cap;
-			const char *wf = getenv("KWAGE_WALK_ANY_FILL");
-			walk_fill_ok = (wf && atoi(wf) != 0) || rounds >= 8 || last*10 >= cap*6;
-		}
-		if(walk_unroll && walk_ee_ok && walk_fill_ok && a.segs == 1 && kib >= 3 && kib <= walk_max_kib && (uint64_t)a.n_queries*coltiles >= walk_min_q &&
-		   (uint64_t)a.n_queries*coltiles <= 0x7FFFFFFFull){
-			SearchArgs wa = a;
-			wa.chunks = coltiles;                            // column tiles per row
-			sl->kernel_name = "and_walk_kernel";
-			const dim3 grid((uint32_t)((uint64_t)a.n_queries*coltiles)), block(SEARCH_THREADS);
+			const char *ww = getenv("KWAGE_WALK_WAVES");                     // tuning / tests: exactly this many waves
+			const uint64_t chip_waves = (uint64_t)std::max(ncu, 1)*(walk_unroll == 3 ? 8 : 16);
+			const uint64_t want_waves = (ww && atoi(ww) > 0) ? std::min<uint64_t>((uint64_t)atoi(ww), walk_slots)
+				: std::max<uint64_t>(1, std::min<uint64_t>(chip_waves, walk_slots*a.num_hash/WALK_MIN_ROWS_PER_WAVE));
+			const uint32_t wgs = (uint32_t)((want_waves + 3)/4);
+			const uint64_t waves = (uint64_t)wgs*4;
+			WalkArgs wa;
+			wa.total_slots = walk_slots;
+			wa.per_wave = (walk_slots + waves - 1)/waves;
+			wa.coltiles = coltiles;
+			// cut-pair slots: one per wave, 16 KiB each whatever CH is, zeroed when (re)allocated -- the kernel leaves them zero
+			const uint64_t or_bytes = waves*16*1024, done_bytes = waves*2*sizeof(uint32_t);
+			if(or_bytes > sl->walk_or.cap){
+				if((rc = sl->walk_or.reserve(or_bytes))){ return rc; }
+				HIP_TRY(hipMemsetAsync(sl->walk_or.p, 0, sl->walk_or.cap, sl->stream));
+			}
+			if(done_bytes > sl->walk_done.cap){
+				if((rc = sl->walk_done.reserve(done_bytes))){ return rc; }
+				HIP_TRY(hipMemsetAsync(sl->walk_done.p, 0, sl->walk_done.cap, sl->stream));
+			}
+			wa.orbuf = (uint32_t*)sl->walk_or.p;
+			wa.done = (uint32_t*)sl->walk_done.p;
+			{ const char *wf = getenv("KWAGE_WALK_FENCES"); wa.full_fences = (wf && atoi(wf) != 0) ? 1 : 0; }
+			a.segs = 1;
+			a.chunks = coltiles;
+			const bool walk_deep = (walk_unroll == 3);      // KWAGE_WALK=3: two rows, every KiB of both requested up front
+			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_walk_kernel<%u,%d%s>", walk_ch, (walk_deep || walk_unroll == 2) ? 2 : 4, walk_deep ? ",deep" : "");
+			const dim3 grid(wgs), block(SEARCH_THREADS);
 #define KWAGE_WALK_CASE(CH) case CH: \
-				if(walk_unroll == 2){ hipLaunchKernelGGL((and_walk_kernel<CH, 2>), grid, block, 0, sl->stream, wa); } \
-				else{ hipLaunchKernelGGL((and_walk_kernel<CH, 4>), grid, block, 0, sl->stream, wa); } break;
+				if(walk_deep){ hipLaunchKernelGGL((and_walk_kernel<CH, 2, true>), grid, block, 0, sl->stream, a, wa, a.rows, a.pos_off, a.nkmer); } \
+				else if(walk_unroll == 2){ hipLaunchKernelGGL((and_walk_kernel<CH, 2, false>), grid, block, 0, sl->stream, a, wa, a.rows, a.pos_off, a.nkmer); } \
+				else{ hipLaunchKernelGGL((and_walk_kernel<CH, 4, false>), grid, block, 0, sl->stream, a, wa, a.rows, a.pos_off, a.nkmer); } break;
 			switch(walk_ch){
 				KWAGE_WALK_CASE(3) KWAGE_WALK_CASE(4) KWAGE_WALK_CASE(5) KWAGE_WALK_CASE(6) KWAGE_WALK_CASE(7)
 				KWAGE_WALK_CASE(8) KWAGE_WALK_CASE(9) KWAGE_WALK_CASE(10) KWAGE_WALK_CASE(11) KWAGE_WALK_CASE(12)
@@ -535,7 +583,10 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 			HIP_TRY(hipMemsetAsync(sl->partial.p, 0xFF, bytes, sl->stream));
 			a.partial = (uint32_t*)sl->partial.p;
 		}
-		sl->kernel_name = "and_kernel";
+		{
+			const int eff_unroll = (cfg.unroll == 4) ? 4 : (cfg.unroll == 16 && cfg.vec < 4) ? 16 : (cfg.unroll == 32 && cfg.vec == 1) ? 32 : 8;     // launch_and_u
+			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_kernel<%d,%d,%s>%s", cfg.vec, eff_unroll, cfg.nt ? "nt" : "t", a.segs > 1 ? "+segments" : "");
+		}
 		if(cfg.nt){ launch_and_v<true>(a, sl->stream, cfg); }
 		else{ launch_and_v<false>(a, sl->stream, cfg); }
 		if(a.segs > 1){
@@ -545,26 +596,28 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 	else{
 		a.chunks = (a.units_per_row + WAVE - 1)/WAVE;
 		// counter planes: enough bits for the largest possible num_query_kmer of the batch
-		uint32_t bits = 1;
-		while(bits < 32 && (b->max_pos >> bits) != 0){ ++bits; }
-		const uint32_t planes = (bits <= 7) ? 7 : (bits <= 10) ? 10 : (bits <= 14) ? 14 : (bits <= 20) ? 20 : 32;
-		// the combine pass walks a query's segments serially per 16-byte unit: keep them few
-		choose_segments(a, b->max_pos, 64);
+		const uint32_t planes = planes_for(b->max_pos);
+		// Long queries: segments of the k-mer list are counted by different waves into a slab of partial counters
+		// and added by count_combine_kernel (a tree per (query, 64 units)); a segment's counters need only the
+		// planes its own k-mer count can reach.
+		choose_segments(a, b->max_pos, 1024);
+		uint32_t seg_planes = (a.segs > 1) ? planes_for(a.seg_kmers) : planes;
 		// keep the slab of partial counters bounded (1 GiB)
-		while(a.segs > 1 && (uint64_t)a.n_queries*a.segs*planes*g->stride > (1ull << 30)){
+		while(a.segs > 1 && (uint64_t)a.n_queries*a.segs*seg_planes*g->stride > (1ull << 30)){
 			const uint64_t want = a.segs/2;
 			a.seg_kmers = (uint32_t)((b->max_pos + want - 1)/std::max<uint64_t>(want, 1));
 			a.segs = (uint32_t)((b->max_pos + a.seg_kmers - 1)/a.seg_kmers);
+			seg_planes = (a.segs > 1) ? planes_for(a.seg_kmers) : planes;
 		}
 		if((uint64_t)a.n_queries*a.segs*a.chunks/4 + 1 > 0x7FFFFFFFull){ return fail(KWAGE_ERR_ARG, "batch too large for one launch"); }
 		if(a.segs > 1){
-			if((rc = sl->partial.reserve((uint64_t)a.n_queries*a.segs*planes*g->stride))){ return rc; }
+			if((rc = sl->partial.reserve((uint64_t)a.n_queries*a.segs*seg_planes*g->stride))){ return rc; }
 			a.partial = (uint32_t*)sl->partial.p;
 		}
 		static const bool narrow_ok = []() { const char *e = getenv("KWAGE_NARROW"); return !(e && atoi(e) == 0); }();
 		if(narrow_ok && a.segs == 1 && a.units_per_row <= 32 && a.units_per_row > 8 && a.n_queries >= 64 && planes <= 14){
 			// one reference file (<= 2048 columns = 16 units) or two: 4 resp. 2 queries per wave
-			sl->kernel_name = "count_narrow_kernel";
+			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_narrow_kernel<%u,%u,%d>", planes, a.num_hash, a.units_per_row <= 16 ? 4 : 2);
 			if(a.units_per_row <= 16){
 				if(planes == 7){ launch_count_narrow<7, 4>(a, sl->stream); }
 				else if(planes == 10){ launch_count_narrow<10, 4>(a, sl->stream); }
@@ -578,13 +631,23 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 			HIP_TRY(hipGetLastError());
 			return KWAGE_OK;
 		}
-		sl->kernel_name = "count_kernel";
-		switch(planes){
-			case 7: launch_count_nh<7>(a, sl->stream); break;
-			case 10: launch_count_nh<10>(a, sl->stream); break;
-			case 14: launch_count_nh<14>(a, sl->stream); break;
-			case 20: launch_count_nh<20>(a, sl->stream); break;
-			default: launch_count_nh<32>(a, sl->stream); break;
+		if(a.segs > 1){
+			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_kernel<%u,%u>+segments->%u", seg_planes, std::min(a.num_hash, 5u), planes);
+		}
+		else{
+			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_kernel<%u,%u>", planes, std::min(a.num_hash, 5u));
+		}
+		launch_count_planes(seg_planes, a, sl->stream);
+		if(a.segs > 1){
+			HIP_TRY(hipGetLastError());
+			switch(planes){
+				case 7: rc = launch_count_combine<7>(a, seg_planes, sl->stream); break;
+				case 10: rc = launch_count_combine<10>(a, seg_planes, sl->stream); break;
+				case 14: rc = launch_count_combine<14>(a, seg_planes, sl->stream); break;
+				case 20: rc = launch_count_combine<20>(a, seg_planes, sl->stream); break;
+				default: rc = launch_count_combine<32>(a, seg_planes, sl->stream); break;
+			}
+			if(rc){ return rc; }
 		}
 	}
 	HIP_TRY(hipGetLastError());
@@ -599,7 +662,7 @@ struct SearchOutcome {
 	uint64_t total_kmers = 0;
 	float kmer_ms = 0, search_ms = 0;
 	uint32_t launches = 0;
-	const char *kernel_name = "";
+	char kernel_name[64] = "";
 };
 
 // Enqueue, on the slot's stream: search kernel(s) + ONE D2H copy that brings back the counters, the
@@ -696,7 +759,7 @@ int collect_search(Slot *sl, SearchOutcome *out)
 	}
 	out->staged_hits = sl->staged_hits;
 	out->launches = sl->launches;
-	out->kernel_name = sl->kernel_name;
+	memcpy(out->kernel_name, sl->kernel_name, sizeof(out->kernel_name));
 	if(timing_kmer){ HIP_TRY(hipEventElapsedTime(&out->kmer_ms, sl->ev[0], sl->ev[1])); }
 	if(timing && sl->launches){ HIP_TRY(hipEventElapsedTime(&out->search_ms, sl->ev[2], sl->ev[3])); }
 	return KWAGE_OK;
@@ -770,6 +833,7 @@ extern "C" void kwage_shutdown(kwage_ctx *ctx)
 		if(sl->stream){ (void)hipStreamSynchronize(sl->stream); }
 		sl->rows.release(); sl->tables.release(); sl->result.release();
 		sl->partial.release(); sl->h_stage.release();
+		sl->walk_or.release(); sl->walk_done.release();
 		for(int i = 0; i < 4; ++i){ if(sl->ev[i]){ (void)hipEventDestroy(sl->ev[i]); } }
 		if(sl->search_done){ (void)hipEventDestroy(sl->search_done); }
 		if(sl->stream){ (void)hipStreamDestroy(sl->stream); }
@@ -1246,6 +1310,7 @@ struct ResultStorage {
 	kwage_result pub;
 	std::vector<kwage_hit> hits;
 	std::vector<uint32_t> nkmer, qthr;
+	char kernel[64];
 };
 
 // Build the host result of a collected search from the slot's staging buffer.
@@ -1289,7 +1354,8 @@ int build_result(Slot *sl, kwage_group *g, kwage_batch *b, const SearchOutcome &
 	r.kmer_kernel_ms = so.kmer_ms;
 	r.search_kernel_ms = so.search_ms;
 	r.search_kernel_launches = so.launches;
-	r.search_kernel = so.kernel_name;
+	memcpy(rs->kernel, so.kernel_name, sizeof(rs->kernel));
+	r.search_kernel = rs->kernel;
 	*out = &rs->pub;
 	return KWAGE_OK;
 }
@@ -1449,6 +1515,8 @@ int run_shared_kmer_pass(kwage_ctx *ctx, const kwage_params &p, kwage_batch *b, 
 	if((rc = layout_result(sl, b->n, 0, false))){ return rc; }
 	uint32_t lg = 10;
 	while((1ull << lg) < 2*std::max<uint64_t>(b->total_pos, 1)){ ++lg; }
+	// (KWAGE_SHARED_TABLE_LOG2 raises the table size: tests exercise the >= 2^32-slot arithmetic on small inputs)
+	if(const char *e = getenv("KWAGE_SHARED_TABLE_LOG2")){ lg = std::max<uint32_t>(lg, (uint32_t)atoi(e)); }
 	if(lg > 36){ return fail(KWAGE_ERR_ARG, "too many k-mer positions for one sample"); }
 	if((rc = sl->tables.reserve((1ull << lg)*sizeof(uint64_t)))){ return rc; }
 	HIP_TRY(hipMemsetAsync(sl->tables.p, 0xFF, (1ull << lg)*sizeof(uint64_t), ctx->stream));

@@ -6,9 +6,9 @@
 //                 (row index) + kwage.cpp:388 (float32 threshold).
 //   and_kernel    kwage.cpp:404-470 at threshold == 1.0f: gather the addressed bit-slice rows,
 //                 AND them (bloom.h:245-262), extract hits (kwage.cpp:489-538).
-//   and_walk_kernel  the same reduction for rows of 3..16 KiB and >= 900 queries: one workgroup per query,
-//                 each wave walks a quarter of the rows over the whole row width through bounds-checked
-//                 buffer loads; the quarters meet in LDS.
+//   and_walk_kernel  the same reduction for rows of 3..16 KiB: a persistent grid, every wave walks an equal share
+//                 of the batch's row list over the whole row width through bounds-checked buffer loads; (query,
+//                 tile) pairs cut by a share boundary are finished through a small OR buffer in memory.
 //   count_kernel  the threshold < 1 path: per k-mer AND over hashes, then bit-sliced (vertical)
 //                 per-column counters in registers instead of bloom.h:291-330's per-bit loop.
 //
@@ -45,11 +45,13 @@ __device__ __forceinline__ uint32_t table_log2(uint64_t npos)
 }
 
 // Insert into an open-addressing set. Returns true when this call created the entry.
+// Slot arithmetic is 64-bit: the shared table of a whole sample (Bloom construction) and the table of a query
+// above 2^30 positions have 2^32 slots or more.
 template <typename PTR>
 __device__ __forceinline__ bool set_insert(PTR tab, uint32_t lg, uint64_t w)
 {
-	const uint32_t mask = (1u << lg) - 1u;
-	uint32_t s = (uint32_t)((w * 0x9E3779B97F4A7C15ull) >> (64 - lg)) & mask;
+	const uint64_t mask = (1ull << lg) - 1ull;
+	uint64_t s = ((w * 0x9E3779B97F4A7C15ull) >> (64 - lg)) & mask;
 	while(true){
 		const unsigned long long old = atomicCAS(&tab[s], (unsigned long long)KM_EMPTY, (unsigned long long)w);
 		if(old == KM_EMPTY){ return true; }
@@ -361,87 +363,190 @@ __global__ __launch_bounds__(SEARCH_THREADS) void and_kernel(SearchArgs a)
 	}
 }
 
-// threshold == 1.0f, "walk" form of the gather + AND.
-// One 4-wave workgroup per (query, column tile of CH <= 16 KiB); wave w takes the w-th quarter of the query's
-// row list and walks each of its rows over the WHOLE tile width, UNROLL rows at a time, one KiB-chunk
-// after the other (CH accumulators per lane).  A row's consecutive KiB are then requested back to back by
-// one wave instead of by different waves at different times as in and_kernel's (query, 2 KiB tile) form.
-// Worth 1-2.4 % on rows of 12.5 KB (C2: 1.831 vs 1.876 ms, tools/tune_walk.py; the isolated access
-// patterns differ by 2-4 %, tools/micro/stream_variants.hip), nothing on 125 KB rows, so the host uses it
-// for rows of 3..16 KiB only.  The four quarter results meet in LDS (no global pass), wave 0 extracts hits.
-template <int CH, int UNROLL>
-__global__ __launch_bounds__(SEARCH_THREADS, 4) void and_walk_kernel(SearchArgs a)
-{
-	__shared__ uint32_t red[CH][4][WAVE];                // one CH-KiB mask: wave 0's result, ANDed into by waves 1..3
-	const uint32_t lane = threadIdx.x & (WAVE - 1);
-	const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const uint32_t q = blockIdx.x / a.chunks;            // a.chunks = column tiles per row here
-	const uint32_t c = blockIdx.x % a.chunks;
-	const uint32_t n = a.nkmer[q];
-	if(n == 0){ return; }                                // the whole workgroup leaves
-	const uint32_t per = (n + 3)/4;
-	const uint32_t k0 = min(n, w*per), k1 = min(n, k0 + per);
-	const uint32_t nrows = (k1 - k0)*a.num_hash;
-	const uint32_t *rq = a.rows + (a.pos_off[q] + k0)*a.num_hash;
+// threshold == 1.0f, "walk" form of the gather + AND for rows of 3..16 KiB: a wave walks each of its rows over
+// the WHOLE width of a column tile (CH KiB, CH accumulators per lane), UNROLL rows at a time, so a row's
+// consecutive KiB are requested back to back by one wave instead of by different waves at different times as in
+// and_kernel's (query, 2 KiB tile) form (+1-2.4 % on 12.5 KB rows, nothing on 125 KB rows).
+//
+// The grid is PERSISTENT and the work statically balanced: the launch has exactly as many waves as the chip
+// holds at once (or fewer for small batches), and the batch's concatenated position list -- `slots`: for every
+// query and column tile its positions, query-major -- is cut into equal contiguous ranges, one per wave.  Row
+// lists are addressed by position (pos_off) and trimmed to the distinct k-mers the k-mer stage found (nkmer),
+// so every wave reads the same number of bytes unless a query lost many positions to duplicates or N.  There is
+// no "last round": 1030 queries cost 1.03x what 1000 do.
+//   - a (query, tile) pair that lies inside one wave's range is reduced in registers and emitted at once;
+//   - a pair cut by a range boundary is finished through memory: every wave that holds a part folds its partial
+//     mask into the pair's slot (slot = the wave whose range holds the pair's first position, so no two cut
+//     pairs share one) -- an all-zero mask by raising a flag, anything else by ORing its complement into
+//     `orbuf` -- and adds its k-mer count to the slot's counter; the wave whose add completes the pair's nkmer
+//     reads the result back, emits, and leaves slot, flags and counter ZERO again: the buffers are cleared
+//     once when they are allocated, never per search.
+static constexpr uint32_t WALK_DEAD = 1u;      // some part of the pair has an all-zero mask: nothing to report
+static constexpr uint32_t WALK_DIRTY = 2u;     // some part ORed its mask into the slot: clear it when the pair is done
 
-	// Rows are read through buffer descriptors (base = the row, num_records = the row's bytes): the address of
-	// chunk j is "descriptor + lane offset + scalar j KiB" with no per-chunk vector arithmetic, and lanes past
-	// the row end (last chunk(s) of the last column tile) are bounds-checked by the hardware -- they return 0
-	// without touching memory, and are never reported.
-	const uint32_t u0 = c*CH*WAVE + lane;
+struct WalkArgs {
+	uint64_t total_slots;           // column tiles per row x positions of the batch
+	uint64_t per_wave;              // slots per wave: ceil(total_slots / waves of the launch)
+	uint32_t coltiles;              // column tiles per row (balanced, each <= 16 KiB)
+	uint32_t *orbuf;                // [waves][CH][4][64] complemented partial masks of the cut pairs
+	uint32_t *done;                 // [waves][2]: k-mers folded into the slot so far, and its WALK_DEAD / WALK_DIRTY flags
+	int full_fences;                // measurement only: agent-scope release/acquire fences around the count (see the kernel)
+};
+
+// (rows, pos_off and nkmer are passed as __restrict__ parameters of their own besides SearchArgs: the kernel stores
+// hits and updates the cut-pair slots inside its work loop, and only with the no-alias promise does the compiler
+// keep the row-index loads on the scalar path -- otherwise every row descriptor goes through a waterfall loop)
+template <int CH, int UNROLL, bool DEEP>
+__global__ __launch_bounds__(SEARCH_THREADS, DEEP ? 2 : 4) void and_walk_kernel(SearchArgs a, WalkArgs wa, const uint32_t *__restrict__ rows,
+                                                                     const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ nkmer)
+{
+	const uint32_t lane = threadIdx.x & (WAVE - 1);
+	const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x*(SEARCH_THREADS/WAVE) + (threadIdx.x >> 6));
+	uint64_t s = (uint64_t)gw*wa.per_wave;
+	const uint64_t s1 = min(wa.total_slots, s + wa.per_wave);
+	if(s >= s1){ return; }
+	const uint32_t ct = wa.coltiles;
 	const uint32_t row_bytes = a.units_per_row*16u;
-	u32x4 acc[CH];
-#pragma unroll
-	for(int j = 0; j < CH; ++j){ acc[j] = ~(u32x4)(0u); }
-	for(uint32_t i = 0; i < nrows; i += UNROLL){
-		__amdgpu_buffer_rsrc_t rs[UNROLL];
-#pragma unroll
-		for(int u = 0; u < UNROLL; ++u){
-			const uint32_t r = rq[min(i + u, nrows - 1)];        // past the end: the last row again (AND is idempotent)
-			rs[u] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.db + (uint64_t)r*a.stride), 0, row_bytes, 0x00020000);
-		}
-#pragma unroll
-		for(int j = 0; j < CH; ++j){
-			u32x4 x[UNROLL];
-#pragma unroll
-			for(int u = 0; u < UNROLL; ++u){ x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs[u], u0*16u, j*1024, 2 /* nt */); }
-#pragma unroll
-			for(int u = 0; u < UNROLL; ++u){ acc[j] &= x[u]; }
-		}
-		if(a.early_exit){     // kwage.cpp:466-470: this quarter alone already rules every column out
-			bool nz = false;
-#pragma unroll
-			for(int j = 0; j < CH; ++j){ nz |= ((acc[j].x | acc[j].y | acc[j].z | acc[j].w) != 0); }
-			if(!__any(nz)){ break; }
+	const uint32_t umax = a.units_per_row - 1;
+
+	// the query that holds slot s: the largest q with ct*pos_off[q] <= s (pos_off[n_queries]*ct = total_slots > s)
+	uint32_t q = 0;
+	{
+		uint32_t hi = a.n_queries;
+		while(hi - q > 1){
+			const uint32_t mid = q + (hi - q)/2;
+			if((uint64_t)ct*pos_off[mid] <= s){ q = mid; } else { hi = mid; }
 		}
 	}
-	// the four quarters meet in LDS: wave 0 stores its mask, the others AND theirs in (ds_and_b32; CH KiB of LDS
-	// per workgroup instead of 3*CH, which leaves room for the next batch's k-mer workgroups beside four resident
-	// walk workgroups per CU), wave 0 reads the result back
-	if(w == 0){
+
+	while(s < s1){
+		const uint64_t p0 = pos_off[q];
+		const uint64_t npos = pos_off[q + 1] - p0;
+		if(npos == 0){ ++q; continue; }                      // a query shorter than k: no slots (q stays in range: s < total_slots)
+		const uint64_t rem = s - (uint64_t)ct*p0;
+		const uint32_t c = __builtin_amdgcn_readfirstlane((uint32_t)(rem / npos));
+		const uint32_t j0 = __builtin_amdgcn_readfirstlane((uint32_t)(rem % npos));
+		const uint32_t take = (uint32_t)min(npos - j0, s1 - s);
+		const uint32_t j1 = j0 + take;
+		const uint32_t n = nkmer[q];
+		const uint32_t jv1 = min(j1, n);                     // positions past the distinct k-mers hold no rows
+		if(j0 < jv1){
+			const uint32_t nrows = (jv1 - j0)*a.num_hash;
+			const uint32_t *rq = rows + (p0 + j0)*a.num_hash;
+			// Rows are read through buffer descriptors (base = the row, num_records = the row's bytes): the address of
+			// chunk j is "descriptor + lane offset + scalar j KiB" with no per-chunk vector arithmetic, and lanes past
+			// the row end (last chunk(s) of the last column tile) are bounds-checked by the hardware -- they return 0
+			// without touching memory, and are never reported.
+			const uint32_t u0 = c*CH*WAVE + lane;
+			u32x4 acc[CH];
 #pragma unroll
-		for(int j = 0; j < CH; ++j){
+			for(int j = 0; j < CH; ++j){ acc[j] = ~(u32x4)(0u); }
+			for(uint32_t i = 0; i < nrows; i += UNROLL){
+				__amdgpu_buffer_rsrc_t rs[UNROLL];
 #pragma unroll
-			for(int d = 0; d < 4; ++d){ red[j][d][lane] = acc[j][d]; }
+				for(int u = 0; u < UNROLL; ++u){
+					const uint32_t r = rq[min(i + u, nrows - 1)];        // past the end: the last row again (AND is idempotent)
+					rs[u] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.db + (uint64_t)r*a.stride), 0, row_bytes, 0x00020000);
+				}
+				if(DEEP){
+					// all UNROLL x CH KiB requested before the first one is waited for (UNROLL*CH*4 VGPRs: 2 waves/SIMD)
+					u32x4 x[UNROLL][CH];
+#pragma unroll
+					for(int u = 0; u < UNROLL; ++u){
+#pragma unroll
+						for(int j = 0; j < CH; ++j){ x[u][j] = __builtin_amdgcn_raw_buffer_load_b128(rs[u], u0*16u, j*1024, 2 /* nt */); }
+					}
+					__builtin_amdgcn_sched_barrier(0);         // keep the scheduler from sinking the loads next to their uses
+#pragma unroll
+					for(int u = 0; u < UNROLL; ++u){
+#pragma unroll
+						for(int j = 0; j < CH; ++j){ acc[j] &= x[u][j]; }
+					}
+				}
+				else{
+#pragma unroll
+					for(int j = 0; j < CH; ++j){
+						u32x4 x[UNROLL];
+#pragma unroll
+						for(int u = 0; u < UNROLL; ++u){ x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs[u], u0*16u, j*1024, 2 /* nt */); }
+#pragma unroll
+						for(int u = 0; u < UNROLL; ++u){ acc[j] &= x[u]; }
+					}
+				}
+				if(a.early_exit){     // kwage.cpp:466-470: this part alone already rules every column of the tile out
+					bool nz = false;
+#pragma unroll
+					for(int j = 0; j < CH; ++j){ nz |= ((acc[j].x | acc[j].y | acc[j].z | acc[j].w) != 0); }
+					if(!__any(nz)){ break; }
+				}
+			}
+
+			bool emit = true;
+			if(j0 != 0 || jv1 != n){
+				// A cut pair: fold this part into the pair's slot; the part that completes the pair emits.
+				// A part whose mask is all zero (the rule after a few dozen random rows, unless a column really matches)
+				// decides the pair -- nothing can be reported -- so it only raises the slot's DEAD flag; only parts with
+				// surviving columns pay for ORing CH KiB of complemented mask into the slot (and raise DIRTY, so that
+				// whoever finishes the pair knows the slot has to be cleared).
+				const uint32_t slot = (uint32_t)(((uint64_t)ct*p0 + (uint64_t)c*npos)/wa.per_wave);
+				uint32_t *ob = wa.orbuf + (uint64_t)slot*(CH*4*WAVE) + lane;
+				uint32_t *state = wa.done + 2*(uint64_t)slot;                // [0] k-mers folded so far, [1] WALK_DEAD | WALK_DIRTY
+				bool nz = false;
+#pragma unroll
+				for(int j = 0; j < CH; ++j){ nz |= ((acc[j].x | acc[j].y | acc[j].z | acc[j].w) != 0); }
+				const bool live = __any(nz);
+				if(live){
+#pragma unroll
+					for(int j = 0; j < CH; ++j){
+#pragma unroll
+						for(int d = 0; d < 4; ++d){
+							const uint32_t v = ~acc[j][d];
+							if(v){ __hip_atomic_fetch_or(ob + (j*4 + d)*WAVE, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+						}
+					}
+				}
+				if(lane == 0){ __hip_atomic_fetch_or(state + 1, live ? WALK_DIRTY : WALK_DEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+				// The ORs and the flag must be performed before the count says so.  Everything this protocol exchanges
+				// goes through device-scope atomics, which are performed at the device's point of coherence and
+				// acknowledged from there, so waiting for the acknowledgements (vmcnt) orders them.  A C++ release fence
+				// would do it too but also writes the L2 back (buffer_wbl2 sc1) once per cut pair, and the waves all
+				// reach this point together at the end of the kernel: +0.14 ms per launch, measured (tools/walk_sizes.py,
+				// KWAGE_WALK_FENCES=1).
+				if(wa.full_fences){ __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+				else{ asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+				uint32_t old = 0;
+				if(lane == 0){ old = __hip_atomic_fetch_add(state, jv1 - j0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+				old = __builtin_amdgcn_readfirstlane(old);
+				emit = false;
+				if(old + (jv1 - j0) == n){                                       // this part completes the pair
+					if(wa.full_fences){ __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }       // (the reads below are device-scope loads)
+					const uint32_t fl = __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if(fl & WALK_DIRTY){
+						emit = !(fl & WALK_DEAD);
+#pragma unroll
+						for(int j = 0; j < CH; ++j){
+#pragma unroll
+							for(int d = 0; d < 4; ++d){
+								if(emit){ acc[j][d] = ~__hip_atomic_load(ob + (j*4 + d)*WAVE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+								__hip_atomic_store(ob + (j*4 + d)*WAVE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							}
+						}
+					}
+					if(lane == 0){
+						__hip_atomic_store(state, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						__hip_atomic_store(state + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					}
+				}
+			}
+			if(emit){
+#pragma unroll
+				for(int j = 0; j < CH; ++j){
+					emit_mask_hits(a, q, min(u0 + (uint32_t)j*WAVE, umax), acc[j], n, u0 + (uint32_t)j*WAVE <= umax);
+				}
+			}
 		}
-	}
-	__syncthreads();
-	if(w){
-#pragma unroll
-		for(int j = 0; j < CH; ++j){
-#pragma unroll
-			for(int d = 0; d < 4; ++d){ if(acc[j][d] != ~0u){ atomicAnd(&red[j][d][lane], acc[j][d]); } }
-		}
-	}
-	__syncthreads();
-	if(w == 0){
-		const uint32_t umax = a.units_per_row - 1;
-#pragma unroll
-		for(int j = 0; j < CH; ++j){
-#pragma unroll
-			for(int d = 0; d < 4; ++d){ acc[j][d] = red[j][d][lane]; }
-			emit_mask_hits(a, q, min(u0 + (uint32_t)j*WAVE, umax), acc[j], n, u0 + (uint32_t)j*WAVE <= umax);
-		}
+		s += take;
+		if(j1 == npos && c + 1 == ct){ ++q; }
 	}
 }
 
@@ -694,35 +799,63 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_narrow_kernel(SearchArgs
 	emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q], active);
 }
 
-// Second pass of the segmented count: add the per-segment bit-sliced counters (a ripple-carry
-// adder across planes, bit-parallel over columns), then threshold + emit.
-template <int PLANES>
-__global__ __launch_bounds__(256) void count_combine_kernel(SearchArgs a)
+// Add two bit-sliced counters: acc (PLANES planes) += b (the first nb planes of `b`, the rest zero).
+template <int PLANES, typename LOADB>
+__device__ __forceinline__ void planes_accumulate(u32x4 (&acc)[PLANES], int nb, LOADB loadb)
 {
-	const uint32_t u0 = blockIdx.x*blockDim.x + threadIdx.x;
+	u32x4 carry = (u32x4)(0u);
+#pragma unroll
+	for(int p = 0; p < PLANES; ++p){
+		const u32x4 b = (p < nb) ? loadb(p) : (u32x4)(0u);
+		const u32x4 x = acc[p] ^ b;
+		const u32x4 cnext = (acc[p] & b) | (carry & x);
+		acc[p] = x ^ carry;
+		carry = cnext;
+	}
+}
+
+// Second pass of the segmented count: add the per-segment bit-sliced counters (ripple-carry adders across
+// planes, bit-parallel over columns), then threshold + emit.  One workgroup per (query, 64 units); its
+// COMBINE_WAVES waves each add every COMBINE_WAVES-th segment -- loads of different segments are independent,
+// so they are all in flight together -- and the partial sums meet in LDS as a binary tree.  The slab holds
+// `seg_planes` planes per segment (enough for seg_kmers), the result PLANES (enough for the whole query).
+static constexpr int COMBINE_WAVES = 4;
+
+template <int PLANES>
+__global__ __launch_bounds__(COMBINE_WAVES*WAVE) void count_combine_kernel(SearchArgs a, uint32_t seg_planes)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char combine_lds[];     // (COMBINE_WAVES/2) x PLANES x 64 x 16 B
+	u32x4 (*red)[PLANES][WAVE] = reinterpret_cast<u32x4 (*)[PLANES][WAVE]>(combine_lds);
+	const uint32_t lane = threadIdx.x & (WAVE - 1);
+	const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t u0 = blockIdx.x*WAVE + lane;
 	const uint32_t q = blockIdx.y;
 	const uint32_t n = a.nkmer[q];
 	if(n == 0){ return; }                                  // uniform per workgroup
 	const bool on = (u0 < a.units_per_row);
 	const uint32_t unit = on ? u0 : 0;
 	const uint32_t nseg = (n + a.seg_kmers - 1)/a.seg_kmers;
-	const u32x4 *slab = reinterpret_cast<const u32x4*>(a.partial) + (uint64_t)q*a.segs*PLANES*a.units_per_row + unit;
+	const u32x4 *slab = reinterpret_cast<const u32x4*>(a.partial) + (uint64_t)q*a.segs*seg_planes*a.units_per_row + unit;
 	u32x4 plane[PLANES];
 #pragma unroll
-	for(int p = 0; p < PLANES; ++p){ plane[p] = slab[(uint64_t)p*a.units_per_row]; }
-	for(uint32_t sg = 1; sg < nseg; ++sg){
-		const u32x4 *s2 = slab + (uint64_t)sg*PLANES*a.units_per_row;
-		u32x4 carry = (u32x4)(0u);
-#pragma unroll
-		for(int p = 0; p < PLANES; ++p){
-			const u32x4 b = s2[(uint64_t)p*a.units_per_row];
-			const u32x4 x = plane[p] ^ b;
-			const u32x4 cnext = (plane[p] & b) | (carry & x);
-			plane[p] = x ^ carry;
-			carry = cnext;
-		}
+	for(int p = 0; p < PLANES; ++p){ plane[p] = (u32x4)(0u); }
+	for(uint32_t sg = w; sg < nseg; sg += COMBINE_WAVES){
+		const u32x4 *s2 = slab + (uint64_t)sg*seg_planes*a.units_per_row;
+		planes_accumulate<PLANES>(plane, (int)seg_planes, [&](int p){ return s2[(uint64_t)p*a.units_per_row]; });
 	}
-	emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q], on);
+#pragma unroll
+	for(int half = COMBINE_WAVES/2; half >= 1; half >>= 1){
+		if(w >= (uint32_t)half && w < 2u*half){
+#pragma unroll
+			for(int p = 0; p < PLANES; ++p){ red[w - half][p][lane] = plane[p]; }
+		}
+		__syncthreads();
+		if(w < (uint32_t)half){
+			planes_accumulate<PLANES>(plane, PLANES, [&](int p){ return red[w][p][lane]; });
+		}
+		__syncthreads();
+	}
+	if(w == 0){ emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q], on); }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1,38 +1,37 @@
-// kwage_amd/csrc/kwage_main.cpp -- the `kwage` command-line program, drop-in for the reference's
-// kwage.cpp: same options (options.cpp:39-192), same `.db` files, same CSV / JSON output
-// (output.h:35-112), but the two nested search loops of kwage.cpp:86-148 are replaced by
-// batched calls into the MI355X engine (include/kwage_amd.h):
+// kwage_amd/csrc/kwage_main.cpp -- the `kwage` command-line program, drop-in for the reference's kwage
+// (kwage.cpp main, options.cpp:39-192 for the option surface, output.h:35-112 for the report bytes): same
+// options, same `.db` files, same CSV / JSON output.  The structure is this repo's own:
 //
 //   reference:  for each .db file: for each query: search()  -- seek+read one slice per (k-mer, hash)
-//   here:       for each parameter group: load all its files' columns into one HBM matrix,
-//               then kwage_search() whole batches of queries against it.
+//   here:       for each parameter group: load all its files' columns into one HBM matrix, then STREAM the
+//               queries through it in batches (kwage_search_submit / _collect, two in flight): while the GPU
+//               searches batch i the host parses batch i+1.  Host memory is O(batch + hits), as in the
+//               reference (one record at a time, kwage.cpp:129-148), never O(query set).
 //
-// Results are order-independent, so the inversion is invisible in the
-// output.  Extra knobs are environment variables only, to keep the option surface verbatim:
+// Results are order-independent, so the loop inversion is invisible in the output.
+// Extra knobs are environment variables only, to keep the option surface verbatim:
 //   KWAGE_DEVICE      HIP device index (default 0)
 //   KWAGE_DEVICES     "all" or "0,1,...": shard the database files over several GPUs
 //   KWAGE_EARLY_EXIT  1 = enable the reference's early-exit shortcut on the device (default 1)
-//   KWAGE_BATCH_BASES max bases per query batch (default 256 Mi)
+//   KWAGE_BATCH_BASES max bases per query batch (default 64 Mi)
 //   KWAGE_MAX_GROUP_BYTES  cap on the HBM bit matrix of one pass (default: 7/8 of the free device memory);
 //                     larger parameter groups are searched in several passes over whole files
 //   KWAGE_VERBOSE     1 = per-stage wall times on stderr
 #include <algorithm>
 #include <chrono>
-#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
 #include <deque>
 #include <fstream>
-#include <iomanip>
 #include <iostream>
 #include <map>
+#include <memory>
 #include <mutex>
-#include <thread>
 #include <sstream>
 #include <string>
-#include <unordered_map>
+#include <thread>
 #include <vector>
 
 #include <dirent.h>
@@ -45,154 +44,236 @@
 using namespace std;
 using namespace kwage;
 
-#define KWAGE_VERSION "0.4d"                 // reference kwage.h:4 (usage text)
-#define DEFAULT_SEARCH_THRESHOLD 1.0f        // reference options.h:148
-
 namespace {
 
-struct SearchOptions {                       // reference options.h:16-41
-	enum { OUTPUT_CSV, OUTPUT_JSON };
-	deque<string> query_files, query_seq, subject_files;
-	string output_file;
-	float threshold = DEFAULT_SEARCH_THRESHOLD;
-	int output_format = OUTPUT_JSON;         // options.h:149
-	bool quit = false;
+// =====================================================================================================
+// command line
+// =====================================================================================================
+struct Cli {
+	enum Format { JSON, CSV };                  // JSON is the default (reference options.h:149)
+	vector<string> db_roots, query_files, query_seqs;
+	string output_path;
+	float threshold = 1.0f;                     // reference options.h:148
+	Format format = JSON;
+	bool show_usage = false;
 };
+
+// One row per flag: how getopt sees it and what it does.  Long-only flags get codes above the char range.
+struct FlagSpec {
+	int code;
+	const char *long_name;
+	bool takes_value;
+	void (*apply)(Cli &, const char *);
+};
+
+const FlagSpec FLAG_TABLE[] = {
+	{'o', nullptr, true, [](Cli &c, const char *v) { c.output_path = v; }},
+	{'d', nullptr, true, [](Cli &c, const char *v) { c.db_roots.push_back(v); }},
+	{'i', nullptr, true, [](Cli &c, const char *v) { c.query_files.push_back(v); }},
+	{'t', nullptr, true, [](Cli &c, const char *v) { c.threshold = (float)atof(v); }},     // atof -> float, as the reference stores it
+	{'h', nullptr, false, [](Cli &c, const char *) { c.show_usage = true; }},
+	{'?', nullptr, false, [](Cli &c, const char *) { c.show_usage = true; }},             // also what getopt reports for anything unknown
+	{256, "o.csv", false, [](Cli &c, const char *) { c.format = Cli::CSV; }},
+	{257, "o.json", false, [](Cli &c, const char *) { c.format = Cli::JSON; }},
+};
+
+const char *const USAGE_LINES[] = {
+	"Usage for KWAGE (v. 0.4d):",                                   // version string of reference kwage.h:4
+	"\t[-o <output file>] (default is stdout)",
+	"\t[--o.csv (output CSV) | --o.json (output JSON)]",
+	"\t[-t <search threshold>] (default is 1)",
+	"\t-d <database search path> (can be repeated)",
+	"\t[-i <input sequence file>] (can be repeated)",
+	"\t[<DNA sequence>] (can be repeated)",
+};
+
+const char *const QUERY_SUFFIXES[] = {".fna", ".fna.gz", ".fasta", ".fasta.gz", ".fa", ".fa.gz", ".fastq", ".fastq.gz"};
+
+// The reference accepts a query file name when the FIRST occurrence of some suffix sits at the very end
+// (options.cpp:158-169): "reads.fa.fa" is refused.  Observable, so kept.
+bool accepted_query_name(const string &name)
+{
+	return any_of(begin(QUERY_SUFFIXES), end(QUERY_SUFFIXES), [&](const char *sfx) {
+		const size_t n = strlen(sfx);
+		return n <= name.size() && name.find(sfx) == name.size() - n;
+	});
+}
 
 // Database files: `.db` (options.cpp:30-33) and `.dbz`, which the reference's README.md:260 names but
 // its option parser never accepted (this repo's compressed container).
-static bool is_db_file(const string &p) { return find_file_extension(p, ".db") || find_file_extension(p, ".dbz"); }
+bool is_db_file(const string &p) { return find_file_extension(p, ".db") || find_file_extension(p, ".dbz"); }
 
 // Breadth-first walk in readdir order: regular files are reported as met, directories queued
 // (reference file_util.h:30-125).
-struct FindFiles {
-	deque<string> targets;
-	void add(const string &p) { targets.push_back(p); }
-	void run(deque<string> &out_db)
-	{
-		while(!targets.empty()){
-			const string p = targets.front();
-			targets.pop_front();
-			struct stat st;
-			if(stat(p.c_str(), &st) != 0){ throw "FindFiles::next: Unable to stat entry"; }
-			if(S_ISREG(st.st_mode)){
-				if(is_db_file(p)){ out_db.push_back(p); }
-				continue;
-			}
-			if(!S_ISDIR(st.st_mode)){ throw "FindFiles::next: Unknown filesystem object"; }
-			DIR *dp = opendir(p.c_str());
-			if(!dp){ throw "FindFiles::next: Unable to open directory for reading"; }
-			while(struct dirent *d = readdir(dp)){
-				if(d->d_ino == 0 || !strcmp(d->d_name, ".") || !strcmp(d->d_name, "..")){ continue; }
-				const string name = p + '/' + d->d_name;
-				struct stat ds;
-				if(stat(name.c_str(), &ds) != 0){ closedir(dp); throw "FindFiles::next: Unable to stat entry (2)"; }
-				if(S_ISDIR(ds.st_mode)){ targets.push_back(name); }
-				else if(S_ISREG(ds.st_mode) && is_db_file(name)){ out_db.push_back(name); }
-			}
-			closedir(dp);
-		}
-	}
-};
-
-void parse_options(int argc, char *argv[], SearchOptions &o)     // reference options.cpp:39-192
+void find_database_files(const vector<string> &roots, vector<string> &out_db)
 {
-	const char *options = "o:d:i:t:h?";
-	int config_opt = 0, long_index = 0;
-	struct option long_opts[] = {
-		{"o.csv", false, &config_opt, 1},
-		{"o.json", false, &config_opt, 2},
-		{0, 0, 0, 0}
-	};
-	int opt_code;
-	opterr = 0;
-	bool print_usage = (argc == 1);
-	FindFiles ff;
-
-	while((opt_code = getopt_long(argc, argv, options, long_opts, &long_index)) != EOF){
-		switch(opt_code){
-			case 0:
-				if(config_opt == 1){ o.output_format = SearchOptions::OUTPUT_CSV; break; }
-				if(config_opt == 2){ o.output_format = SearchOptions::OUTPUT_JSON; break; }
-				cerr << "Unknown flag!" << endl;
-				break;
-			case 'o': o.output_file = optarg; break;
-			case 'i': o.query_files.push_back(optarg); break;
-			case 'd': ff.add(optarg); break;
-			case 't': o.threshold = atof(optarg); break;
-			case 'h':
-			case '?': print_usage = true; break;
-			default:
-				cerr << '\"' << (char)opt_code << "\" is not a valid option!" << endl;
-				break;
+	deque<string> todo(roots.begin(), roots.end());
+	while(!todo.empty()){
+		const string p = todo.front();
+		todo.pop_front();
+		struct stat st;
+		if(stat(p.c_str(), &st) != 0){ throw "FindFiles::next: Unable to stat entry"; }
+		if(S_ISREG(st.st_mode)){
+			if(is_db_file(p)){ out_db.push_back(p); }
+			continue;
 		}
-	}
-
-	if(print_usage){
-		o.quit = true;
-		cerr << "Usage for KWAGE (v. " << KWAGE_VERSION << "):" << endl;
-		cerr << "\t[-o <output file>] (default is stdout)" << endl;
-		cerr << "\t[--o.csv (output CSV) | --o.json (output JSON)]" << endl;
-		cerr << "\t[-t <search threshold>] (default is " << DEFAULT_SEARCH_THRESHOLD << ")" << endl;
-		cerr << "\t-d <database search path> (can be repeated)" << endl;
-		cerr << "\t[-i <input sequence file>] (can be repeated)" << endl;
-		cerr << "\t[<DNA sequence>] (can be repeated)" << endl;
-		return;
-	}
-
-	for(int i = optind; i < argc; i++){ o.query_seq.push_back(argv[i]); }
-
-	ff.run(o.subject_files);
-
-	if(o.subject_files.empty()){
-		cerr << "Please provide at least one database file to search (-d)" << endl;
-		o.quit = true;
-		return;
-	}
-	if(o.query_files.empty() && o.query_seq.empty()){
-		cerr << "Please provide at least one query sequence or file" << endl;
-		o.quit = true;
-		return;
-	}
-	static const char *allowed_sequence_extentions[] = {     // options.cpp:22-28
-		".fna", ".fna.gz", ".fasta", ".fasta.gz", ".fa", ".fa.gz", ".fastq", ".fastq.gz", NULL
-	};
-	for(deque<string>::const_iterator i = o.query_files.begin(); i != o.query_files.end(); ++i){
-		bool valid = false;
-		for(const char **ext = allowed_sequence_extentions; *ext != NULL; ++ext){
-			const size_t ext_len = strlen(*ext);
-			if(ext_len > i->size()){ continue; }
-			if(i->find(*ext) == (i->size() - ext_len)){ valid = true; break; }     // case-sensitive, first occurrence
+		if(!S_ISDIR(st.st_mode)){ throw "FindFiles::next: Unknown filesystem object"; }
+		DIR *dp = opendir(p.c_str());
+		if(!dp){ throw "FindFiles::next: Unable to open directory for reading"; }
+		while(struct dirent *d = readdir(dp)){
+			if(d->d_ino == 0 || !strcmp(d->d_name, ".") || !strcmp(d->d_name, "..")){ continue; }
+			const string name = p + '/' + d->d_name;
+			struct stat ds;
+			if(stat(name.c_str(), &ds) != 0){ closedir(dp); throw "FindFiles::next: Unable to stat entry (2)"; }
+			if(S_ISDIR(ds.st_mode)){ todo.push_back(name); }
+			else if(S_ISREG(ds.st_mode) && is_db_file(name)){ out_db.push_back(name); }
 		}
-		if(!valid){
-			cerr << "The query sequence file name, " << *i << ", does not have an allowed file extension" << endl;
-			o.quit = true;
-			return;
-		}
-	}
-	if((o.threshold <= 0.0) || (o.threshold > 1.0)){
-		cerr << "Please provide: 0.0 < search threshold <= 1.0" << endl;
-		o.quit = true;
-		return;
+		closedir(dp);
 	}
 }
 
-// One hit, before its metadata is fetched (reference output.h:9-33 MatchResult).
+// Parse argv into `cli` and the list of database files.  Returns false when the program should stop
+// (usage shown or a complaint printed) -- with exit status 0, like the reference.
+bool read_command_line(int argc, char *argv[], Cli &cli, vector<string> &db_files)
+{
+	string shorts;
+	vector<struct option> longs;
+	for(const FlagSpec &f : FLAG_TABLE){
+		if(f.long_name){ longs.push_back({f.long_name, f.takes_value ? required_argument : no_argument, nullptr, f.code}); }
+		else{ shorts += (char)f.code; if(f.takes_value){ shorts += ':'; } }
+	}
+	longs.push_back({nullptr, 0, nullptr, 0});
+	opterr = 0;
+	cli.show_usage = (argc == 1);
+	for(int code; (code = getopt_long(argc, argv, shorts.c_str(), longs.data(), nullptr)) != -1; ){
+		const FlagSpec *f = find_if(begin(FLAG_TABLE), end(FLAG_TABLE), [&](const FlagSpec &x) { return x.code == code; });
+		if(f != end(FLAG_TABLE)){ f->apply(cli, optarg); }
+	}
+	if(cli.show_usage){
+		for(const char *line : USAGE_LINES){ cerr << line << endl; }
+		return false;
+	}
+	cli.query_seqs.assign(argv + optind, argv + argc);          // getopt has moved the non-options to the end
+	find_database_files(cli.db_roots, db_files);
+
+	const string *bad_name = nullptr;
+	for(const string &q : cli.query_files){ if(!bad_name && !accepted_query_name(q)){ bad_name = &q; } }
+	// complaints in the reference's order; the first that applies ends the run
+	const struct { bool failed; string text; } checks[] = {
+		{db_files.empty(), "Please provide at least one database file to search (-d)"},
+		{cli.query_files.empty() && cli.query_seqs.empty(), "Please provide at least one query sequence or file"},
+		{bad_name != nullptr, "The query sequence file name, " + (bad_name ? *bad_name : string()) + ", does not have an allowed file extension"},
+		{(cli.threshold <= 0.0) || (cli.threshold > 1.0), "Please provide: 0.0 < search threshold <= 1.0"},
+	};
+	for(const auto &c : checks){
+		if(c.failed){ cerr << c.text << endl; return false; }
+	}
+	return true;
+}
+
+// =====================================================================================================
+// queries, streamed
+// =====================================================================================================
+// One hit, before its metadata is fetched (what the reference keeps as output.h:9-33 MatchResult).
 struct Match {
 	unsigned int num_kmers_found;
 	unsigned int num_query_kmer;
-	uint32_t file_index;      // index into opt.subject_files
+	uint32_t file_index;      // index into the list of database files
 	uint32_t column;          // column within that file
-	bool operator<(const Match &rhs) const { return num_kmers_found > rhs.num_kmers_found; }   // descending
 };
 
-typedef unordered_map<size_t, deque<Match> > ResultMap;
-
-struct Query {
-	size_t id;
-	string seq;
+// Everything the report needs, keyed by query id (ordered: the report walks ids ascending).
+struct Findings {
+	map<size_t, vector<Match> > by_query;
+	map<size_t, string> defline;            // file queries only, and only those with a hit (kwage.cpp:137-143)
+	void absorb(Findings &other)
+	{
+		for(auto &kv : other.by_query){
+			vector<Match> &dst = by_query[kv.first];
+			dst.insert(dst.end(), kv.second.begin(), kv.second.end());
+		}
+		for(auto &kv : other.defline){ defline.emplace(kv.first, std::move(kv.second)); }
+	}
 };
 
+// A batch of queries as kwage_batch_create wants it, plus what maps hits back to the caller's ids.
+struct QueryBatch {
+	string bases;                   // concatenated sequences
+	vector<uint64_t> offsets;       // n + 1
+	vector<size_t> ids;
+	vector<string> deflines;        // empty for command-line sequences
+	size_t size() const { return ids.size(); }
+	void clear() { bases.clear(); offsets.assign(1, 0); ids.clear(); deflines.clear(); }
+	void add(size_t id, const string &seq, const string *defline)
+	{
+		bases += seq;
+		offsets.push_back(bases.size());
+		ids.push_back(id);
+		if(defline){ deflines.push_back(*defline); }
+	}
+};
+
+// Where batches come from.  fill() appends queries until the batch holds `max_bases` (always at least one
+// query) and returns false once the source is exhausted and the batch is empty.
+struct QuerySource {
+	virtual ~QuerySource() {}
+	virtual bool fill(QueryBatch &b, uint64_t max_bases) = 0;
+};
+
+const size_t MAX_QUERIES_PER_BATCH = 1u << 24;
+
+struct CommandLineQueries : QuerySource {
+	const vector<string> &seqs;
+	size_t next = 0;
+	explicit CommandLineQueries(const vector<string> &s) : seqs(s) {}
+	bool fill(QueryBatch &b, uint64_t max_bases) override
+	{
+		b.clear();
+		while(next < seqs.size() && b.size() < MAX_QUERIES_PER_BATCH && (b.size() == 0 || b.bases.size() + seqs[next].size() <= max_bases)){
+			b.add(next, seqs[next], nullptr);          // the id is the position on the command line (kwage.cpp:119-125)
+			++next;
+		}
+		return b.size() != 0;
+	}
+};
+
+// The records of the -i files, one after the other; ids run on across files (kwage.cpp:127-147).
+struct FileQueries : QuerySource {
+	const vector<string> &paths;
+	size_t file = 0, next_id = 0;
+	SeqFile reader;
+	bool open = false, held = false;            // held: reader.seq / curr_defline is a record that did not fit the last batch
+	explicit FileQueries(const vector<string> &p) : paths(p) {}
+	bool fill(QueryBatch &b, uint64_t max_bases) override
+	{
+		b.clear();
+		string err;
+		while(b.size() < MAX_QUERIES_PER_BATCH){
+			if(!held){
+				if(!open){
+					if(file == paths.size()){ break; }
+					if(!reader.open(paths[file], err)){
+						cerr << err << endl;
+						throw "SequenceIterator::SequenceIterator: Unable to open sequence file";
+					}
+					open = true;
+				}
+				const int r = reader.next(err);
+				if(r < 0){ throw err; }
+				if(r == 0){ open = false; ++file; continue; }
+				held = true;
+			}
+			if(b.size() != 0 && b.bases.size() + reader.seq.size() > max_bases){ break; }
+			b.add(next_id++, reader.seq, &reader.curr_defline);
+			held = false;
+		}
+		return b.size() != 0;
+	}
+};
+
+// =====================================================================================================
+// search
+// =====================================================================================================
 struct DbFileEntry {
 	string path;
 	kwage_db_header header;
@@ -204,121 +285,213 @@ void check(int rc)
 	if(rc != KWAGE_OK){ throw string(kwage_last_error()); }
 }
 
-// Search one set of queries against one loaded group; append matches.  Batches are software-pipelined
-// through the context's two search slots: batch i+1 is submitted before batch i is collected, so the
-// host-side mapping of hits overlaps with the device work of the next batch.
-void search_queries(kwage_ctx *ctx, kwage_group *grp, const vector<DbFileEntry*> &files,
-                    const vector<uint32_t> &file_index, const vector<Query> &queries, float threshold,
-                    uint32_t flags, uint64_t max_batch_bases, ResultMap &results)
+// The columns of one loaded group: which file each global column came from.
+struct ColumnMap {
+	vector<const DbFileEntry*> files;      // increasing first_column
+	vector<uint32_t> file_index;
+	void locate(uint32_t column, uint32_t &file, uint32_t &local) const
+	{
+		size_t lo = 0, hi = files.size();
+		while(hi - lo > 1){
+			const size_t mid = (lo + hi)/2;
+			if(files[mid]->first_column <= column){ lo = mid; } else { hi = mid; }
+		}
+		file = file_index[lo];
+		local = (uint32_t)(column - files[lo]->first_column);
+	}
+};
+
+// Stream one query source through one loaded group.  Two batches are in flight: batch i+1 is parsed and
+// submitted while the device works on batch i, then batch i is collected and its hits mapped.
+void search_stream(kwage_ctx *ctx, kwage_group *grp, const ColumnMap &cols, QuerySource &source, float threshold,
+                   uint32_t flags, uint64_t max_batch_bases, Findings &found)
 {
 	struct InFlight {
-		kwage_batch *batch = NULL;
-		kwage_pending *pending = NULL;
-		size_t q0 = 0;
+		QueryBatch q;
+		kwage_batch *batch = nullptr;
+		kwage_pending *pending = nullptr;
+	};
+	InFlight slot[2];
+	auto drop = [](InFlight &f) {
+		if(f.pending){ kwage_result *r = nullptr; if(kwage_search_collect(f.pending, &r) == KWAGE_OK){ kwage_result_free(r); } f.pending = nullptr; }
+		if(f.batch){ kwage_batch_destroy(f.batch); f.batch = nullptr; }
 	};
 	auto finish = [&](InFlight &f) {
-		kwage_result *res = NULL;
+		kwage_result *res = nullptr;
 		const int rc = kwage_search_collect(f.pending, &res);
-		f.pending = NULL;
-		if(rc != KWAGE_OK){ kwage_batch_destroy(f.batch); f.batch = NULL; check(rc); }
+		f.pending = nullptr;
+		if(rc != KWAGE_OK){ drop(f); check(rc); }
 		for(uint64_t i = 0; i < res->n_hits; ++i){
 			const kwage_hit &h = res->hits[i];
-			// global column -> (file, local column): files are laid out in increasing first_column
-			size_t lo = 0, hi = files.size();
-			while(hi - lo > 1){
-				const size_t mid = (lo + hi)/2;
-				if(files[mid]->first_column <= h.column){ lo = mid; } else { hi = mid; }
-			}
 			Match m;
 			m.num_kmers_found = h.num_match;
 			m.num_query_kmer = res->num_query_kmer[h.query];
-			m.file_index = file_index[lo];
-			m.column = (uint32_t)(h.column - files[lo]->first_column);
-			results[queries[f.q0 + h.query].id].push_back(m);
+			cols.locate(h.column, m.file_index, m.column);
+			const size_t id = f.q.ids[h.query];
+			found.by_query[id].push_back(m);
+			if(!f.q.deflines.empty()){ found.defline.emplace(id, f.q.deflines[h.query]); }
 		}
 		kwage_result_free(res);
-		kwage_batch_destroy(f.batch);
-		f.batch = NULL;
+		drop(f);
 	};
-
-	InFlight prev;
-	size_t q0 = 0;
 	try{
-		while(q0 < queries.size()){
-			// assemble one batch
-			string concat;
-			vector<uint64_t> offs(1, 0);
-			size_t q1 = q0;
-			while(q1 < queries.size() && (q1 == q0 || concat.size() + queries[q1].seq.size() <= max_batch_bases) &&
-			      (q1 - q0) < (1u << 24)){
-				concat += queries[q1].seq;
-				offs.push_back(concat.size());
-				++q1;
-			}
-			InFlight cur;
-			cur.q0 = q0;
-			check(kwage_batch_create(ctx, concat.data(), offs.data(), (uint32_t)(q1 - q0), &cur.batch));
-			const int rc = kwage_search_submit(grp, cur.batch, threshold, flags, &cur.pending);
-			if(rc != KWAGE_OK){ kwage_batch_destroy(cur.batch); check(rc); }
-			if(prev.pending){ finish(prev); }
-			prev = cur;
-			q0 = q1;
+		int cur = 0;
+		while(source.fill(slot[cur].q, max_batch_bases)){
+			InFlight &f = slot[cur];
+			check(kwage_batch_create(ctx, f.q.bases.data(), f.q.offsets.data(), (uint32_t)f.q.size(), &f.batch));
+			check(kwage_search_submit(grp, f.batch, threshold, flags, &f.pending));
+			f.q.bases = string();                                  // resident on the device now
+			if(slot[cur ^ 1].pending){ finish(slot[cur ^ 1]); }
+			cur ^= 1;
 		}
-		if(prev.pending){ finish(prev); }
+		if(slot[cur ^ 1].pending){ finish(slot[cur ^ 1]); }
 	}
 	catch(...){
-		if(prev.pending){ kwage_result *r = NULL; if(kwage_search_collect(prev.pending, &r) == KWAGE_OK){ kwage_result_free(r); } }
-		if(prev.batch){ kwage_batch_destroy(prev.batch); }
+		drop(slot[0]);
+		drop(slot[1]);
 		throw;
 	}
 }
 
-// reference output.h:35-54
-void write_csv_header(ostream &out) { out << "query,num_kmers,num_kmers_found,percent_kmers_found,sample_metadata\n"; }
-
-void write_csv(ostream &out, const string &query, const deque<Match> &ms, const vector<DbInfo> &infos)
+// =====================================================================================================
+// report (bytes as the reference's output.h:35-112 writes them; the text is data, the printer generic)
+// =====================================================================================================
+string number(const char *fmt, double v)
 {
-	for(deque<Match>::const_iterator i = ms.begin(); i != ms.end(); ++i){
-		const float norm = i->num_query_kmer ? 1.0f/i->num_query_kmer : 0.0f;
-		FilterInfo fi;
-		if(!infos[i->file_index].info(i->column, fi)){ throw "binary_read<FilterInfo>: Unable to read FilterInfo"; }
-		out << '"' << query << "\"," << i->num_query_kmer << ',' << i->num_kmers_found << ','
-			<< (100.0f*i->num_kmers_found)*norm << ",\"" << fi.csv_string() << '"' << std::endl;
-	}
+	char buf[64];
+	snprintf(buf, sizeof(buf), fmt, v);
+	return buf;
 }
 
-// reference output.h:61-112
-void write_json_header(ostream &out, bool multiple) { if(multiple){ out << '['; } }
+struct Report {
+	virtual ~Report() {}
+	virtual void begin(size_t queries_with_hits) = 0;
+	virtual void query(const string &name, const vector<Match> &ms, const vector<DbInfo> &infos) = 0;
+	virtual void end() = 0;
+};
 
-void write_json(ostream &out, const string &query, bool multiple, bool first_match, const float &threshold,
-                const deque<Match> &ms, const vector<DbInfo> &infos)
+FilterInfo metadata_of(const Match &m, const vector<DbInfo> &infos)
 {
-	const string prefix = multiple ? "\t" : "";
-	out << ((multiple && !first_match) ? "," : "") << '\n' << prefix
-		<< "{\n" << prefix << "\t\"query\": \"" << query << "\",\n" << prefix
-		<< "\t\"threshold\": "
-		<< std::showpoint << std::setprecision(1) << std::fixed << threshold
-		<< ",\n" << prefix << "\t\"results\": [";
-	for(deque<Match>::const_iterator i = ms.begin(); i != ms.end(); ++i){
-		const float norm = i->num_query_kmer ? 1.0f/i->num_query_kmer : 0.0f;
-		FilterInfo fi;
-		if(!infos[i->file_index].info(i->column, fi)){ throw "binary_read<FilterInfo>: Unable to read FilterInfo"; }
-		out << ((i != ms.begin()) ? "," : "")
-			<< "\n" << prefix << "\t\t{\n" << prefix
-			<< "\t\t\t\"percent_kmers_found\": "
-			<< (100.0*i->num_kmers_found)*norm
-			<< ",\n" << prefix << "\t\t\t\"num_kmers\": " << i->num_query_kmer
-			<< ",\n" << prefix << "\t\t\t\"num_kmers_found\": " << i->num_kmers_found
-			<< ",\n" << prefix << "\t\t\t\"sample_metadata\": {\n"
-			<< fi.json_string(prefix + "\t\t\t\t")
-			<< "\n" << prefix
-			<< "\t\t\t}\n" << prefix << "\t\t}";
-	}
-	if(!ms.empty()){ out << "\n" << prefix << '\t'; }
-	out << "]\n" << prefix << "}";
+	FilterInfo fi;
+	if(!infos[m.file_index].info(m.column, fi)){ throw "binary_read<FilterInfo>: Unable to read FilterInfo"; }
+	return fi;
 }
 
-void write_json_footer(ostream &out, bool multiple) { if(multiple){ out << "\n]\n"; } }
+struct CsvReport : Report {
+	ostream &out;
+	explicit CsvReport(ostream &o) : out(o) {}
+	void begin(size_t) override { out << "query,num_kmers,num_kmers_found,percent_kmers_found,sample_metadata\n"; }
+	void query(const string &name, const vector<Match> &ms, const vector<DbInfo> &infos) override
+	{
+		for(const Match &m : ms){
+			// float arithmetic and the stream's default float format (6 significant digits), output.h:43-51
+			const float norm = m.num_query_kmer ? 1.0f/m.num_query_kmer : 0.0f;
+			const float percent = (100.0f*m.num_kmers_found)*norm;
+			out << '"' << name << "\"," << m.num_query_kmer << ',' << m.num_kmers_found << ',' << number("%.6g", percent)
+			    << ",\"" << metadata_of(m, infos).csv_string() << "\"\n";
+		}
+		out.flush();
+	}
+	void end() override {}
+};
+
+// A pretty printer with ONE layout rule for objects and arrays: every member starts on a new line, one tab
+// deeper than its container; the closing bracket of a non-empty container goes on a line of its own at the
+// container's depth; an empty array closes at once.  The reference's hand-written JSON follows this rule
+// throughout, including its habit of starting the document with a newline.
+struct JsonPrinter {
+	ostream &out;
+	struct Level { size_t members; };
+	vector<Level> stack;
+	int base_depth;                 // -1: the top-level list is not wrapped in [ ]
+	JsonPrinter(ostream &o, bool wrapped) : out(o), base_depth(wrapped ? 0 : -1)
+	{
+		stack.push_back(Level{0});
+		if(wrapped){ out << '['; }
+	}
+	string indent(int extra = 0) const { const int d = base_depth + (int)stack.size() - 1 + extra; return string(d > 0 ? (size_t)d : 0, '\t'); }
+	void member()
+	{
+		out << (stack.back().members++ ? "," : "") << '\n' << indent(1);
+	}
+	void key(const char *name) { member(); out << '"' << name << "\": "; }
+	void open(char bracket) { out << bracket; stack.push_back(Level{0}); }
+	void close(char bracket, bool own_line_even_if_empty)
+	{
+		const bool any = stack.back().members != 0;
+		stack.pop_back();
+		if(any || own_line_even_if_empty){ out << '\n' << indent(1); }
+		out << bracket;
+	}
+	void finish() { if(base_depth == 0){ out << "\n]\n"; } }
+};
+
+struct JsonReport : Report {
+	ostream &out;
+	float threshold;
+	unique_ptr<JsonPrinter> js;
+	JsonReport(ostream &o, float t) : out(o), threshold(t) {}
+	void begin(size_t queries_with_hits) override { js.reset(new JsonPrinter(out, queries_with_hits > 1)); }     // [ ] only around several
+	void query(const string &name, const vector<Match> &ms, const vector<DbInfo> &infos) override
+	{
+		JsonPrinter &j = *js;
+		j.member(); j.open('{');
+		j.key("query"); out << '"' << name << '"';
+		j.key("threshold"); out << number("%.1f", threshold);                     // fixed, one decimal (output.h:73-75)
+		j.key("results"); j.open('[');
+		for(const Match &m : ms){
+			// double arithmetic with a float reciprocal, printed fixed with one decimal (the reference's stream
+			// flags stay set after the threshold), output.h:82-90
+			const float norm = m.num_query_kmer ? 1.0f/m.num_query_kmer : 0.0f;
+			const double percent = (100.0*m.num_kmers_found)*norm;
+			j.member(); j.open('{');
+			j.key("percent_kmers_found"); out << number("%.1f", percent);
+			j.key("num_kmers"); out << m.num_query_kmer;
+			j.key("num_kmers_found"); out << m.num_kmers_found;
+			j.key("sample_metadata"); out << "{\n" << metadata_of(m, infos).json_string(j.indent(2)) << '\n' << j.indent(1) << '}';
+			j.close('}', true);
+		}
+		j.close(']', false);
+		j.close('}', true);
+	}
+	void end() override { if(js){ js->finish(); } }
+};
+
+double now_s() { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// resident set size of this process in MB, now and at its peak (KWAGE_VERBOSE)
+string rss_mb()
+{
+	ifstream st("/proc/self/status");
+	string line, cur = "?", peak = "?";
+	while(getline(st, line)){
+		if(line.compare(0, 6, "VmRSS:") == 0){ cur = to_string(atol(line.c_str() + 6)/1024); }
+		if(line.compare(0, 6, "VmHWM:") == 0){ peak = to_string(atol(line.c_str() + 6)/1024); }
+	}
+	return cur + " MB resident (peak " + peak + ")";
+}
+
+uint64_t env_u64(const char *name, uint64_t fallback)
+{
+	const char *e = getenv(name);
+	return e ? strtoull(e, nullptr, 10) : fallback;
+}
+
+vector<int> chosen_devices()
+{
+	vector<int> devices;
+	if(const char *dl = getenv("KWAGE_DEVICES")){
+		if(string(dl) == "all"){
+			for(int d = 0; d < kwage_device_count(); ++d){ devices.push_back(d); }
+		}
+		else{
+			stringstream ss(dl);
+			for(string tok; getline(ss, tok, ','); ){ if(!tok.empty()){ devices.push_back(atoi(tok.c_str())); } }
+		}
+	}
+	if(devices.empty()){ devices.push_back((int)env_u64("KWAGE_DEVICE", 0)); }
+	return devices;
+}
 
 }  // namespace
 
@@ -328,28 +501,27 @@ int main(int argc, char *argv[])
 	// (HIP's default is 4 queues per device for all streams of the process); an explicit setting wins
 	setenv("GPU_MAX_HW_QUEUES", "8", 0);
 	try{
-		time_t profile = time(NULL);
+		const time_t started = time(nullptr);
 
-		SearchOptions opt;
-		parse_options(argc, argv, opt);
-		if(opt.quit){ return EXIT_SUCCESS; }
+		Cli cli;
+		vector<string> db_paths;
+		if(!read_command_line(argc, argv, cli, db_paths)){ return EXIT_SUCCESS; }
 
 		ofstream fout;
-		if(!opt.output_file.empty()){
-			fout.open(opt.output_file.c_str());
+		if(!cli.output_path.empty()){
+			fout.open(cli.output_path.c_str());
 			if(!fout){
-				cerr << "Unable to open " << opt.output_file << " for writing" << endl;
+				cerr << "Unable to open " << cli.output_path << " for writing" << endl;
 				return EXIT_FAILURE;
 			}
 		}
 		ostream &out = fout.is_open() ? fout : cout;
 
-		// ---- headers + metadata of every database file (kwage.cpp:89-113) -------------------
-		const size_t num_subject_files = opt.subject_files.size();
-		vector<DbFileEntry> files(num_subject_files);
-		vector<DbInfo> infos(num_subject_files);
-		for(size_t i = 0; i < num_subject_files; ++i){
-			files[i].path = opt.subject_files[i];
+		// ---- headers + metadata of every database file, read once (kwage.cpp:89-113, 505-515) ------------
+		vector<DbFileEntry> files(db_paths.size());
+		vector<DbInfo> infos(db_paths.size());
+		for(size_t i = 0; i < db_paths.size(); ++i){
+			files[i].path = db_paths[i];
 			if(kwage_db_read_header(files[i].path.c_str(), &files[i].header) != KWAGE_OK){
 				cerr << kwage_last_error() << endl;
 				throw "main: I/O error";
@@ -361,97 +533,63 @@ int main(int argc, char *argv[])
 			}
 		}
 
-		// ---- queries, parsed once (the reference re-parses per database file) ---------------
-		vector<Query> cmdline_queries, file_queries;
-		unordered_map<size_t, string> all_file_deflines;
-		for(size_t i = 0; i < opt.query_seq.size(); ++i){ cmdline_queries.push_back(Query{i, opt.query_seq[i]}); }
-		size_t query_id = 0;
-		for(deque<string>::const_iterator qf = opt.query_files.begin(); qf != opt.query_files.end(); ++qf){
-			SeqFile sf;
-			string err;
-			if(!sf.open(*qf, err)){
-				cerr << err << endl;
-				throw "SequenceIterator::SequenceIterator: Unable to open sequence file";
+		// ---- files grouped by (k, hashes, log2 length, hash function): one HBM matrix per group ------------
+		struct GroupKey {
+			uint32_t kmer_len, num_hash, log_2_filter_len; int32_t hash_func;
+			bool operator<(const GroupKey &o) const
+			{
+				return std::tie(kmer_len, num_hash, log_2_filter_len, hash_func) < std::tie(o.kmer_len, o.num_hash, o.log_2_filter_len, o.hash_func);
 			}
-			int r;
-			while((r = sf.next(err)) == 1){
-				file_queries.push_back(Query{query_id, sf.seq});
-				all_file_deflines[query_id] = sf.curr_defline;
-				++query_id;                   // ids run on across files, kwage.cpp:127-147
-			}
-			if(r < 0){ throw err; }
-		}
-
-		// ---- devices --------------------------------------------------------------------------
-		// KWAGE_DEVICES="all" | "0,1,..." shards every group's files (whole files, contiguous, balanced
-		// by column count) over several GPUs, one host thread + one kwage_ctx per GPU -- the
-		// reference's only parallel axis is the same one (OpenMP over files, kwage.cpp:76-87).
-		vector<int> devices;
-		if(const char *dl = getenv("KWAGE_DEVICES")){
-			if(string(dl) == "all"){
-				for(int d = 0; d < kwage_device_count(); ++d){ devices.push_back(d); }
-			}
-			else{
-				stringstream ss(dl);
-				string tok;
-				while(getline(ss, tok, ',')){ if(!tok.empty()){ devices.push_back(atoi(tok.c_str())); } }
-			}
-		}
-		if(devices.empty()){
-			const char *dev_env = getenv("KWAGE_DEVICE");
-			devices.push_back(dev_env ? atoi(dev_env) : 0);
-		}
-		const size_t ndev = devices.size();
-		const char *ee = getenv("KWAGE_EARLY_EXIT");
-		const uint32_t flags = (ee && atoi(ee) == 0) ? 0u : KWAGE_SEARCH_EARLY_EXIT;
-		const char *bb = getenv("KWAGE_BATCH_BASES");
-		const uint64_t max_batch_bases = bb ? strtoull(bb, NULL, 10) : (256ull << 20);
-		const char *mg = getenv("KWAGE_MAX_GROUP_BYTES");
-		const uint64_t max_group_bytes = mg ? strtoull(mg, NULL, 10) : 0;       // 0 = what is free on the device
-
-		ResultMap file_search_results, command_line_search_results;
-
-		// ---- group files by (k, hashes, log2 length, hash function) --------------------------
-		typedef pair<pair<uint32_t, uint32_t>, pair<uint32_t, int32_t> > Key;
-		map<Key, vector<uint32_t> > groups;
-		for(size_t i = 0; i < num_subject_files; ++i){
+		};
+		map<GroupKey, vector<uint32_t> > groups;
+		for(size_t i = 0; i < files.size(); ++i){
 			const kwage_db_header &h = files[i].header;
-			groups[Key(make_pair(h.kmer_len, h.num_hash), make_pair(h.log_2_filter_len, h.hash_func))].push_back((uint32_t)i);
+			groups[GroupKey{h.kmer_len, h.num_hash, h.log_2_filter_len, h.hash_func}].push_back((uint32_t)i);
 		}
 
+		// KWAGE_DEVICES="all" | "0,1,..." shards every group's files (whole files, contiguous, balanced by column
+		// count) over several GPUs, one host thread + one kwage_ctx per GPU -- the reference's only parallel axis is
+		// the same one (OpenMP over files, kwage.cpp:76-87).  Every worker streams the query files itself.
+		const vector<int> devices = chosen_devices();
+		const size_t ndev = devices.size();
+		const uint32_t flags = env_u64("KWAGE_EARLY_EXIT", 1) ? KWAGE_SEARCH_EARLY_EXIT : 0u;
+		const uint64_t max_batch_bases = env_u64("KWAGE_BATCH_BASES", 64ull << 20);
+		const uint64_t max_group_bytes = env_u64("KWAGE_MAX_GROUP_BYTES", 0);       // 0 = what is free on the device
+		const bool verbose = env_u64("KWAGE_VERBOSE", 0) != 0;
+
+		Findings from_command_line, from_files;
 		mutex merge_lock;
 		vector<string> worker_error(ndev);
-		const bool verbose = getenv("KWAGE_VERBOSE") && atoi(getenv("KWAGE_VERBOSE")) != 0;
-		auto now = []() { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); };
-		const double t_start = now();
+		const double t_start = now_s();
 
 		auto worker = [&](size_t di) {
 			try{
-				kwage_ctx *ctx = NULL;
+				kwage_ctx *ctx = nullptr;
 				check(kwage_init(devices[di], &ctx));
+				if(verbose){ lock_guard<mutex> lk(merge_lock); cerr << "[kwage] device " << devices[di] << " ready: " << rss_mb() << endl; }
 				double t_load = 0, t_search = 0, gb_loaded = 0;
-				const double t_init = now() - t_start;
-				ResultMap local_file_results, local_cmdline_results;
-				for(map<Key, vector<uint32_t> >::const_iterator gi = groups.begin(); gi != groups.end(); ++gi){
+				const double t_init = now_s() - t_start;
+				Findings local_cmdline, local_files;
+				for(const auto &grp_entry : groups){
 					// this device's share: a file belongs to the device that owns its middle column
 					uint64_t total = 0;
-					for(size_t m = 0; m < gi->second.size(); ++m){ total += files[gi->second[m]].header.num_filter; }
+					for(uint32_t fi : grp_entry.second){ total += files[fi].header.num_filter; }
 					vector<uint32_t> members;
-					uint64_t prefix = 0;
-					for(size_t m = 0; m < gi->second.size(); ++m){
-						const uint64_t nf = files[gi->second[m]].header.num_filter;
-						const size_t owner = min<size_t>(ndev - 1, (size_t)(((long double)prefix + nf/2.0L)*ndev/max<uint64_t>(total, 1)));
-						if(owner == di){ members.push_back(gi->second[m]); }
-						prefix += nf;
+					uint64_t before = 0;
+					for(uint32_t fi : grp_entry.second){
+						const uint64_t nf = files[fi].header.num_filter;
+						const size_t owner = min<size_t>(ndev - 1, (size_t)(((long double)before + nf/2.0L)*ndev/max<uint64_t>(total, 1)));
+						if(owner == di){ members.push_back(fi); }
+						before += nf;
 					}
 					if(members.empty()){ continue; }
 					kwage_params p;
-					p.kmer_len = gi->first.first.first;
-					p.num_hash = gi->first.first.second;
-					p.log_2_filter_len = gi->first.second.first;
-					p.hash_func = gi->first.second.second;
-					// A group larger than the HBM that is free is searched in several passes over
-					// sub-groups of whole files (queries are re-run per pass; results are additive).
+					p.kmer_len = grp_entry.first.kmer_len;
+					p.num_hash = grp_entry.first.num_hash;
+					p.log_2_filter_len = grp_entry.first.log_2_filter_len;
+					p.hash_func = grp_entry.first.hash_func;
+					// A group larger than the HBM that is free is searched in several passes over sub-groups of
+					// whole files (the queries are streamed again per pass; results are additive).
 					uint64_t budget = max_group_bytes;
 					if(budget == 0){
 						uint64_t free_b = 0, total_b = 0;
@@ -459,8 +597,7 @@ int main(int argc, char *argv[])
 						budget = free_b - free_b/8;          // leave room for staging buffers, row indices, hits
 					}
 					const uint64_t nrows = 1ull << p.log_2_filter_len;
-					size_t m0 = 0;
-					while(m0 < members.size()){
+					for(size_t m0 = 0; m0 < members.size(); ){
 						uint64_t span_bytes = 0;
 						size_t m1 = m0;
 						while(m1 < members.size()){
@@ -469,47 +606,43 @@ int main(int argc, char *argv[])
 							span_bytes = next;
 							++m1;
 						}
-						const vector<uint32_t> part(members.begin() + m0, members.begin() + m1);
-						kwage_group *grp = NULL;
-						double t0 = now();
+						kwage_group *grp = nullptr;
+						double t0 = now_s();
 						check(kwage_group_create(ctx, &p, span_bytes*8, &grp));
-						vector<DbFileEntry*> gfiles;
-						for(size_t m = 0; m < part.size(); ++m){
-							DbFileEntry &f = files[part[m]];       // each file is touched by exactly one worker
+						ColumnMap cols;
+						for(size_t m = m0; m < m1; ++m){
+							DbFileEntry &f = files[members[m]];       // each file is touched by exactly one worker
 							uint32_t nf = 0;
-							int rc = kwage_group_add_db_file(grp, f.path.c_str(), &f.first_column, &nf);
+							const int rc = kwage_group_add_db_file(grp, f.path.c_str(), &f.first_column, &nf);
 							if(rc != KWAGE_OK){ kwage_group_destroy(grp); check(rc); }
-							gfiles.push_back(&f);
+							cols.files.push_back(&f);
+							cols.file_index.push_back(members[m]);
 						}
-						check(kwage_group_finalize(grp));
-						t_load += now() - t0;
-						gb_loaded += (double)kwage_group_row_bytes(grp)*(double)nrows/1e9;
-						t0 = now();
-						search_queries(ctx, grp, gfiles, part, cmdline_queries, opt.threshold, flags, max_batch_bases,
-						               local_cmdline_results);
-						search_queries(ctx, grp, gfiles, part, file_queries, opt.threshold, flags, max_batch_bases,
-						               local_file_results);
-						t_search += now() - t0;
+						try{
+							check(kwage_group_finalize(grp));
+							t_load += now_s() - t0;
+							gb_loaded += (double)kwage_group_row_bytes(grp)*(double)nrows/1e9;
+							if(verbose){ lock_guard<mutex> lk(merge_lock); cerr << "[kwage] device " << devices[di] << " group loaded: " << rss_mb() << endl; }
+							t0 = now_s();
+							CommandLineQueries typed(cli.query_seqs);
+							search_stream(ctx, grp, cols, typed, cli.threshold, flags, max_batch_bases, local_cmdline);
+							FileQueries from_disk(cli.query_files);
+							search_stream(ctx, grp, cols, from_disk, cli.threshold, flags, max_batch_bases, local_files);
+							t_search += now_s() - t0;
+						}
+						catch(...){ kwage_group_destroy(grp); throw; }
 						kwage_group_destroy(grp);
 						m0 = m1;
 					}
 				}
 				kwage_shutdown(ctx);
+				lock_guard<mutex> lk(merge_lock);        // as the reference's `omp critical` section, kwage.cpp:154-177
 				if(verbose){
-					lock_guard<mutex> lk(merge_lock);
 					cerr << "[kwage] device " << devices[di] << ": init " << t_init << " s, loaded " << gb_loaded << " GB in " << t_load
-						<< " s (" << (t_load > 0 ? gb_loaded/t_load : 0) << " GB/s), search " << t_search << " s" << endl;
+						<< " s (" << (t_load > 0 ? gb_loaded/t_load : 0) << " GB/s), search " << t_search << " s; " << rss_mb() << endl;
 				}
-				// merge, as the reference's `omp critical` section does (kwage.cpp:154-177)
-				lock_guard<mutex> lk(merge_lock);
-				for(ResultMap::const_iterator i = local_file_results.begin(); i != local_file_results.end(); ++i){
-					deque<Match> &ref = file_search_results[i->first];
-					ref.insert(ref.end(), i->second.begin(), i->second.end());
-				}
-				for(ResultMap::const_iterator i = local_cmdline_results.begin(); i != local_cmdline_results.end(); ++i){
-					deque<Match> &ref = command_line_search_results[i->first];
-					ref.insert(ref.end(), i->second.begin(), i->second.end());
-				}
+				from_command_line.absorb(local_cmdline);
+				from_files.absorb(local_files);
 			}
 			catch(const char *error){ worker_error[di] = error; }
 			catch(const string &error){ worker_error[di] = error; }
@@ -519,67 +652,46 @@ int main(int argc, char *argv[])
 		if(ndev == 1){ worker(0); }
 		else{
 			vector<thread> pool;
-			for(size_t di = 0; di < ndev; ++di){ pool.push_back(thread(worker, di)); }
-			for(size_t di = 0; di < ndev; ++di){ pool[di].join(); }
+			for(size_t di = 0; di < ndev; ++di){ pool.emplace_back(worker, di); }
+			for(thread &t : pool){ t.join(); }
 		}
-		for(size_t di = 0; di < ndev; ++di){
-			if(!worker_error[di].empty()){
-				cerr << "Caught the search error: " << worker_error[di] << endl;
-				throw worker_error[di];
+		for(const string &e : worker_error){
+			if(!e.empty()){
+				cerr << "Caught the search error: " << e << endl;
+				throw e;
 			}
 		}
 
-		// ---- order: as the single-threaded reference builds each deque (file order, then column),
-		// then its unstable descending sort by hits (kwage.cpp:191-201) --------------------------
-		ResultMap *maps[2] = {&command_line_search_results, &file_search_results};
-		for(int k = 0; k < 2; ++k){
-			for(ResultMap::iterator i = maps[k]->begin(); i != maps[k]->end(); ++i){
-				std::sort(i->second.begin(), i->second.end(), [](const Match &a, const Match &b){
+		// ---- order: each query's hits as the single-threaded reference collects them (file order, then
+		// column), then its unstable descending sort by hits (kwage.cpp:191-201) -------------------------------
+		for(Findings *f : {&from_command_line, &from_files}){
+			for(auto &kv : f->by_query){
+				sort(kv.second.begin(), kv.second.end(), [](const Match &a, const Match &b) {
 					return (a.file_index != b.file_index) ? (a.file_index < b.file_index) : (a.column < b.column);
 				});
-				std::sort(i->second.begin(), i->second.end());
+				sort(kv.second.begin(), kv.second.end(), [](const Match &a, const Match &b) { return a.num_kmers_found > b.num_kmers_found; });
 			}
 		}
 
-		const bool multiple_query_matches = (command_line_search_results.size() + file_search_results.size()) > 1;
-
-		if(opt.output_format == SearchOptions::OUTPUT_CSV){ write_csv_header(out); }
-		else{ write_json_header(out, multiple_query_matches); }
-
-		bool first_match = true;
-		vector<size_t> id;
-		for(ResultMap::const_iterator i = command_line_search_results.begin(); i != command_line_search_results.end(); ++i){ id.push_back(i->first); }
-		std::sort(id.begin(), id.end());
-		for(vector<size_t>::const_iterator i = id.begin(); i != id.end(); ++i){
-			stringstream ssin;
-			ssin << "command line seq " << *i;          // kwage.cpp:237-240
-			const deque<Match> &ms = command_line_search_results[*i];
-			if(opt.output_format == SearchOptions::OUTPUT_CSV){ write_csv(out, ssin.str(), ms, infos); }
-			else{ write_json(out, ssin.str(), multiple_query_matches, first_match, opt.threshold, ms, infos); }
-			first_match = false;
+		unique_ptr<Report> report;
+		if(cli.format == Cli::CSV){ report.reset(new CsvReport(out)); }
+		else{ report.reset(new JsonReport(out, cli.threshold)); }
+		report->begin(from_command_line.by_query.size() + from_files.by_query.size());
+		for(const auto &kv : from_command_line.by_query){                       // command-line queries first, by position
+			report->query("command line seq " + to_string(kv.first), kv.second, infos);     // kwage.cpp:237-240
 		}
-
-		id.clear();
-		for(ResultMap::const_iterator i = file_search_results.begin(); i != file_search_results.end(); ++i){ id.push_back(i->first); }
-		std::sort(id.begin(), id.end());
-		for(vector<size_t>::const_iterator i = id.begin(); i != id.end(); ++i){
-			const string &defline = all_file_deflines[*i];
-			const deque<Match> &ms = file_search_results[*i];
-			if(opt.output_format == SearchOptions::OUTPUT_CSV){ write_csv(out, defline, ms, infos); }
-			else{ write_json(out, defline, multiple_query_matches, first_match, opt.threshold, ms, infos); }
-			first_match = false;
+		for(const auto &kv : from_files.by_query){                              // then file queries by global id
+			report->query(from_files.defline[kv.first], kv.second, infos);
 		}
+		report->end();
 
-		if(opt.output_format == SearchOptions::OUTPUT_JSON){ write_json_footer(out, multiple_query_matches); }
-
-		profile = time(NULL) - profile;
-		cerr << "Search complete in " << profile << " sec" << endl;
+		cerr << "Search complete in " << (time(nullptr) - started) << " sec" << endl;
 	}
 	catch(const char *error){
 		cerr << "Caught the error " << error << endl;
 		return EXIT_FAILURE;
 	}
-	catch(const string error){
+	catch(const string &error){
 		cerr << "Caught the error " << error << endl;
 		return EXIT_FAILURE;
 	}

@@ -287,7 +287,9 @@ class PipelinedDeviceSearcher:
     def __init__(self, group, flags: int = 0, device: str = "cuda", initial_capacity: int = 1 << 18):
         import torch
         self.group, self.flags, self.device = group, flags, device
-        self.bufs = [torch.zeros((1 + initial_capacity, 3), dtype=torch.int32, device=device) for _ in range(2)]
+        # torch.empty, not zeros: a fill kernel would run on torch's stream, unordered with the engine's own
+        # streams that write the count word and the records (it could land AFTER them and wipe a result)
+        self.bufs = [torch.empty((1 + initial_capacity, 3), dtype=torch.int32, device=device) for _ in range(2)]
         self.turn = 0
         self.last_kernel_ms = 0.0          # HIP-event time of the last collected search (SEARCH_TIMING flag)
 
@@ -313,7 +315,7 @@ class PipelinedDeviceSearcher:
         n, ms = C.c_uint64(), C.c_float()
         check(lib().kwage_search_device_collect(h, C.byref(n), None, C.byref(ms)))
         while n.value > self.bufs[i].shape[0] - 1:     # rare: grow this buffer and redo the search
-            self.bufs[i] = torch.zeros((int(n.value * 1.25) + 2, 3), dtype=torch.int32, device=self.device)
+            self.bufs[i] = torch.empty((int(n.value * 1.25) + 2, 3), dtype=torch.int32, device=self.device)
             check(lib().kwage_search_device_collect(self._submit_into(self.bufs[i], batch, threshold), C.byref(n), None, C.byref(ms)))
         self.last_kernel_ms = float(ms.value)
         return self.bufs[i], int(n.value)

@@ -14,6 +14,13 @@
 //   ref_tool build <out.db> <k> <L> <nhash> <list>   run the reference's build_db() on existing
 //                                   .bloom files (one path per line in <list>): CPU baseline of
 //                                   the device builder
+//   ref_tool zslice <slice_bytes> <slices.bin> <out.bin>    run the reference's CompressSlice (slice_z.h:153-267,
+//                                   included in place) over consecutive <slice_bytes>-byte slices; per slice
+//                                   write u32 payload length + payload (the deflate stream, or the raw slice
+//                                   when compress() says "not smaller")
+//   ref_tool zinflate <slice_bytes> <records.bin> <out.bin> the inverse with the reference's InflateSlice
+//                                   (slice_z.h:12-150): records as written by zslice (payload length ==
+//                                   slice_bytes means stored raw) -> the concatenated slices
 //
 // Spec format for mkdb (one record per line, fields separated by single TABs):
 //   DB <out.db> <kmer_len> <log_2_filter_len> <num_hash> <tmp_dir>
@@ -44,6 +51,8 @@
 #include "binary_io.h"
 #include "sra_accession.h"
 #include "date.h"
+#include <cstring>
+#include "slice_z.h"
 
 using namespace std;
 
@@ -208,9 +217,65 @@ static int cmd_kmers(int k, int nhash, const string &seq)
 	return 0;
 }
 
+// The codec works on slices of at most MAX_COMPRESSED_BYTES (256 bytes = the 2048 filters a database file holds,
+// slice_z.h:8): InflateSlice always offers exactly that much output room, so both sides are instantiated with it.
+static bool read_all(const char *path, vector<unsigned char> &buf)
+{
+	ifstream f(path, ios::binary);
+	if(!f){ return false; }
+	buf.assign(istreambuf_iterator<char>(f), istreambuf_iterator<char>());
+	return true;
+}
+
+static int cmd_zslice(unsigned int slice_bytes, const char *in_path, const char *out_path)
+{
+	vector<unsigned char> in;
+	if(slice_bytes == 0 || slice_bytes > MAX_COMPRESSED_BYTES || !read_all(in_path, in) || in.size() % slice_bytes){
+		cerr << "zslice: bad slice size or input" << endl;
+		return 1;
+	}
+	ofstream out(out_path, ios::binary);
+	CompressSlice<MAX_COMPRESSED_BYTES> z;
+	for(size_t o = 0; o < in.size(); o += slice_bytes){
+		const bool smaller = z.compress(&in[o], slice_bytes);
+		const uint32_t len = smaller ? z.size() : slice_bytes;
+		out.write((const char*)&len, 4);
+		out.write(smaller ? (const char*)z.ptr() : (const char*)&in[o], len);
+	}
+	return out ? 0 : 1;
+}
+
+static int cmd_zinflate(unsigned int slice_bytes, const char *in_path, const char *out_path)
+{
+	vector<unsigned char> in;
+	if(slice_bytes == 0 || slice_bytes > MAX_COMPRESSED_BYTES || !read_all(in_path, in)){
+		cerr << "zinflate: bad slice size or input" << endl;
+		return 1;
+	}
+	ofstream out(out_path, ios::binary);
+	InflateSlice<MAX_COMPRESSED_BYTES> z;
+	for(size_t o = 0; o < in.size(); ){
+		uint32_t len;
+		if(o + 4 > in.size()){ cerr << "zinflate: truncated record" << endl; return 1; }
+		memcpy(&len, &in[o], 4);
+		o += 4;
+		if(len > slice_bytes || o + len > in.size()){ cerr << "zinflate: bad record length" << endl; return 1; }
+		if(len == slice_bytes){ out.write((const char*)&in[o], len); }
+		else{
+			z.inflate(&in[o], len);
+			if(z.size() != slice_bytes){ cerr << "zinflate: slice inflated to " << z.size() << " bytes" << endl; return 1; }
+			out.write((const char*)z.ptr(), slice_bytes);
+		}
+		o += len;
+	}
+	return out ? 0 : 1;
+}
+
 int main(int argc, char *argv[])
 {
 	try{
+		if(argc == 5 && string(argv[1]) == "zslice"){ return cmd_zslice(atoi(argv[2]), argv[3], argv[4]); }
+		if(argc == 5 && string(argv[1]) == "zinflate"){ return cmd_zinflate(atoi(argv[2]), argv[3], argv[4]); }
 		if(argc == 3 && string(argv[1]) == "mkdb"){
 			return cmd_mkdb(argv[2]);
 		}
@@ -245,7 +310,7 @@ int main(int argc, char *argv[])
 			cout << a << '\t' << accession_to_str(a) << '\n';
 			return 0;
 		}
-		cerr << "usage: ref_tool mkdb <spec> | kmers <k> <nhash> <seq> | accession <str> | build <out.db> <k> <L> <nhash> <list>" << endl;
+		cerr << "usage: ref_tool mkdb <spec> | kmers <k> <nhash> <seq> | accession <str> | build <out.db> <k> <L> <nhash> <list> | zslice <bytes> <in> <out> | zinflate <bytes> <in> <out>" << endl;
 		return 2;
 	}
 	catch(const char *error){

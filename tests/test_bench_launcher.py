@@ -1,0 +1,103 @@
+"""bench.py's contract with the driver: `python bench.py --gpus N` must work without an external launcher (the
+parent starts the ranks as a child process and never touches the GPU itself), and with one
+(torch.distributed.run sets WORLD_SIZE).  The launcher half is checked here on the CPU; the ranks themselves
+run in the GPU test at the bottom (two ranks sharing the box's one GPU, gloo instead of RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+
+
+def test_launch_command_is_one_rank_per_gpu_on_localhost():
+    import bench
+    cmd = bench.launch_command(8, ["--gpus", "8", "--steps", "5"], port=29999)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5"]
+    free = bench.launch_command(2, [])          # picks a free port by itself
+    assert 1024 < int(free[free.index("--master-port") + 1]) < 65536
+
+
+def test_parent_relays_the_result_line_last_and_the_exit_code(monkeypatch, capfd, tmp_path):
+    import bench
+    stub = tmp_path / "ranks.py"
+    stub.write_text("import sys\nprint('{\"metric\": \"m\", \"value\": 1}')\nprint('NCCL version banner')\nsys.exit(int(sys.argv[1]))\n")
+    for rc in (0, 3):
+        monkeypatch.setattr(bench, "launch_command", lambda n, argv, port=None: [sys.executable, str(stub), str(rc)])
+        assert bench.launch_ranks(2, ["--gpus", "2"]) == rc
+        out = capfd.readouterr().out.strip().splitlines()
+        assert out[0] == "NCCL version banner" and json.loads(out[-1]) == {"metric": "m", "value": 1}
+    # ranks that end without a result are a failure even when they exit 0
+    stub.write_text("print('nothing')\n")
+    monkeypatch.setattr(bench, "launch_command", lambda n, argv, port=None: [sys.executable, str(stub)])
+    assert bench.launch_ranks(2, []) != 0
+
+
+def test_multi_gpu_request_without_a_launcher_starts_ranks_instead_of_exiting(monkeypatch):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset goes through launch_ranks (round 1 exited with a usage
+    message here); with WORLD_SIZE set the process is a rank."""
+    import bench
+    seen = {}
+    monkeypatch.setattr(bench, "launch_ranks", lambda n, argv: seen.setdefault("launch", (n, list(argv))) and 0)
+    monkeypatch.setattr(bench, "rank_main", lambda args: seen.setdefault("rank", args.gpus))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    with pytest.raises(SystemExit):
+        bench.main()
+    assert seen["launch"] == (2, ["--gpus", "2", "--steps", "3"]) and "rank" not in seen
+    seen.clear()
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    bench.main()
+    assert seen == {"rank": 2}
+    seen.clear()
+    monkeypatch.delenv("WORLD_SIZE")
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    bench.main()
+    assert seen == {"rank": 1}
+
+
+def test_traffic_is_reported_only_for_the_kernel_that_was_profiled():
+    import bench
+    rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    for name, entry in rec.items():
+        if name.startswith("_"):
+            continue
+        t, src = bench.measured_traffic(name, entry["kernel"], False)
+        assert t == entry["hbm_read_bytes_per_launch"] and src["status"] == "kernel matches" and src["kernel"] == entry["kernel"]
+        t, src = bench.measured_traffic(name, "some_other_kernel<1,2>", False)
+        assert t is None and src["status"].startswith("stale")
+        assert bench.measured_traffic(name, entry["kernel"], True)[0] is None
+    assert bench.measured_traffic("no-such-workload", "k", False)[0] is None
+
+
+@pytest.mark.gpu
+def test_bench_self_launches_two_ranks_on_one_gpu():
+    """The whole N>1 path of bench.py as the driver would start it -- no launcher -- on a one-GPU box: two ranks
+    share device 0 and exchange over gloo (RCCL refuses two ranks on one device).  One JSON line with the
+    aggregate block, every rank's kernel time, and twice the single-rank work."""
+    env = dict(os.environ, KWAGE_BENCH_BACKEND="gloo", KWAGE_BENCH_ONE_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--workload", "tiny"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["scaling"] == "weak"
+    agg = line["aggregate"]
+    assert agg["n_gpus"] == 2 and len(agg["kernel_ms_per_rank"]) == 2 and all(x > 0 for x in agg["kernel_ms_per_rank"])
+    assert agg["kernel_ms_max"] >= agg["kernel_ms_mean"] > 0 and 0 < agg["aggregate_frac"] < 1
+    assert line["rccl"]["world"] == 2 and line["rccl"]["backend"] == "gloo"
+    assert line["sustained"]["steps"] >= 4 and len(line["sustained"]["kernel_ms_mean_per_rank"]) == 2
+    assert line["config"]["step_pipeline"] == "on"
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--workload", "tiny", "--no-cpu-baseline", "--no-sustained"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    single = json.loads(one.stdout.strip().splitlines()[-1])
+    assert single["n_gpus"] == 1 and "sustained" not in single
+    assert line["roofline"]["algorithmic_bytes_per_launch"] == single["roofline"]["algorithmic_bytes_per_launch"]    # weak scaling: same share per GPU

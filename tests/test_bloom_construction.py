@@ -113,6 +113,36 @@ def test_distinct_kmer_count_and_long_sequences(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lg", [31, 32, 33])
+def test_distinct_set_with_2_pow_32_slots_or_more(oracle, lg, monkeypatch):
+    """A sample above ~1 G k-mer positions (a human or plant assembly) gets ONE shared distinct set of 2^32 slots or
+    more; the probe arithmetic must be 64-bit there (a 32-bit mask wraps to 0 or 1 and the k-mer stage never
+    returns).  KWAGE_SHARED_TABLE_LOG2 forces such a table (34 / 69 GB of HBM) under a small input."""
+    import kwage_amd as ka
+    rng = np.random.default_rng(lg)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    chrom = acgt[rng.integers(0, 4, size=50_000)].tobytes().decode()
+    seqs = [chrom, chrom[100:9000], "ACGT" * 30]
+    exp = len(np.unique(np.concatenate([oracle.unique_kmers(s, 31) for s in seqs])))
+    monkeypatch.setenv("KWAGE_SHARED_TABLE_LOG2", str(lg))
+    with ka.Context(0) as ctx:
+        free, _ = ctx.mem_info()
+        if free < (8 << lg) + (4 << 30):
+            pytest.skip("not enough free HBM for a 2^%d-slot table" % lg)
+        b = ka.Batch(ctx, seqs)
+        cnt = C.c_uint64()
+        native.check(native.lib().kwage_count_distinct_kmers(ctx._h, b._h, 31, C.byref(cnt)))
+        assert cnt.value == exp
+        prm = native.Params(31, 2, 20, 0)
+        bits = np.zeros((1 << 20) // 8, dtype=np.uint8)
+        nd = C.c_uint64()
+        native.check(native.lib().kwage_bloom_bits_from_batch(ctx._h, C.byref(prm), b._h, bits.ctypes.data, C.byref(nd)))
+        b.close()
+        assert nd.value == exp
+        assert np.array_equal(bits, oracle.bloom_bits_from_sequences(seqs, 31, 2, 20))
+
+
+@pytest.mark.gpu
 def test_pipeline_fasta_to_db_to_search(oracle, tmp_path):
     """FASTA per sample -> device Bloom filters -> device-built `.db` files -> the drop-in CLI finds each
     sample by its own sequence; the REFERENCE binary (when present) agrees on the same files."""

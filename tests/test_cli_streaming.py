@@ -1,0 +1,102 @@
+"""The `kwage` CLI streams its query files (kwage.cpp:129-148 holds one record at a time): host memory must be
+O(batch + hits), never O(query set) -- a 100 M-read FASTQ would otherwise sit in RAM before the GPU sees a byte."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_with_peak_rss(argv, env):
+    """-> (exit status, stdout, stderr, peak resident set size of the child in bytes)."""
+    import tempfile
+    with tempfile.TemporaryFile() as so, tempfile.TemporaryFile() as se:
+        p = subprocess.Popen(argv, stdout=so, stderr=se, env=env)
+        _, status, ru = os.wait4(p.pid, 0)
+        p.returncode = os.waitstatus_to_exitcode(status)
+        so.seek(0), se.seek(0)
+        return p.returncode, so.read().decode(), se.read().decode(), ru.ru_maxrss * 1024
+
+
+def test_query_file_larger_than_the_memory_the_cli_may_use(oracle, tmp_path):
+    from kwage_amd import native
+    rng = np.random.default_rng(77)
+    k, nh, L, ncol = 31, 2, 14, 40
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    genome = acgt[rng.integers(0, 4, size=3000)].tobytes().decode()
+    rows = np.zeros((1 << L, (ncol + 7) // 8), dtype=np.uint8)
+    planted = (3, 17, 39)
+    for r in oracle.row_indices(oracle.unique_kmers(genome, k), k, nh, L).reshape(-1):
+        for c in planted:
+            rows[r, c // 8] |= np.uint8(1 << (c % 8))
+    infos = [oracle.FilterInfo(run_accession=oracle.str_to_accession("SRR%07d" % j)) for j in range(ncol)]
+    db = str(tmp_path / "one.db")
+    oracle.write_db(db, k, nh, L, rows, ncol, infos)
+
+    # 1.2 M reads x 150 bp = 180 MB of bases, 370 MB of FASTQ; a handful of them come from the planted genome
+    n_reads, read_len = 1_200_000, 150
+    special = {5: 10, 400_000: 500, 799_999: 1500, n_reads - 1: 2850}        # read index -> offset in the genome
+    big = str(tmp_path / "big.fastq")
+    small = str(tmp_path / "small.fastq")
+    batch_bases = 4 << 20
+    n_small = 3 * batch_bases // read_len
+    qual = b"I" * read_len
+    with open(big, "wb") as fh, open(small, "wb") as fs:
+        chunk = 100_000
+        for c0 in range(0, n_reads, chunk):
+            bases = acgt[rng.integers(0, 4, size=(chunk, read_len))]
+            parts = []
+            for i in range(chunk):
+                idx = c0 + i
+                seq = genome[special[idx]:special[idx] + read_len].encode() if idx in special else bases[i].tobytes()
+                parts.append(b"@r%d\n%s\n+\n%s\n" % (idx, seq, qual))
+            fh.write(b"".join(parts))
+            if c0 < n_small:
+                # the yardstick: the first three batches' worth of the same file (both search slots and every
+                # per-batch buffer of the engine, the HIP runtime's staging pools ... reach their size), 1/14 of the reads
+                fs.write(b"".join(parts[:n_small - c0]))
+    file_bytes = os.path.getsize(big)
+    assert file_bytes > 350 << 20 and os.path.getsize(small) < file_bytes // 12
+
+    env = dict(os.environ, KWAGE_BATCH_BASES=str(batch_bases), KWAGE_VERBOSE="1")
+    rc0, out0, err0, rss_small = _run_with_peak_rss([native.KWAGE_BIN, "-d", db, "-i", small, "--o.csv"], env)
+    assert rc0 == 0, err0
+    rc, out, err, rss_big = _run_with_peak_rss([native.KWAGE_BIN, "-d", db, "-i", big, "--o.csv"], env)
+    assert rc == 0, err
+    print(err0, err)
+    # 14 times the reads must not cost memory: a query set held in RAM would add 180 MB of bases (plus a
+    # std::string per read); streaming adds nothing but allocator slack
+    assert rss_big - rss_small < 40 << 20, (rss_small >> 20, rss_big >> 20, err0, err)
+
+    # and the report is right: exactly the planted reads, each found in exactly the planted samples
+    rep = oracle.parse_csv(out)
+    assert sorted(rep) == sorted("r%d" % i for i in special)
+    assert sorted(oracle.parse_csv(out0)) == sorted("r%d" % i for i in special if i < n_small)
+    nk = read_len - k + 1
+    want = sorted(("SRR%07d" % c, nk, nk) for c in planted)
+    for name in rep:
+        assert sorted((acc, n, f) for acc, n, f, _ in rep[name]) == want
+
+
+def test_batches_of_every_size_give_the_same_report(oracle, tmp_path, golden_dir):
+    """KWAGE_BATCH_BASES from 'one query per batch' to 'everything in one' on a golden multi-file case with two -i
+    files and command-line sequences: identical bytes (ids run on across files and batches)."""
+    from kwage_amd import native
+    base = os.path.join(golden_dir, "multi")
+    qs = sorted(os.path.join(base, f) for f in os.listdir(base) if f.endswith((".fa", ".fasta", ".fna", ".fastq", ".fa.gz", ".fastq.gz")))
+    if not qs:
+        pytest.skip("no query files in the golden multi case")
+    argv = [native.KWAGE_BIN, "-d", os.path.join(base, "dbs"), "-t", "0.5"]
+    for q in qs:
+        argv += ["-i", q]
+    argv += ["ACGTACGTACGTACGTACGTACGTACGTACGTACGT"]
+    outs = {}
+    for fmt in ("--o.csv", "--o.json"):
+        for bb in ("1", "300", "5000", str(64 << 20)):
+            r = subprocess.run(argv + [fmt], capture_output=True, env=dict(os.environ, KWAGE_BATCH_BASES=bb))
+            assert r.returncode == 0, r.stderr.decode()
+            outs[(fmt, bb)] = r.stdout
+        assert len({outs[(fmt, bb)] for bb in ("1", "300", "5000", str(64 << 20))}) == 1, fmt
+        assert outs[(fmt, "1")]

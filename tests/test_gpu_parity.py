@@ -557,12 +557,15 @@ def test_pipelined_device_search_and_counted_exchange(ka, ctx):
 
 @pytest.mark.parametrize("n_cols", [16500, 40000, 100000, 131072, 131073, 300000])
 def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, monkeypatch):
-    """Rows of >= 3 KiB with >= 900 (query, column tile) pairs take and_walk_kernel (one workgroup per pair,
-    four waves each walking a quarter of the row list over the tile's whole width, LDS reduce): ragged query
-    lengths so that quarters are empty / one k-mer long / uneven, hits in the first, middle and last columns;
-    131073 columns (17 KiB) needs two column tiles whose last chunk lies wholly past the row end, 300000
-    columns three tiles (by default rows wider than 16 KiB stay with the tiled kernel: the limit is raised here)."""
+    """Rows of >= 3 KiB take and_walk_kernel when the batch is large (a persistent grid, every wave walks an
+    equal share of the batch's positions over a column tile's whole width; pairs cut by a share boundary meet
+    in memory): ragged query lengths so that shares start and end inside, between and across queries, empty and
+    too-short queries in between, hits in the first, middle and last columns; 131073 columns (17 KiB) needs two
+    column tiles whose last chunk lies wholly past the row end, 300000 columns three tiles (by default rows wider
+    than 16 KiB and batches below 256k rows stay with the tiled kernel: both limits are moved here).  Every case
+    with the natural number of waves and with shares of a handful of positions."""
     monkeypatch.setenv("KWAGE_WALK_MAX_KIB", "64")
+    monkeypatch.setenv("KWAGE_WALK_MIN_ROWS", "1")
     rng = np.random.default_rng(n_cols)
     k, nh, L = 31, 2, 10
     image = _make_random_db(rng, L, n_cols, 0.9)
@@ -585,14 +588,20 @@ def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, monkeypatch):
     g.finalize()
     b = ka.Batch(ctx, seqs)
     exp = [oracle.search_image(image, image.shape[1], k, nh, L, n_cols, oracle.unique_kmers(s, k), 1.0)[0] for s in seqs]
-    for flags, ee in ((0, "0"), (ka.SEARCH_EARLY_EXIT, "1"), (ka.SEARCH_EARLY_EXIT, "0")):
-        monkeypatch.setenv("KWAGE_WALK_EARLY_EXIT", ee)      # with early exit the host prefers the tiled kernel unless told otherwise
-        r = g.search(b, 1.0, flags)
-        assert r.search_kernel == ("and_kernel" if (flags and ee == "0") else "and_walk_kernel")
-        assert r.per_query() == exp, (n_cols, flags)
+    for waves in (None, "5", "3001", "16384"):
+        if waves is None:
+            monkeypatch.delenv("KWAGE_WALK_WAVES", raising=False)
+        else:
+            monkeypatch.setenv("KWAGE_WALK_WAVES", waves)
+        for flags, ee in ((0, "0"), (ka.SEARCH_EARLY_EXIT, "1"), (ka.SEARCH_EARLY_EXIT, "0")):
+            monkeypatch.setenv("KWAGE_WALK_EARLY_EXIT", ee)      # with early exit the host prefers the tiled kernel unless told otherwise
+            r = g.search(b, 1.0, flags)
+            assert r.search_kernel.startswith("and_kernel<" if (flags and ee == "0") else "and_walk_kernel<"), r.search_kernel
+            assert r.per_query() == exp, (n_cols, flags, waves)
+    monkeypatch.delenv("KWAGE_WALK_WAVES", raising=False)
     monkeypatch.setenv("KWAGE_WALK", "0")
     r = g.search(b, 1.0, 0)
-    assert r.search_kernel == "and_kernel" and r.per_query() == exp
+    assert r.search_kernel.startswith("and_kernel<") and r.per_query() == exp
     planted = [e for s, e in zip(seqs, exp) if len(s) >= 31 and s in genome]
     assert planted and all({c for c, _ in e} >= set(cols) for e in planted)
     b.close()

@@ -62,7 +62,7 @@ def test_random_configuration(oracle, seed, monkeypatch):
                 kmers = oracle.unique_kmers(s, k)
                 e, _ = oracle.search_image(image, image.shape[1], k, nh, L, n_cols, kmers, thr32)
                 exp.append((len(kmers), e))
-            for flags, force in ((0, None), (ka.SEARCH_EARLY_EXIT, None), (0, str(int(rng.choice([2, 5, 33])))), (ka.SEARCH_EARLY_EXIT, "3")):
+            for flags, force in ((0, None), (ka.SEARCH_EARLY_EXIT, None), (0, str(int(rng.choice([2, 5, 33, 300])))), (ka.SEARCH_EARLY_EXIT, "3")):
                 if force is None:
                     monkeypatch.delenv("KWAGE_FORCE_SEGS", raising=False)
                 else:
@@ -73,18 +73,23 @@ def test_random_configuration(oracle, seed, monkeypatch):
                     assert r.num_query_kmer[i] == nk, (seed, thr, i)
                     assert per_q[i] == e, (seed, k, nh, L, n_cols, thr, flags, force, i, len(per_q[i]), len(e))
             if thr == 1.0 and n_cols > 16384:
-                # the walk form of the AND kernel (normally for >= 900 queries and rows <= 16 KiB), both unrolls
-                monkeypatch.setenv("KWAGE_FORCE_SEGS", "1")           # no row-list segments, or the tiled kernel is the only choice
-                monkeypatch.setenv("KWAGE_WALK_MIN_QUERIES", "1")
+                # the walk form of the AND kernel (normally for batches of >= 256k rows and rows of 3..16 KiB), both
+                # unrolls, with the batch's positions cut into few / many / very many wave shares: the long queries
+                # are then finished through the cut-pair slots by dozens of waves each
+                monkeypatch.setenv("KWAGE_WALK_MIN_ROWS", "1")
                 monkeypatch.setenv("KWAGE_WALK_MAX_KIB", "64")
                 monkeypatch.setenv("KWAGE_WALK_EARLY_EXIT", "1")
-                monkeypatch.setenv("KWAGE_WALK_ANY_FILL", "1")
-                for unroll, flags in (("4", 0), ("2", ka.SEARCH_EARLY_EXIT)):
+                for unroll, flags, waves in (("4", 0, None), ("2", ka.SEARCH_EARLY_EXIT, "7"), ("4", 0, "1000"), ("2", 0, "4096")):
                     monkeypatch.setenv("KWAGE_WALK", unroll)
-                    r = g.search(b, thr, flags)
-                    assert r.search_kernel == "and_walk_kernel"
-                    assert [(int(n), e) for n, e in zip(r.num_query_kmer, r.per_query())] == exp, (seed, n_cols, unroll)
-                for v in ("KWAGE_WALK_MIN_QUERIES", "KWAGE_WALK_MAX_KIB", "KWAGE_WALK", "KWAGE_WALK_EARLY_EXIT", "KWAGE_WALK_ANY_FILL", "KWAGE_FORCE_SEGS"):
+                    if waves is None:
+                        monkeypatch.delenv("KWAGE_WALK_WAVES", raising=False)
+                    else:
+                        monkeypatch.setenv("KWAGE_WALK_WAVES", waves)
+                    for _ in range(2):         # twice: the kernel must leave its cut-pair slots clean
+                        r = g.search(b, thr, flags)
+                        assert r.search_kernel.startswith("and_walk_kernel<")
+                        assert [(int(n), e) for n, e in zip(r.num_query_kmer, r.per_query())] == exp, (seed, n_cols, unroll, waves)
+                for v in ("KWAGE_WALK_MIN_ROWS", "KWAGE_WALK_MAX_KIB", "KWAGE_WALK", "KWAGE_WALK_EARLY_EXIT", "KWAGE_WALK_WAVES"):
                     monkeypatch.delenv(v, raising=False)
         b.close()
         g.close()

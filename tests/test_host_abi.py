@@ -163,6 +163,26 @@ def test_cli_usage_and_validation_without_gpu():
     assert "Please provide: 0.0 < search threshold <= 1.0" in r.stderr
 
 
+def test_cli_option_handling_matches_the_reference_binary(oracle):
+    """Every way the option parser can end a run before the search (usage, complaints, getopt corner cases such as
+    abbreviated / ambiguous long options, missing values, `-?`) against the reference binary: same exit status, same
+    stdout, same stderr bytes."""
+    import subprocess
+    if not os.access(oracle.REF_KWAGE, os.X_OK):
+        pytest.skip("reference binary not built (oracle/_ref)")
+    db = os.path.join(GOLDEN, "k32", "k32.db")
+    cases = [[], ["-h"], ["-?"], ["--bogus"], ["-x"], ["--o"], ["--o.c", "-d", db], ["--o.j", "-d", db],
+             ["-d", os.path.join(GOLDEN, "multi", "dbs", "not_a_db.txt"), "ACGT"], ["-d", db], ["-d", db, "-i", "reads.txt"],
+             ["-d", db, "-i", "x.fa.fa"], ["-d", db, "-i", "x.fastq.gz.fa"], ["-d", db, "-i", "a.fna", "-i", "b.txt"],
+             ["-d", db, "-t", "1.5", "ACGT"], ["-d", db, "-t", "0", "ACGT"], ["-d", db, "-t", "-1", "ACGT"], ["-d", db, "-t", "abc", "ACGT"],
+             ["-d", db, "-t", "1.0000001", "ACGT"], ["ACGT", "-d", db, "-t"], ["-d"], ["-d", db, "-o"], ["-i", "q.fa"], ["-t", "0.5"],
+             ["ACGT", "-h", "-d", db]]
+    for argv in cases:
+        ref = subprocess.run([oracle.REF_KWAGE] + argv, capture_output=True)
+        own = subprocess.run([native.KWAGE_BIN] + argv, capture_output=True)
+        assert (own.returncode, own.stdout, own.stderr) == (ref.returncode, ref.stdout, ref.stderr), argv
+
+
 def test_header_is_plain_c99(tmp_path):
     """include/kwage_amd.h must be consumable from C (the FFI boundary): compile the C example strictly."""
     import shutil

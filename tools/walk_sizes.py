@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""and_walk_kernel vs and_kernel over batch sizes around the chip's resident capacity (1024 workgroups at 4 per
-CU): is there a slow second round?   python tools/walk_sizes.py"""
+"""and_walk_kernel (persistent grid, equal shares of the batch's row list per wave) vs the tiled and_kernel over
+batch sizes: small batches (where does the walk form start to pay?) and sizes around what used to be a partly
+filled last round of one-workgroup-per-query (1030, 2100 queries).   python tools/walk_sizes.py [waves ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,14 +14,24 @@ s = synth.build(ctx, w)
 rng = np.random.default_rng(5)
 acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
 extra = [acgt[rng.integers(0, 4, size=1000)].tobytes().decode() for _ in range(4000)]
-for nq in (900, 1000, 1024, 1030, 1100, 1300, 1500, 2048, 2100, 3000, 5000):
+variants = [("tiled", {"KWAGE_WALK": "0"}), ("walk", {"KWAGE_WALK": "4", "KWAGE_WALK_MIN_ROWS": "1"})]
+for wv in sys.argv[1:]:
+    if wv == "deep":
+        variants.append(("walk/deep", {"KWAGE_WALK": "3", "KWAGE_WALK_MIN_ROWS": "1"}))
+    elif wv == "fences":
+        variants.append(("walk/full fences", {"KWAGE_WALK": "4", "KWAGE_WALK_MIN_ROWS": "1", "KWAGE_WALK_FENCES": "1"}))
+    else:
+        variants.append(("walk/%s waves" % wv, {"KWAGE_WALK": "4", "KWAGE_WALK_MIN_ROWS": "1", "KWAGE_WALK_WAVES": wv}))
+for nq in (50, 100, 200, 300, 500, 700, 900, 1000, 1024, 1030, 1100, 1300, 1500, 2048, 2100, 3000, 5000):
     qs = (s.queries + extra)[:nq]
     b = ka.Batch(ctx, qs)
     out = []
-    for v in ("0", "4"):
-        os.environ["KWAGE_WALK"] = v
+    for name, env in variants:
+        for k in ("KWAGE_WALK", "KWAGE_WALK_MIN_ROWS", "KWAGE_WALK_WAVES", "KWAGE_WALK_FENCES"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
         ms = [s.group.search(b, 1.0, ka.SEARCH_TIMING).search_kernel_ms for _ in range(6)]
         r = s.group.search(b, 1.0, ka.SEARCH_TIMING)
-        out.append((r.search_kernel, float(np.median(ms[1:])), r.algorithmic_bytes))
+        out.append("%s %s %.3f ms (%.0f GB/s)" % (name, r.search_kernel, float(np.median(ms[1:])), r.algorithmic_bytes / float(np.median(ms[1:])) / 1e6))
     b.close()
-    print("%5d queries: %s %.3f ms (%.0f GB/s) | %s %.3f ms (%.0f GB/s)" % (nq, out[0][0], out[0][1], out[0][2] / out[0][1] / 1e6, out[1][0], out[1][1], out[1][2] / out[1][1] / 1e6), flush=True)
+    print("%5d queries: %s" % (nq, " | ".join(out)), flush=True)
