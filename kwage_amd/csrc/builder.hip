@@ -363,6 +363,7 @@ extern "C" int kwage_repack_db(kwage_ctx *ctx, const char *out_path, const char 
 	if(e == hipSuccess){ e = hipMalloc(&d_src, chunk_rows*max_width); }
 	if(e == hipSuccess){ e = hipHostMalloc(&h_buf, host_bytes, hipHostMallocDefault); }
 	uint32_t crc = 0;
+	std::vector<uint32_t> src_crc(n, 0);          // CRC32 of every source's slice block, checked against its header (merge_db.cpp:608-614)
 	std::vector<unsigned char> packed;
 	for(uint64_t r0 = 0; r0 < nrows && ok && e == hipSuccess; r0 += chunk_rows){
 		const uint64_t nr = std::min(chunk_rows, nrows - r0);
@@ -372,6 +373,7 @@ extern "C" int kwage_repack_db(kwage_ctx *ctx, const char *out_path, const char 
 			if(!src[i].read_rows(r0, nr, (unsigned char*)h_buf, err)){ ok = false; break; }
 			e = hipMemcpyAsync(d_src, h_buf, nr*src[i].slice_size, hipMemcpyHostToDevice, stream);
 			if(e != hipSuccess){ break; }
+			src_crc[i] = crc32_parallel(src_crc[i], (const unsigned char*)h_buf, nr*src[i].slice_size);      // while the copy runs
 			const uint64_t nbits = src[i].header.num_filter;
 			const uint64_t work = nr*((bit0 + nbits + 31)/32 - bit0/32);
 			hipLaunchKernelGGL(pack_columns_kernel, dim3((uint32_t)std::min<uint64_t>((work + 255)/256, 8192)), dim3(256), 0, stream,
@@ -402,6 +404,15 @@ extern "C" int kwage_repack_db(kwage_ctx *ctx, const char *out_path, const char 
 	if(h_buf){ (void)hipHostFree(h_buf); }
 	if(e != hipSuccess){ fclose(fout); return fail(KWAGE_ERR_DEVICE, "kwage_repack_db: %s", hipGetErrorString(e)); }
 	if(!ok){ fclose(fout); return fail(KWAGE_ERR_IO, "kwage_repack_db: %s", err.empty() ? "I/O error" : err.c_str()); }
+	for(uint32_t i = 0; i < n; ++i){
+		// the reference's merge refuses a source whose slices do not match the CRC32 in its header (merge_db.cpp:608-614)
+		if(src_crc[i] != src[i].header.crc32){
+			fclose(fout);
+			(void)remove(out_path);
+			return fail(KWAGE_ERR_FORMAT, "kwage_repack_db: Invalid CRC32 value for source database file %s (header %08x, slices %08x)",
+			            in_paths[i], src[i].header.crc32, src_crc[i]);
+		}
+	}
 
 	// metadata: records verbatim in column order, fresh index
 	const uint64_t info_start = DB_HEADER_BYTES + nrows*out_slice;

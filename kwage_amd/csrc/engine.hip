@@ -9,12 +9,14 @@
 
 #include <algorithm>
 #include <chrono>
+#include <deque>
 #include <cstdio>
 #include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -124,13 +126,54 @@ struct kwage_ctx {
 	void *map_base = nullptr;
 	size_t map_len = 0;
 	hipEvent_t map_done = nullptr;      // recorded behind the last copy that reads the mapping
+	// direct loading: file windows locked through HSA whose copy kernels may still be running, oldest first
+	struct LockedWindow { void *base; size_t len; hipEvent_t done; };
+	std::deque<LockedWindow> locked;
+	std::vector<hipEvent_t> spare_events;
 };
 
 namespace {
 
+// hsa_amd_memory_lock / _unlock of the HSA runtime the HIP runtime of this process sits on, looked up at run time
+// (no link dependency: the Python binding runs on PyTorch's bundled ROCm, the CLI on the system's).  Unlike
+// hipHostRegister / hipHostUnregister they do not synchronise the device, so pinning the next file and
+// un-pinning the previous one overlap with the copy that is running.
+struct HsaLock {
+	typedef int (*lock_fn)(void *host_ptr, size_t size, void *agents, int num_agent, void **agent_ptr);
+	typedef int (*unlock_fn)(void *host_ptr);
+	lock_fn lock = nullptr;
+	unlock_fn unlock = nullptr;
+	HsaLock()
+	{
+		lock = (lock_fn)dlsym(RTLD_DEFAULT, "hsa_amd_memory_lock");
+		unlock = (unlock_fn)dlsym(RTLD_DEFAULT, "hsa_amd_memory_unlock");
+		if(!lock || !unlock){ lock = nullptr; unlock = nullptr; }
+	}
+};
+
+const HsaLock &hsa_lock()
+{
+	static const HsaLock h;
+	return h;
+}
+
+// Release locked file windows, oldest first, until at most `keep` remain (each after its copy kernel has finished).
+void release_locked(kwage_ctx *ctx, size_t keep)
+{
+	while(ctx->locked.size() > keep){
+		kwage_ctx::LockedWindow w = ctx->locked.front();
+		ctx->locked.pop_front();
+		(void)hipEventSynchronize(w.done);
+		(void)hsa_lock().unlock(w.base);
+		(void)munmap(w.base, w.len);
+		ctx->spare_events.push_back(w.done);
+	}
+}
+
 // Wait for the copies that read the pending file mapping, then unpin and unmap it.
 void release_mapping(kwage_ctx *ctx)
 {
+	release_locked(ctx, 0);
 	if(!ctx->map_base){ return; }
 	if(ctx->map_done){ (void)hipEventSynchronize(ctx->map_done); }
 	else{ (void)hipStreamSynchronize(ctx->stream); }
@@ -310,6 +353,7 @@ int launch_kmer_stage(Slot *sl, const kwage_params &p, kwage_batch *b, float thr
 }
 
 static const uint32_t WALK_MIN_ROWS_PER_WAVE = 64;   // and_walk_kernel: below this share per wave the tiled kernel is used
+static const uint32_t WALK_WAVES_PER_CU = 8;         // 2 workgroups: 2048 waves measured 1-2 % faster than 4096 (half the cut pairs)
 
 static int g_and_lds_bytes = 0;     // tuning only: dynamic LDS per workgroup caps waves per CU
 static int g_and_block_waves = SEARCH_THREADS/WAVE;   // tuning only: waves per workgroup of and_kernel
@@ -517,7 +561,7 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 		// (read per call, like KWAGE_AND_CFG: tools/tune_walk.py switches them inside one process)
 		const char *we = getenv("KWAGE_WALK"), *wr = getenv("KWAGE_WALK_MIN_ROWS");
 		const int walk_unroll = we ? atoi(we) : 4;
-		const uint64_t walk_min_rows = wr ? strtoull(wr, nullptr, 10) : (uint64_t)WALK_MIN_ROWS_PER_WAVE*4096;
+		const uint64_t walk_min_rows = wr ? strtoull(wr, nullptr, 10) : (uint64_t)WALK_MIN_ROWS_PER_WAVE*256*WALK_WAVES_PER_CU;
 		const uint32_t kib = (a.units_per_row + WAVE - 1)/WAVE;
 		// (the kernel handles wider rows as several balanced column tiles -- KWAGE_WALK_MAX_KIB raises the limit --
 		// but 125 KB rows measured no gain over the tiled kernel)
@@ -531,12 +575,12 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 		const bool walk_ee_ok = !a.early_exit || (wx && atoi(wx) != 0);
 		const uint64_t walk_slots = (uint64_t)coltiles*b->total_pos;
 		if(walk_unroll && walk_ee_ok && kib >= 3 && kib <= walk_max_kib && walk_slots*a.num_hash >= walk_min_rows && walk_slots > 0){
-			// as many waves as the chip holds at once (4 workgroups of 4 waves per CU: __launch_bounds__(256, 4)),
+			// WALK_WAVES_PER_CU waves per CU, all resident at once (__launch_bounds__(256, 4) allows twice as many),
 			// fewer when the batch is small: a wave should have WALK_MIN_ROWS_PER_WAVE rows to walk
 			int ncu = 0;
 			(void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, g->ctx->device);
 			const char *ww = getenv("KWAGE_WALK_WAVES");                     // tuning / tests: exactly this many waves
-			const uint64_t chip_waves = (uint64_t)std::max(ncu, 1)*(walk_unroll == 3 ? 8 : 16);
+			const uint64_t chip_waves = (uint64_t)std::max(ncu, 1)*WALK_WAVES_PER_CU;
 			const uint64_t want_waves = (ww && atoi(ww) > 0) ? std::min<uint64_t>((uint64_t)atoi(ww), walk_slots)
 				: std::max<uint64_t>(1, std::min<uint64_t>(chip_waves, walk_slots*a.num_hash/WALK_MIN_ROWS_PER_WAVE));
 			const uint32_t wgs = (uint32_t)((want_waves + 3)/4);
@@ -560,13 +604,11 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 			{ const char *wf = getenv("KWAGE_WALK_FENCES"); wa.full_fences = (wf && atoi(wf) != 0) ? 1 : 0; }
 			a.segs = 1;
 			a.chunks = coltiles;
-			const bool walk_deep = (walk_unroll == 3);      // KWAGE_WALK=3: two rows, every KiB of both requested up front
-			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_walk_kernel<%u,%d%s>", walk_ch, (walk_deep || walk_unroll == 2) ? 2 : 4, walk_deep ? ",deep" : "");
+			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_walk_kernel<%u,%d>", walk_ch, walk_unroll == 2 ? 2 : 4);
 			const dim3 grid(wgs), block(SEARCH_THREADS);
 #define KWAGE_WALK_CASE(CH) case CH: \
-				if(walk_deep){ hipLaunchKernelGGL((and_walk_kernel<CH, 2, true>), grid, block, 0, sl->stream, a, wa, a.rows, a.pos_off, a.nkmer); } \
-				else if(walk_unroll == 2){ hipLaunchKernelGGL((and_walk_kernel<CH, 2, false>), grid, block, 0, sl->stream, a, wa, a.rows, a.pos_off, a.nkmer); } \
-				else{ hipLaunchKernelGGL((and_walk_kernel<CH, 4, false>), grid, block, 0, sl->stream, a, wa, a.rows, a.pos_off, a.nkmer); } break;
+				if(walk_unroll == 2){ hipLaunchKernelGGL((and_walk_kernel<CH, 2>), grid, block, 0, sl->stream, a, wa, a.rows, a.pos_off, a.nkmer); } \
+				else{ hipLaunchKernelGGL((and_walk_kernel<CH, 4>), grid, block, 0, sl->stream, a, wa, a.rows, a.pos_off, a.nkmer); } break;
 			switch(walk_ch){
 				KWAGE_WALK_CASE(3) KWAGE_WALK_CASE(4) KWAGE_WALK_CASE(5) KWAGE_WALK_CASE(6) KWAGE_WALK_CASE(7)
 				KWAGE_WALK_CASE(8) KWAGE_WALK_CASE(9) KWAGE_WALK_CASE(10) KWAGE_WALK_CASE(11) KWAGE_WALK_CASE(12)
@@ -828,6 +870,7 @@ extern "C" void kwage_shutdown(kwage_ctx *ctx)
 	(void)hipSetDevice(ctx->device);
 	release_mapping(ctx);
 	if(ctx->map_done){ (void)hipEventDestroy(ctx->map_done); }
+	for(hipEvent_t e : ctx->spare_events){ (void)hipEventDestroy(e); }
 	for(int k = 0; k < 2; ++k){
 		Slot *sl = &ctx->slot[k];
 		if(sl->stream){ (void)hipStreamSynchronize(sl->stream); }
@@ -1002,6 +1045,15 @@ extern "C" int kwage_group_add_db_file(kwage_group *g, const char *path, uint64_
 	if(rc){ return rc; }
 
 	const uint64_t width = src.slice_size;
+	// KWAGE_VERIFY_CRC=1: refuse a file whose slice block does not match the CRC32 in its header, as the reference's
+	// merge does for its sources (merge_db.cpp:608-614; its `kwage` checks nothing, kwage.cpp:99-105).  A separate
+	// pass over the file on the host, so off by default.
+	static const bool verify_crc = []() { const char *e = getenv("KWAGE_VERIFY_CRC"); return e && atoi(e) != 0; }();
+	if(verify_crc){
+		uint32_t crc = 0;
+		if(!src.slice_crc32(crc, err)){ return fail(KWAGE_ERR_IO, "%s: %s", path, err.c_str()); }
+		if(crc != h.crc32){ return fail(KWAGE_ERR_FORMAT, "%s: Invalid CRC32 value (header %08x, slices %08x)", path, h.crc32, crc); }
+	}
 	uint64_t byte0 = 0;
 	if((rc = group_reserve_columns(g, h.num_filter, &byte0))){ return rc; }
 
@@ -1027,7 +1079,50 @@ extern "C" int kwage_group_add_db_file(kwage_group *g, const char *path, uint64_
 		if(!rc && !done[i] && hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess){ rc = fail(KWAGE_ERR_DEVICE, "hipEventCreate failed"); }
 	}
 	if(rc){ return rc; }
-	if(mmap_ok && h.compression == KWAGE_COMPRESSION_NONE){
+	// Direct path (raw files whose rows are dword multiples, e.g. the 256-byte rows of a full 2048-column file): map
+	// a window of the file, lock it through HSA, and let ONE copy kernel read the page cache over PCIe and write the
+	// rows where they belong in the strided matrix -- no staging buffer, no second pass over HBM, and no
+	// hipHostRegister/Unregister (which wait for the device: the copy engine sat idle 2.3 ms per 256 MB file).
+	// Up to two windows stay locked behind the one being queued; they are released as their kernels finish.
+	// 16 x 268 MB files: 46.8 GB/s against 40.4 GB/s for the staged path on the same box; an SDMA rect copy into
+	// the matrix reaches 33 GB/s (256-byte lines) and hipMemcpyAsync does not recognise HSA-locked memory (19 GB/s):
+	// tools/micro/lock_copy_probe.hip, profiles/r02_loader_probe.txt.  KWAGE_LOAD_DIRECT=0 disables it.
+	static const bool direct_ok = []() { const char *e = getenv("KWAGE_LOAD_DIRECT"); return !(e && atoi(e) == 0); }();
+	if(mmap_ok && direct_ok && h.compression == KWAGE_COMPRESSION_NONE && width % 4 == 0 && hsa_lock().lock){
+		const uint64_t win_rows = std::max<uint64_t>(1, std::min<uint64_t>(g->nrows, window_target/width));
+		const long page = sysconf(_SC_PAGESIZE);
+		uint64_t r0 = 0;
+		for(; r0 < g->nrows; ){
+			const uint64_t wr = std::min(win_rows, g->nrows - r0);
+			const uint64_t off = DB_HEADER_BYTES + r0*width, off0 = off/page*page;
+			const size_t maplen = (size_t)(off - off0 + wr*width);
+			void *base = mmap(nullptr, maplen, PROT_READ, MAP_PRIVATE, src.fd, (off_t)off0);      // (the lock faults the pages in)
+			if(base == MAP_FAILED){ break; }
+			void *dev_view = nullptr;
+			if(hsa_lock().lock(base, maplen, nullptr, 0, &dev_view) != 0 || !dev_view){ (void)munmap(base, maplen); break; }
+			hipEvent_t ev = nullptr;
+			if(!ctx->spare_events.empty()){ ev = ctx->spare_events.back(); ctx->spare_events.pop_back(); }
+			else if(hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess){ (void)hsa_lock().unlock(base); (void)munmap(base, maplen); break; }
+			hipLaunchKernelGGL(copy_rows_kernel, dim3(256*8), dim3(256), 0, ctx->stream, g->d_bits, g->stride, r0, byte0,
+			                   (const uint8_t*)dev_view + (off - off0), width, wr);
+			e = hipGetLastError();
+			if(e == hipSuccess){ e = hipEventRecord(ev, ctx->stream); }
+			ctx->locked.push_back(kwage_ctx::LockedWindow{base, maplen, ev});
+			if(e != hipSuccess){
+				release_mapping(ctx);
+				return fail(KWAGE_ERR_DEVICE, "kwage_group_add_db_file: %s", hipGetErrorString(e));
+			}
+			release_locked(ctx, 2);
+			r0 += wr;
+		}
+		if(r0 >= g->nrows){
+			if(first_column){ *first_column = byte0*8; }
+			if(num_filter){ *num_filter = h.num_filter; }
+			return KWAGE_OK;
+		}
+		first_row_pread = r0;          // could not map or lock a window: the staged paths below do the rest
+	}
+	if(first_row_pread == 0 && mmap_ok && h.compression == KWAGE_COMPRESSION_NONE){
 		// windows of at most 512 MiB (whole chunks): pinned page-cache pages cannot be evicted, so a file larger
 		// than host memory must never be pinned as a whole; two windows are alive at most (one being copied from)
 		const uint64_t win_rows = std::max<uint64_t>(chunk_rows, (window_target/chunk_bytes)*chunk_rows);

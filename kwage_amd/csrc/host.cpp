@@ -384,6 +384,19 @@ bool DbSliceSource::read_rows(uint64_t r0, uint64_t nr, unsigned char *dst, std:
 	return true;
 }
 
+bool DbSliceSource::slice_crc32(uint32_t &crc, std::string &err)
+{
+	const uint64_t chunk_rows = std::max<uint64_t>(1, std::min<uint64_t>(nrows, (64ull << 20)/std::max<uint64_t>(slice_size, 1)));
+	std::vector<unsigned char> buf(chunk_rows*slice_size);
+	crc = 0;
+	for(uint64_t r0 = 0; r0 < nrows; r0 += chunk_rows){
+		const uint64_t nr = std::min(chunk_rows, nrows - r0);
+		if(!read_rows(r0, nr, buf.data(), err)){ return false; }
+		crc = (uint32_t)crc32_z(crc, buf.data(), nr*slice_size);
+	}
+	return true;
+}
+
 // ---- file_util.cpp:95-121 -------------------------------------------------------------------
 bool find_file_extension(const std::string &path, const char *ext)
 {

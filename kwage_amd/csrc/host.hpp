@@ -58,6 +58,7 @@ struct DbSliceSource {
 	std::vector<uint64_t> offsets;          // compressed only: nrows + 1 absolute file offsets
 	bool open(const std::string &path, std::string &err);
 	bool read_rows(uint64_t r0, uint64_t nr, unsigned char *dst, std::string &err);   // nr*slice_size bytes
+	bool slice_crc32(uint32_t &crc, std::string &err);      // CRC32 of the (uncompressed) slice block, as build_db stores it in the header
 	void close();
 	~DbSliceSource() { close(); }
 };

@@ -368,8 +368,8 @@ __global__ __launch_bounds__(SEARCH_THREADS) void and_kernel(SearchArgs a)
 // consecutive KiB are requested back to back by one wave instead of by different waves at different times as in
 // and_kernel's (query, 2 KiB tile) form (+1-2.4 % on 12.5 KB rows, nothing on 125 KB rows).
 //
-// The grid is PERSISTENT and the work statically balanced: the launch has exactly as many waves as the chip
-// holds at once (or fewer for small batches), and the batch's concatenated position list -- `slots`: for every
+// The grid is PERSISTENT and the work statically balanced: the launch has 8 waves per CU (2 workgroups; 16 per CU
+// measured 1-2 % slower -- twice the cut pairs -- and a deeper prefetch no better), fewer for small batches, and the batch's concatenated position list -- `slots`: for every
 // query and column tile its positions, query-major -- is cut into equal contiguous ranges, one per wave.  Row
 // lists are addressed by position (pos_off) and trimmed to the distinct k-mers the k-mer stage found (nkmer),
 // so every wave reads the same number of bytes unless a query lost many positions to duplicates or N.  There is
@@ -396,8 +396,8 @@ struct WalkArgs {
 // (rows, pos_off and nkmer are passed as __restrict__ parameters of their own besides SearchArgs: the kernel stores
 // hits and updates the cut-pair slots inside its work loop, and only with the no-alias promise does the compiler
 // keep the row-index loads on the scalar path -- otherwise every row descriptor goes through a waterfall loop)
-template <int CH, int UNROLL, bool DEEP>
-__global__ __launch_bounds__(SEARCH_THREADS, DEEP ? 2 : 4) void and_walk_kernel(SearchArgs a, WalkArgs wa, const uint32_t *__restrict__ rows,
+template <int CH, int UNROLL>
+__global__ __launch_bounds__(SEARCH_THREADS, 4) void and_walk_kernel(SearchArgs a, WalkArgs wa, const uint32_t *__restrict__ rows,
                                                                      const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ nkmer)
 {
 	const uint32_t lane = threadIdx.x & (WAVE - 1);
@@ -448,30 +448,20 @@ __global__ __launch_bounds__(SEARCH_THREADS, DEEP ? 2 : 4) void and_walk_kernel(
 					const uint32_t r = rq[min(i + u, nrows - 1)];        // past the end: the last row again (AND is idempotent)
 					rs[u] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.db + (uint64_t)r*a.stride), 0, row_bytes, 0x00020000);
 				}
-				if(DEEP){
-					// all UNROLL x CH KiB requested before the first one is waited for (UNROLL*CH*4 VGPRs: 2 waves/SIMD)
-					u32x4 x[UNROLL][CH];
+				// (the opposite extreme, all UNROLL x CH KiB requested before the first wait -- 172 VGPRs, 2 waves/SIMD -- measured
+				// the same or 1 % slower at every batch size: removed)
 #pragma unroll
-					for(int u = 0; u < UNROLL; ++u){
+				for(int j = 0; j < CH; ++j){
+					u32x4 x[UNROLL];
 #pragma unroll
-						for(int j = 0; j < CH; ++j){ x[u][j] = __builtin_amdgcn_raw_buffer_load_b128(rs[u], u0*16u, j*1024, 2 /* nt */); }
-					}
-					__builtin_amdgcn_sched_barrier(0);         // keep the scheduler from sinking the loads next to their uses
+					for(int u = 0; u < UNROLL; ++u){ x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs[u], u0*16u, j*1024, 2 /* nt */); }
 #pragma unroll
-					for(int u = 0; u < UNROLL; ++u){
-#pragma unroll
-						for(int j = 0; j < CH; ++j){ acc[j] &= x[u][j]; }
-					}
-				}
-				else{
-#pragma unroll
-					for(int j = 0; j < CH; ++j){
-						u32x4 x[UNROLL];
-#pragma unroll
-						for(int u = 0; u < UNROLL; ++u){ x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs[u], u0*16u, j*1024, 2 /* nt */); }
-#pragma unroll
-						for(int u = 0; u < UNROLL; ++u){ acc[j] &= x[u]; }
-					}
+					for(int u = 0; u < UNROLL; ++u){ acc[j] &= x[u]; }
+					// One KiB-step of UNROLL rows at a time: nothing of step j+1 is requested before step j is in.  What the
+					// memory system likes is ~8192 sequential row streams chip-wide (8 waves per CU x 4 rows), each a KiB
+					// deep; left alone the scheduler keeps 8-9 KiB per wave in flight, which measures 1 % slower, and more
+					// streams (16 waves per CU, or 8 rows) 2-3 % slower (profiles/r02_walk_sizes_schedules.txt).
+					__builtin_amdgcn_sched_barrier(0);
 				}
 				if(a.early_exit){     // kwage.cpp:466-470: this part alone already rules every column of the tile out
 					bool nz = false;
@@ -932,6 +922,31 @@ __global__ void place_rows_kernel(uint8_t *db, uint64_t stride, uint64_t row0, u
 		for(uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x*blockDim.x){
 			const uint64_t r = i / width, b = i % width;
 			db[(row0 + r)*stride + byte0 + b] = src[r*src_stride + b];
+		}
+	}
+}
+
+// Loader, direct path: rows of `width` bytes (a multiple of 4), contiguous in `src` -- a window of a `.db` file locked
+// in host memory and read over PCIe; only dword aligned, the body of a file starts at byte 44 -- to rows row0.. of
+// the strided matrix at byte column byte0 (16-byte aligned).  16 bytes per lane where the row length allows.
+typedef u32x4 u32x4_dword_aligned __attribute__((aligned(4)));
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(uint8_t *db, uint64_t stride, uint64_t row0, uint64_t byte0,
+                                                        const uint8_t *src, uint64_t width, uint64_t nrows)
+{
+	if((width & 15ull) == 0){
+		const uint64_t upr = width/16, total = nrows*upr;
+		for(uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x*blockDim.x){
+			const uint64_t r = i/upr, u = i%upr;
+			const u32x4 v = *reinterpret_cast<const u32x4_dword_aligned*>(src + r*width + 16*u);
+			*reinterpret_cast<u32x4*>(db + (row0 + r)*stride + byte0 + 16*u) = v;
+		}
+	}
+	else{
+		const uint64_t wpr = width/4, total = nrows*wpr;
+		for(uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x*blockDim.x){
+			const uint64_t r = i/wpr, w = i%wpr;
+			*reinterpret_cast<uint32_t*>(db + (row0 + r)*stride + byte0 + 4*w) = *reinterpret_cast<const uint32_t*>(src + r*width + 4*w);
 		}
 	}
 }

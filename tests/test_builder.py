@@ -4,11 +4,12 @@ reference through oracle/_ref/ref_tool) and against the numpy restatement on syn
 import ctypes as C
 import glob
 import os
+import sys
 
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 
 
 def _blooms(case):
@@ -129,6 +130,29 @@ def test_repack_is_the_column_concatenation(oracle, tmp_path):
         _repack(ctx, inputs, out)
         with pytest.raises(ka.KwageError):
             _repack(ctx, inputs + [os.path.join(GOLDEN, "k32", "k32.db")], str(tmp_path / "bad.db"))   # other parameters
+        # a source whose slices do not match the CRC32 in its header is refused (merge_db.cpp:608-614), raw or compressed,
+        # and no output is left behind
+        for victim in (paths[3], z):
+            raw = bytearray(open(victim, "rb").read())
+            raw[-1 - len(raw) // 3 if victim == z else 44 + 500] ^= 0x10
+            flipped = str(tmp_path / ("flipped" + os.path.splitext(victim)[1]))
+            open(flipped, "wb").write(raw)
+            bad_out = str(tmp_path / "bad_crc.db")
+            with pytest.raises(ka.KwageError) as ei:
+                _repack(ctx, [paths[0], flipped], bad_out)
+            if victim != z:
+                assert "Invalid CRC32 value for source database file" in str(ei.value)
+            assert not os.path.exists(bad_out)
+        # ... and so does the loader when asked to check (KWAGE_VERIFY_CRC=1; the knob is read once per process)
+        code = ("import sys; sys.path.insert(0, %r)\nimport kwage_amd as ka\n"
+                "with ka.Context(0) as ctx:\n    g = ka.Group(ctx, 25, 2, 10, 4096)\n    print(g.add_db_file(sys.argv[1]))\n" % ROOT)
+        flipped_raw = str(tmp_path / "flipped.db")
+        for env, path, ok in (({"KWAGE_VERIFY_CRC": "1"}, paths[3], True), ({"KWAGE_VERIFY_CRC": "1"}, flipped_raw, False),
+                              ({}, flipped_raw, True)):
+            r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, env=dict(os.environ, **env))
+            assert (r.returncode == 0) == ok, r.stderr[-800:]
+            if not ok:
+                assert "Invalid CRC32 value" in r.stderr
     wide = oracle.read_db(out)
     total = sum(m.shape[1] for m in mats)
     assert wide.header.num_filter == total and wide.header.compression == 0

@@ -1,5 +1,7 @@
-"""Full-size GPU checks (BASELINE.json configs[1] = C2: 100k samples x 2^23-bit filters, 105 GB
-resident) through size-independent properties, because no CPU can hold or scan the matrix:
+"""Full-size GPU checks of every BASELINE.json configuration that fits one GPU -- C2 (100k samples x 2^23-bit
+filters, 105 GB resident), C3 (1 M samples x 2^20, 100k x 150 bp reads, 131 GB), the per-GPU share of C4
+(1.25 M samples x 2^20, 10k x 1 kb, 164 GB) and the per-GPU share of C5 (eight filter-size groups 2^18..2^25,
+5 hashes, t = 0.8, 189 GB) -- through size-independent properties, because no CPU can hold or scan the matrix:
 
   * planted positives: every query cut from a planted genome reports (at least) the columns the
     genome was planted in, with num_match == num_query_kmer;
@@ -31,17 +33,30 @@ def _check_sampled(ka, oracle, s, res, sample, threshold):
         assert per_q[qi] == exp, (qi, len(per_q[qi]), len(exp))
 
 
-def _check_planted(s, res):
+def _check_planted(s, res, complete_match=True):
+    """Every query cut from a planted genome reports the genome's columns with every k-mer found; at threshold 1
+    nothing else can be reported with fewer."""
     per_q = res.per_query()
     n_planted_q = 0
     for qi, gi in enumerate(s.query_genome):
         if gi < 0:
             continue
         n_planted_q += 1
-        cols = {c for c, _ in per_q[qi]}
-        assert set(s.planted[gi]) <= cols, qi
-        assert all(m == res.num_query_kmer[qi] for _, m in per_q[qi])
+        found = dict(per_q[qi])
+        assert set(s.planted[gi]) <= set(found), qi
+        assert all(found[c] == res.num_query_kmer[qi] for c in s.planted[gi])
+        if complete_match:
+            assert all(m == res.num_query_kmer[qi] for m in found.values())
+        else:
+            assert all(res.query_threshold[qi] <= m <= res.num_query_kmer[qi] for m in found.values())
     assert n_planted_q > 0
+
+
+def _sample_queries(s, n_hit, n_miss):
+    hitq = [i for i, g in enumerate(s.query_genome) if g >= 0]
+    missq = [i for i, g in enumerate(s.query_genome) if g < 0]
+    pick = lambda xs, n: [xs[(len(xs) - 1) * j // max(n - 1, 1)] for j in range(min(n, len(xs)))]     # first ... last
+    return pick(hitq, n_hit) + pick(missq, n_miss)
 
 
 @pytest.mark.timeout(900)
@@ -70,6 +85,84 @@ def test_c2_full_size_properties(ka, oracle):
         _check_sampled(ka, oracle, s, r4, hitq[:2] + missq[:2], 0.3)
         s.batch.close()
         s.group.close()
+
+
+@pytest.mark.timeout(900)
+def test_c3_full_size_properties(ka, oracle):
+    """BASELINE.json configs[2]: 1 M samples x 2^20-bit filters (125 KB rows, 131 GB), 100 k x 150 bp reads, t = 1.0 --
+    one launch of 3.05 M workgroups, more queries than a grid's y dimension holds."""
+    from kwage_amd import synth
+    w = synth.WORKLOADS["c3"]
+    with ka.Context(0) as ctx:
+        free, _ = ctx.mem_info()
+        if free < 150e9:
+            pytest.skip("needs ~135 GB of free HBM")
+        s = synth.build(ctx, w)
+        assert s.group.device_bytes == (1 << 20) * 125056 and len(s.queries) == 100_000
+        r1 = s.group.search(s.batch, 1.0, ka.SEARCH_TIMING)
+        assert r1.total_kmers == 120 * 100_000 and r1.algorithmic_bytes == 120 * 100_000 * 125_000
+        assert r1.search_kernel.startswith("and_kernel<")
+        _check_planted(s, r1)
+        _check_sampled(ka, oracle, s, r1, _sample_queries(s, 4, 4), 1.0)
+        r2 = s.group.search(s.batch, 1.0, ka.SEARCH_EARLY_EXIT)
+        assert np.array_equal(r1.hits, r2.hits)                # kwage.cpp:437-483 never changes results
+        r3 = s.group.search(s.batch, 1.0)
+        assert np.array_equal(r1.hits, r3.hits)                # idempotent
+        s.batch.close()
+        s.group.close()
+
+
+@pytest.mark.timeout(900)
+def test_c4_per_gpu_share_full_size_properties(ka, oracle):
+    """BASELINE.json configs[3], what ONE of its 8 GPUs holds: 1.25 M samples x 2^20-bit filters (156 KB rows, 164 GB),
+    10 k x 1 kb queries, t = 1.0.  (The 8-GPU exchange itself is covered by tests/test_distributed_gloo.py and
+    tests/test_bench_launcher.py.)"""
+    from kwage_amd import synth
+    w = synth.WORKLOADS["c4"]
+    with ka.Context(0) as ctx:
+        free, _ = ctx.mem_info()
+        if free < 185e9:
+            pytest.skip("needs ~170 GB of free HBM")
+        s = synth.build(ctx, w)
+        assert s.group.device_bytes == (1 << 20) * 156288 and len(s.queries) == 10_000
+        r1 = s.group.search(s.batch, 1.0)
+        assert r1.total_kmers == 970 * 10_000 and r1.algorithmic_bytes == 970 * 10_000 * 156_250
+        _check_planted(s, r1)
+        _check_sampled(ka, oracle, s, r1, _sample_queries(s, 2, 2), 1.0)
+        r2 = s.group.search(s.batch, 1.0, ka.SEARCH_EARLY_EXIT)
+        assert np.array_equal(r1.hits, r2.hits)
+        r3 = s.group.search(s.batch, 1.0)
+        assert np.array_equal(r1.hits, r3.hits)
+        s.batch.close()
+        s.group.close()
+
+
+@pytest.mark.timeout(1200)
+def test_c5_per_gpu_share_full_size_properties(ka, oracle):
+    """BASELINE.json configs[4], what ONE of its 8 GPUs holds: the eight adaptive filter-size groups 2^18 .. 2^25
+    (1.09 M samples, 189 GB resident together), 5 hash functions, threshold 0.8 (count path), 1 k x 1 kb queries
+    searched against every group."""
+    from kwage_amd import synth
+    w = synth.WORKLOADS["c5"]
+    with ka.Context(0) as ctx:
+        free, _ = ctx.mem_info()
+        if free < 210e9:
+            pytest.skip("needs ~195 GB of free HBM")
+        multi = synth.build_multi(ctx, synth.C5_GROUPS, w)
+        assert sum(m.group.device_bytes for m in multi) > 185e9
+        assert [m.workload.log_2_filter_len for m in multi] == list(range(18, 26))
+        for m in multi:
+            r1 = m.group.search(multi[0].batch, 0.8)
+            assert r1.total_kmers == 970 * 1000
+            assert r1.algorithmic_bytes == 970 * 1000 * 5 * ((m.workload.num_samples + 7) // 8)
+            assert (r1.query_threshold == 776).all()                      # (unsigned)(0.8f * 970), kwage.cpp:388
+            _check_planted(m, r1, complete_match=False)
+            _check_sampled(ka, oracle, m, r1, _sample_queries(m, 1, 1), 0.8)
+            r2 = m.group.search(multi[0].batch, 0.8, ka.SEARCH_EARLY_EXIT)
+            assert np.array_equal(r1.hits, r2.hits)                       # kwage.cpp:478-481 never changes results
+        for m in multi:
+            m.batch.close()
+            m.group.close()
 
 
 @pytest.mark.timeout(900)

@@ -609,11 +609,14 @@ def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{}, {"KWAGE_LOAD_MMAP": "0"}, {"KWAGE_LOAD_CHUNK_KB": "8", "KWAGE_LOAD_WINDOW_KB": "20"},
-                                 {"KWAGE_LOAD_CHUNK_KB": "3", "KWAGE_LOAD_WINDOW_KB": "3"}])
+                                 {"KWAGE_LOAD_CHUNK_KB": "3", "KWAGE_LOAD_WINDOW_KB": "3"}, {"KWAGE_LOAD_DIRECT": "0"},
+                                 {"KWAGE_LOAD_DIRECT": "0", "KWAGE_LOAD_CHUNK_KB": "8", "KWAGE_LOAD_WINDOW_KB": "20"}])
 def test_loader_paths_give_the_same_matrix(ka, oracle, tmp_path, env):
-    """kwage_group_add_db_file: zero-copy path (file mapping pinned with hipHostRegister, copies left in flight
-    across files), the same with many small windows / chunks, and the pread path -- the resident matrix must be
-    the file's rows, for several files of odd widths in one group.  (The knobs are read once per process.)"""
+    """kwage_group_add_db_file: the direct path (file windows locked through HSA, one copy kernel reads them over PCIe
+    into the strided matrix; rows that are dword multiples), the staged zero-copy path (mapping pinned with
+    hipHostRegister, copies left in flight across files), both with many small windows / chunks, and the pread path
+    -- the resident matrix must be the file's rows, for several files of odd and even widths in one group.
+    (The knobs are read once per process.)"""
     import subprocess
     import sys
     from conftest import ROOT
@@ -623,7 +626,7 @@ sys.path.insert(0, %r); sys.path.insert(0, %r + "/oracle")
 import kwage_amd as ka, kwage_oracle as oracle
 rng = np.random.default_rng(8)
 files = []
-for j, ncol in enumerate((100, 2048, 13, 777)):
+for j, ncol in enumerate((100, 2048, 13, 777, 800, 96, 2016)):
     rows = rng.integers(0, 256, size=(1 << 12, (ncol + 7) // 8), dtype=np.uint8)
     if ncol %% 8:
         rows[:, -1] &= np.uint8((1 << (ncol %% 8)) - 1)

@@ -16,13 +16,14 @@ acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
 extra = [acgt[rng.integers(0, 4, size=1000)].tobytes().decode() for _ in range(4000)]
 variants = [("tiled", {"KWAGE_WALK": "0"}), ("walk", {"KWAGE_WALK": "4", "KWAGE_WALK_MIN_ROWS": "1"})]
 for wv in sys.argv[1:]:
-    if wv == "deep":
-        variants.append(("walk/deep", {"KWAGE_WALK": "3", "KWAGE_WALK_MIN_ROWS": "1"}))
+    if wv.startswith("cfg:"):        # cfg:<rows in flight>:<waves>
+        _, u, wvs = wv.split(":")
+        variants.append(("walk u%s %s waves" % (u, wvs), {"KWAGE_WALK": u, "KWAGE_WALK_MIN_ROWS": "1", "KWAGE_WALK_WAVES": wvs}))
     elif wv == "fences":
         variants.append(("walk/full fences", {"KWAGE_WALK": "4", "KWAGE_WALK_MIN_ROWS": "1", "KWAGE_WALK_FENCES": "1"}))
     else:
         variants.append(("walk/%s waves" % wv, {"KWAGE_WALK": "4", "KWAGE_WALK_MIN_ROWS": "1", "KWAGE_WALK_WAVES": wv}))
-for nq in (50, 100, 200, 300, 500, 700, 900, 1000, 1024, 1030, 1100, 1300, 1500, 2048, 2100, 3000, 5000):
+for nq in [int(x) for x in os.environ.get("WALK_SIZES", "50,100,200,300,500,700,900,1000,1024,1030,1100,1300,1500,2048,2100,3000,5000").split(",")]:
     qs = (s.queries + extra)[:nq]
     b = ka.Batch(ctx, qs)
     out = []
