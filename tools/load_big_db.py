@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive wall time of loading a database the size of C2 (105 GB) through the `kwage` CLI: N reference-format
+files (2048 columns x 2^20 rows, 268 MB each) in a tmpfs / page-cache directory, one short query, KWAGE_VERBOSE=1.
+
+    python tools/load_big_db.py [n_files=392] [dir=/dev/shm]"""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+
+import kwage_oracle as oracle
+from kwage_amd import native
+
+n_files = int(sys.argv[1]) if len(sys.argv) > 1 else 392
+base = sys.argv[2] if len(sys.argv) > 2 else "/dev/shm"
+L, ncol, k, nh = 20, 2048, 31, 1
+free = shutil.disk_usage(base).free
+need = n_files * ((1 << L) * 256 + 200_000)
+if free < need * 1.02:
+    n_files = int(free / 1.02 // ((1 << L) * 256 + 200_000))
+    print("only %.0f GB free under %s: %d files" % (free / 1e9, base, n_files))
+tmp = tempfile.mkdtemp(prefix="kwage_big_", dir=base)
+try:
+    rng = np.random.default_rng(3)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    genome = acgt[rng.integers(0, 4, size=2000)].tobytes().decode()
+    a = rng.integers(0, 1 << 63, size=(1 << L, ncol // 64), dtype=np.uint64)
+    b = rng.integers(0, 1 << 63, size=(1 << L, ncol // 64), dtype=np.uint64)
+    rows = (a & b).view(np.uint8).reshape(1 << L, ncol // 8).copy()
+    for r in oracle.row_indices(oracle.unique_kmers(genome, k), k, nh, L).reshape(-1):
+        rows[r, 5] |= np.uint8(1 << 3)                      # column 43 of every file holds the genome
+    infos = [oracle.FilterInfo(run_accession=oracle.str_to_accession("SRR%07d" % j)) for j in range(ncol)]
+    os.makedirs(os.path.join(tmp, "db"))
+    first = os.path.join(tmp, "db", "part0000.db")
+    t0 = time.perf_counter()
+    oracle.write_db(first, k, nh, L, rows, ncol, infos)
+    for f in range(1, n_files):
+        shutil.copyfile(first, os.path.join(tmp, "db", "part%04d.db" % f))
+    gb = n_files * (1 << L) * 256 / 1e9
+    print("wrote %d files, %.1f GB, in %.1f s" % (n_files, gb, time.perf_counter() - t0), flush=True)
+    for env_extra in ({}, {"KWAGE_LOAD_DIRECT": "0"}):
+        t0 = time.perf_counter()
+        r = subprocess.run([native.KWAGE_BIN, "-d", os.path.join(tmp, "db"), "--o.csv", genome[100:1100]], capture_output=True, text=True,
+                           env=dict(os.environ, KWAGE_VERBOSE="1", **env_extra))
+        wall = time.perf_counter() - t0
+        assert r.returncode == 0, r.stderr
+        hits = len(r.stdout.strip().splitlines()) - 1
+        print("%s: wall %.2f s for %.1f GB (%.1f GB/s end to end, PCIe + metadata + search + report), %d hits (expected %d)"
+              % ("direct path" if not env_extra else "staged path (KWAGE_LOAD_DIRECT=0)", wall, gb, gb / wall, hits, n_files))
+        print("   " + "\n   ".join(l for l in r.stderr.strip().splitlines() if l.startswith("[kwage]")), flush=True)
+        assert hits >= n_files
+finally:
+    shutil.rmtree(tmp, ignore_errors=True)
