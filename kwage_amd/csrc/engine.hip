@@ -127,7 +127,7 @@ struct kwage_ctx {
 	size_t map_len = 0;
 	hipEvent_t map_done = nullptr;      // recorded behind the last copy that reads the mapping
 	// direct loading: file windows locked through HSA whose copy kernels may still be running, oldest first
-	struct LockedWindow { void *base; size_t len; hipEvent_t done; };
+	struct LockedWindow { void *base; size_t len; hipEvent_t done; bool owns_event; };     // the windows of one launch share its event; the last one owns it
 	std::deque<LockedWindow> locked;
 	std::vector<hipEvent_t> spare_events;
 };
@@ -163,10 +163,11 @@ void release_locked(kwage_ctx *ctx, size_t keep)
 	while(ctx->locked.size() > keep){
 		kwage_ctx::LockedWindow w = ctx->locked.front();
 		ctx->locked.pop_front();
-		(void)hipEventSynchronize(w.done);
+		if(w.done){ (void)hipEventSynchronize(w.done); }
+		else{ (void)hipStreamSynchronize(ctx->stream); }
 		(void)hsa_lock().unlock(w.base);
 		(void)munmap(w.base, w.len);
-		ctx->spare_events.push_back(w.done);
+		if(w.done && w.owns_event){ ctx->spare_events.push_back(w.done); }
 	}
 }
 
@@ -1027,10 +1028,25 @@ extern "C" int kwage_group_add_columns(kwage_group *g, const void *host_rows, ui
 	return KWAGE_OK;
 }
 
-extern "C" int kwage_group_add_db_file(kwage_group *g, const char *path, uint64_t *first_column, uint32_t *num_filter)
+namespace {
+
+static const uint32_t LOAD_GANG = LOAD_GANG_MAX;      // files whose rows one copy kernel writes side by side (16 x 256 B = 4 KiB per matrix row)
+
+bool load_env_flag(const char *name, bool fallback)
 {
-	if(!g || !path){ return fail(KWAGE_ERR_ARG, "kwage_group_add_db_file: NULL argument"); }
-	DbSliceSource src;       // raw layout or this repo's deflate container (inflated on the host)
+	const char *e = getenv(name);
+	return e ? atoi(e) != 0 : fallback;
+}
+
+uint64_t load_env_kb(const char *name, uint64_t fallback_bytes)
+{
+	const char *e = getenv(name);
+	return (e && atoll(e) > 0) ? (uint64_t)atoll(e) << 10 : fallback_bytes;
+}
+
+// Open a database file for loading into `g`: header checks, optional CRC check, column reservation.
+int open_source_for_group(kwage_group *g, const char *path, DbSliceSource &src, uint64_t *byte0)
+{
 	std::string err;
 	if(!src.open(path, err)){ return fail(KWAGE_ERR_IO, "%s", err.c_str()); }
 	const kwage_db_header &h = src.header;
@@ -1040,34 +1056,125 @@ extern "C" int kwage_group_add_db_file(kwage_group *g, const char *path, uint64_
 		            path, h.kmer_len, h.num_hash, h.log_2_filter_len, h.hash_func);
 	}
 	if(h.num_filter == 0){ return fail(KWAGE_ERR_FORMAT, "%s: num_filter is 0", path); }
-	kwage_ctx *ctx = g->ctx;
-	int rc = set_device(ctx);
-	if(rc){ return rc; }
-
-	const uint64_t width = src.slice_size;
 	// KWAGE_VERIFY_CRC=1: refuse a file whose slice block does not match the CRC32 in its header, as the reference's
 	// merge does for its sources (merge_db.cpp:608-614; its `kwage` checks nothing, kwage.cpp:99-105).  A separate
 	// pass over the file on the host, so off by default.
-	static const bool verify_crc = []() { const char *e = getenv("KWAGE_VERIFY_CRC"); return e && atoi(e) != 0; }();
+	static const bool verify_crc = load_env_flag("KWAGE_VERIFY_CRC", false);
 	if(verify_crc){
 		uint32_t crc = 0;
 		if(!src.slice_crc32(crc, err)){ return fail(KWAGE_ERR_IO, "%s: %s", path, err.c_str()); }
 		if(crc != h.crc32){ return fail(KWAGE_ERR_FORMAT, "%s: Invalid CRC32 value (header %08x, slices %08x)", path, h.crc32, crc); }
 	}
-	uint64_t byte0 = 0;
-	if((rc = group_reserve_columns(g, h.num_filter, &byte0))){ return rc; }
+	return group_reserve_columns(g, h.num_filter, byte0);
+}
 
+// Can the direct path take this file?  Raw layout, rows a multiple of 4 bytes, HSA lock available, and asked for
+// (KWAGE_LOAD_DIRECT=1: it is NOT the default, see load_gang_direct).
+bool direct_loadable(const DbSliceSource &src)
+{
+	static const bool mmap_ok = load_env_flag("KWAGE_LOAD_MMAP", true), direct_ok = load_env_flag("KWAGE_LOAD_DIRECT", false);
+	return mmap_ok && direct_ok && src.header.compression == KWAGE_COMPRESSION_NONE && src.slice_size % 4 == 0 && hsa_lock().lock != nullptr;
+}
+
+// Direct path (opt-in, KWAGE_LOAD_DIRECT=1): rows of up to KWAGE_LOAD_GANG (default 16) raw files go from the page cache
+// straight into the strided matrix.  Windows of the files are mapped and locked through HSA (no
+// hipHostRegister/Unregister, which wait for the device), ONE copy kernel per window reads them over PCIe and writes
+// the rows where they belong -- no staging buffer, no second pass over HBM.  The windows of up to two launches stay
+// locked behind the one being queued and are released as their kernels finish.
+// Why it is not the default (profiles/r02_loader_probe.txt, r02_e2e_cli_32files.txt, r02_load_105gb.txt):
+//   32 x 268 MB files (8.6 GB matrix, 8 KiB stride): one file per launch 38-47 GB/s, gangs of 16 35 GB/s, staged path
+//     40-41 GB/s -- the kernel's 64-byte PCIe reads cap it below the copy engine's 57 GB/s, so dropping the staging
+//     hop buys little (an SDMA rect copy straight into the matrix reaches 33 GB/s, and hipMemcpyAsync does not
+//     recognise HSA-locked memory: 19 GB/s);
+//   392 files (105 GB matrix, 100 KB stride): 24 GB/s warm and 11 GB/s in the first runs after the files were
+//     written, against 30-33 GB/s for the staged path, every time -- 256-byte pieces 100 KB apart miss the TLB and
+//     the open DRAM page on every store, which hurts a kernel that holds PCIe reads in flight more than the staged
+//     path's short HBM-to-HBM scatter bursts.
+// *rows_done = rows of every file that are on their way when the call returns (all of them unless a window could not
+// be mapped or locked; the caller finishes the rest through the staged paths).
+int load_gang_direct(kwage_group *g, DbSliceSource *const *srcs, const uint64_t *byte0, uint32_t n, uint64_t *rows_done)
+{
+	kwage_ctx *ctx = g->ctx;
+	static const uint64_t window_target = load_env_kb("KWAGE_LOAD_WINDOW_KB", 512ull << 20);
+	const long page = sysconf(_SC_PAGESIZE);
+	uint64_t total_width = 0;
+	bool vec16 = true;
+	for(uint32_t i = 0; i < n; ++i){ total_width += srcs[i]->slice_size; vec16 = vec16 && (srcs[i]->slice_size % 16 == 0); }
+	const uint32_t ub = vec16 ? 16 : 4;
+	// rows per launch: 512 MiB of file windows for one file, up to 2 GiB for a gang (a lock has a fixed cost too)
+	const uint64_t win_rows = std::max<uint64_t>(1, std::min<uint64_t>(g->nrows, window_target*std::min<uint32_t>(n, 4)/total_width));
+	*rows_done = 0;
+	for(uint64_t r0 = 0; r0 < g->nrows; ){
+		const uint64_t wr = std::min(win_rows, g->nrows - r0);
+		GangArgs ga;
+		memset(&ga, 0, sizeof(ga));
+		ga.n = n;
+		std::vector<kwage_ctx::LockedWindow> wins;
+		bool ok = true;
+		uint64_t max_bytes = 0;
+		for(uint32_t i = 0; i < n && ok; ++i){
+			const uint64_t width = srcs[i]->slice_size;
+			const uint64_t off = DB_HEADER_BYTES + r0*width, off0 = off/page*page;
+			const size_t maplen = (size_t)(off - off0 + wr*width);
+			void *base = mmap(nullptr, maplen, PROT_READ, MAP_PRIVATE, srcs[i]->fd, (off_t)off0);      // (the lock faults the pages in)
+			if(base == MAP_FAILED){ ok = false; break; }
+			void *dev_view = nullptr;
+			if(hsa_lock().lock(base, maplen, nullptr, 0, &dev_view) != 0 || !dev_view){ (void)munmap(base, maplen); ok = false; break; }
+			wins.push_back(kwage_ctx::LockedWindow{base, maplen, nullptr, false});
+			ga.f[i].src = (const uint8_t*)dev_view + (off - off0);
+			ga.f[i].byte0 = byte0[i];
+			ga.f[i].width = width;
+			max_bytes = std::max(max_bytes, wr*width);
+		}
+		hipEvent_t ev = nullptr;
+		if(ok){
+			if(!ctx->spare_events.empty()){ ev = ctx->spare_events.back(); ctx->spare_events.pop_back(); }
+			else if(hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess){ ev = nullptr; ok = false; }
+		}
+		if(!ok){
+			for(auto &w : wins){ (void)hsa_lock().unlock(w.base); (void)munmap(w.base, w.len); }
+			return KWAGE_OK;           // *rows_done tells the caller where to go on
+		}
+		const uint64_t items = (uint64_t)n*4*((max_bytes + (uint64_t)4*WAVE*ub - 1)/((uint64_t)4*WAVE*ub));     // (256-lane stretch, file, quarter) triples
+		const uint32_t blocks = grid_for(items*WAVE, 256, 256*8);
+		if(ub == 16){ hipLaunchKernelGGL((copy_rows_gang_kernel<16>), dim3(blocks), dim3(256), 0, ctx->stream, g->d_bits, g->stride, r0, ga, wr, items); }
+		else{ hipLaunchKernelGGL((copy_rows_gang_kernel<4>), dim3(blocks), dim3(256), 0, ctx->stream, g->d_bits, g->stride, r0, ga, wr, items); }
+		hipError_t e = hipGetLastError();
+		if(e == hipSuccess){ e = hipEventRecord(ev, ctx->stream); }
+		for(auto &w : wins){ w.done = ev; }              // every window of the launch waits for the same event ...
+		wins.back().owns_event = true;                   // ... and the last one to go returns it to the pool
+		for(auto &w : wins){ ctx->locked.push_back(w); }
+		if(e != hipSuccess){
+			release_mapping(ctx);
+			return fail(KWAGE_ERR_DEVICE, "loading database rows: %s", hipGetErrorString(e));
+		}
+		release_locked(ctx, 2*(size_t)n);
+		r0 += wr;
+		*rows_done = r0;
+	}
+	return KWAGE_OK;
+}
+
+// Staged paths for rows first_row.. of one file: the pinned file mapping feeding the copy engine (raw files, from row 0)
+// or pread / inflate into pinned buffers, each followed by place_rows_kernel.
+int load_source_rows_staged(kwage_group *g, DbSliceSource &src, const char *path, uint64_t byte0, uint64_t first_row)
+{
+	kwage_ctx *ctx = g->ctx;
+	const kwage_db_header &h = src.header;
+	const uint64_t width = src.slice_size;
+	std::string err;
+	int rc = KWAGE_OK;
 	// Raw files: map the file read-only, pin the mapping (hipHostRegister) and let the copy engine read the
 	// page cache directly -- no pread copy into a staging buffer (that copy, not PCIe, limited the loader to
 	// 30 GB/s; the mapping feeds H2D at the box's 57 GB/s, tools/micro/hostreg_probe.hip).  The copies of THIS
 	// file are left in flight when the call returns, so the next file's mmap + pinning (3-4 ms per 256 MB)
 	// overlaps with them; the mapping is released by the next call, by finalize, or when the group goes.
 	// KWAGE_LOAD_MMAP=0, a compressed file, or a failure to map or pin falls back to the pread path below.
-	static const bool mmap_ok = []() { const char *e = getenv("KWAGE_LOAD_MMAP"); return !(e && atoi(e) == 0); }();
-	uint64_t first_row_pread = 0;
+	static const bool mmap_ok = load_env_flag("KWAGE_LOAD_MMAP", true);
+	uint64_t first_row_pread = first_row;
 	// (KWAGE_LOAD_CHUNK_KB / KWAGE_LOAD_WINDOW_KB shrink the 64 MiB staging chunk and the 512 MiB window: tests)
-	static const uint64_t chunk_target = []() { const char *e = getenv("KWAGE_LOAD_CHUNK_KB"); return (e && atoll(e) > 0) ? (uint64_t)atoll(e) << 10 : (64ull << 20); }();
-	static const uint64_t window_target = []() { const char *e = getenv("KWAGE_LOAD_WINDOW_KB"); return (e && atoll(e) > 0) ? (uint64_t)atoll(e) << 10 : (512ull << 20); }();
+	static const uint64_t chunk_target = load_env_kb("KWAGE_LOAD_CHUNK_KB", 64ull << 20);
+	static const uint64_t window_target = load_env_kb("KWAGE_LOAD_WINDOW_KB", 512ull << 20);
 	const uint64_t chunk_rows = std::max<uint64_t>(1, std::min<uint64_t>(g->nrows, chunk_target/width));
 	const uint64_t chunk_bytes = chunk_rows*width;
 	PinBuf *pin = ctx->load_pin;
@@ -1079,50 +1186,7 @@ extern "C" int kwage_group_add_db_file(kwage_group *g, const char *path, uint64_
 		if(!rc && !done[i] && hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess){ rc = fail(KWAGE_ERR_DEVICE, "hipEventCreate failed"); }
 	}
 	if(rc){ return rc; }
-	// Direct path (raw files whose rows are dword multiples, e.g. the 256-byte rows of a full 2048-column file): map
-	// a window of the file, lock it through HSA, and let ONE copy kernel read the page cache over PCIe and write the
-	// rows where they belong in the strided matrix -- no staging buffer, no second pass over HBM, and no
-	// hipHostRegister/Unregister (which wait for the device: the copy engine sat idle 2.3 ms per 256 MB file).
-	// Up to two windows stay locked behind the one being queued; they are released as their kernels finish.
-	// 16 x 268 MB files: 46.8 GB/s against 40.4 GB/s for the staged path on the same box; an SDMA rect copy into
-	// the matrix reaches 33 GB/s (256-byte lines) and hipMemcpyAsync does not recognise HSA-locked memory (19 GB/s):
-	// tools/micro/lock_copy_probe.hip, profiles/r02_loader_probe.txt.  KWAGE_LOAD_DIRECT=0 disables it.
-	static const bool direct_ok = []() { const char *e = getenv("KWAGE_LOAD_DIRECT"); return !(e && atoi(e) == 0); }();
-	if(mmap_ok && direct_ok && h.compression == KWAGE_COMPRESSION_NONE && width % 4 == 0 && hsa_lock().lock){
-		const uint64_t win_rows = std::max<uint64_t>(1, std::min<uint64_t>(g->nrows, window_target/width));
-		const long page = sysconf(_SC_PAGESIZE);
-		uint64_t r0 = 0;
-		for(; r0 < g->nrows; ){
-			const uint64_t wr = std::min(win_rows, g->nrows - r0);
-			const uint64_t off = DB_HEADER_BYTES + r0*width, off0 = off/page*page;
-			const size_t maplen = (size_t)(off - off0 + wr*width);
-			void *base = mmap(nullptr, maplen, PROT_READ, MAP_PRIVATE, src.fd, (off_t)off0);      // (the lock faults the pages in)
-			if(base == MAP_FAILED){ break; }
-			void *dev_view = nullptr;
-			if(hsa_lock().lock(base, maplen, nullptr, 0, &dev_view) != 0 || !dev_view){ (void)munmap(base, maplen); break; }
-			hipEvent_t ev = nullptr;
-			if(!ctx->spare_events.empty()){ ev = ctx->spare_events.back(); ctx->spare_events.pop_back(); }
-			else if(hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess){ (void)hsa_lock().unlock(base); (void)munmap(base, maplen); break; }
-			hipLaunchKernelGGL(copy_rows_kernel, dim3(256*8), dim3(256), 0, ctx->stream, g->d_bits, g->stride, r0, byte0,
-			                   (const uint8_t*)dev_view + (off - off0), width, wr);
-			e = hipGetLastError();
-			if(e == hipSuccess){ e = hipEventRecord(ev, ctx->stream); }
-			ctx->locked.push_back(kwage_ctx::LockedWindow{base, maplen, ev});
-			if(e != hipSuccess){
-				release_mapping(ctx);
-				return fail(KWAGE_ERR_DEVICE, "kwage_group_add_db_file: %s", hipGetErrorString(e));
-			}
-			release_locked(ctx, 2);
-			r0 += wr;
-		}
-		if(r0 >= g->nrows){
-			if(first_column){ *first_column = byte0*8; }
-			if(num_filter){ *num_filter = h.num_filter; }
-			return KWAGE_OK;
-		}
-		first_row_pread = r0;          // could not map or lock a window: the staged paths below do the rest
-	}
-	if(first_row_pread == 0 && mmap_ok && h.compression == KWAGE_COMPRESSION_NONE){
+	if(first_row == 0 && mmap_ok && h.compression == KWAGE_COMPRESSION_NONE){
 		// windows of at most 512 MiB (whole chunks): pinned page-cache pages cannot be evicted, so a file larger
 		// than host memory must never be pinned as a whole; two windows are alive at most (one being copied from)
 		const uint64_t win_rows = std::max<uint64_t>(chunk_rows, (window_target/chunk_bytes)*chunk_rows);
@@ -1167,11 +1231,7 @@ extern "C" int kwage_group_add_db_file(kwage_group *g, const char *path, uint64_
 			if(ctx->map_done){ (void)hipEventRecord(ctx->map_done, ctx->stream); }
 			r0 += wr;
 		}
-		if(!fell_back){
-			if(first_column){ *first_column = byte0*8; }
-			if(num_filter){ *num_filter = h.num_filter; }
-			return KWAGE_OK;
-		}
+		if(!fell_back){ return KWAGE_OK; }
 		// could not map or pin a window (rows below r0 are already on their way): the pread path does the rest
 		first_row_pread = r0;
 	}
@@ -1197,9 +1257,54 @@ extern "C" int kwage_group_add_db_file(kwage_group *g, const char *path, uint64_
 		used[cur] = true;
 	}
 	(void)hipStreamSynchronize(ctx->stream);
+	return rc;
+}
+
+}  // namespace
+
+extern "C" int kwage_group_add_db_file(kwage_group *g, const char *path, uint64_t *first_column, uint32_t *num_filter)
+{
+	if(!g || !path){ return fail(KWAGE_ERR_ARG, "kwage_group_add_db_file: NULL argument"); }
+	return kwage_group_add_db_files(g, &path, 1, first_column, num_filter);
+}
+
+extern "C" int kwage_group_add_db_files(kwage_group *g, const char *const *paths, uint32_t n, uint64_t *first_columns, uint32_t *num_filters)
+{
+	if(!g || !paths || n == 0){ return fail(KWAGE_ERR_ARG, "kwage_group_add_db_files: NULL argument"); }
+	for(uint32_t i = 0; i < n; ++i){ if(!paths[i]){ return fail(KWAGE_ERR_ARG, "kwage_group_add_db_files: path %u is NULL", i); } }
+	int rc = set_device(g->ctx);
 	if(rc){ return rc; }
-	if(first_column){ *first_column = byte0*8; }
-	if(num_filter){ *num_filter = h.num_filter; }
+	// Files are taken in the order given (that is the column order).  Consecutive files the direct path can take are
+	// loaded LOAD_GANG at a time, their rows written side by side; anything else (compressed, odd row length, no HSA
+	// lock) goes through the staged paths file by file.
+	for(uint32_t i0 = 0; i0 < n; ){
+		DbSliceSource srcs[LOAD_GANG];
+		DbSliceSource *ptrs[LOAD_GANG];
+		uint64_t byte0[LOAD_GANG];
+		uint32_t cnt = 0, n_direct = 0;
+		static const uint32_t gang_max = []() { const char *e = getenv("KWAGE_LOAD_GANG"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= (int)LOAD_GANG) ? (uint32_t)v : LOAD_GANG; }();
+		while(i0 + cnt < n && cnt < gang_max){
+			DbSliceSource &src = srcs[cnt];
+			if((rc = open_source_for_group(g, paths[i0 + cnt], src, &byte0[cnt]))){ return rc; }
+			if(first_columns){ first_columns[i0 + cnt] = byte0[cnt]*8; }
+			if(num_filters){ num_filters[i0 + cnt] = src.header.num_filter; }
+			ptrs[cnt] = &src;
+			++cnt;
+			if(!direct_loadable(src)){ break; }          // this file ends the gang and is staged on its own
+			n_direct = cnt;
+		}
+		uint64_t rows_done = 0;
+		if(n_direct){
+			if((rc = load_gang_direct(g, ptrs, byte0, n_direct, &rows_done))){ return rc; }
+		}
+		for(uint32_t k = 0; k < cnt; ++k){
+			const uint64_t from = (k < n_direct) ? rows_done : 0;
+			if(from < g->nrows){
+				if((rc = load_source_rows_staged(g, srcs[k], paths[i0 + k], byte0[k], from))){ return rc; }
+			}
+		}
+		i0 += cnt;
+	}
 	return KWAGE_OK;
 }
 

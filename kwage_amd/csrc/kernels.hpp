@@ -926,27 +926,40 @@ __global__ void place_rows_kernel(uint8_t *db, uint64_t stride, uint64_t row0, u
 	}
 }
 
-// Loader, direct path: rows of `width` bytes (a multiple of 4), contiguous in `src` -- a window of a `.db` file locked
-// in host memory and read over PCIe; only dword aligned, the body of a file starts at byte 44 -- to rows row0.. of
-// the strided matrix at byte column byte0 (16-byte aligned).  16 bytes per lane where the row length allows.
+// Loader, direct path.  Rows of up to LOAD_GANG files -- windows of `.db` files locked in host memory, read over PCIe;
+// only dword aligned: the body of a file starts at byte 44 -- to rows row0.. of the strided matrix, every file at its
+// own byte column (16-byte aligned, adjacent for full 2048-column files).  UB = bytes per lane: 16 when every row
+// length is a multiple of 16, else 4.  Consecutive lanes write consecutive bytes of ONE matrix row across the files
+// of the gang, so a 100 KB-wide matrix is written 4 KiB at a time instead of 256 bytes at a time (one file per
+// kernel filled a 105 GB matrix at 14 GB/s: every 256-byte piece opened another DRAM page and another TLB entry).
+static constexpr uint32_t LOAD_GANG_MAX = 16;
+struct GangSource { const uint8_t *src; uint64_t byte0; uint64_t width; };        // window of one file, its byte column in the matrix, its row length
+struct GangArgs { GangSource f[LOAD_GANG_MAX]; uint32_t n; };
+
 typedef u32x4 u32x4_dword_aligned __attribute__((aligned(4)));
 
-__global__ __launch_bounds__(256) void copy_rows_kernel(uint8_t *db, uint64_t stride, uint64_t row0, uint64_t byte0,
-                                                        const uint8_t *src, uint64_t width, uint64_t nrows)
+// One work item = 64 lanes x UB consecutive bytes of ONE file's window, and the four waves of a workgroup take four
+// consecutive items of the same file: a workgroup reads a contiguous 4 KiB (one host page of the page cache) exactly as
+// a plain sequential copy would.  Consecutive workgroups take the same stretch of consecutive files, so the pieces that
+// are neighbours in a matrix row are written at about the same time, by neighbouring workgroups, into the same DRAM
+// pages and through the same TLB entries.
+template <int UB>
+__global__ __launch_bounds__(256) void copy_rows_gang_kernel(uint8_t *db, uint64_t stride, uint64_t row0, GangArgs ga, uint64_t nrows, uint64_t items)
 {
-	if((width & 15ull) == 0){
-		const uint64_t upr = width/16, total = nrows*upr;
-		for(uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x*blockDim.x){
-			const uint64_t r = i/upr, u = i%upr;
-			const u32x4 v = *reinterpret_cast<const u32x4_dword_aligned*>(src + r*width + 16*u);
-			*reinterpret_cast<u32x4*>(db + (row0 + r)*stride + byte0 + 16*u) = v;
-		}
-	}
-	else{
-		const uint64_t wpr = width/4, total = nrows*wpr;
-		for(uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x*blockDim.x){
-			const uint64_t r = i/wpr, w = i%wpr;
-			*reinterpret_cast<uint32_t*>(db + (row0 + r)*stride + byte0 + 4*w) = *reinterpret_cast<const uint32_t*>(src + r*width + 4*w);
+	const uint32_t lane = threadIdx.x & (WAVE - 1);
+	const uint64_t nwaves = ((uint64_t)gridDim.x*blockDim.x) >> 6;
+	for(uint64_t it = ((uint64_t)blockIdx.x*blockDim.x + threadIdx.x) >> 6; it < items; it += nwaves){
+		// it = ((stretch*n + file)*4 + quarter): quarter = wave within the workgroup
+		const uint32_t fi = __builtin_amdgcn_readfirstlane((uint32_t)((it >> 2) % ga.n));
+		const uint64_t chunk = ((it >> 2) / ga.n)*4 + (it & 3);
+		const uint64_t width = ga.f[fi].width;
+		const uint64_t off = chunk*(WAVE*UB) + (uint64_t)lane*UB;        // byte offset within this file's window
+		if(off < nrows*width){
+			const uint64_t r = off / width, col = off % width;           // UB divides width: a lane never straddles two rows
+			const uint8_t *s = ga.f[fi].src + off;
+			uint8_t *d = db + (row0 + r)*stride + ga.f[fi].byte0 + col;
+			if(UB == 16){ *reinterpret_cast<u32x4*>(d) = *reinterpret_cast<const u32x4_dword_aligned*>(s); }
+			else{ *reinterpret_cast<uint32_t*>(d) = *reinterpret_cast<const uint32_t*>(s); }
 		}
 	}
 }

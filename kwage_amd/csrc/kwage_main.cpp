@@ -610,13 +610,18 @@ int main(int argc, char *argv[])
 						double t0 = now_s();
 						check(kwage_group_create(ctx, &p, span_bytes*8, &grp));
 						ColumnMap cols;
-						for(size_t m = m0; m < m1; ++m){
-							DbFileEntry &f = files[members[m]];       // each file is touched by exactly one worker
-							uint32_t nf = 0;
-							const int rc = kwage_group_add_db_file(grp, f.path.c_str(), &f.first_column, &nf);
+						{
+							vector<const char*> paths;
+							for(size_t m = m0; m < m1; ++m){ paths.push_back(files[members[m]].path.c_str()); }
+							vector<uint64_t> firsts(paths.size());
+							const int rc = kwage_group_add_db_files(grp, paths.data(), (uint32_t)paths.size(), firsts.data(), nullptr);
 							if(rc != KWAGE_OK){ kwage_group_destroy(grp); check(rc); }
-							cols.files.push_back(&f);
-							cols.file_index.push_back(members[m]);
+							for(size_t m = m0; m < m1; ++m){
+								DbFileEntry &f = files[members[m]];       // each file is touched by exactly one worker
+								f.first_column = firsts[m - m0];
+								cols.files.push_back(&f);
+								cols.file_index.push_back(members[m]);
+							}
 						}
 						try{
 							check(kwage_group_finalize(grp));

@@ -614,14 +614,15 @@ def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{}, {"KWAGE_LOAD_MMAP": "0"}, {"KWAGE_LOAD_CHUNK_KB": "8", "KWAGE_LOAD_WINDOW_KB": "20"},
-                                 {"KWAGE_LOAD_CHUNK_KB": "3", "KWAGE_LOAD_WINDOW_KB": "3"}, {"KWAGE_LOAD_DIRECT": "0"},
-                                 {"KWAGE_LOAD_DIRECT": "0", "KWAGE_LOAD_CHUNK_KB": "8", "KWAGE_LOAD_WINDOW_KB": "20"}])
+                                 {"KWAGE_LOAD_CHUNK_KB": "3", "KWAGE_LOAD_WINDOW_KB": "3"}, {"KWAGE_LOAD_DIRECT": "1"},
+                                 {"KWAGE_LOAD_DIRECT": "1", "KWAGE_LOAD_GANG": "1"}, {"KWAGE_LOAD_DIRECT": "1", "KWAGE_LOAD_GANG": "3", "KWAGE_LOAD_WINDOW_KB": "20"},
+                                 {"KWAGE_LOAD_DIRECT": "1", "KWAGE_LOAD_CHUNK_KB": "3", "KWAGE_LOAD_WINDOW_KB": "3"}])
 def test_loader_paths_give_the_same_matrix(ka, oracle, tmp_path, env):
-    """kwage_group_add_db_file: the direct path (file windows locked through HSA, one copy kernel reads them over PCIe
-    into the strided matrix; rows that are dword multiples), the staged zero-copy path (mapping pinned with
-    hipHostRegister, copies left in flight across files), both with many small windows / chunks, and the pread path
-    -- the resident matrix must be the file's rows, for several files of odd and even widths in one group.
-    (The knobs are read once per process.)"""
+    """kwage_group_add_db_file(s): the staged zero-copy path (mapping pinned with hipHostRegister, copies left in flight
+    across files; the default), the pread path, and the opt-in direct path (file windows locked through HSA, one copy
+    kernel reads up to 16 files over PCIe into the strided matrix; rows that are dword multiples), each with many
+    small windows / chunks -- the resident matrix must be the file's rows, for many files of odd and even widths in
+    one group.  (The knobs are read once per process.)"""
     import subprocess
     import sys
     from conftest import ROOT
@@ -631,7 +632,7 @@ sys.path.insert(0, %r); sys.path.insert(0, %r + "/oracle")
 import kwage_amd as ka, kwage_oracle as oracle
 rng = np.random.default_rng(8)
 files = []
-for j, ncol in enumerate((100, 2048, 13, 777, 800, 96, 2016)):
+for j, ncol in enumerate((100, 2048, 13, 777, 800, 96, 2016) + (2048,) * 19 + (64, 2048)):
     rows = rng.integers(0, 256, size=(1 << 12, (ncol + 7) // 8), dtype=np.uint8)
     if ncol %% 8:
         rows[:, -1] &= np.uint8((1 << (ncol %% 8)) - 1)
@@ -640,15 +641,21 @@ for j, ncol in enumerate((100, 2048, 13, 777, 800, 96, 2016)):
     oracle.write_db(p, 31, 2, 12, rows, ncol, infos)
     files.append((p, ncol, rows))
 with ka.Context(0) as ctx:
-    g = ka.Group(ctx, 31, 2, 12, sum(((n + 127) // 128) * 128 for _, n, _ in files))
-    firsts = [g.add_db_file(p)[0] for p, _, _ in files]
-    g.finalize()
-    image = g.read_rows(np.arange(1 << 12))
-    for (p, ncol, rows), first in zip(files, firsts):
-        assert first %% 128 == 0
-        got = image[:, first // 8: first // 8 + rows.shape[1]]
-        assert np.array_equal(got, rows), p
-    g.close()
+    for together in (True, False):       # kwage_group_add_db_files (gangs of up to 16 raw files side by side) and file by file
+        g = ka.Group(ctx, 31, 2, 12, sum(((n + 127) // 128) * 128 for _, n, _ in files))
+        if together:
+            loaded = g.add_db_files([p for p, _, _ in files])
+            assert [nf for _, nf in loaded] == [n for _, n, _ in files]
+            firsts = [f for f, _ in loaded]
+        else:
+            firsts = [g.add_db_file(p)[0] for p, _, _ in files]
+        g.finalize()
+        image = g.read_rows(np.arange(1 << 12))
+        for (p, ncol, rows), first in zip(files, firsts):
+            assert first %% 128 == 0
+            got = image[:, first // 8: first // 8 + rows.shape[1]]
+            assert np.array_equal(got, rows), (p, together)
+        g.close()
 print("ok")
 ''' % (ROOT, ROOT, str(tmp_path))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env))
