@@ -241,6 +241,34 @@ __device__ __forceinline__ unsigned long long reserve_hits(const SearchArgs &a, 
 	return base + (incl - cnt);
 }
 
+// The same for a whole workgroup of `nw` waves that ALL reach this point once: the wave totals meet in LDS and one lane
+// does the atomic for all of them.  The narrow kernels end with it: their waves are short (a few dozen rows each) and
+// most of them carry a hit, so per-wave atomics on the one counter were 10 % of the kernel (100k x 150 bp reads
+// against one 2048-column file: 0.513 ms with hits, 0.466 ms without).
+struct WgHitScratch { uint32_t total[SEARCH_THREADS/WAVE]; unsigned long long base; };
+
+__device__ __forceinline__ unsigned long long reserve_hits_wg(const SearchArgs &a, uint32_t cnt, WgHitScratch *sc)
+{
+	const uint32_t lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+	uint32_t incl = cnt;
+#pragma unroll
+	for(int d = 1; d < WAVE; d <<= 1){
+		const uint32_t up = __shfl_up(incl, d);
+		if((int)lane >= d){ incl += up; }
+	}
+	if(lane == WAVE - 1){ sc->total[w] = incl; }
+	__syncthreads();
+	if(threadIdx.x == 0){
+		uint32_t sum = 0;
+		for(uint32_t v = 0; v < nw; ++v){ sum += sc->total[v]; }
+		sc->base = sum ? atomicAdd(a.hit_count, (unsigned long long)sum) : 0ull;
+	}
+	__syncthreads();
+	unsigned long long base = sc->base;
+	for(uint32_t v = 0; v < w; ++v){ base += sc->total[v]; }
+	return base + (incl - cnt);
+}
+
 __device__ __forceinline__ void store_hit(const SearchArgs &a, unsigned long long slot, uint32_t q, uint32_t col, uint32_t nm)
 {
 	if(slot < a.cap){
@@ -251,12 +279,12 @@ __device__ __forceinline__ void store_hit(const SearchArgs &a, unsigned long lon
 
 // hit extraction at threshold == 1 (kwage.cpp:489-499,517-518), restricted to real columns.
 // `on` = this lane holds a real tile position; every lane of the wave must call it.
-__device__ __forceinline__ void emit_mask_hits(const SearchArgs &a, uint32_t q, uint32_t unit, u32x4 acc, uint32_t n, bool on = true)
+__device__ __forceinline__ void emit_mask_hits(const SearchArgs &a, uint32_t q, uint32_t unit, u32x4 acc, uint32_t n, bool on = true, WgHitScratch *wg = nullptr)
 {
 	u32x4 m = (u32x4)(0u);
 	if(on){ m = acc & reinterpret_cast<const u32x4*>(a.valid)[unit]; }
 	const uint32_t cnt = __popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w);
-	unsigned long long slot = reserve_hits(a, cnt);
+	unsigned long long slot = wg ? reserve_hits_wg(a, cnt, wg) : reserve_hits(a, cnt);
 #pragma unroll
 	for(int d = 0; d < 4; ++d){
 		uint32_t bits = m[d];
@@ -575,7 +603,8 @@ __global__ __launch_bounds__(SEARCH_THREADS) void and_narrow_kernel(SearchArgs a
 			if(a.early_exit && !__any((acc.x | acc.y | acc.z | acc.w) != 0)){ break; }
 		}
 	}
-	emit_mask_hits(a, q, unit, acc, n, active);
+	__shared__ WgHitScratch wg_scratch;
+	emit_mask_hits(a, q, unit, acc, n, active, &wg_scratch);      // every wave of the workgroup gets here, exactly once
 }
 
 // Second pass of the segmented AND: one thread per (query, 16-byte unit).
@@ -637,11 +666,12 @@ __device__ __forceinline__ u32x4 planes_ge(const u32x4 (&plane)[PLANES], uint32_
 // (`on` = the lane holds a real tile position): the records are placed with one atomic per wave.
 template <int PLANES>
 __device__ __forceinline__ void emit_count_hits(const SearchArgs &a, uint32_t q, uint32_t unit,
-                                                const u32x4 (&plane)[PLANES], uint32_t thr, bool on)
+                                                const u32x4 (&plane)[PLANES], uint32_t thr, bool on, WgHitScratch *wg = nullptr)
 {
 	u32x4 ge = (u32x4)(0u);
 	if(on){ ge = planes_ge<PLANES>(plane, thr) & reinterpret_cast<const u32x4*>(a.valid)[unit]; }
-	unsigned long long slot = reserve_hits(a, __popc(ge.x) + __popc(ge.y) + __popc(ge.z) + __popc(ge.w));
+	const uint32_t nge = __popc(ge.x) + __popc(ge.y) + __popc(ge.z) + __popc(ge.w);
+	unsigned long long slot = wg ? reserve_hits_wg(a, nge, wg) : reserve_hits(a, nge);
 #pragma unroll
 	for(int d = 0; d < 4; ++d){
 		uint32_t bits = ge[d];
@@ -684,13 +714,16 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 #pragma unroll
 	for(int p = 0; p < PLANES; ++p){ plane[p] = (u32x4)(0u); }
 
-	// four k-mers per step: 4*NH row loads in flight, then a carry-save tree so that the ripple
-	// through the upper planes happens once per four k-mers (planes 0,1 are the CSA residues).
+	// KPS = four k-mers per step: 4*NH row loads in flight, then a carry-save tree so that the ripple through the
+	// upper planes happens once per four k-mers (planes 0,1 are the CSA residues).  (Eight per step -- 94 VGPRs, 5
+	// waves/SIMD -- measured the same with one and two hash functions at C2's shape: 1.916 vs 1.921 ms, 3.752 vs
+	// 3.755 ms, tools/ab_count_kps.py in round 2; not kept.)
+	constexpr int KPS = 4;
 	uint32_t i = 0;
-	for(; i + 4 <= nk; i += 4){
-		u32x4 m[4];
+	for(; i + KPS <= nk; i += KPS){
+		u32x4 m[KPS];
 #pragma unroll
-		for(int u = 0; u < 4; ++u){
+		for(int u = 0; u < KPS; ++u){
 			u32x4 x[NH];
 #pragma unroll
 			for(int h = 0; h < NH; ++h){
@@ -701,21 +734,24 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 #pragma unroll
 			for(int h = 1; h < NH; ++h){ m[u] &= x[h]; }    // kmer_match &= slice
 		}
-		if(PLANES >= 3){
-			u32x4 twoA, twoB, four, s;
-			csa(s, twoA, plane[0], m[0], m[1]);
-			csa(plane[0], twoB, s, m[2], m[3]);
-			csa(plane[1], four, plane[1], twoA, twoB);
-			planes_add<PLANES>(plane, four, 2);
-		}
-		else{
 #pragma unroll
-			for(int u = 0; u < 4; ++u){ planes_add<PLANES>(plane, m[u], 0); }
+		for(int g4 = 0; g4 < KPS; g4 += 4){
+			if(PLANES >= 3){
+				u32x4 twoA, twoB, four, s;
+				csa(s, twoA, plane[0], m[g4 + 0], m[g4 + 1]);
+				csa(plane[0], twoB, s, m[g4 + 2], m[g4 + 3]);
+				csa(plane[1], four, plane[1], twoA, twoB);
+				planes_add<PLANES>(plane, four, 2);
+			}
+			else{
+#pragma unroll
+				for(int u = 0; u < 4; ++u){ planes_add<PLANES>(plane, m[g4 + u], 0); }
+			}
 		}
 		// kwage.cpp:478-481 per tile: stop once no column of the tile can still reach the threshold
 		// even if every remaining k-mer matched (max count + remaining < threshold)
-		if(!SEG && a.early_exit && ((i + 4) & 63u) == 0){
-			const uint32_t remaining = nk - (i + 4);
+		if(!SEG && a.early_exit && ((i + KPS) & 63u) == 0){
+			const uint32_t remaining = nk - (i + KPS);
 			const uint32_t thr = a.qthr[q];
 			if(thr > remaining){
 				const u32x4 can = planes_ge<PLANES>(plane, thr - remaining);
@@ -786,7 +822,8 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_narrow_kernel(SearchArgs
 		csa(plane[1], four, plane[1], twoA, twoB);
 		planes_add<PLANES>(plane, four, 2);
 	}
-	emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q], active);
+	__shared__ WgHitScratch wg_scratch;
+	emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q], active, &wg_scratch);      // every wave of the workgroup gets here, exactly once
 }
 
 // Add two bit-sliced counters: acc (PLANES planes) += b (the first nb planes of `b`, the rest zero).
