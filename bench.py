@@ -110,7 +110,7 @@ def cpu_baseline(w, queries, n_files):
     cores = os.cpu_count() or 1
     if n_files <= 0:
         n_files = 2*min(cores, 16)         # two files per thread: ~15-30 core-seconds of reference work per run
-    L = min(w.log_2_filter_len, 20)
+    L = min(w.log_2_filter_len, 20) if w.log_2_filter_len else 20      # (multi-group workloads carry no single filter length)
     ncol = 2048
     k, nh = w.kmer_len, w.num_hash
     rng = np.random.default_rng(99)
@@ -244,10 +244,11 @@ def rank_main(args):
     w = synth.WORKLOADS[args.workload]
     t_build = time.perf_counter()
     multi = None
-    if args.workload == "c5":
+    groups = {"c5": synth.C5_GROUPS, "c5tiny": synth.C5_TEST_GROUPS}.get(args.workload)
+    if groups is not None:
         # adaptive filter sizes: several groups searched back to back; everything below treats the first
         # group as `s` for the shared query batch and sums work / kernel time over the groups
-        multi = synth.build_multi(ctx, synth.C5_GROUPS, w, seed=1, column_seed=rank)
+        multi = synth.build_multi(ctx, groups, w, seed=1, column_seed=rank)
         s = multi[0]
     else:
         s = synth.build(ctx, w, seed=1, column_seed=rank)
@@ -449,11 +450,11 @@ def rank_main(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": w.name, "samples_per_gpu": int(sum(ns for _, ns in synth.C5_GROUPS)) if multi else w.num_samples, "log_2_filter_len": w.log_2_filter_len,
+            "config": {"workload": w.name, "samples_per_gpu": int(sum(ns for _, ns in groups)) if multi else w.num_samples, "log_2_filter_len": w.log_2_filter_len,
                        "kmer_len": w.kmer_len, "num_hash": w.num_hash, "queries": w.num_queries, "query_len": w.query_len,
                        "threshold": w.threshold, "early_exit": bool(args.early_exit), "density": w.density_q8 / 256.0,
                        "db_bytes_per_gpu": int(sum(m.group.device_bytes for m in multi)) if multi else int(s.group.device_bytes),
-                       "groups": [[lg, ns] for lg, ns in synth.C5_GROUPS] if multi else None, "sharding": "columns (samples) over %d GPU(s)" % world, "step_pipeline": pipeline_note,
+                       "groups": [[lg, ns] for lg, ns in groups] if multi else None, "sharding": "columns (samples) over %d GPU(s)" % world, "step_pipeline": pipeline_note,
                        "total_kmers_per_step": int(probe.total_kmers) if not multi else None, "hits_per_step": int(nhits),
                        "db_build_s": round(t_build, 2),
                        "seeds": {"queries_and_planted_genomes": 1, "columns": "rank (splitmix64 keyed by seed, row, word; kwage_amd/synth.py)"}},

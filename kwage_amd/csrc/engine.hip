@@ -760,6 +760,9 @@ int submit_search(Slot *sl, kwage_group *g, kwage_batch *b, float threshold, uin
 		for(int i = 0; i < 2; ++i){ if(ctx->slot[i].busy && ctx->slot[i].b == b){ return fail(KWAGE_ERR_STATE, "batch is in use by a pending search with another k-mer length"); } }
 	}
 	if((rc = batch_prepare(b, g->params.kmer_len))){ return rc; }
+	if(b->max_pos*g->params.num_hash > 0xFFFFFFFFull){      // the kernels index a query's row list with 32 bits
+		return fail(KWAGE_ERR_ARG, "a query of %llu k-mer positions x %u hash functions exceeds 2^32 rows", (unsigned long long)b->max_pos, g->params.num_hash);
+	}
 	if((rc = sl->rows.reserve(std::max<uint64_t>(b->total_pos*g->params.num_hash, 1)*sizeof(uint32_t)))){ return rc; }
 	sl->g = g; sl->b = b; sl->threshold = threshold; sl->flags = flags;
 	sl->ext_hits = ext_hits; sl->ext_cap = ext_cap; sl->ext_count = ext_count;

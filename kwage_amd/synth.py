@@ -52,6 +52,8 @@ WORKLOADS: Dict[str, Workload] = {
     # BASELINE.json configs[4], per-GPU share; the groups are C5_GROUPS (bench.py --workload c5)
     "c5": Workload("C5: adaptive 2^18-2^25-bit filter groups (1.09M samples/GPU), 5 hashes, 1k x 1 kb queries, t=0.8", 0, 0, 31, 5,
                    1000, 1000, 0.8, density_q8=194, num_genomes=32, genome_len=50_000),
+    # the C5 code path (several groups searched back to back) on toy groups: C5_TEST_GROUPS (tests of bench.py)
+    "c5tiny": Workload("C5 code path on toy groups 2^10-2^13", 0, 0, 31, 5, 64, 300, 0.8, density_q8=194, num_genomes=4, genome_len=1000),
     # small shapes for tests
     "tiny": Workload("tiny", 5000, 14, 31, 2, 64, 300, 1.0, density_q8=128, num_genomes=4, genome_len=1000),
 }

@@ -101,3 +101,11 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     single = json.loads(one.stdout.strip().splitlines()[-1])
     assert single["n_gpus"] == 1 and "sustained" not in single
     assert line["roofline"]["algorithmic_bytes_per_launch"] == single["roofline"]["algorithmic_bytes_per_launch"]    # weak scaling: same share per GPU
+    # the C5 code path (several filter-size groups per rank, one exchange per group and step) on toy groups, two ranks
+    r5 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "c5tiny", "--no-sustained"],
+                        capture_output=True, text=True, env=env, timeout=900)
+    assert r5.returncode == 0, r5.stderr[-3000:]
+    l5 = json.loads(r5.stdout.strip().splitlines()[-1])
+    assert l5["n_gpus"] == 2 and len(l5["config"]["groups"]) == 4 and l5["config"]["threshold"] == 0.8
+    assert len(l5["aggregate"]["kernel_ms_per_rank"]) == 2 and all(x > 0 for x in l5["aggregate"]["kernel_ms_per_rank"])
+    assert l5["roofline"]["kernel"].startswith("count_")

@@ -75,7 +75,9 @@ try:
     print("with KWAGE_LOAD_DIRECT=1 KWAGE_LOAD_GANG=1 (copy kernel reading HSA-locked file windows, one file per launch):\n" + r.stderr.decode().strip())
     assert open(os.path.join(tmp, "o.csv")).read() == open(os.path.join(tmp, "o2.csv")).read()
     for rep in range(2):
-        for extra in ({"KWAGE_LOAD_DIRECT": "1", "KWAGE_LOAD_GANG": "1"}, {"KWAGE_LOAD_DIRECT": "1"}, {}):
+        for extra in ({"KWAGE_LOAD_DIRECT": "1", "KWAGE_LOAD_GANG": "1"}, {"KWAGE_LOAD_DIRECT": "1"}, {},
+                      {"KWAGE_LOAD_MMAP": "0", "KWAGE_LOAD_THREADS": "8"}, {"KWAGE_LOAD_MMAP": "0", "KWAGE_LOAD_THREADS": "16"},
+                      {"KWAGE_LOAD_MMAP": "0", "KWAGE_LOAD_THREADS": "32"}, {"KWAGE_LOAD_MMAP": "0", "KWAGE_LOAD_THREADS": "64"}):
             r = subprocess.run([native.KWAGE_BIN, "-d", os.path.join(tmp, "db"), "-i", q, "--o.csv", "-o", os.path.join(tmp, "o3.csv")], capture_output=True,
                                env=dict(os.environ, KWAGE_VERBOSE="1", **extra))
             print("%s: %s" % (extra or "default (staged)", [l for l in r.stderr.decode().splitlines() if "loaded" in l and "GB/s" in l][0]))
