@@ -166,8 +166,9 @@ typedef struct {
 	float kmer_kernel_ms;           /* with KWAGE_SEARCH_TIMING, else 0                       */
 	float search_kernel_ms;         /* the gather + AND / count kernel                        */
 	uint32_t search_kernel_launches;/* >1 if the hit buffer had to grow and the kernel re-ran */
-	const char *search_kernel;      /* which gather kernel ran (static string): "and_kernel", "and_walk_kernel",
-	                                 * "and_narrow_kernel", "count_kernel", "count_narrow_kernel", "" if none */
+	const char *search_kernel;      /* which gather kernel ran, with its template shape: "and_kernel<2,8,nt>",
+	                                 * "and_walk_kernel<13,4>", "and_narrow_kernel<4,8>", "count_kernel<10,5>",
+	                                 * "count_narrow_kernel<7,1,4>", "...+segments"; "" if none.  Owned by the result. */
 } kwage_result;
 
 int kwage_search(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
