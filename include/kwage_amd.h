@@ -89,6 +89,17 @@ int kwage_group_create(kwage_ctx *ctx, const kwage_params *params, uint64_t colu
                        kwage_group **out);
 void kwage_group_destroy(kwage_group *g);
 
+/* A SPARSE group: the resident matrix holds only the slices `rows[0..n_rows)` (strictly ascending row indices below
+ * 2^log_2_filter_len) of every file added to it -- for a few queries against a database far larger than what they
+ * address.  The reference reads only the addressed slices too (one seekg + read per k-mer and hash,
+ * kwage.cpp:414-416); here the distinct addressed slices of a whole batch are fetched once per file (host threads,
+ * I/O proportional to the queries, not to the database), and searches translate row indices to positions in the
+ * list on the device.  Get the rows of a batch from kwage_hash_batch (sort + unique them); searching a batch that
+ * addresses a row outside the list fails with KWAGE_ERR_STATE.  kwage_group_add_columns takes images of n_rows rows
+ * for such a group; hits, columns and everything else are as for a full group. */
+int kwage_group_create_sparse(kwage_ctx *ctx, const kwage_params *params, uint64_t column_capacity,
+                              const uint32_t *rows, uint64_t n_rows, kwage_group **out);
+
 /* Append `num_filter` columns from a host image of a file's bit-slice block
  * (2^L rows of ceil(num_filter/8) bytes, `host_row_stride` bytes apart).  The block is placed at
  * the next byte-aligned column; *first_column receives the global index of its column 0. */

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <dlfcn.h>
@@ -198,6 +199,10 @@ struct kwage_group {
 	uint64_t alloc_bytes = 0;
 	std::vector<uint8_t> h_valid;
 	bool finalized = false;
+	// sparse group (kwage_group_create_sparse): the matrix holds only the listed rows of every file, in this order
+	// (sorted, distinct); row indices from the k-mer stage are translated to positions in the list before the gather
+	std::vector<uint32_t> h_row_map;
+	uint32_t *d_row_map = nullptr;
 };
 
 struct kwage_batch {
@@ -771,6 +776,11 @@ int submit_search(Slot *sl, kwage_group *g, kwage_batch *b, float threshold, uin
 	const bool timing_kmer = (flags & KWAGE_SEARCH_TIMING) && (flags & KWAGE_SEARCH_TIMING_KMER);
 	if(timing_kmer){ HIP_TRY(hipEventRecord(sl->ev[0], sl->stream)); }
 	if((rc = launch_kmer_stage(sl, g->params, b, threshold, (uint32_t*)sl->rows.p, nullptr))){ return rc; }
+	if(g->d_row_map && b->n){      // sparse group: row index -> position in the group's row list (counter 2 = indices not listed)
+		hipLaunchKernelGGL(remap_rows_kernel, dim3(b->n), dim3(256), 0, sl->stream, (uint32_t*)sl->rows.p, b->d_pos_off, sl->d_nkmer,
+		                   g->params.num_hash, g->d_row_map, (uint32_t)g->h_row_map.size(), (unsigned long long*)sl->d_counters + 2);
+		HIP_TRY(hipGetLastError());
+	}
 	if(timing_kmer){ HIP_TRY(hipEventRecord(sl->ev[1], sl->stream)); }
 	if((rc = enqueue_search_and_copy(sl))){ return rc; }
 	sl->busy = true;
@@ -792,6 +802,10 @@ int collect_search(Slot *sl, SearchOutcome *out)
 	while(true){
 		HIP_TRY(hipStreamSynchronize(sl->stream));     // (polling an event instead measured no faster)
 		const uint64_t *hc = (const uint64_t*)sl->h_stage.p;
+		if(hc[2] != 0){
+			return fail(KWAGE_ERR_STATE, "%llu row indices of this batch are not among the rows of the sparse group (it was created for other queries)",
+			            (unsigned long long)hc[2]);
+		}
 		out->n_hits = hc[0];
 		out->total_kmers = 0;
 		const uint32_t *hn = (const uint32_t*)((const char*)sl->h_stage.p + 32);      // staged nkmer[]
@@ -918,10 +932,11 @@ extern "C" int kwage_sync(kwage_ctx *ctx)
 // ------------------------------------------------------------------------------------------
 // database group
 // ------------------------------------------------------------------------------------------
-extern "C" int kwage_group_create(kwage_ctx *ctx, const kwage_params *params, uint64_t column_capacity,
-                                  kwage_group **out)
+namespace {
+
+// Allocate and clear a group's matrix of `nrows` rows for `column_capacity` columns.
+int group_allocate(kwage_ctx *ctx, const kwage_params *params, uint64_t column_capacity, uint64_t nrows, kwage_group **out)
 {
-	if(!ctx || !params || !out){ return fail(KWAGE_ERR_ARG, "kwage_group_create: NULL argument"); }
 	*out = nullptr;
 	int rc = check_params(params);
 	if(rc){ return rc; }
@@ -932,7 +947,7 @@ extern "C" int kwage_group_create(kwage_ctx *ctx, const kwage_params *params, ui
 	if(!g){ return fail(KWAGE_ERR_DEVICE, "out of host memory"); }
 	g->ctx = ctx;
 	g->params = *params;
-	g->nrows = 1ull << params->log_2_filter_len;
+	g->nrows = nrows;
 	const uint64_t row_bytes = (column_capacity + 7)/8;
 	g->stride = (row_bytes + 127)/128*128;
 	if(g->stride/16 > 0x7FFFFFFFull){ delete g; return fail(KWAGE_ERR_ARG, "kwage_group_create: row too wide"); }
@@ -963,6 +978,45 @@ extern "C" int kwage_group_create(kwage_ctx *ctx, const kwage_params *params, ui
 	return KWAGE_OK;
 }
 
+}  // namespace
+
+extern "C" int kwage_group_create(kwage_ctx *ctx, const kwage_params *params, uint64_t column_capacity,
+                                  kwage_group **out)
+{
+	if(!ctx || !params || !out){ return fail(KWAGE_ERR_ARG, "kwage_group_create: NULL argument"); }
+	*out = nullptr;
+	int rc = check_params(params);
+	if(rc){ return rc; }
+	return group_allocate(ctx, params, column_capacity, 1ull << params->log_2_filter_len, out);
+}
+
+extern "C" int kwage_group_create_sparse(kwage_ctx *ctx, const kwage_params *params, uint64_t column_capacity,
+                                         const uint32_t *rows, uint64_t n_rows, kwage_group **out)
+{
+	if(!ctx || !params || !out || !rows){ return fail(KWAGE_ERR_ARG, "kwage_group_create_sparse: NULL argument"); }
+	*out = nullptr;
+	int rc = check_params(params);
+	if(rc){ return rc; }
+	if(n_rows == 0 || n_rows > 0xFFFFFFFFull){ return fail(KWAGE_ERR_ARG, "kwage_group_create_sparse: need 1 .. 2^32-1 rows"); }
+	const uint64_t filter_len = 1ull << params->log_2_filter_len;
+	for(uint64_t i = 0; i < n_rows; ++i){
+		if(rows[i] >= filter_len || (i && rows[i] <= rows[i - 1])){
+			return fail(KWAGE_ERR_ARG, "kwage_group_create_sparse: rows must be strictly ascending and below 2^%u", params->log_2_filter_len);
+		}
+	}
+	kwage_group *g = nullptr;
+	if((rc = group_allocate(ctx, params, column_capacity, n_rows, &g))){ return rc; }
+	g->h_row_map.assign(rows, rows + n_rows);
+	hipError_t e = hipMalloc((void**)&g->d_row_map, n_rows*sizeof(uint32_t));
+	if(e == hipSuccess){ e = hipMemcpy(g->d_row_map, rows, n_rows*sizeof(uint32_t), hipMemcpyHostToDevice); }
+	if(e != hipSuccess){
+		kwage_group_destroy(g);
+		return fail(KWAGE_ERR_DEVICE, "kwage_group_create_sparse: %s", hipGetErrorString(e));
+	}
+	*out = g;
+	return KWAGE_OK;
+}
+
 extern "C" void kwage_group_destroy(kwage_group *g)
 {
 	if(!g){ return; }
@@ -972,6 +1026,7 @@ extern "C" void kwage_group_destroy(kwage_group *g)
 	(void)hipStreamSynchronize(g->ctx->slot[1].stream);
 	if(g->d_bits){ (void)hipFree(g->d_bits); }
 	if(g->d_valid){ (void)hipFree(g->d_valid); }
+	if(g->d_row_map){ (void)hipFree(g->d_row_map); }
 	delete g;
 }
 
@@ -1263,6 +1318,66 @@ int load_source_rows_staged(kwage_group *g, DbSliceSource &src, const char *path
 	return rc;
 }
 
+// Sparse group: fetch only the listed slices of up to LOAD_GANG files -- I/O proportional to what the queries address,
+// like the reference's seekg + read per slice (kwage.cpp:414-416) -- one host thread per file (several per file when
+// the list is long) into ONE pinned staging buffer, one copy, then place_rows_kernel per file.
+int load_gang_sparse(kwage_group *g, DbSliceSource *const *srcs, const char *const *paths, const uint64_t *byte0, uint32_t n)
+{
+	kwage_ctx *ctx = g->ctx;
+	static const uint64_t chunk_target = load_env_kb("KWAGE_LOAD_CHUNK_KB", 64ull << 20);
+	uint64_t total_width = 0;
+	for(uint32_t i = 0; i < n; ++i){ total_width += srcs[i]->slice_size; }
+	const uint64_t chunk_rows = std::max<uint64_t>(1, std::min<uint64_t>(g->nrows, chunk_target/total_width));
+	const uint64_t chunk_bytes = chunk_rows*total_width;
+	PinBuf *pin = ctx->load_pin;
+	DevBuf *dev = ctx->load_dev;
+	hipEvent_t *done = ctx->load_done;
+	int rc = KWAGE_OK;
+	release_mapping(ctx);       // the staging buffers are shared with copies of an earlier (dense) load
+	for(int i = 0; i < 2 && rc == KWAGE_OK; ++i){
+		rc = dev[i].reserve(chunk_bytes);
+		if(!rc){ rc = pin[i].reserve(chunk_bytes); }
+		if(!rc && !done[i] && hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess){ rc = fail(KWAGE_ERR_DEVICE, "hipEventCreate failed"); }
+	}
+	if(rc){ return rc; }
+	bool used[2] = {false, false};
+	int cur = 0;
+	hipError_t e = hipSuccess;
+	for(uint64_t r0 = 0; r0 < g->nrows && rc == KWAGE_OK; r0 += chunk_rows, cur ^= 1){
+		const uint64_t nr = std::min(chunk_rows, g->nrows - r0);
+		if(used[cur]){ e = hipEventSynchronize(done[cur]); if(e != hipSuccess){ rc = fail(KWAGE_ERR_DEVICE, "%s", hipGetErrorString(e)); break; } }
+		// file i's nr slices land at offset nr * (widths of the files before it)
+		std::vector<uint64_t> off(n + 1, 0);
+		for(uint32_t i = 0; i < n; ++i){ off[i + 1] = off[i] + nr*srcs[i]->slice_size; }
+		std::vector<std::string> errs(n);
+		std::vector<char> ok(n, 1);
+		const unsigned inner = (n == 1) ? 16u : 1u;      // one file: its list is split over threads; a gang: one thread per file
+		auto fetch = [&](uint32_t i) {
+			ok[i] = srcs[i]->read_row_list(g->h_row_map.data() + r0, nr, (unsigned char*)pin[cur].p + off[i], errs[i], inner) ? 1 : 0;
+		};
+		std::vector<std::thread> pool;
+		for(uint32_t i = 1; i < n; ++i){ pool.emplace_back(fetch, i); }
+		fetch(0);
+		for(auto &t : pool){ t.join(); }
+		for(uint32_t i = 0; i < n; ++i){
+			if(!ok[i]){ rc = fail(KWAGE_ERR_IO, "%s: %s", paths[i], errs[i].c_str()); break; }
+		}
+		if(rc){ break; }
+		e = hipMemcpyAsync(dev[cur].p, pin[cur].p, off[n], hipMemcpyHostToDevice, ctx->stream);
+		for(uint32_t i = 0; i < n && e == hipSuccess; ++i){
+			const uint64_t width = srcs[i]->slice_size;
+			hipLaunchKernelGGL(place_rows_kernel, dim3(grid_for(nr*width/4 + 1, 256)), dim3(256), 0, ctx->stream,
+			                   g->d_bits, g->stride, r0, byte0[i], (const uint8_t*)dev[cur].p + off[i], width, width, nr);
+			e = hipGetLastError();
+		}
+		if(e == hipSuccess){ e = hipEventRecord(done[cur], ctx->stream); }
+		if(e != hipSuccess){ rc = fail(KWAGE_ERR_DEVICE, "kwage_group_add_db_files: %s", hipGetErrorString(e)); break; }
+		used[cur] = true;
+	}
+	(void)hipStreamSynchronize(ctx->stream);
+	return rc;
+}
+
 }  // namespace
 
 extern "C" int kwage_group_add_db_file(kwage_group *g, const char *path, uint64_t *first_column, uint32_t *num_filter)
@@ -1293,8 +1408,16 @@ extern "C" int kwage_group_add_db_files(kwage_group *g, const char *const *paths
 			if(num_filters){ num_filters[i0 + cnt] = src.header.num_filter; }
 			ptrs[cnt] = &src;
 			++cnt;
+			if(g->d_row_map){ continue; }                // sparse group: gangs of any files
 			if(!direct_loadable(src)){ break; }          // this file ends the gang and is staged on its own
 			n_direct = cnt;
+		}
+		if(g->d_row_map){          // sparse group: only the listed slices of these files
+			const char *gp[LOAD_GANG];
+			for(uint32_t k = 0; k < cnt; ++k){ gp[k] = paths[i0 + k]; }
+			if((rc = load_gang_sparse(g, ptrs, gp, byte0, cnt))){ return rc; }
+			i0 += cnt;
+			continue;
 		}
 		uint64_t rows_done = 0;
 		if(n_direct){

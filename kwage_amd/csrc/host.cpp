@@ -384,6 +384,46 @@ bool DbSliceSource::read_rows(uint64_t r0, uint64_t nr, unsigned char *dst, std:
 	return true;
 }
 
+bool DbSliceSource::read_row_list(const uint32_t *rows, uint64_t n, unsigned char *dst, std::string &err, unsigned max_threads)
+{
+	for(uint64_t i = 0; i < n; ++i){ if(rows[i] >= nrows){ err = "slice index out of range"; return false; } }
+	const unsigned nt = (n >= 4096 && max_threads > 1) ? host_threads(max_threads) : 1;
+	std::atomic<uint64_t> next(0);
+	std::atomic<bool> bad(false);
+	auto work = [&]() {
+		z_stream z;
+		const bool packed = (header.compression != KWAGE_COMPRESSION_NONE);
+		if(packed){
+			memset(&z, 0, sizeof(z));
+			if(inflateInit2(&z, SLICE_Z_WINDOW_BITS) != Z_OK){ bad = true; return; }
+		}
+		std::vector<unsigned char> comp(packed ? slice_size : 0);
+		const uint64_t grain = 256;
+		for(uint64_t b = next.fetch_add(grain); b < n && !bad; b = next.fetch_add(grain)){
+			for(uint64_t i = b; i < std::min(n, b + grain); ++i){
+				unsigned char *out = dst + i*slice_size;
+				if(!packed){
+					if(!pread_all(fd, out, slice_size, DB_HEADER_BYTES + (uint64_t)rows[i]*slice_size)){ bad = true; break; }
+					continue;
+				}
+				const uint64_t o = offsets[rows[i]], len = offsets[rows[i] + 1] - o;
+				if(len == slice_size){ if(!pread_all(fd, out, len, o)){ bad = true; break; } continue; }      // stored raw
+				if(!pread_all(fd, comp.data(), len, o)){ bad = true; break; }
+				z.next_in = comp.data(); z.avail_in = (uInt)len;
+				z.next_out = out; z.avail_out = (uInt)slice_size;
+				if(inflate(&z, Z_FINISH) != Z_STREAM_END || z.avail_out != 0 || inflateReset(&z) != Z_OK){ bad = true; break; }
+			}
+		}
+		if(packed){ inflateEnd(&z); }
+	};
+	std::vector<std::thread> pool;
+	for(unsigned t = 1; t < nt; ++t){ pool.emplace_back(work); }
+	work();
+	for(auto &t : pool){ t.join(); }
+	if(bad){ err = "Error reading slice from file"; return false; }
+	return true;
+}
+
 bool DbSliceSource::slice_crc32(uint32_t &crc, std::string &err)
 {
 	const uint64_t chunk_rows = std::max<uint64_t>(1, std::min<uint64_t>(nrows, (64ull << 20)/std::max<uint64_t>(slice_size, 1)));

@@ -58,6 +58,9 @@ struct DbSliceSource {
 	std::vector<uint64_t> offsets;          // compressed only: nrows + 1 absolute file offsets
 	bool open(const std::string &path, std::string &err);
 	bool read_rows(uint64_t r0, uint64_t nr, unsigned char *dst, std::string &err);   // nr*slice_size bytes
+	// the listed slices (any order), n*slice_size bytes: what the reference's seekg + read per addressed slice does
+	// (kwage.cpp:414-416), batched and on several threads
+	bool read_row_list(const uint32_t *rows, uint64_t n, unsigned char *dst, std::string &err, unsigned max_threads = 16);
 	bool slice_crc32(uint32_t &crc, std::string &err);      // CRC32 of the (uncompressed) slice block, as build_db stores it in the header
 	void close();
 	~DbSliceSource() { close(); }

@@ -183,6 +183,27 @@ __global__ __launch_bounds__(KM_THREADS) void kmer_kernel(KmerArgs a)
 	}
 }
 
+// Sparse groups (kwage_group_create_sparse): the matrix holds only the rows listed in `map` (ascending).  Translate
+// every VALID row index of the batch (the first nkmer[q]*num_hash entries of query q) into its position in the list;
+// an index that is not listed is a caller error and is counted in *missing.  One workgroup per query.
+__global__ __launch_bounds__(256) void remap_rows_kernel(uint32_t *rows, const uint64_t *pos_off, const uint32_t *nkmer, uint32_t num_hash,
+                                                         const uint32_t *map, uint32_t map_len, unsigned long long *missing)
+{
+	const uint32_t q = blockIdx.x;
+	uint32_t *rq = rows + pos_off[q]*num_hash;
+	const uint32_t n = nkmer[q]*num_hash;
+	for(uint32_t e = threadIdx.x; e < n; e += blockDim.x){
+		const uint32_t r = rq[e];
+		uint32_t lo = 0, hi = map_len;                  // first position with map[pos] >= r
+		while(lo < hi){
+			const uint32_t mid = lo + (hi - lo)/2;
+			if(map[mid] < r){ lo = mid + 1; } else { hi = mid; }
+		}
+		if(lo < map_len && map[lo] == r){ rq[e] = lo; }
+		else{ rq[e] = 0; atomicAdd(missing, 1ull); }
+	}
+}
+
 // ------------------------------------------------------------------------------------------
 // search kernels
 // ------------------------------------------------------------------------------------------

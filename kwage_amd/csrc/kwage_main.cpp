@@ -16,6 +16,10 @@
 //   KWAGE_BATCH_BASES max bases per query batch (default 64 Mi)
 //   KWAGE_MAX_GROUP_BYTES  cap on the HBM bit matrix of one pass (default: 7/8 of the free device memory);
 //                     larger parameter groups are searched in several passes over whole files
+//   KWAGE_SPARSE      how a SMALL query set (everything fits one batch of KWAGE_SPARSE_BASES, default 4 Mi bases) is
+//                     searched: "auto" (default) loads only the slices the queries address when they address at most
+//                     1/8 of a group's rows -- I/O proportional to the queries, like the reference's seek + read per
+//                     slice --, "1" always does, "0" always loads whole files
 //   KWAGE_VERBOSE     1 = per-stage wall times on stderr
 #include <algorithm>
 #include <chrono>
@@ -271,6 +275,20 @@ struct FileQueries : QuerySource {
 	}
 };
 
+// A batch that was read before (a small query set is parsed ONCE and reused for every group and pass).
+struct PreloadedQueries : QuerySource {
+	const QueryBatch &stored;
+	bool given = false;
+	explicit PreloadedQueries(const QueryBatch &b) : stored(b) {}
+	bool fill(QueryBatch &b, uint64_t) override
+	{
+		if(given || stored.size() == 0){ return false; }
+		b = stored;
+		given = true;
+		return true;
+	}
+};
+
 // =====================================================================================================
 // search
 // =====================================================================================================
@@ -300,6 +318,30 @@ struct ColumnMap {
 		local = (uint32_t)(column - files[lo]->first_column);
 	}
 };
+
+// The distinct bit-slice rows the queries of `q` address under parameters `p` (sorted), appended to `rows`: the device
+// k-mer stage gives them (kwage_hash_batch), exactly the rows search() would seek to (kwage.cpp:404-416).
+void addressed_rows(kwage_ctx *ctx, const kwage_params &p, const QueryBatch &q, vector<uint32_t> &rows)
+{
+	if(q.size() == 0){ return; }
+	kwage_batch *b = nullptr;
+	check(kwage_batch_create(ctx, q.bases.data(), q.offsets.data(), (uint32_t)q.size(), &b));
+	vector<uint64_t> off(q.size() + 1);
+	vector<uint32_t> nk(q.size());
+	int rc = kwage_hash_batch(ctx, &p, b, off.data(), nk.data(), nullptr, nullptr);      // sizes
+	vector<uint32_t> all;
+	if(rc == KWAGE_OK && off.back()){
+		all.resize(off.back()*p.num_hash);
+		rc = kwage_hash_batch(ctx, &p, b, off.data(), nk.data(), nullptr, all.data());
+	}
+	kwage_batch_destroy(b);
+	check(rc);
+	for(size_t i = 0; i < q.size(); ++i){
+		rows.insert(rows.end(), all.begin() + off[i]*p.num_hash, all.begin() + (off[i] + nk[i])*p.num_hash);
+	}
+	sort(rows.begin(), rows.end());
+	rows.erase(unique(rows.begin(), rows.end()), rows.end());
+}
 
 // Stream one query source through one loaded group.  Two batches are in flight: batch i+1 is parsed and
 // submitted while the device works on batch i, then batch i is collected and its hits mapped.
@@ -557,6 +599,23 @@ int main(int argc, char *argv[])
 		const uint64_t max_group_bytes = env_u64("KWAGE_MAX_GROUP_BYTES", 0);       // 0 = what is free on the device
 		const bool verbose = env_u64("KWAGE_VERBOSE", 0) != 0;
 
+		// A small query set is read ONCE, up front, and reused for every group and pass; it is also what makes the sparse
+		// path possible (the rows to fetch must be known before the files are read).
+		const string sparse_mode = getenv("KWAGE_SPARSE") ? getenv("KWAGE_SPARSE") : "auto";
+		const uint64_t small_bases = min<uint64_t>(env_u64("KWAGE_SPARSE_BASES", 4ull << 20), max_batch_bases);
+		QueryBatch typed_all, disk_all;
+		bool small_set = false;
+		{
+			CommandLineQueries typed(cli.query_seqs);
+			FileQueries from_disk(cli.query_files);
+			QueryBatch extra;
+			const bool any_typed = typed.fill(typed_all, small_bases);
+			const bool typed_done = !any_typed || !typed.fill(extra, small_bases);
+			const bool any_disk = typed_done && from_disk.fill(disk_all, small_bases);
+			small_set = typed_done && (!any_disk || !from_disk.fill(extra, small_bases));
+			if(!small_set){ typed_all.clear(); disk_all.clear(); }
+		}
+
 		Findings from_command_line, from_files;
 		mutex merge_lock;
 		vector<string> worker_error(ndev);
@@ -596,7 +655,16 @@ int main(int argc, char *argv[])
 						check(kwage_mem_info(ctx, &free_b, &total_b));
 						budget = free_b - free_b/8;          // leave room for staging buffers, row indices, hits
 					}
-					const uint64_t nrows = 1ull << p.log_2_filter_len;
+					// Sparse path: only the slices the (small) query set addresses are fetched and kept resident.
+					vector<uint32_t> sparse_rows;
+					bool sparse = false;
+					if(small_set && sparse_mode != "0"){
+						addressed_rows(ctx, p, typed_all, sparse_rows);
+						addressed_rows(ctx, p, disk_all, sparse_rows);
+						sparse = (sparse_mode == "1") || (uint64_t)sparse_rows.size()*8 <= (1ull << p.log_2_filter_len);
+						if(sparse && sparse_rows.empty()){ continue; }          // no valid k-mer in any query: nothing can match (kwage.cpp:369-371)
+					}
+					const uint64_t nrows = sparse ? sparse_rows.size() : (1ull << p.log_2_filter_len);
 					for(size_t m0 = 0; m0 < members.size(); ){
 						uint64_t span_bytes = 0;
 						size_t m1 = m0;
@@ -608,7 +676,8 @@ int main(int argc, char *argv[])
 						}
 						kwage_group *grp = nullptr;
 						double t0 = now_s();
-						check(kwage_group_create(ctx, &p, span_bytes*8, &grp));
+						if(sparse){ check(kwage_group_create_sparse(ctx, &p, span_bytes*8, sparse_rows.data(), sparse_rows.size(), &grp)); }
+						else{ check(kwage_group_create(ctx, &p, span_bytes*8, &grp)); }
 						ColumnMap cols;
 						{
 							vector<const char*> paths;
@@ -627,12 +696,23 @@ int main(int argc, char *argv[])
 							check(kwage_group_finalize(grp));
 							t_load += now_s() - t0;
 							gb_loaded += (double)kwage_group_row_bytes(grp)*(double)nrows/1e9;
-							if(verbose){ lock_guard<mutex> lk(merge_lock); cerr << "[kwage] device " << devices[di] << " group loaded: " << rss_mb() << endl; }
+							if(verbose){
+								lock_guard<mutex> lk(merge_lock);
+								cerr << "[kwage] device " << devices[di] << " group loaded (" << (sparse ? to_string(nrows) + " addressed slices of 2^" + to_string(p.log_2_filter_len) : string("all slices"))
+									<< " per file): " << rss_mb() << endl;
+							}
 							t0 = now_s();
-							CommandLineQueries typed(cli.query_seqs);
-							search_stream(ctx, grp, cols, typed, cli.threshold, flags, max_batch_bases, local_cmdline);
-							FileQueries from_disk(cli.query_files);
-							search_stream(ctx, grp, cols, from_disk, cli.threshold, flags, max_batch_bases, local_files);
+							if(small_set){
+								PreloadedQueries typed(typed_all), from_disk(disk_all);
+								search_stream(ctx, grp, cols, typed, cli.threshold, flags, max_batch_bases, local_cmdline);
+								search_stream(ctx, grp, cols, from_disk, cli.threshold, flags, max_batch_bases, local_files);
+							}
+							else{
+								CommandLineQueries typed(cli.query_seqs);
+								search_stream(ctx, grp, cols, typed, cli.threshold, flags, max_batch_bases, local_cmdline);
+								FileQueries from_disk(cli.query_files);
+								search_stream(ctx, grp, cols, from_disk, cli.threshold, flags, max_batch_bases, local_files);
+							}
 							t_search += now_s() - t0;
 						}
 						catch(...){ kwage_group_destroy(grp); throw; }

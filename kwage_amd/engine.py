@@ -61,6 +61,19 @@ class Group:
         self._h = C.c_void_p()
         check(lib().kwage_group_create(ctx._h, C.byref(self.params), column_capacity, C.byref(self._h)))
 
+    @classmethod
+    def sparse(cls, ctx: Context, kmer_len: int, num_hash: int, log_2_filter_len: int, column_capacity: int,
+               rows: np.ndarray, hash_func: int = 0) -> "Group":
+        """A group holding only the listed slices (sorted distinct row indices) of every file added to it
+        (kwage_group_create_sparse): for a few queries against a large database."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        g = cls.__new__(cls)
+        g.ctx = ctx
+        g.params = Params(kmer_len, num_hash, log_2_filter_len, hash_func)
+        g._h = C.c_void_p()
+        check(lib().kwage_group_create_sparse(ctx._h, C.byref(g.params), column_capacity, rows.ctypes.data, rows.size, C.byref(g._h)))
+        return g
+
     def close(self) -> None:
         if self._h:
             lib().kwage_group_destroy(self._h)
@@ -69,7 +82,6 @@ class Group:
     def add_columns(self, rows: np.ndarray, num_filter: int) -> int:
         """rows: uint8 [2^L, >= ceil(num_filter/8)] host image of a file's bit-slice block."""
         assert rows.dtype == np.uint8 and rows.ndim == 2 and rows.strides[1] == 1
-        assert rows.shape[0] == (1 << self.params.log_2_filter_len)
         first = C.c_uint64()
         check(lib().kwage_group_add_columns(self._h, rows.ctypes.data, rows.strides[0], num_filter, C.byref(first)))
         return first.value

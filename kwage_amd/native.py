@@ -104,6 +104,7 @@ _SIGNATURES = [
     ("kwage_sync", C.c_int, [_P]),
     ("kwage_group_create", C.c_int, [_P, C.POINTER(Params), C.c_uint64, C.POINTER(_P)]),
     ("kwage_group_destroy", None, [_P]),
+    ("kwage_group_create_sparse", C.c_int, [_P, C.POINTER(Params), C.c_uint64, _P, C.c_uint64, C.POINTER(_P)]),
     ("kwage_group_add_columns", C.c_int, [_P, _P, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("kwage_group_add_db_file", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     ("kwage_group_add_db_files", C.c_int, [_P, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),

@@ -95,9 +95,9 @@ def _make_case(oracle, rng, root, n_files):
     return os.path.join(root, "db"), fasta, cmd
 
 
-def _run(exe, db, fasta, cmd, thr, fmt="csv"):
+def _run(exe, db, fasta, cmd, thr, fmt="csv", env=None):
     r = subprocess.run([exe, "-d", db, "-i", fasta, "-t", thr, "--o." + fmt] + cmd, capture_output=True,
-                       env=dict(os.environ, OMP_NUM_THREADS="1"))
+                       env=dict(os.environ, OMP_NUM_THREADS="1", **(env or {})))
     assert r.returncode == 0, r.stderr.decode()
     return r.stdout.decode("latin-1")
 
@@ -131,6 +131,12 @@ def test_cli_equals_reference_binary(oracle, tmp_path, seed):
         for fmt in ("csv", "json"):
             exp = _run(REF, db, fasta, cmd, thr, fmt)
             got = _run(native.KWAGE_BIN, db, fasta, cmd, thr, fmt)
+            # the three ways the CLI may fetch the database give the same bytes: only the addressed slices (sparse),
+            # whole files with the query set preloaded, whole files with the queries streamed batch by batch
+            assert _run(native.KWAGE_BIN, db, fasta, cmd, thr, fmt, {"KWAGE_SPARSE": "1"}) == got, (seed, thr, fmt)
+            assert _run(native.KWAGE_BIN, db, fasta, cmd, thr, fmt, {"KWAGE_SPARSE": "0"}) == got, (seed, thr, fmt)
+            if seed % 4 == 0:
+                assert _run(native.KWAGE_BIN, db, fasta, cmd, thr, fmt, {"KWAGE_SPARSE_BASES": "1"}) == got, (seed, thr, fmt)
             # tie order is unspecified in the reference (readdir order x unstable sort): compare the
             # multiset of lines and the exact sequence of scores / query names
             assert sorted(got.splitlines()) == sorted(exp.splitlines()), (seed, thr, fmt)

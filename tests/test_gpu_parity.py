@@ -253,6 +253,68 @@ def test_cli_matches_reference_output(ka, oracle, case):
         assert score(got) == score(exp)
     if len(case["db"]) == 1 and case["name"] != "multi":
         assert got == exp                               # single file: byte-identical
+    for mode in ({"KWAGE_SPARSE": "1"}, {"KWAGE_SPARSE": "0"}, {"KWAGE_SPARSE_BASES": "1"}):      # sparse fetch / whole files / streamed
+        r2 = subprocess.run(args, cwd=cdir, capture_output=True, env=dict(os.environ, **mode))
+        assert r2.returncode == 0 and r2.stdout == r.stdout, mode
+
+
+def test_sparse_group_gives_the_same_hits(ka, ctx, oracle, tmp_path):
+    """kwage_group_create_sparse: only the slices a batch addresses are fetched from the files (raw and compressed) and
+    kept resident; hit lists equal those of the full group for every kernel family (AND / count, narrow / tiled / walk
+    widths), a batch that addresses other rows is refused, and add_columns takes a compact image."""
+    from kwage_amd import native
+    import ctypes as C
+    rng = np.random.default_rng(99)
+    k, nh, L = 31, 3, 13
+    genome = rand_seq(rng, 2500)
+    files, full_cols = [], 0
+    for f, ncol in enumerate((2048, 100, 30000, 2048)):
+        img = _make_random_db(rng, L, ncol, 0.8)
+        for r in oracle.row_indices(oracle.unique_kmers(genome, k), k, nh, L).reshape(-1):
+            img[r, (7 + f) // 8] |= np.uint8(1 << ((7 + f) % 8))
+        infos = [oracle.FilterInfo(run_accession=oracle.str_to_accession("SRR%07d" % (f * 100000 + j))) for j in range(ncol)]
+        p = str(tmp_path / ("s%d.db" % f))
+        oracle.write_db(p, k, nh, L, img, ncol, infos)
+        if f == 1:                                          # one of them in the compressed container
+            z = str(tmp_path / "s1.dbz")
+            native.check(native.lib().kwage_db_compress(p.encode(), z.encode(), 2))
+            p = z
+        files.append(p)
+        full_cols += ((ncol + 127) // 128) * 128
+    seqs = [genome[100:600], rand_seq(rng, 300), genome[1000:1200].lower(), "ACGT", rand_seq(rng, 150), genome[:2000]]
+    b = ka.Batch(ctx, seqs)
+    _, rows = ka.hash_batch(ctx, k, nh, L, b)
+    need = np.unique(np.concatenate([r.reshape(-1) for r in rows]))
+    assert 0 < need.size < (1 << L)
+    full = ka.Group(ctx, k, nh, L, full_cols)
+    firsts_full = full.add_db_files(files)
+    full.finalize()
+    sp = ka.Group.sparse(ctx, k, nh, L, full_cols, need)
+    assert sp.add_db_files(files) == firsts_full and sp.device_bytes < full.device_bytes
+    sp.finalize()
+    for thr in (1.0, 0.8, 0.3):
+        for flags in (0, ka.SEARCH_EARLY_EXIT):
+            a, c = full.search(b, thr, flags), sp.search(b, thr, flags)
+            assert np.array_equal(a.hits, c.hits) and np.array_equal(a.num_query_kmer, c.num_query_kmer), (thr, flags)
+            assert len(a.hits) > 0
+    other = ka.Batch(ctx, [rand_seq(rng, 400)])
+    with pytest.raises(ka.KwageError) as ei:
+        sp.search(other, 1.0)
+    assert "not among the rows of the sparse group" in str(ei.value)
+    assert np.array_equal(sp.search(b, 1.0).hits, full.search(b, 1.0).hits)          # the group is still usable afterwards
+    other.close()
+    # a compact host image through add_columns
+    img = _make_random_db(rng, L, 500, 0.9)
+    sp2 = ka.Group.sparse(ctx, k, nh, L, 512, need)
+    sp2.add_columns(np.ascontiguousarray(img[need]), 500)
+    sp2.finalize()
+    dense = ka.Group(ctx, k, nh, L, 512)
+    dense.add_columns(img, 500)
+    dense.finalize()
+    assert np.array_equal(sp2.search(b, 0.5).hits, dense.search(b, 0.5).hits)
+    for g in (full, sp, sp2, dense):
+        g.close()
+    b.close()
 
 
 # ---------------------------------------------------------------------------------------------
