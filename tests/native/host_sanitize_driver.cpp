@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "kwage_amd.h"
+#include "host.hpp"        // DbSliceSource: the loader's view of a file (not part of the C ABI, but fed the same damaged files)
 
 static std::vector<unsigned char> slurp(const std::string &p)
 {
@@ -50,6 +51,33 @@ static int exercise_db(const std::string &path, bool expect_ok)
 	return bad;
 }
 
+// The slice readers the loader uses: whole row ranges, listed rows (sparse groups: first, last, middle, unordered,
+// repeated) and the CRC pass, on whatever the file claims to be.
+static int exercise_slices(const std::string &path, bool expect_ok)
+{
+	kwage::DbSliceSource src;
+	std::string err;
+	if(!src.open(path, err)){ return expect_ok ? 1 : 0; }
+	if(src.nrows > (1ull << 22) || src.slice_size > (1u << 20)){ return 0; }      // a damaged header may claim anything: do not allocate for it
+	std::vector<uint32_t> rows = {0, (uint32_t)(src.nrows - 1), (uint32_t)(src.nrows/2), 1 % (uint32_t)src.nrows, (uint32_t)(src.nrows/2), 0};
+	for(uint32_t i = 0; i < 5000; ++i){ rows.push_back((uint32_t)((i*2654435761ull) % src.nrows)); }
+	std::vector<unsigned char> some(rows.size()*src.slice_size + 1), all(src.nrows*src.slice_size + 1);
+	const bool a = src.read_row_list(rows.data(), rows.size(), some.data(), err, 4);
+	const bool b = src.read_rows(0, src.nrows, all.data(), err);
+	int bad = 0;
+	if(a && b){
+		for(size_t i = 0; i < rows.size(); ++i){
+			if(memcmp(some.data() + i*src.slice_size, all.data() + (size_t)rows[i]*src.slice_size, src.slice_size) != 0){ bad = 1; }
+		}
+	}
+	uint32_t crc = 0;
+	const bool c = src.slice_crc32(crc, err);
+	if(expect_ok && (!a || !b || !c || crc != src.header.crc32)){ bad = 1; }
+	const uint32_t beyond = (uint32_t)src.nrows;
+	if(src.read_row_list(&beyond, 1, some.data(), err, 1)){ bad = 1; }            // out of range must be refused
+	return bad;
+}
+
 static int exercise_seq(const std::string &path)
 {
 	kwage_seqfile *f = NULL;
@@ -72,10 +100,12 @@ int main(int argc, char **argv)
 	for(const char *rel : dbs){
 		const std::string p = golden + rel;
 		bad += exercise_db(p, true);
+		bad += exercise_slices(p, true);
 		// compressed container round trip
 		const std::string z = tmp + "/x.dbz", back = tmp + "/back.db";
 		if(kwage_db_compress(p.c_str(), z.c_str(), 3) != KWAGE_OK){ fprintf(stderr, "compress failed: %s\n", kwage_last_error()); ++bad; continue; }
 		bad += exercise_db(z, true);
+		bad += exercise_slices(z, true);
 		if(kwage_db_decompress(z.c_str(), back.c_str()) != KWAGE_OK || slurp(back) != slurp(p)){ fprintf(stderr, "round trip failed for %s\n", rel); ++bad; }
 
 		// damaged copies: truncations and byte flips of both layouts must fail cleanly or parse safely
@@ -87,6 +117,7 @@ int main(int argc, char **argv)
 				std::vector<unsigned char> t(orig.begin(), orig.begin() + c);
 				spit(tmp + "/cut.db", t);
 				(void)exercise_db(tmp + "/cut.db", false);
+				(void)exercise_slices(tmp + "/cut.db", false);
 				(void)kwage_db_decompress((tmp + "/cut.db").c_str(), (tmp + "/cut_out.db").c_str());
 				(void)kwage_db_compress((tmp + "/cut.db").c_str(), (tmp + "/cut_out.dbz").c_str(), 2);
 			}
@@ -99,6 +130,7 @@ int main(int argc, char **argv)
 				t[pos] ^= (unsigned char)(1u << (s % 8)) | (unsigned char)(s >> 24);
 				spit(tmp + "/flip.db", t);
 				(void)exercise_db(tmp + "/flip.db", false);
+				if(i % 4 == 0){ (void)exercise_slices(tmp + "/flip.db", false); }
 				(void)kwage_db_decompress((tmp + "/flip.db").c_str(), (tmp + "/flip_out.db").c_str());
 			}
 		}
