@@ -6,6 +6,8 @@
 // which together replace the reference's search() (kwage.cpp:340-541) for a whole batch of
 // queries.  There is no CPU fallback anywhere in this file.
 #include <hip/hip_runtime.h>
+#include <hsa/hsa.h>                 // types only: every HSA function is looked up at run time (see HsaApi)
+#include <hsa/hsa_ext_amd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -121,8 +123,8 @@ struct kwage_ctx {
 	DevBuf kmers;                       // kwage_hash_batch output
 	// database loading: two pinned + two device staging buffers, kept across files
 	PinBuf load_pin[2];
-	DevBuf load_dev[2];
-	hipEvent_t load_done[2] = {nullptr, nullptr};
+	DevBuf load_dev[3];                 // [2] is used by the copy-engine pipeline only (three chunks in flight)
+	hipEvent_t load_done[3] = {nullptr, nullptr, nullptr};
 	// zero-copy loading: the file mapping whose H2D copies may still be in flight on `stream`
 	void *map_base = nullptr;
 	size_t map_len = 0;
@@ -155,6 +157,39 @@ struct HsaLock {
 const HsaLock &hsa_lock()
 {
 	static const HsaLock h;
+	return h;
+}
+
+// The rest of the HSA runtime the loader's copy-engine pipeline needs (same run-time lookup).
+struct HsaApi {
+	decltype(&hsa_amd_memory_async_copy) async_copy = nullptr;
+	decltype(&hsa_signal_create) signal_create = nullptr;
+	decltype(&hsa_signal_destroy) signal_destroy = nullptr;
+	decltype(&hsa_signal_store_relaxed) signal_store = nullptr;
+	decltype(&hsa_signal_wait_scacquire) signal_wait = nullptr;
+	decltype(&hsa_iterate_agents) iterate_agents = nullptr;
+	decltype(&hsa_agent_get_info) agent_get_info = nullptr;
+	decltype(&hsa_amd_pointer_info) pointer_info = nullptr;
+	bool ok = false;
+	HsaApi()
+	{
+#define KWAGE_HSA_SYM(member, name) member = (decltype(member))dlsym(RTLD_DEFAULT, name)
+		KWAGE_HSA_SYM(async_copy, "hsa_amd_memory_async_copy");
+		KWAGE_HSA_SYM(signal_create, "hsa_signal_create");
+		KWAGE_HSA_SYM(signal_destroy, "hsa_signal_destroy");
+		KWAGE_HSA_SYM(signal_store, "hsa_signal_store_relaxed");
+		KWAGE_HSA_SYM(signal_wait, "hsa_signal_wait_scacquire");
+		KWAGE_HSA_SYM(iterate_agents, "hsa_iterate_agents");
+		KWAGE_HSA_SYM(agent_get_info, "hsa_agent_get_info");
+		KWAGE_HSA_SYM(pointer_info, "hsa_amd_pointer_info");
+#undef KWAGE_HSA_SYM
+		ok = async_copy && signal_create && signal_destroy && signal_store && signal_wait && iterate_agents && agent_get_info && pointer_info;
+	}
+};
+
+const HsaApi &hsa_api()
+{
+	static const HsaApi h;
 	return h;
 }
 
@@ -903,6 +938,7 @@ extern "C" void kwage_shutdown(kwage_ctx *ctx)
 	for(int i = 0; i < 2; ++i){
 		ctx->load_pin[i].release(); ctx->load_dev[i].release();
 		if(ctx->load_done[i]){ (void)hipEventDestroy(ctx->load_done[i]); }
+		if(i == 1){ ctx->load_dev[2].release(); if(ctx->load_done[2]){ (void)hipEventDestroy(ctx->load_done[2]); } }
 	}
 	delete ctx;
 }
@@ -1213,6 +1249,141 @@ int load_gang_direct(kwage_group *g, DbSliceSource *const *srcs, const uint64_t 
 	return KWAGE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Copy-engine pipeline for raw files (the default): page cache -> staging buffer -> place_rows_kernel, at the copy
+// engine's rate and without hipHostRegister.  Windows of a file (<= 256 MiB) are mapped and locked through HSA -- no
+// device synchronisation, so pinning the next window and un-pinning the previous one overlap with the copy that is
+// running --, hsa_amd_memory_async_copy (SDMA, linear) moves one window at a time into one of THREE staging buffers,
+// the host waits for the copy's completion signal and launches place_rows_kernel behind it on the loading stream.
+// Three windows are in flight: one being copied, one being scattered, one being pinned.  16 files x 268 MB:
+// 48-52 GB/s; 392 files into a 105 GB matrix: 54 GB/s (tools/micro/sdma_stage_probe.hip, profiles/r02_loader_probe.txt)
+// against 40 and 33 GB/s for the hipHostRegister + hipMemcpyAsync form, which stays as the fallback.
+// ------------------------------------------------------------------------------------------------------------------
+struct SdmaPipe {
+	kwage_group *g = nullptr;
+	hsa_agent_t gpu{}, cpu{};
+	bool usable = false;
+	uint64_t chunk_bytes = 0;
+	struct Chunk { hsa_signal_t sig{}; bool sig_valid = false; int stage = 0; uint64_t row0 = 0, nr = 0, byte0 = 0, width = 0; };
+	Chunk ring[3];
+	uint64_t issued = 0, finished = 0;                     // chunk counters (ring index = counter % 3)
+	struct Window { void *base; size_t len; uint64_t last_chunk; };
+	std::deque<Window> windows;                            // locked windows, oldest first
+
+	int init(kwage_group *grp)
+	{
+		g = grp;
+		const HsaApi &h = hsa_api();
+		if(!h.ok || !hsa_lock().lock){ return KWAGE_OK; }
+		hsa_amd_pointer_info_t info;
+		memset(&info, 0, sizeof(info));
+		info.size = sizeof(info);
+		if(h.pointer_info(g->d_bits, &info, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || info.type == HSA_EXT_POINTER_TYPE_UNKNOWN){ return KWAGE_OK; }
+		gpu = info.agentOwner;                             // the HSA agent behind this context's HIP device
+		struct Find { const HsaApi *h; hsa_agent_t cpu; bool found; } f = {&h, {}, false};
+		h.iterate_agents([](hsa_agent_t a, void *p) -> hsa_status_t {
+			Find *fd = (Find*)p;
+			hsa_device_type_t t;
+			if(!fd->found && fd->h->agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) == HSA_STATUS_SUCCESS && t == HSA_DEVICE_TYPE_CPU){ fd->cpu = a; fd->found = true; }
+			return HSA_STATUS_SUCCESS;
+		}, &f);
+		if(!f.found){ return KWAGE_OK; }
+		cpu = f.cpu;
+		for(auto &c : ring){ c.sig_valid = false; }
+		for(int i = 0; i < 3; ++i){
+			if(h.signal_create(1, 0, nullptr, &ring[i].sig) != HSA_STATUS_SUCCESS){ return KWAGE_OK; }
+			ring[i].sig_valid = true;
+			ring[i].stage = i;
+		}
+		HIP_TRY(hipStreamSynchronize(g->ctx->stream));       // nothing queued earlier may still read the staging buffers
+		usable = true;
+		return KWAGE_OK;
+	}
+
+	// the oldest unfinished chunk: wait for its copy, scatter it, release windows whose last chunk it was
+	int finish_one()
+	{
+		kwage_ctx *ctx = g->ctx;
+		Chunk &c = ring[finished % 3];
+		hsa_api().signal_wait(c.sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
+		hipLaunchKernelGGL(place_rows_kernel, dim3(grid_for(c.nr*c.width/4 + 1, 256)), dim3(256), 0, ctx->stream,
+		                   g->d_bits, g->stride, c.row0, c.byte0, (const uint8_t*)ctx->load_dev[c.stage].p, c.width, c.width, c.nr);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipEventRecord(ctx->load_done[c.stage], ctx->stream));
+		while(!windows.empty() && windows.front().last_chunk == finished){
+			(void)hsa_lock().unlock(windows.front().base);
+			(void)munmap(windows.front().base, windows.front().len);
+			windows.pop_front();
+		}
+		++finished;
+		return KWAGE_OK;
+	}
+
+	// Queue every row of `src` (raw layout): one window = one copy.  *rows_done = rows that are on their way (all of them
+	// unless a window could not be mapped or locked, or the copy engine refused: the caller finishes the rest through the
+	// other paths).
+	int add_file(DbSliceSource &src, uint64_t byte0, uint64_t *rows_done)
+	{
+		kwage_ctx *ctx = g->ctx;
+		const HsaApi &h = hsa_api();
+		// 256 MiB per copy: pinning the next window (~12 us per MB) then takes less time than the copy that is running
+		static const uint64_t window_target = load_env_kb("KWAGE_LOAD_WINDOW_KB", 256ull << 20);
+		const uint64_t width = src.slice_size;
+		const uint64_t win_rows = std::max<uint64_t>(1, std::min<uint64_t>(g->nrows, window_target/width));
+		const long page = sysconf(_SC_PAGESIZE);
+		int rc;
+		for(int i = 0; i < 3; ++i){
+			if(ctx->load_dev[i].cap < win_rows*width){
+				// growing a staging buffer: every copy into the old one and every kernel that reads it must be done first
+				if((rc = flush())){ return rc; }
+				HIP_TRY(hipStreamSynchronize(ctx->stream));
+				if((rc = ctx->load_dev[i].reserve(win_rows*width))){ return rc; }
+			}
+			if(!ctx->load_done[i]){ HIP_TRY(hipEventCreateWithFlags(&ctx->load_done[i], hipEventDisableTiming)); HIP_TRY(hipEventRecord(ctx->load_done[i], ctx->stream)); }
+		}
+		*rows_done = 0;
+		for(uint64_t r0 = 0; r0 < g->nrows; ){
+			const uint64_t wr = std::min(win_rows, g->nrows - r0);
+			const uint64_t off = DB_HEADER_BYTES + r0*width, off0 = off/page*page;
+			const size_t maplen = (size_t)(off - off0 + wr*width);
+			void *base = mmap(nullptr, maplen, PROT_READ, MAP_PRIVATE, src.fd, (off_t)off0);      // (the lock faults the pages in)
+			if(base == MAP_FAILED){ return KWAGE_OK; }
+			void *dev_view = nullptr;
+			if(hsa_lock().lock(base, maplen, nullptr, 0, &dev_view) != 0 || !dev_view){ (void)munmap(base, maplen); return KWAGE_OK; }
+			Chunk &c = ring[issued % 3];
+			HIP_TRY(hipEventSynchronize(ctx->load_done[c.stage]));          // the scatter kernel that last read this staging buffer
+			c.row0 = r0; c.nr = wr; c.byte0 = byte0; c.width = width;
+			h.signal_store(c.sig, 1);
+			if(h.async_copy(ctx->load_dev[c.stage].p, gpu, (const char*)dev_view + (off - off0), cpu, wr*width, 0, nullptr, c.sig) != HSA_STATUS_SUCCESS){
+				(void)hsa_lock().unlock(base);
+				(void)munmap(base, maplen);
+				usable = false;                                 // the caller flushes and goes on with the staged paths
+				return KWAGE_OK;
+			}
+			windows.push_back(Window{base, maplen, issued});
+			++issued;
+			r0 += wr;
+			*rows_done = r0;
+			if(issued - finished >= 2){ if((rc = finish_one())){ return rc; } }       // one copy stays in flight while the next window is pinned
+		}
+		return KWAGE_OK;
+	}
+
+	int flush()
+	{
+		int rc;
+		while(finished < issued){ if((rc = finish_one())){ return rc; } }
+		return KWAGE_OK;
+	}
+
+	~SdmaPipe()
+	{
+		if(g){ (void)flush(); }
+		while(!windows.empty()){ (void)hsa_lock().unlock(windows.front().base); (void)munmap(windows.front().base, windows.front().len); windows.pop_front(); }
+		for(auto &c : ring){ if(c.sig_valid){ (void)hsa_api().signal_destroy(c.sig); } }
+	}
+};
+
 // Staged paths for rows first_row.. of one file: the pinned file mapping feeding the copy engine (raw files, from row 0)
 // or pread / inflate into pinned buffers, each followed by place_rows_kernel.
 int load_source_rows_staged(kwage_group *g, DbSliceSource &src, const char *path, uint64_t byte0, uint64_t first_row)
@@ -1392,9 +1563,12 @@ extern "C" int kwage_group_add_db_files(kwage_group *g, const char *const *paths
 	for(uint32_t i = 0; i < n; ++i){ if(!paths[i]){ return fail(KWAGE_ERR_ARG, "kwage_group_add_db_files: path %u is NULL", i); } }
 	int rc = set_device(g->ctx);
 	if(rc){ return rc; }
-	// Files are taken in the order given (that is the column order).  Consecutive files the direct path can take are
-	// loaded LOAD_GANG at a time, their rows written side by side; anything else (compressed, odd row length, no HSA
-	// lock) goes through the staged paths file by file.
+	// Files are taken in the order given (that is the column order).  Raw files go through the copy-engine pipeline
+	// (SdmaPipe; KWAGE_LOAD_SDMA=0 disables it), or -- opt-in -- LOAD_GANG at a time through the direct copy kernel;
+	// compressed files, sparse groups and whatever those paths cannot take go through the staged paths file by file.
+	static const bool sdma_ok = load_env_flag("KWAGE_LOAD_SDMA", true) && load_env_flag("KWAGE_LOAD_MMAP", true);
+	SdmaPipe pipe;
+	if(sdma_ok && !g->d_row_map && !load_env_flag("KWAGE_LOAD_DIRECT", false)){ if((rc = pipe.init(g))){ return rc; } }
 	for(uint32_t i0 = 0; i0 < n; ){
 		DbSliceSource srcs[LOAD_GANG];
 		DbSliceSource *ptrs[LOAD_GANG];
@@ -1424,13 +1598,19 @@ extern "C" int kwage_group_add_db_files(kwage_group *g, const char *const *paths
 			if((rc = load_gang_direct(g, ptrs, byte0, n_direct, &rows_done))){ return rc; }
 		}
 		for(uint32_t k = 0; k < cnt; ++k){
-			const uint64_t from = (k < n_direct) ? rows_done : 0;
+			uint64_t from = (k < n_direct) ? rows_done : 0;
+			if(from == 0 && pipe.usable && srcs[k].header.compression == KWAGE_COMPRESSION_NONE){
+				if((rc = pipe.add_file(srcs[k], byte0[k], &from))){ return rc; }
+				if(from < g->nrows){ if((rc = pipe.flush())){ return rc; } }       // the staged paths share the staging buffers
+			}
+			else if(pipe.usable){ if((rc = pipe.flush())){ return rc; } }
 			if(from < g->nrows){
 				if((rc = load_source_rows_staged(g, srcs[k], paths[i0 + k], byte0[k], from))){ return rc; }
 			}
 		}
 		i0 += cnt;
 	}
+	if(pipe.usable || pipe.issued){ if((rc = pipe.flush())){ return rc; } }
 	return KWAGE_OK;
 }
 

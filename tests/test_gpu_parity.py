@@ -676,12 +676,14 @@ def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{}, {"KWAGE_LOAD_MMAP": "0"}, {"KWAGE_LOAD_CHUNK_KB": "8", "KWAGE_LOAD_WINDOW_KB": "20"},
-                                 {"KWAGE_LOAD_CHUNK_KB": "3", "KWAGE_LOAD_WINDOW_KB": "3"}, {"KWAGE_LOAD_DIRECT": "1"},
+                                 {"KWAGE_LOAD_CHUNK_KB": "3", "KWAGE_LOAD_WINDOW_KB": "3"}, {"KWAGE_LOAD_SDMA": "0"},
+                                 {"KWAGE_LOAD_SDMA": "0", "KWAGE_LOAD_CHUNK_KB": "8", "KWAGE_LOAD_WINDOW_KB": "20"}, {"KWAGE_LOAD_DIRECT": "1"},
                                  {"KWAGE_LOAD_DIRECT": "1", "KWAGE_LOAD_GANG": "1"}, {"KWAGE_LOAD_DIRECT": "1", "KWAGE_LOAD_GANG": "3", "KWAGE_LOAD_WINDOW_KB": "20"},
                                  {"KWAGE_LOAD_DIRECT": "1", "KWAGE_LOAD_CHUNK_KB": "3", "KWAGE_LOAD_WINDOW_KB": "3"}])
 def test_loader_paths_give_the_same_matrix(ka, oracle, tmp_path, env):
-    """kwage_group_add_db_file(s): the staged zero-copy path (mapping pinned with hipHostRegister, copies left in flight
-    across files; the default), the pread path, and the opt-in direct path (file windows locked through HSA, one copy
+    """kwage_group_add_db_file(s): the copy-engine pipeline (file windows locked through HSA, hsa_amd_memory_async_copy
+    into three staging buffers, scatter kernels behind the completion signals; the default), the hipHostRegister form it
+    replaces (KWAGE_LOAD_SDMA=0), the pread path, and the opt-in direct path (file windows locked through HSA, one copy
     kernel reads up to 16 files over PCIe into the strided matrix; rows that are dword multiples), each with many
     small windows / chunks -- the resident matrix must be the file's rows, for many files of odd and even widths in
     one group.  (The knobs are read once per process.)"""

@@ -70,7 +70,7 @@ try:
     print("wrote %d files, %.1f GB, in %.1f s" % (n_files, gb, time.perf_counter() - t0), flush=True)
     # (a run that follows a whole-database run pays ~2.7 s of HIP initialisation for the release of the other's 105 GB:
     # the sparse runs are therefore done twice in a row)
-    for env_extra in ({"KWAGE_SPARSE": "0"}, {}, {}, {"KWAGE_SPARSE": "0"}, {}, {}):
+    for env_extra in ({"KWAGE_SPARSE": "0"}, {"KWAGE_SPARSE": "0", "KWAGE_LOAD_SDMA": "0"}, {"KWAGE_SPARSE": "0"}, {"KWAGE_SPARSE": "0", "KWAGE_LOAD_SDMA": "0"}, {}, {}):
         t0 = time.perf_counter()
         r = subprocess.run([native.KWAGE_BIN, "-d", os.path.join(tmp, "db"), "--o.csv", genome[100:1100]], capture_output=True, text=True,
                            env=dict(os.environ, KWAGE_VERBOSE="1", **env_extra))
