@@ -74,6 +74,9 @@ struct SeqFile {
 	void *fin;
 	int type;
 	std::string seq, curr_defline, next_defline;
+	std::vector<char> rbuf;            // block buffer behind get_line()
+	size_t rpos = 0, rend = 0;
+	char *get_line(char *out, int len);
 	SeqFile();
 	~SeqFile();
 	bool open(const std::string &path, std::string &err);
