@@ -254,6 +254,12 @@ struct kwage_batch {
 	uint64_t table_slots = 0;      // global hash-set slots needed by long queries
 	uint64_t *d_pos_off = nullptr; // n+1
 	uint64_t *d_tab_off = nullptr; // n
+	// k-mer stage work list: one workgroup per chunk; a query above KM_LDS_SLOTS/2 positions is cut into chunks of
+	// KM_CHUNK positions that share its global distinct set, everything shorter is one chunk
+	uint32_t *d_chunk_q = nullptr;     // n_chunks: query of the chunk
+	uint64_t *d_chunk_t0 = nullptr;    // n_chunks: its first position within the query
+	uint64_t n_chunks = 0, chunk_cap = 0;
+	bool multi_chunk = false;          // some query has more than one chunk
 	std::vector<uint64_t> h_pos_off;
 };
 
@@ -334,6 +340,31 @@ int batch_prepare(kwage_batch *b, uint32_t k)
 			}
 		}
 	}
+	std::vector<uint32_t> chunk_q;
+	std::vector<uint64_t> chunk_t0;
+	chunk_q.reserve(n);
+	chunk_t0.reserve(n);
+	b->multi_chunk = false;
+	for(uint32_t i = 0; i < n; ++i){
+		const uint64_t npos = b->h_pos_off[i + 1] - b->h_pos_off[i];
+		const bool is_long = npos && (1ull << host_table_log2(npos)) > KM_LDS_SLOTS;      // the same rule as the table choice above
+		if(!is_long || npos <= KM_CHUNK){ chunk_q.push_back(i); chunk_t0.push_back(0); continue; }
+		b->multi_chunk = true;
+		for(uint64_t t0 = 0; t0 < npos; t0 += KM_CHUNK){ chunk_q.push_back(i); chunk_t0.push_back(t0); }
+	}
+	if(chunk_q.size() > 0x7FFFFFFFull){ return fail(KWAGE_ERR_ARG, "batch too large for one k-mer launch"); }
+	if(chunk_q.size() > b->chunk_cap){
+		if(b->d_chunk_q){ (void)hipFree(b->d_chunk_q); b->d_chunk_q = nullptr; }
+		if(b->d_chunk_t0){ (void)hipFree(b->d_chunk_t0); b->d_chunk_t0 = nullptr; }
+		b->chunk_cap = chunk_q.size();
+		HIP_TRY(hipMalloc(&b->d_chunk_q, std::max<size_t>(b->chunk_cap, 1)*sizeof(uint32_t)));
+		HIP_TRY(hipMalloc(&b->d_chunk_t0, std::max<size_t>(b->chunk_cap, 1)*sizeof(uint64_t)));
+	}
+	b->n_chunks = chunk_q.size();
+	if(b->n_chunks){
+		HIP_TRY(hipMemcpyAsync(b->d_chunk_q, chunk_q.data(), chunk_q.size()*sizeof(uint32_t), hipMemcpyHostToDevice, b->ctx->stream));
+		HIP_TRY(hipMemcpyAsync(b->d_chunk_t0, chunk_t0.data(), chunk_t0.size()*sizeof(uint64_t), hipMemcpyHostToDevice, b->ctx->stream));
+	}
 	if(!b->d_pos_off){ HIP_TRY(hipMalloc(&b->d_pos_off, ((size_t)n + 1)*sizeof(uint64_t))); }
 	if(!b->d_tab_off){ HIP_TRY(hipMalloc(&b->d_tab_off, std::max<size_t>(n, 1)*sizeof(uint64_t))); }
 	HIP_TRY(hipMemcpyAsync(b->d_pos_off, b->h_pos_off.data(), ((size_t)n + 1)*sizeof(uint64_t),
@@ -342,7 +373,7 @@ int batch_prepare(kwage_batch *b, uint32_t k)
 		HIP_TRY(hipMemcpyAsync(b->d_tab_off, tab_off.data(), (size_t)n*sizeof(uint64_t),
 		                       hipMemcpyHostToDevice, b->ctx->stream));
 	}
-	HIP_TRY(hipStreamSynchronize(b->ctx->stream));   // tab_off is a local
+	HIP_TRY(hipStreamSynchronize(b->ctx->stream));   // tab_off and the chunk lists are locals
 	b->total_pos = b->h_pos_off[n];
 	b->max_pos = maxp;
 	b->table_slots = slots;
@@ -382,14 +413,23 @@ int launch_kmer_stage(Slot *sl, const kwage_params &p, kwage_batch *b, float thr
 	a.total_kmers = nullptr;           // summed on the host from nkmer[] (a per-workgroup atomic serialises)
 	a.shared_lg = 0;
 	a.bloom_bits = nullptr;
+	a.chunk_q = b->d_chunk_q;
+	a.chunk_t0 = b->d_chunk_t0;
+	if(b->multi_chunk){      // the chunks of a long query add their new k-mers into nkmer[q]
+		HIP_TRY(hipMemsetAsync(sl->d_nkmer, 0, (size_t)b->n*sizeof(uint32_t), sl->stream));
+	}
 	// workgroup and LDS table sized for the longest query of the batch: queries whose table would not fit
 	// KM_LDS_SLOTS use the global tables laid out by batch_prepare (same rule there)
 	uint32_t slots = 64;
 	while(slots < KM_LDS_SLOTS && slots < 2*b->max_pos){ slots *= 2; }
 	a.lds_slots = slots;
 	const uint32_t threads = (b->max_pos <= 192) ? 64 : (b->max_pos <= 768) ? 128 : KM_THREADS;
-	hipLaunchKernelGGL(kmer_kernel, dim3(b->n), dim3(threads), (size_t)slots*sizeof(uint64_t), sl->stream, a);
+	hipLaunchKernelGGL(kmer_kernel, dim3((uint32_t)b->n_chunks), dim3(threads), (size_t)slots*sizeof(uint64_t), sl->stream, a);
 	HIP_TRY(hipGetLastError());
+	if(b->multi_chunk){      // thresholds of the queries whose k-mers were counted by several workgroups
+		hipLaunchKernelGGL(kmer_finish_kernel, dim3((b->n + 255)/256), dim3(256), 0, sl->stream, a, b->n);
+		HIP_TRY(hipGetLastError());
+	}
 	return KWAGE_OK;
 }
 
@@ -1764,6 +1804,8 @@ extern "C" void kwage_batch_destroy(kwage_batch *b)
 	if(b->d_seq_off){ (void)hipFree(b->d_seq_off); }
 	if(b->d_pos_off){ (void)hipFree(b->d_pos_off); }
 	if(b->d_tab_off){ (void)hipFree(b->d_tab_off); }
+	if(b->d_chunk_q){ (void)hipFree(b->d_chunk_q); }
+	if(b->d_chunk_t0){ (void)hipFree(b->d_chunk_t0); }
 	delete b;
 }
 
@@ -2039,6 +2081,7 @@ int run_shared_kmer_pass(kwage_ctx *ctx, const kwage_params &p, kwage_batch *b, 
 		a.total_kmers = (unsigned long long*)sl->d_counters + 1;
 		a.shared_lg = lg;
 		a.bloom_bits = d_bloom_bits;
+		a.chunk_q = nullptr; a.chunk_t0 = nullptr;       // one workgroup per sequence
 		a.lds_slots = 0;                 // the shared global table is used for every sequence
 		hipLaunchKernelGGL(kmer_kernel, dim3(b->n), dim3(KM_THREADS), 0, ctx->stream, a);
 		HIP_TRY(hipGetLastError());

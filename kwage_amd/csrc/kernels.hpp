@@ -31,6 +31,7 @@ namespace kwage {
 static constexpr int WAVE = 64;
 static constexpr int KM_THREADS = 256;               // largest k-mer workgroup; short queries use 64 or 128
 static constexpr uint32_t KM_LDS_SLOTS = 4096;      // 32 KiB of u64 slots: queries up to 2048 positions
+static constexpr uint32_t KM_CHUNK = 4096;          // positions per workgroup of a long query (16 tiles of 256)
 static constexpr uint64_t KM_EMPTY = ~0ull;         // never a canonical word: min(w, rc) < all-ones
 static constexpr int SEARCH_THREADS = 256;          // 4 waves, one tile each
 
@@ -79,12 +80,19 @@ struct KmerArgs {
 	uint32_t lds_slots;             // capacity of the dynamic-LDS table (a power of two <= KM_LDS_SLOTS)
 	uint32_t shared_lg;             // 0 = one set per query (search); else log2 slots of the shared table
 	uint32_t *bloom_bits;           // may be null
+	// work list (null: workgroup i = sequence i, whole): the query of every workgroup and the first position of its
+	// chunk; a query longer than KM_CHUNK positions with a global set is handled by several workgroups
+	const uint32_t *chunk_q;
+	const uint64_t *chunk_t0;
 };
 
-template <bool LDS_TAB, typename TAB>
+// MULTI: this workgroup handles positions [t_begin, t_end) of a query that other workgroups work on too (they share
+// its global set): new k-mers are counted per tile in LDS, ONE global add per tile reserves their places behind
+// nkmer[q] (zeroed before the launch), and the threshold is left to kmer_finish_kernel.
+template <bool LDS_TAB, bool MULTI, typename TAB>
 __device__ __forceinline__ void kmer_body(const KmerArgs &a, uint32_t q, uint64_t s0, uint64_t len,
-                                          uint64_t npos, TAB tab, uint32_t lg,
-                                          uint8_t *codes, uint32_t *count)
+                                          uint64_t t_begin, uint64_t t_end, TAB tab, uint32_t lg,
+                                          uint8_t *codes, uint32_t *count, uint32_t *tile_base)
 {
 	const uint32_t k = a.k;
 	const uint64_t base = a.pos_off[q];
@@ -96,7 +104,7 @@ __device__ __forceinline__ void kmer_body(const KmerArgs &a, uint32_t q, uint64_
 	if(threadIdx.x == 0){ *count = 0; }
 	__syncthreads();
 
-	for(uint64_t t0 = 0; t0 < npos; t0 += blockDim.x){
+	for(uint64_t t0 = t_begin; t0 < t_end; t0 += blockDim.x){
 		// stage the 2-bit codes of characters [t0, t0 + blockDim.x + k - 1)
 		const uint32_t nchar = (uint32_t)min((uint64_t)(blockDim.x + k - 1), len - t0);
 		for(uint32_t i = threadIdx.x; i < nchar; i += blockDim.x){
@@ -105,7 +113,9 @@ __device__ __forceinline__ void kmer_body(const KmerArgs &a, uint32_t q, uint64_
 		__syncthreads();
 
 		const uint64_t p = t0 + threadIdx.x;
-		if(p < npos){
+		bool fresh = false;
+		uint64_t canon = 0;
+		if(p < t_end){
 			uint64_t w = 0;
 			uint32_t bad = 0;
 			for(uint32_t j = 0; j < k; ++j){
@@ -116,32 +126,45 @@ __device__ __forceinline__ void kmer_body(const KmerArgs &a, uint32_t q, uint64_
 			if(!bad){   // ValidWord: k consecutive good bases end here (word.h:162)
 				w &= kmask;
 				const uint64_t rc = revcomp2(w, k);
-				const uint64_t canon = (w < rc) ? w : rc;          // word.h:165
-				if(set_insert(tab, lg, canon)){                    // first time this k-mer is seen
-					const uint32_t idx = atomicAdd(count, 1u);
-					if(a.kmers_out){ a.kmers_out[base + idx] = canon; }
-					if(a.bloom_bits){
-						MurmurKeys mk;
-						murmur_keys(canon, k, mk);
-						for(uint32_t h = 0; h < a.num_hash; ++h){
-							const uint32_t bit = murmur_finish(mk, k, h) & a.row_mask;
-							atomicOr(a.bloom_bits + (bit >> 5), 1u << (bit & 31));      // LSB first, bloom.h:162
-						}
-					}
-					if(a.rows){
-						MurmurKeys mk;
-						murmur_keys(canon, k, mk);
-						for(uint32_t h = 0; h < a.num_hash; ++h){  // seed = hash index, kwage.cpp:409-412
-							a.rows[(base + idx)*a.num_hash + h] = murmur_finish(mk, k, h) & a.row_mask;
-						}
-					}
+				canon = (w < rc) ? w : rc;                         // word.h:165
+				fresh = set_insert(tab, lg, canon);                // first time this k-mer is seen
+			}
+		}
+		uint32_t idx = 0;
+		if(MULTI){
+			if(fresh){ idx = atomicAdd(count, 1u); }               // rank within the tile
+			__syncthreads();
+			if(threadIdx.x == 0){
+				const uint32_t n_new = *count;
+				*tile_base = n_new ? atomicAdd(a.nkmer + q, n_new) : 0u;
+				*count = 0;
+			}
+			__syncthreads();
+			idx += *tile_base;
+		}
+		else if(fresh){ idx = atomicAdd(count, 1u); }
+		if(fresh){
+			if(a.kmers_out){ a.kmers_out[base + idx] = canon; }
+			if(a.bloom_bits){
+				MurmurKeys mk;
+				murmur_keys(canon, k, mk);
+				for(uint32_t h = 0; h < a.num_hash; ++h){
+					const uint32_t bit = murmur_finish(mk, k, h) & a.row_mask;
+					atomicOr(a.bloom_bits + (bit >> 5), 1u << (bit & 31));      // LSB first, bloom.h:162
+				}
+			}
+			if(a.rows){
+				MurmurKeys mk;
+				murmur_keys(canon, k, mk);
+				for(uint32_t h = 0; h < a.num_hash; ++h){  // seed = hash index, kwage.cpp:409-412
+					a.rows[(base + idx)*a.num_hash + h] = murmur_finish(mk, k, h) & a.row_mask;
 				}
 			}
 		}
 		__syncthreads();
 	}
 
-	if(threadIdx.x == 0){
+	if(!MULTI && threadIdx.x == 0){
 		const uint32_t n = *count;
 		a.nkmer[q] = n;
 		// kwage.cpp:388: unsigned = float * unsigned  ->  float32 product, truncation
@@ -158,9 +181,10 @@ __global__ __launch_bounds__(KM_THREADS) void kmer_kernel(KmerArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned long long lds_tab[];
 	__shared__ uint8_t codes[KM_THREADS + KWAGE_MAX_WORD_LEN];
-	__shared__ uint32_t count;
+	__shared__ uint32_t count, tile_base;
 
-	const uint32_t q = blockIdx.x;
+	const uint32_t q = a.chunk_q ? a.chunk_q[blockIdx.x] : blockIdx.x;
+	const uint64_t t_begin = a.chunk_q ? a.chunk_t0[blockIdx.x] : 0;
 	const uint64_t s0 = a.seq_off[q];
 	const uint64_t len = a.seq_off[q + 1] - s0;
 	const uint64_t npos = (len >= a.k) ? (len - a.k + 1) : 0;
@@ -171,16 +195,27 @@ __global__ __launch_bounds__(KM_THREADS) void kmer_kernel(KmerArgs a)
 	}
 
 	if(a.shared_lg){
-		kmer_body<false>(a, q, s0, len, npos, a.g_tables, a.shared_lg, codes, &count);
+		kmer_body<false, false>(a, q, s0, len, 0, npos, a.g_tables, a.shared_lg, codes, &count, &tile_base);
 		return;
 	}
 	const uint32_t lg = table_log2(npos);
 	if((1ull << lg) <= a.lds_slots){
-		kmer_body<true>(a, q, s0, len, npos, lds_tab, lg, codes, &count);
+		kmer_body<true, false>(a, q, s0, len, 0, npos, lds_tab, lg, codes, &count, &tile_base);
 	}
-	else{
-		kmer_body<false>(a, q, s0, len, npos, a.g_tables + a.tab_off[q], lg, codes, &count);
+	else if(npos <= KM_CHUNK){
+		kmer_body<false, false>(a, q, s0, len, 0, npos, a.g_tables + a.tab_off[q], lg, codes, &count, &tile_base);
 	}
+	else{             // one of several workgroups on this query (the host cut it the same way, batch_prepare)
+		kmer_body<false, true>(a, q, s0, len, t_begin, min(npos, t_begin + (uint64_t)KM_CHUNK), a.g_tables + a.tab_off[q], lg, codes, &count, &tile_base);
+	}
+}
+
+// Thresholds after a launch in which long queries were counted by several workgroups (kwage.cpp:388 again: the
+// single-workgroup queries have written the same value already).
+__global__ __launch_bounds__(256) void kmer_finish_kernel(KmerArgs a, uint32_t n_queries)
+{
+	const uint32_t q = blockIdx.x*blockDim.x + threadIdx.x;
+	if(q < n_queries){ a.qthr[q] = a.complete_match ? 0u : (uint32_t)__fmul_rn(a.threshold, (float)a.nkmer[q]); }
 }
 
 // Sparse groups (kwage_group_create_sparse): the matrix holds only the rows listed in `map` (ascending).  Translate
