@@ -852,8 +852,11 @@ int submit_search(Slot *sl, kwage_group *g, kwage_batch *b, float threshold, uin
 	if(timing_kmer){ HIP_TRY(hipEventRecord(sl->ev[0], sl->stream)); }
 	if((rc = launch_kmer_stage(sl, g->params, b, threshold, (uint32_t*)sl->rows.p, nullptr))){ return rc; }
 	if(g->d_row_map && b->n){      // sparse group: row index -> position in the group's row list (counter 2 = indices not listed)
-		hipLaunchKernelGGL(remap_rows_kernel, dim3(b->n), dim3(256), 0, sl->stream, (uint32_t*)sl->rows.p, b->d_pos_off, sl->d_nkmer,
-		                   g->params.num_hash, g->d_row_map, (uint32_t)g->h_row_map.size(), (unsigned long long*)sl->d_counters + 2);
+		// (a workgroup per 4096 row indices of the longest query, so that a genome-length query is not one workgroup's job)
+		const uint64_t per_q = std::max<uint64_t>(1, (b->max_pos*g->params.num_hash + 4095)/4096);
+		const uint64_t wgs_per_q = std::min<uint64_t>(per_q, std::max<uint64_t>(1, 0x7FFFFFFFull/b->n));
+		hipLaunchKernelGGL(remap_rows_kernel, dim3((uint32_t)(b->n*wgs_per_q)), dim3(256), 0, sl->stream, (uint32_t*)sl->rows.p, b->d_pos_off, sl->d_nkmer,
+		                   g->params.num_hash, g->d_row_map, (uint32_t)g->h_row_map.size(), (unsigned long long*)sl->d_counters + 2, (uint32_t)wgs_per_q);
 		HIP_TRY(hipGetLastError());
 	}
 	if(timing_kmer){ HIP_TRY(hipEventRecord(sl->ev[1], sl->stream)); }

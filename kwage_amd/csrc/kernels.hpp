@@ -220,14 +220,14 @@ __global__ __launch_bounds__(256) void kmer_finish_kernel(KmerArgs a, uint32_t n
 
 // Sparse groups (kwage_group_create_sparse): the matrix holds only the rows listed in `map` (ascending).  Translate
 // every VALID row index of the batch (the first nkmer[q]*num_hash entries of query q) into its position in the list;
-// an index that is not listed is a caller error and is counted in *missing.  One workgroup per query.
+// an index that is not listed is a caller error and is counted in *missing.  wgs_per_query workgroups per query.
 __global__ __launch_bounds__(256) void remap_rows_kernel(uint32_t *rows, const uint64_t *pos_off, const uint32_t *nkmer, uint32_t num_hash,
-                                                         const uint32_t *map, uint32_t map_len, unsigned long long *missing)
+                                                         const uint32_t *map, uint32_t map_len, unsigned long long *missing, uint32_t wgs_per_query)
 {
-	const uint32_t q = blockIdx.x;
+	const uint32_t q = blockIdx.x / wgs_per_query, part = blockIdx.x % wgs_per_query;      // long queries are shared by several workgroups
 	uint32_t *rq = rows + pos_off[q]*num_hash;
-	const uint32_t n = nkmer[q]*num_hash;
-	for(uint32_t e = threadIdx.x; e < n; e += blockDim.x){
+	const uint64_t n = (uint64_t)nkmer[q]*num_hash;
+	for(uint64_t e = (uint64_t)part*blockDim.x + threadIdx.x; e < n; e += (uint64_t)wgs_per_query*blockDim.x){
 		const uint32_t r = rq[e];
 		uint32_t lo = 0, hi = map_len;                  // first position with map[pos] >= r
 		while(lo < hi){
