@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <chrono>
 #include <deque>
+#include <memory>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -100,6 +101,7 @@ struct Slot {
 	kwage_hit *d_hits = nullptr;
 	uint64_t hit_cap = 0, head_bytes = 0;
 	PinBuf h_stage;        // host image of the head of the result block + the first SPEC_HITS records
+	DevBuf sort_scratch;   // key / value buffers of the device hit sort (lists beyond SPEC_HITS only)
 	// the submission occupying the slot
 	bool busy = false;
 	kwage_group *g = nullptr;
@@ -778,6 +780,8 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 }
 
 static const uint64_t SPEC_HITS = 8192;     // hit records copied back together with the counters
+static const uint64_t RESULT_PIECE_HITS = 1u << 20;       // a longer list comes back in pieces of this many records (12 MiB)
+static const uint64_t SORT_SCRATCH_KEEP = 1ull << 30;     // device sort buffers above this size are freed after use
 
 struct SearchOutcome {
 	uint64_t staged_hits = 0;      // hit records already in the slot's h_stage
@@ -971,7 +975,7 @@ extern "C" void kwage_shutdown(kwage_ctx *ctx)
 		Slot *sl = &ctx->slot[k];
 		if(sl->stream){ (void)hipStreamSynchronize(sl->stream); }
 		sl->rows.release(); sl->tables.release(); sl->result.release();
-		sl->partial.release(); sl->h_stage.release();
+		sl->partial.release(); sl->h_stage.release(); sl->sort_scratch.release();
 		sl->walk_or.release(); sl->walk_done.release();
 		for(int i = 0; i < 4; ++i){ if(sl->ev[i]){ (void)hipEventDestroy(sl->ev[i]); } }
 		if(sl->search_done){ (void)hipEventDestroy(sl->search_done); }
@@ -1819,13 +1823,13 @@ extern "C" uint32_t kwage_batch_num_queries(const kwage_batch *b) { return b ? b
 // ------------------------------------------------------------------------------------------
 namespace {
 
-// Order hits by (query, column): std::sort for short lists, otherwise an LSD radix sort on the
-// 64-bit key (11-bit digits; digits on which all keys agree are skipped).
-void sort_hits(std::vector<kwage_hit> &hits)
+// Order hits by (query, column) on the host -- the lists of at most SPEC_HITS records that come back with the
+// counters (longer ones are sorted on the device, hit_sort.hip): std::sort for short lists, otherwise an LSD
+// radix sort on the 64-bit key (11-bit digits; digits on which all keys agree are skipped).
+void sort_hits(kwage_hit *hits, size_t n)
 {
-	const size_t n = hits.size();
 	if(n < 256){
-		std::sort(hits.begin(), hits.end(), [](const kwage_hit &x, const kwage_hit &y){
+		std::sort(hits, hits + n, [](const kwage_hit &x, const kwage_hit &y){
 			return (x.query != y.query) ? (x.query < y.query) : (x.column < y.column);
 		});
 		return;
@@ -1859,7 +1863,7 @@ void sort_hits(std::vector<kwage_hit> &hits)
 
 struct ResultStorage {
 	kwage_result pub;
-	std::vector<kwage_hit> hits;
+	std::unique_ptr<kwage_hit[]> hits;
 	std::vector<uint32_t> nkmer, qthr;
 	char kernel[64];
 };
@@ -1869,7 +1873,8 @@ int build_result(Slot *sl, kwage_group *g, kwage_batch *b, const SearchOutcome &
 {
 	ResultStorage *rs = new (std::nothrow) ResultStorage();
 	if(!rs){ return fail(KWAGE_ERR_DEVICE, "out of host memory"); }
-	rs->hits.resize(so.n_hits);
+	rs->hits.reset(new (std::nothrow) kwage_hit[std::max<uint64_t>(so.n_hits, 1)]);      // not zero-filled: every record is written below
+	if(!rs->hits){ delete rs; return fail(KWAGE_ERR_DEVICE, "out of host memory (%llu hits)", (unsigned long long)so.n_hits); }
 	rs->nkmer.resize(b->n);
 	rs->qthr.resize(b->n);
 	const uint64_t nq_bytes = (uint64_t)b->n*sizeof(uint32_t);
@@ -1879,23 +1884,54 @@ int build_result(Slot *sl, kwage_group *g, kwage_batch *b, const SearchOutcome &
 		memcpy(rs->qthr.data(), hs + 32 + nq_bytes, nq_bytes);
 	}
 	const uint64_t have = std::min(so.n_hits, so.staged_hits);
-	if(have){ memcpy(rs->hits.data(), hs + sl->head_bytes, have*sizeof(kwage_hit)); }
-	if(so.n_hits > have){      // a large hit list: fetch the remainder through pinned memory
-		const uint64_t rem_bytes = (so.n_hits - have)*sizeof(kwage_hit);
-		int rc2 = sl->h_stage.reserve(rem_bytes);      // the staged head has been consumed above
+	if(so.n_hits <= have){
+		if(have){ memcpy(rs->hits.get(), hs + sl->head_bytes, have*sizeof(kwage_hit)); }
+		// deterministic order; the reference's own order among ties is unspecified (sort.h:22-27)
+		sort_hits(rs->hits.get(), so.n_hits);
+	} else {
+		// A large hit list is sorted where it lies (hit_sort.hip) and then fetched whole, in pieces through the two
+		// halves of the pinned staging buffer: piece i+1 crosses PCIe while piece i is copied into the result.
+		uint64_t scratch = 0;
+		const char *where = getenv("KWAGE_HIT_SORT");      // "host": the sort of round 1, kept for A/B runs and as the fallback
+		bool on_device = !(where && !strcmp(where, "host"))
+		                 && hit_sort_scratch_bytes(so.n_hits, b->n, g->num_columns, &scratch) == KWAGE_OK
+		                 && sl->sort_scratch.reserve(scratch) == KWAGE_OK
+		                 && sort_hits_on_device(sl->stream, sl->d_hits, so.n_hits, b->n, g->num_columns, sl->sort_scratch.p, sl->sort_scratch.cap) == KWAGE_OK;
+		if(!on_device){ (void)hipGetLastError(); }      // no room for the sort's buffers beside the database: the host sorts
+		const uint64_t first = on_device ? 0 : have;
+		if(first){ memcpy(rs->hits.get(), hs + sl->head_bytes, first*sizeof(kwage_hit)); }
+		const uint64_t piece = std::min<uint64_t>(so.n_hits - first, RESULT_PIECE_HITS), piece_bytes = piece*sizeof(kwage_hit);
+		int rc2 = sl->h_stage.reserve(2*piece_bytes);      // the staged head has been consumed above
 		if(rc2){ delete rs; return rc2; }
-		hipError_t e = hipMemcpyAsync(sl->h_stage.p, sl->d_hits + have, rem_bytes, hipMemcpyDeviceToHost, sl->stream);
-		if(e == hipSuccess){ e = hipStreamSynchronize(sl->stream); }
-		if(e != hipSuccess){ delete rs; return fail(KWAGE_ERR_DEVICE, "kwage_search: copying results failed: %s", hipGetErrorString(e)); }
-		memcpy(rs->hits.data() + have, sl->h_stage.p, rem_bytes);
+		hipError_t e = hipSuccess;
+		uint64_t queued = first, landed = first;
+		int qi = 0, li = 0;
+		while(landed < so.n_hits && e == hipSuccess){
+			while(queued < so.n_hits && qi - li < 2 && e == hipSuccess){
+				const uint64_t m = std::min(piece, so.n_hits - queued);
+				e = hipMemcpyAsync((char*)sl->h_stage.p + (qi & 1)*piece_bytes, sl->d_hits + queued, m*sizeof(kwage_hit), hipMemcpyDeviceToHost, sl->stream);
+				if(e == hipSuccess){ e = hipEventRecord(sl->ev[qi & 1], sl->stream); }
+				queued += m; ++qi;
+			}
+			if(e == hipSuccess){ e = hipEventSynchronize(sl->ev[li & 1]); }
+			if(e == hipSuccess){
+				const uint64_t m = std::min(piece, so.n_hits - landed);
+				memcpy(rs->hits.get() + landed, (const char*)sl->h_stage.p + (li & 1)*piece_bytes, m*sizeof(kwage_hit));
+				landed += m; ++li;
+			}
+		}
+		if(e != hipSuccess){
+			(void)hipStreamSynchronize(sl->stream);
+			delete rs;
+			return fail(KWAGE_ERR_DEVICE, "kwage_search: copying results failed: %s", hipGetErrorString(e));
+		}
+		if(!on_device){ sort_hits(rs->hits.get(), so.n_hits); }
+		if(sl->sort_scratch.cap > SORT_SCRATCH_KEEP){ sl->sort_scratch.release(); }      // a rare giant list: give the memory back
 	}
-
-	// deterministic order; the reference's own order among ties is unspecified (sort.h:22-27)
-	sort_hits(rs->hits);
 
 	kwage_result &r = rs->pub;
 	r.n_hits = so.n_hits;
-	r.hits = rs->hits.data();
+	r.hits = rs->hits.get();
 	r.n_queries = b->n;
 	r.num_query_kmer = rs->nkmer.data();
 	r.query_threshold = rs->qthr.data();

@@ -31,7 +31,7 @@ namespace kwage {
 static constexpr int WAVE = 64;
 static constexpr int KM_THREADS = 256;               // largest k-mer workgroup; short queries use 64 or 128
 static constexpr uint32_t KM_LDS_SLOTS = 4096;      // 32 KiB of u64 slots: queries up to 2048 positions
-static constexpr uint32_t KM_CHUNK = 4096;          // positions per workgroup of a long query (16 tiles of 256)
+static constexpr uint32_t KM_CHUNK = 1024;          // positions per workgroup of a long query (4 tiles of 256)
 static constexpr uint64_t KM_EMPTY = ~0ull;         // never a canonical word: min(w, rc) < all-ones
 static constexpr int SEARCH_THREADS = 256;          // 4 waves, one tile each
 

@@ -169,23 +169,28 @@ def test_multiple_files_in_one_group(ka, ctx, oracle):
     g.close()
 
 
-def test_hit_buffer_growth(ka, ctx, oracle):
+@pytest.mark.parametrize("n_queries", [40, 93])
+def test_hit_buffer_growth(ka, ctx, oracle, n_queries, monkeypatch):
     """threshold truncating to 0 makes EVERY column match (kwage.cpp:388,497): more hits than the
-    initial device buffer holds -> the engine must grow it and still return all of them."""
+    initial device buffer holds -> the engine must grow it and still return all of them.  Lists this long are
+    sorted on the device and come back in pieces (2 and 4 of them here, the last one ragged)."""
     n_cols, L, k = 40000, 6, 31
     g = ka.Group(ctx, k, 1, L, n_cols)
     g.add_random_columns(n_cols, 7, 64)
     g.finalize()
     rng = np.random.default_rng(5)
-    seqs = [rand_seq(rng, 60) for _ in range(40)]
+    seqs = [rand_seq(rng, 60) for _ in range(n_queries)]
     b = ka.Batch(ctx, seqs)
     r = g.search(b, 0.001)
+    monkeypatch.setenv("KWAGE_HIT_SORT", "host")
+    assert np.array_equal(g.search(b, 0.001).hits, r.hits)      # the host's sort of the same list
+    monkeypatch.delenv("KWAGE_HIT_SORT")
     assert len(r.hits) == n_cols * len(seqs) and r.search_kernel_launches == 2
     assert np.array_equal(r.hits["query"], np.repeat(np.arange(len(seqs), dtype=np.uint32), n_cols))
     assert np.array_equal(r.hits["column"][:n_cols], np.arange(n_cols, dtype=np.uint32))
     # counts: against the oracle on the rows actually resident on the device
     image = g.read_rows(np.arange(1 << L))
-    for i in (0, 17, 39):
+    for i in (0, 17, n_queries - 1):
         kmers = oracle.unique_kmers(seqs[i], k)
         exp, _ = oracle.search_image(image, image.shape[1], k, 1, L, n_cols, kmers, float(np.float32(0.001)))
         got = r.hits[r.hits["query"] == i]
