@@ -473,7 +473,13 @@ void SeqFile::close()
 // records on one core).
 char *SeqFile::get_line(char *out, int len)
 {
-	if(len < 1){ return nullptr; }
+	return get_chunk(out, len) ? out : nullptr;
+}
+
+// The same, returning the number of characters stored (0: nothing left).
+int SeqFile::get_chunk(char *out, int len)
+{
+	if(len < 1){ return 0; }
 	int n = 0;
 	while(n < len - 1){
 		if(rpos == rend){
@@ -491,9 +497,8 @@ char *SeqFile::get_line(char *out, int len)
 		rpos += take;
 		if(nl){ break; }
 	}
-	if(n == 0){ return nullptr; }
 	out[n] = 0;
-	return out;
+	return n;
 }
 
 bool SeqFile::open(const std::string &path, std::string &err)
@@ -507,7 +512,18 @@ bool SeqFile::open(const std::string &path, std::string &err)
 	return true;
 }
 
-static inline bool has_eol(const char *b) { return strpbrk(b, "\n\r") != nullptr; }
+// One chunk as the reference's C-string code sees it: `len` = strlen (a chunk with an embedded NUL ends there), `eol` =
+// it holds a '\n' or '\r' (parse_sequence.cpp tests strpbrk(buffer, "\n\r")).  A '\n' can only be the chunk's last
+// character, so the common case is decided without a scan.
+struct Chunk {
+	size_t len;
+	bool eol;
+	Chunk(const char *b, int stored)
+	{
+		len = strlen(b);
+		eol = (len == (size_t)stored && len && b[len - 1] == '\n') || memchr(b, '\r', len) != nullptr;
+	}
+};
 
 // Sequence characters as the reference stores them (parse_sequence.cpp:139-146, 203-214): white space dropped, the rest
 // upper-cased -- isspace / toupper of the "C" locale (the reference never calls setlocale), as one table look-up per
@@ -524,12 +540,26 @@ struct SeqCharTable {
 };
 static const SeqCharTable g_seq_chars;
 
-static inline void append_sequence_chars(std::string &seq, const char *buffer)
+static inline void append_sequence_chars(std::string &seq, const char *buffer, size_t len)
 {
-	for(const unsigned char *p = (const unsigned char*)buffer; *p; ++p){
-		const unsigned char c = g_seq_chars.t[*p];
-		if(c){ seq.push_back((char)c); }
+	const size_t before = seq.size();
+	seq.resize(before + len);
+	char *w = &seq[before];
+	for(size_t i = 0; i < len; ++i){
+		const unsigned char c = g_seq_chars.t[(unsigned char)buffer[i]];
+		*w = (char)c;
+		w += (c != 0);
 	}
+	seq.resize((size_t)(w - seq.data()));
+}
+
+// A defline chunk without its end-of-line characters.
+static inline void append_defline_chars(std::string &info, const char *buffer, size_t len)
+{
+	size_t body = len;
+	while(body && (buffer[body - 1] == '\n' || buffer[body - 1] == '\r')){ --body; }
+	if(memchr(buffer, '\r', body) == nullptr){ info.append(buffer, body); }       // a '\n' cannot be inside
+	else{ for(size_t i = 0; i < body; ++i){ if(buffer[i] != '\r'){ info.push_back(buffer[i]); } } }
 }
 
 // Returns 1 with (curr_defline, seq) set, 0 at end of file, -1 on a malformed FASTQ record.
@@ -539,32 +569,35 @@ int SeqFile::next(std::string &err)
 	const int buffer_len = 2048;            // gzgets chunking is observable in over-long deflines
 	char buffer[buffer_len];
 	seq.clear();
+	int n;
 
 	if(type == 0){      // parse_sequence.cpp:72-151
-		std::string info;
-		while(get_line(buffer, buffer_len)){
-			if(strchr(buffer, '>') != nullptr){         // ANY line containing '>' is a defline (:86)
+		std::string &info = scratch;
+		while((n = get_chunk(buffer, buffer_len)) != 0){
+			Chunk c(buffer, n);
+			if(memchr(buffer, '>', c.len) != nullptr){         // ANY line containing '>' is a defline (:86)
 				info.clear();
-				for(char *p = buffer; *p; ++p){ if(*p != '\n' && *p != '\r'){ info.push_back(*p); } }
-				if(!has_eol(buffer)){
+				append_defline_chars(info, buffer, c.len);
+				if(!c.eol){
 					// :100-108 -- continuation chunks are appended until one holds the end of line;
 					// that last chunk is consumed but NOT appended
-					while(get_line(buffer, buffer_len) && !has_eol(buffer)){
-						for(char *p = buffer; *p; ++p){ if(*p != '\n' && *p != '\r'){ info.push_back(*p); } }
+					while((n = get_chunk(buffer, buffer_len)) != 0){
+						Chunk more(buffer, n);
+						if(more.eol){ break; }
+						append_defline_chars(info, buffer, more.len);
 					}
 				}
 				size_t s = 0;
 				while(s < info.size() && (isspace((unsigned char)info[s]) || info[s] == '>')){ ++s; }
-				info.erase(0, s);
 				if(!seq.empty()){
 					std::swap(curr_defline, next_defline);
-					next_defline = info;
+					next_defline.assign(info, s, std::string::npos);
 					return 1;
 				}
-				next_defline = info;
+				next_defline.assign(info, s, std::string::npos);
 			}
 			else{
-				append_sequence_chars(seq, buffer);
+				append_sequence_chars(seq, buffer, c.len);
 			}
 		}
 		if(!seq.empty()){
@@ -576,25 +609,28 @@ int SeqFile::next(std::string &err)
 	}
 
 	// FASTQ, parse_sequence.cpp:153-262
-	std::string info;
+	std::string &info = scratch;
+	info.clear();
 	while(true){
-		if(get_line(buffer, buffer_len) == nullptr){ close(); return 0; }
-		for(char *p = buffer; *p; ++p){ if(*p != '\n' && *p != '\r'){ info.push_back(*p); } }
-		if(has_eol(buffer)){ break; }
+		if((n = get_chunk(buffer, buffer_len)) == 0){ close(); return 0; }
+		Chunk c(buffer, n);
+		append_defline_chars(info, buffer, c.len);
+		if(c.eol){ break; }
 	}
 	size_t s = 0;
 	while(s < info.size() && (isspace((unsigned char)info[s]) || info[s] == '@')){ ++s; }
-	curr_defline = info.substr(s);
+	curr_defline.assign(info, s, std::string::npos);
 	while(true){
-		if(get_line(buffer, buffer_len) == nullptr){ err = "next_fastq: Unable to read sequence"; return -1; }
-		append_sequence_chars(seq, buffer);
-		if(has_eol(buffer)){ break; }
+		if((n = get_chunk(buffer, buffer_len)) == 0){ err = "next_fastq: Unable to read sequence"; return -1; }
+		Chunk c(buffer, n);
+		append_sequence_chars(seq, buffer, c.len);
+		if(c.eol){ break; }
 	}
-	if(get_line(buffer, buffer_len) == nullptr){ err = "next_fastq: Unable to read '+'"; return -1; }
-	if(!has_eol(buffer)){ err = "next_fastq: Error reading '+' delimiter"; return -1; }
+	if((n = get_chunk(buffer, buffer_len)) == 0){ err = "next_fastq: Unable to read '+'"; return -1; }
+	if(!Chunk(buffer, n).eol){ err = "next_fastq: Error reading '+' delimiter"; return -1; }
 	while(true){
-		if(get_line(buffer, buffer_len) == nullptr){ err = "next_fastq: Unable to read quality"; return -1; }
-		if(has_eol(buffer)){ break; }
+		if((n = get_chunk(buffer, buffer_len)) == 0){ err = "next_fastq: Unable to read quality"; return -1; }
+		if(Chunk(buffer, n).eol){ break; }
 	}
 	if(!seq.empty()){ return 1; }
 	close();           // :253-261: an empty sequence ends the iteration

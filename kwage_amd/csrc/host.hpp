@@ -77,6 +77,8 @@ struct SeqFile {
 	std::vector<char> rbuf;            // block buffer behind get_line()
 	size_t rpos = 0, rend = 0;
 	char *get_line(char *out, int len);
+	int get_chunk(char *out, int len);
+	std::string scratch;
 	SeqFile();
 	~SeqFile();
 	bool open(const std::string &path, std::string &err);

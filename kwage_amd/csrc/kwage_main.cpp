@@ -192,9 +192,11 @@ struct Findings {
 	map<size_t, string> defline;            // file queries only, and only those with a hit (kwage.cpp:137-143)
 	void absorb(Findings &other)
 	{
+		if(by_query.empty() && defline.empty()){ by_query.swap(other.by_query); defline.swap(other.defline); return; }
 		for(auto &kv : other.by_query){
 			vector<Match> &dst = by_query[kv.first];
-			dst.insert(dst.end(), kv.second.begin(), kv.second.end());
+			if(dst.empty()){ dst.swap(kv.second); }
+			else{ dst.insert(dst.end(), kv.second.begin(), kv.second.end()); }
 		}
 		for(auto &kv : other.defline){ defline.emplace(kv.first, std::move(kv.second)); }
 	}
@@ -251,6 +253,7 @@ struct FileQueries : QuerySource {
 	bool fill(QueryBatch &b, uint64_t max_bases) override
 	{
 		b.clear();
+		if(max_bases <= (256ull << 20)){ b.bases.reserve(max_bases); }      // address space only until written: no regrowth copies
 		string err;
 		while(b.size() < MAX_QUERIES_PER_BATCH){
 			if(!held){
@@ -343,6 +346,29 @@ void addressed_rows(kwage_ctx *ctx, const kwage_params &p, const QueryBatch &q, 
 	rows.erase(unique(rows.begin(), rows.end()), rows.end());
 }
 
+// The hits of one collected batch, translated to (file, column within the file) and filed under their query's id.
+void record_hits(const kwage_result &res, const QueryBatch &q, const ColumnMap &cols, Findings &found)
+{
+	// the list is sorted by (query, column): one look-up per query, and ids mostly arrive in increasing order
+	for(uint64_t i = 0; i < res.n_hits; ){
+		const uint32_t qi = res.hits[i].query;
+		uint64_t j = i;
+		while(j < res.n_hits && res.hits[j].query == qi){ ++j; }
+		const size_t id = q.ids[qi];
+		vector<Match> &dst = found.by_query.try_emplace(found.by_query.end(), id)->second;
+		if(!q.deflines.empty()){ found.defline.try_emplace(found.defline.end(), id, q.deflines[qi]); }
+		dst.reserve(dst.size() + (size_t)(j - i));
+		for(; i < j; ++i){
+			const kwage_hit &h = res.hits[i];
+			Match m;
+			m.num_kmers_found = h.num_match;
+			m.num_query_kmer = res.num_query_kmer[qi];
+			cols.locate(h.column, m.file_index, m.column);
+			dst.push_back(m);
+		}
+	}
+}
+
 // Stream one query source through one loaded group.  Two batches are in flight: batch i+1 is parsed and
 // submitted while the device works on batch i, then batch i is collected and its hits mapped.
 void search_stream(kwage_ctx *ctx, kwage_group *grp, const ColumnMap &cols, QuerySource &source, float threshold,
@@ -363,16 +389,7 @@ void search_stream(kwage_ctx *ctx, kwage_group *grp, const ColumnMap &cols, Quer
 		const int rc = kwage_search_collect(f.pending, &res);
 		f.pending = nullptr;
 		if(rc != KWAGE_OK){ drop(f); check(rc); }
-		for(uint64_t i = 0; i < res->n_hits; ++i){
-			const kwage_hit &h = res->hits[i];
-			Match m;
-			m.num_kmers_found = h.num_match;
-			m.num_query_kmer = res->num_query_kmer[h.query];
-			cols.locate(h.column, m.file_index, m.column);
-			const size_t id = f.q.ids[h.query];
-			found.by_query[id].push_back(m);
-			if(!f.q.deflines.empty()){ found.defline.emplace(id, f.q.deflines[h.query]); }
-		}
+		record_hits(*res, f.q, cols, found);
 		kwage_result_free(res);
 		drop(f);
 	};
@@ -398,43 +415,107 @@ void search_stream(kwage_ctx *ctx, kwage_group *grp, const ColumnMap &cols, Quer
 // =====================================================================================================
 // report (bytes as the reference's output.h:35-112 writes them; the text is data, the printer generic)
 // =====================================================================================================
-string number(const char *fmt, double v)
-{
-	char buf[64];
-	snprintf(buf, sizeof(buf), fmt, v);
-	return buf;
-}
+// With the search down to milliseconds the report is most of a hit-heavy run (2 M hits: 0.74 s CSV / 1.7 s JSON of a
+// 1.8 / 2.7 s run through iostream formatting, tools/e2e_many_reads.py), so it is assembled in a memory buffer that
+// goes to the stream a MiB at a time, numbers are formatted by hand, and the two things that repeat -- a column's
+// metadata text (a popular sample is in many queries' lists) and the percentage of a (k-mers, found) pair -- are
+// made once.
+struct TextSink {
+	ostream &out;
+	string buf;
+	explicit TextSink(ostream &o) : out(o) { buf.reserve((1u << 20) + (64u << 10)); }
+	void put(char c) { buf.push_back(c); }
+	void put(const char *s, size_t n) { buf.append(s, n); }
+	void put(const char *s) { buf.append(s); }
+	void put(const string &s) { buf.append(s); }
+	void put(uint64_t v)
+	{
+		char tmp[24];
+		char *e = tmp + sizeof(tmp), *p = e;
+		do{ *--p = (char)('0' + v % 10); v /= 10; } while(v);
+		buf.append(p, (size_t)(e - p));
+	}
+	void drain() { if(buf.size() >= (1u << 20)){ flush(); } }
+	void flush() { out.write(buf.data(), (streamsize)buf.size()); buf.clear(); }
+};
+
+// The text of percent_kmers_found, remembered per (k-mers, found) pair in a small direct-mapped table.
+//   CSV:  float arithmetic and the stream's default float format, 6 significant digits (output.h:43-51)
+//   JSON: double arithmetic with a float reciprocal, fixed with one decimal -- the reference's stream flags stay
+//         set after the threshold (output.h:82-90)
+struct PercentText {
+	struct Entry { uint64_t key = ~0ull; char text[24]; uint8_t len = 0; };
+	vector<Entry> table;
+	bool json;
+	explicit PercentText(bool j) : table(4096), json(j) {}
+	void put(TextSink &to, const Match &m)
+	{
+		const uint64_t key = ((uint64_t)m.num_query_kmer << 32) | m.num_kmers_found;
+		Entry &e = table[(key*0x9E3779B97F4A7C15ull) >> 52];
+		if(e.key != key){
+			const float norm = m.num_query_kmer ? 1.0f/m.num_query_kmer : 0.0f;
+			const int n = json ? snprintf(e.text, sizeof(e.text), "%.1f", (100.0*m.num_kmers_found)*norm)
+			                   : snprintf(e.text, sizeof(e.text), "%.6g", (double)((100.0f*m.num_kmers_found)*norm));
+			e.len = (uint8_t)min<int>(n, (int)sizeof(e.text) - 1);
+			e.key = key;
+		}
+		to.put(e.text, e.len);
+	}
+};
+
+// A column's metadata as the report prints it, formatted the first time the column has a hit.
+struct MetadataText {
+	const vector<DbInfo> &infos;
+	vector<vector<string> > text;           // [file][column]
+	vector<vector<char> > made;
+	explicit MetadataText(const vector<DbInfo> &i) : infos(i), text(i.size()), made(i.size()) {}
+	virtual ~MetadataText() {}
+	virtual string format(const FilterInfo &fi) const = 0;
+	const string &of(const Match &m)
+	{
+		if(text[m.file_index].empty()){
+			text[m.file_index].resize(infos[m.file_index].header.num_filter);
+			made[m.file_index].assign(infos[m.file_index].header.num_filter, 0);
+		}
+		if(m.column >= made[m.file_index].size()){ throw "binary_read<FilterInfo>: Unable to read FilterInfo"; }
+		if(!made[m.file_index][m.column]){
+			FilterInfo fi;
+			if(!infos[m.file_index].info(m.column, fi)){ throw "binary_read<FilterInfo>: Unable to read FilterInfo"; }
+			text[m.file_index][m.column] = format(fi);
+			made[m.file_index][m.column] = 1;
+		}
+		return text[m.file_index][m.column];
+	}
+};
 
 struct Report {
 	virtual ~Report() {}
 	virtual void begin(size_t queries_with_hits) = 0;
-	virtual void query(const string &name, const vector<Match> &ms, const vector<DbInfo> &infos) = 0;
+	virtual void query(const string &name, const vector<Match> &ms) = 0;
 	virtual void end() = 0;
 };
 
-FilterInfo metadata_of(const Match &m, const vector<DbInfo> &infos)
-{
-	FilterInfo fi;
-	if(!infos[m.file_index].info(m.column, fi)){ throw "binary_read<FilterInfo>: Unable to read FilterInfo"; }
-	return fi;
-}
-
 struct CsvReport : Report {
-	ostream &out;
-	explicit CsvReport(ostream &o) : out(o) {}
-	void begin(size_t) override { out << "query,num_kmers,num_kmers_found,percent_kmers_found,sample_metadata\n"; }
-	void query(const string &name, const vector<Match> &ms, const vector<DbInfo> &infos) override
+	TextSink to;
+	PercentText percent;
+	struct Accession : MetadataText {
+		using MetadataText::MetadataText;
+		string format(const FilterInfo &fi) const override { return fi.csv_string(); }
+	} metadata;
+	CsvReport(ostream &o, const vector<DbInfo> &infos) : to(o), percent(false), metadata(infos) {}
+	void begin(size_t) override { to.put("query,num_kmers,num_kmers_found,percent_kmers_found,sample_metadata\n"); }
+	void query(const string &name, const vector<Match> &ms) override
 	{
 		for(const Match &m : ms){
-			// float arithmetic and the stream's default float format (6 significant digits), output.h:43-51
-			const float norm = m.num_query_kmer ? 1.0f/m.num_query_kmer : 0.0f;
-			const float percent = (100.0f*m.num_kmers_found)*norm;
-			out << '"' << name << "\"," << m.num_query_kmer << ',' << m.num_kmers_found << ',' << number("%.6g", percent)
-			    << ",\"" << metadata_of(m, infos).csv_string() << "\"\n";
+			to.put('"'); to.put(name); to.put("\",", 2);
+			to.put((uint64_t)m.num_query_kmer); to.put(',');
+			to.put((uint64_t)m.num_kmers_found); to.put(',');
+			percent.put(to, m);
+			to.put(",\"", 2); to.put(metadata.of(m)); to.put("\"\n", 2);
+			to.drain();
 		}
-		out.flush();
 	}
-	void end() override {}
+	void end() override { to.flush(); to.out.flush(); }
 };
 
 // A pretty printer with ONE layout rule for objects and arrays: every member starts on a new line, one tab
@@ -442,61 +523,75 @@ struct CsvReport : Report {
 // container's depth; an empty array closes at once.  The reference's hand-written JSON follows this rule
 // throughout, including its habit of starting the document with a newline.
 struct JsonPrinter {
-	ostream &out;
+	TextSink &to;
 	struct Level { size_t members; };
 	vector<Level> stack;
 	int base_depth;                 // -1: the top-level list is not wrapped in [ ]
-	JsonPrinter(ostream &o, bool wrapped) : out(o), base_depth(wrapped ? 0 : -1)
+	string tabs;                    // enough of them for any depth used here
+	JsonPrinter(TextSink &t, bool wrapped) : to(t), base_depth(wrapped ? 0 : -1), tabs(16, '\t')
 	{
 		stack.push_back(Level{0});
-		if(wrapped){ out << '['; }
+		if(wrapped){ to.put('['); }
 	}
-	string indent(int extra = 0) const { const int d = base_depth + (int)stack.size() - 1 + extra; return string(d > 0 ? (size_t)d : 0, '\t'); }
+	size_t depth(int extra = 0) const { const int d = base_depth + (int)stack.size() - 1 + extra; return d > 0 ? (size_t)d : 0; }
+	string indent(int extra = 0) const { return string(depth(extra), '\t'); }
 	void member()
 	{
-		out << (stack.back().members++ ? "," : "") << '\n' << indent(1);
+		if(stack.back().members++){ to.put(','); }
+		to.put('\n'); to.put(tabs.data(), depth(1));
 	}
-	void key(const char *name) { member(); out << '"' << name << "\": "; }
-	void open(char bracket) { out << bracket; stack.push_back(Level{0}); }
+	void key(const char *name) { member(); to.put('"'); to.put(name); to.put("\": ", 3); }
+	void open(char bracket) { to.put(bracket); stack.push_back(Level{0}); }
 	void close(char bracket, bool own_line_even_if_empty)
 	{
 		const bool any = stack.back().members != 0;
 		stack.pop_back();
-		if(any || own_line_even_if_empty){ out << '\n' << indent(1); }
-		out << bracket;
+		if(any || own_line_even_if_empty){ to.put('\n'); to.put(tabs.data(), depth(1)); }
+		to.put(bracket);
 	}
-	void finish() { if(base_depth == 0){ out << "\n]\n"; } }
+	void finish() { if(base_depth == 0){ to.put("\n]\n"); } }
 };
 
 struct JsonReport : Report {
-	ostream &out;
-	float threshold;
+	TextSink to;
+	PercentText percent;
+	string threshold_text;
 	unique_ptr<JsonPrinter> js;
-	JsonReport(ostream &o, float t) : out(o), threshold(t) {}
-	void begin(size_t queries_with_hits) override { js.reset(new JsonPrinter(out, queries_with_hits > 1)); }     // [ ] only around several
-	void query(const string &name, const vector<Match> &ms, const vector<DbInfo> &infos) override
+	// the whole "{ ... }" value of sample_metadata at the depth every result's members have (it is the same for all)
+	struct Block : MetadataText {
+		string inner_indent, closing_indent;
+		using MetadataText::MetadataText;
+		string format(const FilterInfo &fi) const override { return "{\n" + fi.json_string(inner_indent) + '\n' + closing_indent + '}'; }
+	} metadata;
+	JsonReport(ostream &o, float t, const vector<DbInfo> &infos) : to(o), percent(true), metadata(infos)
+	{
+		char buf[64];
+		snprintf(buf, sizeof(buf), "%.1f", t);              // fixed, one decimal (output.h:73-75)
+		threshold_text = buf;
+	}
+	void begin(size_t queries_with_hits) override { js.reset(new JsonPrinter(to, queries_with_hits > 1)); }     // [ ] only around several
+	void query(const string &name, const vector<Match> &ms) override
 	{
 		JsonPrinter &j = *js;
 		j.member(); j.open('{');
-		j.key("query"); out << '"' << name << '"';
-		j.key("threshold"); out << number("%.1f", threshold);                     // fixed, one decimal (output.h:73-75)
+		j.key("query"); to.put('"'); to.put(name); to.put('"');
+		j.key("threshold"); to.put(threshold_text);
 		j.key("results"); j.open('[');
 		for(const Match &m : ms){
-			// double arithmetic with a float reciprocal, printed fixed with one decimal (the reference's stream
-			// flags stay set after the threshold), output.h:82-90
-			const float norm = m.num_query_kmer ? 1.0f/m.num_query_kmer : 0.0f;
-			const double percent = (100.0*m.num_kmers_found)*norm;
 			j.member(); j.open('{');
-			j.key("percent_kmers_found"); out << number("%.1f", percent);
-			j.key("num_kmers"); out << m.num_query_kmer;
-			j.key("num_kmers_found"); out << m.num_kmers_found;
-			j.key("sample_metadata"); out << "{\n" << metadata_of(m, infos).json_string(j.indent(2)) << '\n' << j.indent(1) << '}';
+			j.key("percent_kmers_found"); percent.put(to, m);
+			j.key("num_kmers"); to.put((uint64_t)m.num_query_kmer);
+			j.key("num_kmers_found"); to.put((uint64_t)m.num_kmers_found);
+			j.key("sample_metadata");
+			if(metadata.inner_indent.empty()){ metadata.inner_indent = j.indent(2); metadata.closing_indent = j.indent(1); }
+			to.put(metadata.of(m));
 			j.close('}', true);
+			to.drain();
 		}
 		j.close(']', false);
 		j.close('}', true);
 	}
-	void end() override { if(js){ js->finish(); } }
+	void end() override { if(js){ js->finish(); } to.flush(); to.out.flush(); }
 };
 
 double now_s() { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -544,6 +639,7 @@ int main(int argc, char *argv[])
 	setenv("GPU_MAX_HW_QUEUES", "8", 0);
 	try{
 		const time_t started = time(nullptr);
+		const double t_main = now_s();
 
 		Cli cli;
 		vector<string> db_paths;
@@ -620,13 +716,14 @@ int main(int argc, char *argv[])
 		mutex merge_lock;
 		vector<string> worker_error(ndev);
 		const double t_start = now_s();
+		if(env_u64("KWAGE_VERBOSE", 0)){ cerr << "[kwage] command line, headers and metadata of " << files.size() << " files, query preview: " << (t_start - t_main) << " s" << endl; }
 
 		auto worker = [&](size_t di) {
 			try{
 				kwage_ctx *ctx = nullptr;
 				check(kwage_init(devices[di], &ctx));
 				if(verbose){ lock_guard<mutex> lk(merge_lock); cerr << "[kwage] device " << devices[di] << " ready: " << rss_mb() << endl; }
-				double t_load = 0, t_search = 0, gb_loaded = 0;
+				double t_load = 0, t_search = 0, t_free = 0, gb_loaded = 0;
 				const double t_init = now_s() - t_start;
 				Findings local_cmdline, local_files;
 				for(const auto &grp_entry : groups){
@@ -716,15 +813,19 @@ int main(int argc, char *argv[])
 							t_search += now_s() - t0;
 						}
 						catch(...){ kwage_group_destroy(grp); throw; }
+						t0 = now_s();
 						kwage_group_destroy(grp);
+						t_free += now_s() - t0;
 						m0 = m1;
 					}
 				}
+				const double t_down = now_s();
 				kwage_shutdown(ctx);
 				lock_guard<mutex> lk(merge_lock);        // as the reference's `omp critical` section, kwage.cpp:154-177
 				if(verbose){
 					cerr << "[kwage] device " << devices[di] << ": init " << t_init << " s, loaded " << gb_loaded << " GB in " << t_load
-						<< " s (" << (t_load > 0 ? gb_loaded/t_load : 0) << " GB/s), search " << t_search << " s; " << rss_mb() << endl;
+						<< " s (" << (t_load > 0 ? gb_loaded/t_load : 0) << " GB/s), search " << t_search << " s, freeing groups " << t_free
+						<< " s, shutdown " << (now_s() - t_down) << " s; " << rss_mb() << endl;
 				}
 				from_command_line.absorb(local_cmdline);
 				from_files.absorb(local_files);
@@ -747,6 +848,7 @@ int main(int argc, char *argv[])
 			}
 		}
 
+		const double t_searched = now_s();
 		// ---- order: each query's hits as the single-threaded reference collects them (file order, then
 		// column), then its unstable descending sort by hits (kwage.cpp:191-201) -------------------------------
 		for(Findings *f : {&from_command_line, &from_files}){
@@ -758,17 +860,22 @@ int main(int argc, char *argv[])
 			}
 		}
 
+		const double t_ordered = now_s();
 		unique_ptr<Report> report;
-		if(cli.format == Cli::CSV){ report.reset(new CsvReport(out)); }
-		else{ report.reset(new JsonReport(out, cli.threshold)); }
+		if(cli.format == Cli::CSV){ report.reset(new CsvReport(out, infos)); }
+		else{ report.reset(new JsonReport(out, cli.threshold, infos)); }
 		report->begin(from_command_line.by_query.size() + from_files.by_query.size());
 		for(const auto &kv : from_command_line.by_query){                       // command-line queries first, by position
-			report->query("command line seq " + to_string(kv.first), kv.second, infos);     // kwage.cpp:237-240
+			report->query("command line seq " + to_string(kv.first), kv.second);     // kwage.cpp:237-240
 		}
 		for(const auto &kv : from_files.by_query){                              // then file queries by global id
-			report->query(from_files.defline[kv.first], kv.second, infos);
+			report->query(from_files.defline[kv.first], kv.second);
 		}
 		report->end();
+		if(verbose){
+			cerr << "[kwage] workers done " << (t_searched - t_main) << " s after the start of main; hits ordered in " << (t_ordered - t_searched)
+			     << " s, report written in " << (now_s() - t_ordered) << " s; " << rss_mb() << endl;
+		}
 
 		cerr << "Search complete in " << (time(nullptr) - started) << " sec" << endl;
 	}
