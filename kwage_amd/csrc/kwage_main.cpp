@@ -23,11 +23,13 @@
 //   KWAGE_VERBOSE     1 = per-stage wall times on stderr
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
 #include <deque>
+#include <exception>
 #include <fstream>
 #include <iostream>
 #include <map>
@@ -275,6 +277,60 @@ struct FileQueries : QuerySource {
 			held = false;
 		}
 		return b.size() != 0;
+	}
+};
+
+// Batches of another source, parsed ahead on a thread of their own: reading starts when this object is made -- before
+// the group's files are loaded -- and runs beside the loading, the device's work and the filing of hits; inflating a
+// .gz query file is the slowest stage of many runs.  At most `depth` finished batches wait.
+struct PrefetchedQueries : QuerySource {
+	QuerySource &inner;
+	const uint64_t max_bases;
+	const size_t depth;
+	mutex lock;
+	condition_variable changed;
+	deque<QueryBatch> ready;
+	bool finished = false, cancelled = false;
+	exception_ptr failure;
+	thread reader;
+	PrefetchedQueries(QuerySource &source, uint64_t batch_bases, size_t queue_depth = 2)
+		: inner(source), max_bases(batch_bases), depth(queue_depth), reader([this] { read_ahead(); }) {}
+	~PrefetchedQueries() override
+	{
+		{ lock_guard<mutex> lk(lock); cancelled = true; }
+		changed.notify_all();
+		reader.join();
+	}
+	void read_ahead()
+	{
+		try{
+			for(;;){
+				QueryBatch b;
+				if(!inner.fill(b, max_bases)){ break; }
+				unique_lock<mutex> lk(lock);
+				changed.wait(lk, [this] { return cancelled || ready.size() < depth; });
+				if(cancelled){ return; }
+				ready.push_back(std::move(b));
+				changed.notify_all();
+			}
+		}
+		catch(...){ failure = current_exception(); }
+		lock_guard<mutex> lk(lock);
+		finished = true;
+		changed.notify_all();
+	}
+	bool fill(QueryBatch &b, uint64_t) override          // the batch size was fixed when reading began
+	{
+		unique_lock<mutex> lk(lock);
+		changed.wait(lk, [this] { return finished || !ready.empty(); });
+		if(ready.empty()){
+			if(failure){ exception_ptr f = failure; failure = nullptr; rethrow_exception(f); }
+			return false;
+		}
+		b = std::move(ready.front());
+		ready.pop_front();
+		changed.notify_all();
+		return true;
 	}
 };
 
@@ -771,6 +827,13 @@ int main(int argc, char *argv[])
 							span_bytes = next;
 							++m1;
 						}
+						// the query files of this pass are read ahead from now on, beside the loading
+						unique_ptr<FileQueries> disk_source;
+						unique_ptr<PrefetchedQueries> disk_ahead;
+						if(!small_set && !cli.query_files.empty()){
+							disk_source.reset(new FileQueries(cli.query_files));
+							disk_ahead.reset(new PrefetchedQueries(*disk_source, max_batch_bases));
+						}
 						kwage_group *grp = nullptr;
 						double t0 = now_s();
 						if(sparse){ check(kwage_group_create_sparse(ctx, &p, span_bytes*8, sparse_rows.data(), sparse_rows.size(), &grp)); }
@@ -807,8 +870,7 @@ int main(int argc, char *argv[])
 							else{
 								CommandLineQueries typed(cli.query_seqs);
 								search_stream(ctx, grp, cols, typed, cli.threshold, flags, max_batch_bases, local_cmdline);
-								FileQueries from_disk(cli.query_files);
-								search_stream(ctx, grp, cols, from_disk, cli.threshold, flags, max_batch_bases, local_files);
+								if(disk_ahead){ search_stream(ctx, grp, cols, *disk_ahead, cli.threshold, flags, max_batch_bases, local_files); }
 							}
 							t_search += now_s() - t0;
 						}
