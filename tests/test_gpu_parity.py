@@ -199,6 +199,29 @@ def test_hit_buffer_growth(ka, ctx, oracle, n_queries, monkeypatch):
     g.close()
 
 
+@pytest.mark.parametrize("n_cols,n_queries", [(1, 12000), (3, 5000), (9, 1500), (8193, 2), (8193, 33), (100000, 1), (100001, 17), (70000, 300)])
+def test_device_hit_sort_key_widths(ka, ctx, n_cols, n_queries, monkeypatch):
+    """The device sort packs (query, column) into query_bits + column_bits of one key: widths from 0 bits (one
+    query, one column) up, every list longer than the 8192 records that come back with the counters.  At a threshold
+    that truncates to 0 every column matches every query with at least one k-mer, so the sorted list is known in
+    closed form; the counts are compared with the host-sorted run of the same search."""
+    g = ka.Group(ctx, 31, 1, 6, n_cols)
+    g.add_random_columns(n_cols, 11, 128)
+    g.finalize()
+    rng = np.random.default_rng(n_cols + n_queries)
+    seqs = [rand_seq(rng, 31 + int(rng.integers(0, 30))) if i % 7 != 3 else "ACGT" for i in range(n_queries)]     # some without a k-mer
+    b = ka.Batch(ctx, seqs)
+    r = g.search(b, 0.0001)
+    live = np.array([i for i, s in enumerate(seqs) if len(s) >= 31], dtype=np.uint32)
+    assert len(r.hits) == len(live) * n_cols > 8192
+    assert np.array_equal(r.hits["query"], np.repeat(live, n_cols))
+    assert np.array_equal(r.hits["column"], np.tile(np.arange(n_cols, dtype=np.uint32), len(live)))
+    monkeypatch.setenv("KWAGE_HIT_SORT", "host")
+    assert np.array_equal(g.search(b, 0.0001).hits, r.hits)
+    b.close()
+    g.close()
+
+
 def test_errors_are_reported_not_swallowed(ka, ctx):
     with pytest.raises(ka.KwageError):
         ka.Group(ctx, 33, 1, 10, 8)                    # k > MAX_WORD_LEN
