@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Whole synchronous search step (raw C-ABI call) against its two device stages for query shapes other than the
-bench's: where is time spent outside the gather kernel?   python tools/step_breakdown.py"""
+bench's: where is time spent outside the gather kernel?   python tools/step_breakdown.py [substring of a shape's name]"""
 import ctypes as C
 import os
 import sys
@@ -18,7 +18,10 @@ base = synth.Workload("shape", 100_000, 20, 31, 1, 1, 1, 1.0, num_genomes=8, gen
 shapes = [("1000 x 1 kb", 1000, 1000), ("100k x 150 bp", 100_000, 150), ("1M x 50 bp", 1_000_000, 50), ("1 x 10 kb", 1, 10_000),
           ("10 x 100 kb", 10, 100_000), ("20k x 40 bp (k+9)", 20_000, 40), ("200 x 5 kb", 200, 5000)]
 from dataclasses import replace
+only = sys.argv[1] if len(sys.argv) > 1 else ""
 for name, nq, qlen in shapes:
+    if only not in name:
+        continue
     w = replace(base, num_queries=nq, query_len=qlen)
     s = synth.build(ctx, w)
     for thr_v, ee in ((1.0, 0), (1.0, ka.SEARCH_EARLY_EXIT), (0.8, 0), (0.0001, 0)):
