@@ -3,10 +3,11 @@
 // options, same `.db` files, same CSV / JSON output.  The structure is this repo's own:
 //
 //   reference:  for each .db file: for each query: search()  -- seek+read one slice per (k-mer, hash)
-//   here:       for each parameter group: load all its files' columns into one HBM matrix, then STREAM the
-//               queries through it in batches (kwage_search_submit / _collect, two in flight): while the GPU
-//               searches batch i the host parses batch i+1.  Host memory is O(batch + hits), as in the
-//               reference (one record at a time, kwage.cpp:129-148), never O(query set).
+//   here:       for each parameter group: load all its files' columns into one HBM matrix; as many groups as fit
+//               the device are resident together (a pass); then STREAM the queries through the pass in batches
+//               (kwage_search_submit / _collect, two in flight): a reader thread parses ahead, each batch is
+//               uploaded once and searched against every resident matrix.  Host memory is O(batch + hits), as
+//               in the reference (one record at a time, kwage.cpp:129-148), never O(query set).
 //
 // Results are order-independent, so the loop inversion is invisible in the output.
 // Extra knobs are environment variables only, to keep the option surface verbatim:
@@ -14,8 +15,10 @@
 //   KWAGE_DEVICES     "all" or "0,1,...": shard the database files over several GPUs
 //   KWAGE_EARLY_EXIT  1 = enable the reference's early-exit shortcut on the device (default 1)
 //   KWAGE_BATCH_BASES max bases per query batch (default 64 Mi)
-//   KWAGE_MAX_GROUP_BYTES  cap on the HBM bit matrix of one pass (default: 7/8 of the free device memory);
-//                     larger parameter groups are searched in several passes over whole files
+//   KWAGE_MAX_GROUP_BYTES  cap on the HBM bit matrices of one pass (default: 7/8 of the free device memory): the
+//                     parameter groups (filter sizes) that fit together are resident together and the query files
+//                     are read once per pass; a larger database takes several passes over whole files
+//   KWAGE_ONE_UNIT_PER_PASS  1 = one parameter group per pass (measurement: the schedule of earlier versions)
 //   KWAGE_SPARSE      how a SMALL query set (everything fits one batch of KWAGE_SPARSE_BASES, default 4 Mi bases) is
 //                     searched: "auto" (default) loads only the slices the queries address when they address at most
 //                     1/8 of a group's rows -- I/O proportional to the queries, like the reference's seek + read per
@@ -425,45 +428,70 @@ void record_hits(const kwage_result &res, const QueryBatch &q, const ColumnMap &
 	}
 }
 
-// Stream one query source through one loaded group.  Two batches are in flight: batch i+1 is parsed and
-// submitted while the device works on batch i, then batch i is collected and its hits mapped.
-void search_stream(kwage_ctx *ctx, kwage_group *grp, const ColumnMap &cols, QuerySource &source, float threshold,
+// One resident matrix: a span of whole files with equal parameters.
+struct ResidentUnit {
+	kwage_group *group = nullptr;
+	uint32_t kmer_len = 0;
+	ColumnMap cols;
+};
+
+// Stream one query source through every resident unit: each batch is uploaded once (once per distinct k-mer length:
+// the device-side position tables of a batch depend on it) and searched against one unit after the other.  Two
+// searches are in flight: the next one is submitted -- and the next batch parsed -- while the device works, then the
+// older one is collected and its hits filed.
+void search_stream(kwage_ctx *ctx, const vector<ResidentUnit> &units, QuerySource &source, float threshold,
                    uint32_t flags, uint64_t max_batch_bases, Findings &found)
 {
-	struct InFlight {
+	struct Uploaded {               // one query batch on the device, shared by its searches
 		QueryBatch q;
-		kwage_batch *batch = nullptr;
+		map<uint32_t, kwage_batch*> by_k;
+		~Uploaded() { for(auto &kv : by_k){ if(kv.second){ kwage_batch_destroy(kv.second); } } }
+	};
+	struct InFlight {
+		shared_ptr<Uploaded> batch;
+		const ResidentUnit *unit = nullptr;
 		kwage_pending *pending = nullptr;
 	};
-	InFlight slot[2];
-	auto drop = [](InFlight &f) {
-		if(f.pending){ kwage_result *r = nullptr; if(kwage_search_collect(f.pending, &r) == KWAGE_OK){ kwage_result_free(r); } f.pending = nullptr; }
-		if(f.batch){ kwage_batch_destroy(f.batch); f.batch = nullptr; }
+	deque<InFlight> flying;
+	auto abandon = [&]() {
+		for(InFlight &f : flying){
+			kwage_result *r = nullptr;
+			if(f.pending && kwage_search_collect(f.pending, &r) == KWAGE_OK){ kwage_result_free(r); }
+		}
+		flying.clear();
 	};
-	auto finish = [&](InFlight &f) {
+	auto finish_oldest = [&]() {
+		InFlight f = flying.front();
+		flying.pop_front();
 		kwage_result *res = nullptr;
-		const int rc = kwage_search_collect(f.pending, &res);
-		f.pending = nullptr;
-		if(rc != KWAGE_OK){ drop(f); check(rc); }
-		record_hits(*res, f.q, cols, found);
+		check(kwage_search_collect(f.pending, &res));
+		record_hits(*res, f.batch->q, f.unit->cols, found);
 		kwage_result_free(res);
-		drop(f);
 	};
 	try{
-		int cur = 0;
-		while(source.fill(slot[cur].q, max_batch_bases)){
-			InFlight &f = slot[cur];
-			check(kwage_batch_create(ctx, f.q.bases.data(), f.q.offsets.data(), (uint32_t)f.q.size(), &f.batch));
-			check(kwage_search_submit(grp, f.batch, threshold, flags, &f.pending));
-			f.q.bases = string();                                  // resident on the device now
-			if(slot[cur ^ 1].pending){ finish(slot[cur ^ 1]); }
-			cur ^= 1;
+		QueryBatch next;
+		while(source.fill(next, max_batch_bases)){
+			shared_ptr<Uploaded> up = make_shared<Uploaded>();
+			up->q = std::move(next);
+			for(const ResidentUnit &u : units){
+				kwage_batch *&kb = up->by_k[u.kmer_len];
+				if(!kb){ check(kwage_batch_create(ctx, up->q.bases.data(), up->q.offsets.data(), (uint32_t)up->q.size(), &kb)); }
+			}
+			up->q.bases = string();                                // resident on the device now
+			for(const ResidentUnit &u : units){
+				if(flying.size() == 2){ finish_oldest(); }
+				InFlight f;
+				f.batch = up;
+				f.unit = &u;
+				check(kwage_search_submit(u.group, up->by_k[u.kmer_len], threshold, flags, &f.pending));
+				flying.push_back(f);
+			}
+			next = QueryBatch();
 		}
-		if(slot[cur ^ 1].pending){ finish(slot[cur ^ 1]); }
+		while(!flying.empty()){ finish_oldest(); }
 	}
 	catch(...){
-		drop(slot[0]);
-		drop(slot[1]);
+		abandon();
 		throw;
 	}
 }
@@ -782,6 +810,26 @@ int main(int argc, char *argv[])
 				double t_load = 0, t_search = 0, t_free = 0, gb_loaded = 0;
 				const double t_init = now_s() - t_start;
 				Findings local_cmdline, local_files;
+				// ---- plan: this device's files, cut into units (spans of whole files with equal parameters, one resident
+				// matrix each) and the units packed into passes that fit the HBM that is free.  The queries are streamed
+				// once per PASS, against every unit of it: a database whose filter sizes differ (several parameter groups)
+				// but which fits the device is searched with a single reading of the query files.  A group larger than a
+				// pass is continued in the next one (results are additive).
+				struct UnitPlan {
+					kwage_params p;
+					vector<uint32_t> members;           // indices into files[]
+					uint64_t span_bytes = 0, nrows = 0;
+					shared_ptr<vector<uint32_t> > sparse_rows;       // null: all slices
+				};
+				vector<vector<UnitPlan> > passes(1);
+				uint64_t budget = max_group_bytes;       // per pass
+				if(budget == 0){
+					uint64_t free_b = 0, total_b = 0;
+					check(kwage_mem_info(ctx, &free_b, &total_b));
+					budget = free_b - free_b/8;              // leave room for staging buffers, row indices, hits
+				}
+				uint64_t pass_left = budget;
+				const bool one_unit_per_pass = env_u64("KWAGE_ONE_UNIT_PER_PASS", 0) != 0;      // measurement hook: the schedule before units shared passes
 				for(const auto &grp_entry : groups){
 					// this device's share: a file belongs to the device that owns its middle column
 					uint64_t total = 0;
@@ -800,85 +848,108 @@ int main(int argc, char *argv[])
 					p.num_hash = grp_entry.first.num_hash;
 					p.log_2_filter_len = grp_entry.first.log_2_filter_len;
 					p.hash_func = grp_entry.first.hash_func;
-					// A group larger than the HBM that is free is searched in several passes over sub-groups of
-					// whole files (the queries are streamed again per pass; results are additive).
-					uint64_t budget = max_group_bytes;
-					if(budget == 0){
-						uint64_t free_b = 0, total_b = 0;
-						check(kwage_mem_info(ctx, &free_b, &total_b));
-						budget = free_b - free_b/8;          // leave room for staging buffers, row indices, hits
-					}
 					// Sparse path: only the slices the (small) query set addresses are fetched and kept resident.
-					vector<uint32_t> sparse_rows;
-					bool sparse = false;
+					shared_ptr<vector<uint32_t> > sparse_rows;
 					if(small_set && sparse_mode != "0"){
-						addressed_rows(ctx, p, typed_all, sparse_rows);
-						addressed_rows(ctx, p, disk_all, sparse_rows);
-						sparse = (sparse_mode == "1") || (uint64_t)sparse_rows.size()*8 <= (1ull << p.log_2_filter_len);
-						if(sparse && sparse_rows.empty()){ continue; }          // no valid k-mer in any query: nothing can match (kwage.cpp:369-371)
+						vector<uint32_t> rows;
+						addressed_rows(ctx, p, typed_all, rows);
+						addressed_rows(ctx, p, disk_all, rows);
+						if((sparse_mode == "1") || (uint64_t)rows.size()*8 <= (1ull << p.log_2_filter_len)){
+							if(rows.empty()){ continue; }          // no valid k-mer in any query: nothing can match (kwage.cpp:369-371)
+							sparse_rows = make_shared<vector<uint32_t> >(std::move(rows));
+						}
 					}
-					const uint64_t nrows = sparse ? sparse_rows.size() : (1ull << p.log_2_filter_len);
+					const uint64_t nrows = sparse_rows ? sparse_rows->size() : (1ull << p.log_2_filter_len);
 					for(size_t m0 = 0; m0 < members.size(); ){
 						uint64_t span_bytes = 0;
 						size_t m1 = m0;
 						while(m1 < members.size()){
 							const uint64_t next = (span_bytes + 15)/16*16 + ((uint64_t)files[members[m1]].header.num_filter + 7)/8;
-							if(m1 > m0 && ((next + 127)/128*128)*nrows > budget){ break; }
+							// a file that does not fit what is left goes to the next pass -- unless the pass is still empty:
+							// then it is tried alone (and the allocation reports it if it really is too large)
+							if(((next + 127)/128*128)*nrows > pass_left && (m1 > m0 || !passes.back().empty())){ break; }
 							span_bytes = next;
 							++m1;
 						}
-						// the query files of this pass are read ahead from now on, beside the loading
-						unique_ptr<FileQueries> disk_source;
-						unique_ptr<PrefetchedQueries> disk_ahead;
-						if(!small_set && !cli.query_files.empty()){
-							disk_source.reset(new FileQueries(cli.query_files));
-							disk_ahead.reset(new PrefetchedQueries(*disk_source, max_batch_bases));
+						if(m1 > m0){
+							if(one_unit_per_pass && !passes.back().empty()){ passes.emplace_back(); }
+							UnitPlan u;
+							u.p = p;
+							u.members.assign(members.begin() + m0, members.begin() + m1);
+							u.span_bytes = span_bytes;
+							u.nrows = nrows;
+							u.sparse_rows = sparse_rows;
+							const uint64_t used = ((span_bytes + 127)/128*128)*nrows;
+							pass_left -= min(pass_left, used);
+							passes.back().push_back(std::move(u));
+							m0 = m1;
 						}
-						kwage_group *grp = nullptr;
-						double t0 = now_s();
-						if(sparse){ check(kwage_group_create_sparse(ctx, &p, span_bytes*8, sparse_rows.data(), sparse_rows.size(), &grp)); }
-						else{ check(kwage_group_create(ctx, &p, span_bytes*8, &grp)); }
-						ColumnMap cols;
+						if(m0 < members.size()){ passes.emplace_back(); pass_left = budget; }
+					}
+				}
+
+				for(const vector<UnitPlan> &pass : passes){
+					if(pass.empty()){ continue; }
+					// the query files of this pass are read ahead from now on, beside the loading
+					unique_ptr<FileQueries> disk_source;
+					unique_ptr<PrefetchedQueries> disk_ahead;
+					if(!small_set && !cli.query_files.empty()){
+						disk_source.reset(new FileQueries(cli.query_files));
+						disk_ahead.reset(new PrefetchedQueries(*disk_source, max_batch_bases));
+					}
+					vector<ResidentUnit> resident;
+					resident.reserve(pass.size());
+					struct Release {           // the matrices of the pass go when it ends, however it ends
+						vector<ResidentUnit> &units;
+						double &seconds;
+						~Release()
 						{
-							vector<const char*> paths;
-							for(size_t m = m0; m < m1; ++m){ paths.push_back(files[members[m]].path.c_str()); }
-							vector<uint64_t> firsts(paths.size());
-							const int rc = kwage_group_add_db_files(grp, paths.data(), (uint32_t)paths.size(), firsts.data(), nullptr);
-							if(rc != KWAGE_OK){ kwage_group_destroy(grp); check(rc); }
-							for(size_t m = m0; m < m1; ++m){
-								DbFileEntry &f = files[members[m]];       // each file is touched by exactly one worker
-								f.first_column = firsts[m - m0];
-								cols.files.push_back(&f);
-								cols.file_index.push_back(members[m]);
-							}
+							const double t0 = now_s();
+							for(ResidentUnit &u : units){ if(u.group){ kwage_group_destroy(u.group); } }
+							seconds += now_s() - t0;
 						}
-						try{
-							check(kwage_group_finalize(grp));
-							t_load += now_s() - t0;
-							gb_loaded += (double)kwage_group_row_bytes(grp)*(double)nrows/1e9;
-							if(verbose){
-								lock_guard<mutex> lk(merge_lock);
-								cerr << "[kwage] device " << devices[di] << " group loaded (" << (sparse ? to_string(nrows) + " addressed slices of 2^" + to_string(p.log_2_filter_len) : string("all slices"))
-									<< " per file): " << rss_mb() << endl;
-							}
-							t0 = now_s();
-							if(small_set){
-								PreloadedQueries typed(typed_all), from_disk(disk_all);
-								search_stream(ctx, grp, cols, typed, cli.threshold, flags, max_batch_bases, local_cmdline);
-								search_stream(ctx, grp, cols, from_disk, cli.threshold, flags, max_batch_bases, local_files);
-							}
-							else{
-								CommandLineQueries typed(cli.query_seqs);
-								search_stream(ctx, grp, cols, typed, cli.threshold, flags, max_batch_bases, local_cmdline);
-								if(disk_ahead){ search_stream(ctx, grp, cols, *disk_ahead, cli.threshold, flags, max_batch_bases, local_files); }
-							}
-							t_search += now_s() - t0;
+					} release{resident, t_free};
+					double t0 = now_s();
+					for(const UnitPlan &plan : pass){
+						resident.emplace_back();
+						ResidentUnit &u = resident.back();
+						u.kmer_len = plan.p.kmer_len;
+						if(plan.sparse_rows){ check(kwage_group_create_sparse(ctx, &plan.p, plan.span_bytes*8, plan.sparse_rows->data(), plan.sparse_rows->size(), &u.group)); }
+						else{ check(kwage_group_create(ctx, &plan.p, plan.span_bytes*8, &u.group)); }
+						vector<const char*> paths;
+						for(uint32_t fi : plan.members){ paths.push_back(files[fi].path.c_str()); }
+						vector<uint64_t> firsts(paths.size());
+						check(kwage_group_add_db_files(u.group, paths.data(), (uint32_t)paths.size(), firsts.data(), nullptr));
+						for(size_t m = 0; m < plan.members.size(); ++m){
+							DbFileEntry &f = files[plan.members[m]];       // each file is touched by exactly one worker
+							f.first_column = firsts[m];
+							u.cols.files.push_back(&f);
+							u.cols.file_index.push_back(plan.members[m]);
 						}
-						catch(...){ kwage_group_destroy(grp); throw; }
-						t0 = now_s();
-						kwage_group_destroy(grp);
-						t_free += now_s() - t0;
-						m0 = m1;
+						check(kwage_group_finalize(u.group));
+						gb_loaded += (double)kwage_group_row_bytes(u.group)*(double)plan.nrows/1e9;
+						if(verbose){
+							lock_guard<mutex> lk(merge_lock);
+							cerr << "[kwage] device " << devices[di] << " unit loaded: " << plan.members.size() << " files, 2^" << plan.p.log_2_filter_len << " slices, "
+								<< (plan.sparse_rows ? to_string(plan.nrows) + " addressed slices resident" : string("all resident")) << "; " << rss_mb() << endl;
+						}
+					}
+					t_load += now_s() - t0;
+					t0 = now_s();
+					if(small_set){
+						PreloadedQueries typed(typed_all), from_disk(disk_all);
+						search_stream(ctx, resident, typed, cli.threshold, flags, max_batch_bases, local_cmdline);
+						search_stream(ctx, resident, from_disk, cli.threshold, flags, max_batch_bases, local_files);
+					}
+					else{
+						CommandLineQueries typed(cli.query_seqs);
+						search_stream(ctx, resident, typed, cli.threshold, flags, max_batch_bases, local_cmdline);
+						if(disk_ahead){ search_stream(ctx, resident, *disk_ahead, cli.threshold, flags, max_batch_bases, local_files); }
+					}
+					t_search += now_s() - t0;
+					if(verbose){
+						lock_guard<mutex> lk(merge_lock);
+						cerr << "[kwage] device " << devices[di] << " pass of " << resident.size() << " unit(s) searched" << endl;
 					}
 				}
 				const double t_down = now_s();

@@ -144,3 +144,10 @@ def test_cli_equals_reference_binary(oracle, tmp_path, seed):
             assert _run(native.KWAGE_BIN, db, fasta, cmd, thr, fmt, {"KWAGE_SPARSE": "0"}) == got, (seed, thr, fmt)
             if seed % 4 == 0:
                 assert _run(native.KWAGE_BIN, db, fasta, cmd, thr, fmt, {"KWAGE_SPARSE_BASES": "1"}) == got, (seed, thr, fmt)
+            if seed % 4 == 1:
+                # streamed in small batches against several resident units per pass, and against passes so small that
+                # files with different parameters (and k-mer lengths) are split over several of them
+                small = {"KWAGE_SPARSE_BASES": "1", "KWAGE_BATCH_BASES": "300"}
+                assert _run(native.KWAGE_BIN, db, fasta, cmd, thr, fmt, small) == got, (seed, thr, fmt)
+                for budget in ("1", "40000"):
+                    assert _run(native.KWAGE_BIN, db, fasta, cmd, thr, fmt, dict(small, KWAGE_MAX_GROUP_BYTES=budget)) == got, (seed, thr, fmt, budget)
