@@ -1897,7 +1897,13 @@ int build_result(Slot *sl, kwage_group *g, kwage_batch *b, const SearchOutcome &
 		                 && hit_sort_scratch_bytes(so.n_hits, b->n, g->num_columns, &scratch) == KWAGE_OK
 		                 && sl->sort_scratch.reserve(scratch) == KWAGE_OK
 		                 && sort_hits_on_device(sl->stream, sl->d_hits, so.n_hits, b->n, g->num_columns, sl->sort_scratch.p, sl->sort_scratch.cap) == KWAGE_OK;
-		if(!on_device){ (void)hipGetLastError(); }      // no room for the sort's buffers beside the database: the host sorts
+		if(!on_device){
+			(void)hipGetLastError();
+			if(!(where && !strcmp(where, "host"))){      // never silently: the list is still ordered, by the host, and that is slower
+				fprintf(stderr, "[kwage_amd] no room for the device hit sort's buffers (%llu bytes) beside the database: %llu hits ordered by the host\n",
+				        (unsigned long long)scratch, (unsigned long long)so.n_hits);
+			}
+		}
 		const uint64_t first = on_device ? 0 : have;
 		if(first){ memcpy(rs->hits.get(), hs + sl->head_bytes, first*sizeof(kwage_hit)); }
 		const uint64_t piece = std::min<uint64_t>(so.n_hits - first, RESULT_PIECE_HITS), piece_bytes = piece*sizeof(kwage_hit);
