@@ -1893,10 +1893,11 @@ int build_result(Slot *sl, kwage_group *g, kwage_batch *b, const SearchOutcome &
 		// halves of the pinned staging buffer: piece i+1 crosses PCIe while piece i is copied into the result.
 		uint64_t scratch = 0;
 		const char *where = getenv("KWAGE_HIT_SORT");      // "host": the sort of round 1, kept for A/B runs and as the fallback
+		const uint64_t column_span = g->stride*8;      // no hit carries a column beyond the row (files are padded apart: more than num_columns)
 		bool on_device = !(where && !strcmp(where, "host"))
-		                 && hit_sort_scratch_bytes(so.n_hits, b->n, g->num_columns, &scratch) == KWAGE_OK
+		                 && hit_sort_scratch_bytes(so.n_hits, b->n, column_span, &scratch) == KWAGE_OK
 		                 && sl->sort_scratch.reserve(scratch) == KWAGE_OK
-		                 && sort_hits_on_device(sl->stream, sl->d_hits, so.n_hits, b->n, g->num_columns, sl->sort_scratch.p, sl->sort_scratch.cap) == KWAGE_OK;
+		                 && sort_hits_on_device(sl->stream, sl->d_hits, so.n_hits, b->n, column_span, sl->sort_scratch.p, sl->sort_scratch.cap) == KWAGE_OK;
 		if(!on_device){
 			(void)hipGetLastError();
 			if(!(where && !strcmp(where, "host"))){      // never silently: the list is still ordered, by the host, and that is slower

@@ -42,11 +42,12 @@ __global__ __launch_bounds__(256) void unpack_hits_kernel(const uint64_t *__rest
 	}
 }
 
-uint32_t bits_for(uint32_t count)      // bits that hold 0 .. count-1
+uint32_t bits_for(uint64_t count)      // bits that hold 0 .. count-1
 {
+	if(count <= 1){ return 0; }
 	uint32_t b = 0;
-	while(b < 32 && (count - 1) >> b){ ++b; }
-	return count <= 1 ? 0 : b;
+	while(b < 64 && ((count - 1) >> b)){ ++b; }
+	return b;
 }
 
 inline uint64_t align_up(uint64_t x){ return (x + 255) & ~255ull; }
@@ -74,31 +75,33 @@ int layout_for(uint64_t n, unsigned end_bit, Layout *l)
 	return KWAGE_OK;
 }
 
-unsigned key_bits(uint32_t n_queries, uint32_t n_columns, uint32_t *column_bits)
+// `column_span`: one more than the largest column index a hit can carry -- the group's column SPAN (files start at
+// 16-byte boundaries, so it exceeds the number of valid columns), at most 2^32.
+unsigned key_bits(uint32_t n_queries, uint64_t column_span, uint32_t *column_bits)
 {
-	*column_bits = bits_for(n_columns);
+	*column_bits = std::min(32u, bits_for(column_span));
 	return std::max(1u, *column_bits + bits_for(n_queries));
 }
 
 }  // namespace
 
-int hit_sort_scratch_bytes(uint64_t n_hits, uint32_t n_queries, uint32_t n_columns, uint64_t *bytes)
+int hit_sort_scratch_bytes(uint64_t n_hits, uint32_t n_queries, uint64_t column_span, uint64_t *bytes)
 {
 	uint32_t cb;
 	Layout l;
-	int rc = layout_for(n_hits, key_bits(n_queries, n_columns, &cb), &l);
+	int rc = layout_for(n_hits, key_bits(n_queries, column_span, &cb), &l);
 	if(rc){ return rc; }
 	*bytes = l.total;
 	return KWAGE_OK;
 }
 
-int sort_hits_on_device(void *stream, kwage_hit *d_hits, uint64_t n_hits, uint32_t n_queries, uint32_t n_columns,
+int sort_hits_on_device(void *stream, kwage_hit *d_hits, uint64_t n_hits, uint32_t n_queries, uint64_t column_span,
                         void *scratch, uint64_t scratch_bytes)
 {
 	if(n_hits < 2){ return KWAGE_OK; }
 	hipStream_t st = (hipStream_t)stream;
 	uint32_t cb;
-	const unsigned end_bit = key_bits(n_queries, n_columns, &cb);
+	const unsigned end_bit = key_bits(n_queries, column_span, &cb);
 	Layout l;
 	int rc = layout_for(n_hits, end_bit, &l);
 	if(rc){ return rc; }

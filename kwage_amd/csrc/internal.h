@@ -22,8 +22,9 @@ int check_params(const kwage_params *p);
 
 // Ordering a large hit list by (query, column) where it lies in device memory (hit_sort.hip).  `scratch` is a device
 // block of at least hit_sort_scratch_bytes(); the work is queued on `stream` (a hipStream_t) and not waited for.
-int hit_sort_scratch_bytes(uint64_t n_hits, uint32_t n_queries, uint32_t n_columns, uint64_t *bytes);
-int sort_hits_on_device(void *stream, kwage_hit *d_hits, uint64_t n_hits, uint32_t n_queries, uint32_t n_columns,
+// `column_span` bounds the column indices (the group's span, not its count of valid columns: files are padded apart).
+int hit_sort_scratch_bytes(uint64_t n_hits, uint32_t n_queries, uint64_t column_span, uint64_t *bytes);
+int sort_hits_on_device(void *stream, kwage_hit *d_hits, uint64_t n_hits, uint32_t n_queries, uint64_t column_span,
                         void *scratch, uint64_t scratch_bytes);
 
 static const uint32_t KWAGE_MAGIC_NUMBER = 0x20191025u;   // reference kwage.h:22

@@ -222,6 +222,30 @@ def test_device_hit_sort_key_widths(ka, ctx, n_cols, n_queries, monkeypatch):
     g.close()
 
 
+def test_device_hit_sort_with_files_padded_apart(ka, ctx, monkeypatch):
+    """Column indices of a group run over its SPAN: every file starts at a 16-byte boundary, so the largest index
+    exceeds the count of valid columns (here 3 blocks of 1000 + 37 + 3000 columns = 4037 < 2^12 span 1024 + 128 + 3000 =
+    4152 > 2^12).  The sort key must be sized by the span: sized by the count, bit 12 of a column would spill into the
+    query field."""
+    blocks = (1000, 37, 3000)
+    g = ka.Group(ctx, 31, 1, 6, 1024 + 128 + 3000)
+    firsts = [g.add_random_columns(n, 3 + i, 128) for i, n in enumerate(blocks)]
+    g.finalize()
+    assert firsts == [0, 1024, 1152] and g.num_columns == sum(blocks) < 4096 < firsts[-1] + blocks[-1]
+    columns = np.concatenate([np.arange(f, f + n, dtype=np.uint32) for f, n in zip(firsts, blocks)])
+    rng = np.random.default_rng(9)
+    seqs = [rand_seq(rng, 40) for _ in range(23)]
+    b = ka.Batch(ctx, seqs)
+    r = g.search(b, 0.0001)
+    assert len(r.hits) == len(seqs) * len(columns) > 8192
+    assert np.array_equal(r.hits["query"], np.repeat(np.arange(len(seqs), dtype=np.uint32), len(columns)))
+    assert np.array_equal(r.hits["column"], np.tile(columns, len(seqs)))
+    monkeypatch.setenv("KWAGE_HIT_SORT", "host")
+    assert np.array_equal(g.search(b, 0.0001).hits, r.hits)
+    b.close()
+    g.close()
+
+
 def test_errors_are_reported_not_swallowed(ka, ctx):
     with pytest.raises(ka.KwageError):
         ka.Group(ctx, 33, 1, 10, 8)                    # k > MAX_WORD_LEN
