@@ -337,6 +337,21 @@ struct PrefetchedQueries : QuerySource {
 	}
 };
 
+// Batches that were read already, then the rest of the source they came from: the first pass continues where the
+// preview of the query files stopped, so a run of one pass reads every query file exactly once, like the reference.
+struct ResumedQueries : QuerySource {
+	deque<QueryBatch> head;
+	QuerySource &rest;
+	explicit ResumedQueries(QuerySource &r) : rest(r) {}
+	bool fill(QueryBatch &b, uint64_t max_bases) override
+	{
+		if(head.empty()){ return rest.fill(b, max_bases); }
+		b = std::move(head.front());
+		head.pop_front();
+		return true;
+	}
+};
+
 // A batch that was read before (a small query set is parsed ONCE and reused for every group and pass).
 struct PreloadedQueries : QuerySource {
 	const QueryBatch &stored;
@@ -785,15 +800,27 @@ int main(int argc, char *argv[])
 		const uint64_t small_bases = min<uint64_t>(env_u64("KWAGE_SPARSE_BASES", 4ull << 20), max_batch_bases);
 		QueryBatch typed_all, disk_all;
 		bool small_set = false;
+		// a query set that turns out not to be small: what the preview has read of the files, and the reader to go on with
+		unique_ptr<FileQueries> preview_reader(new FileQueries(cli.query_files));
+		unique_ptr<ResumedQueries> preview;
+		mutex preview_lock;
 		{
 			CommandLineQueries typed(cli.query_seqs);
-			FileQueries from_disk(cli.query_files);
 			QueryBatch extra;
 			const bool any_typed = typed.fill(typed_all, small_bases);
 			const bool typed_done = !any_typed || !typed.fill(extra, small_bases);
-			const bool any_disk = typed_done && from_disk.fill(disk_all, small_bases);
-			small_set = typed_done && (!any_disk || !from_disk.fill(extra, small_bases));
-			if(!small_set){ typed_all.clear(); disk_all.clear(); }
+			const bool any_disk = typed_done && preview_reader->fill(disk_all, small_bases);
+			const bool more_disk = any_disk && preview_reader->fill(extra, small_bases);
+			small_set = typed_done && !more_disk;
+			if(!small_set){
+				if(more_disk){
+					preview.reset(new ResumedQueries(*preview_reader));
+					preview->head.push_back(std::move(disk_all));
+					preview->head.push_back(std::move(extra));
+				}
+				typed_all.clear();
+				disk_all.clear();
+			}
 		}
 
 		Findings from_command_line, from_files;
@@ -891,10 +918,14 @@ int main(int argc, char *argv[])
 				for(const vector<UnitPlan> &pass : passes){
 					if(pass.empty()){ continue; }
 					// the query files of this pass are read ahead from now on, beside the loading
-					unique_ptr<FileQueries> disk_source;
+					unique_ptr<QuerySource> disk_source;
 					unique_ptr<PrefetchedQueries> disk_ahead;
 					if(!small_set && !cli.query_files.empty()){
-						disk_source.reset(new FileQueries(cli.query_files));
+						{       // the first pass to get here goes on from the preview; every other one opens the files again
+							lock_guard<mutex> lk(preview_lock);
+							if(preview){ disk_source = std::move(preview); }
+						}
+						if(!disk_source){ disk_source.reset(new FileQueries(cli.query_files)); }
 						disk_ahead.reset(new PrefetchedQueries(*disk_source, max_batch_bases));
 					}
 					vector<ResidentUnit> resident;

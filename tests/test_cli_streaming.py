@@ -100,3 +100,30 @@ def test_batches_of_every_size_give_the_same_report(oracle, tmp_path, golden_dir
             outs[(fmt, bb)] = r.stdout
         assert len({outs[(fmt, bb)] for bb in ("1", "300", "5000", str(64 << 20))}) == 1, fmt
         assert outs[(fmt, "1")]
+
+
+def test_query_files_are_read_once_in_a_single_pass(oracle, tmp_path, golden_dir):
+    """A run that needs one pass over the database reads every query file exactly once, like the reference
+    (kwage.cpp:127-147) -- so a named pipe works as a query file.  Both ways a query set is classified: small (read whole
+    by the preview) and not small (KWAGE_SPARSE_BASES=1: the preview stops after two batches and the first pass goes on
+    from there)."""
+    import threading
+    from kwage_amd import native
+    base = os.path.join(golden_dir, "basic")
+    data = open(os.path.join(base, "q.fa"), "rb").read()
+    argv = [native.KWAGE_BIN, "-d", os.path.join(base, "db"), "-t", "0.5", "--o.csv"]
+    want = subprocess.run(argv + ["-i", os.path.join(base, "q.fa")], capture_output=True)
+    assert want.returncode == 0 and want.stdout.count(b"\n") > 1
+    for env_extra in ({}, {"KWAGE_SPARSE_BASES": "1"}, {"KWAGE_SPARSE_BASES": "1", "KWAGE_BATCH_BASES": "100"}):
+        fifo = str(tmp_path / ("pipe%d.fa" % len(env_extra)))
+        os.mkfifo(fifo)
+
+        def feed():
+            with open(fifo, "wb") as fh:        # a second open() by the reader would block for ever: the test would time out
+                fh.write(data)
+        t = threading.Thread(target=feed, daemon=True)
+        t.start()
+        got = subprocess.run(argv + ["-i", fifo], capture_output=True, env=dict(os.environ, **env_extra), timeout=120)
+        t.join(timeout=10)
+        assert got.returncode == 0, got.stderr.decode()
+        assert got.stdout == want.stdout, env_extra
