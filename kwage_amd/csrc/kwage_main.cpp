@@ -1041,6 +1041,7 @@ int main(int argc, char *argv[])
 			     << " s, report written in " << (now_s() - t_ordered) << " s; " << rss_mb() << endl;
 		}
 
+		if(verbose){ cerr << "[kwage] " << (now_s() - t_main) << " s from the start of main to its last statement" << endl; }
 		cerr << "Search complete in " << (time(nullptr) - started) << " sec" << endl;
 	}
 	catch(const char *error){
