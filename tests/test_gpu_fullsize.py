@@ -83,6 +83,16 @@ def test_c2_full_size_properties(ka, oracle):
         r4 = s.group.search(s.batch, 0.3)
         assert (r4.query_threshold == np.array([oracle.query_threshold(float(np.float32(0.3)), int(n)) for n in r4.num_query_kmer])).all()
         _check_sampled(ka, oracle, s, r4, hitq[:2] + missq[:2], 0.3)
+        # a hit-heavy call on the same matrix: at a threshold that truncates to 0 every sample matches every query
+        # (kwage.cpp:388,497) -- 2 M records, ordered on the device, fetched in pieces; order in closed form, counts
+        # of the first and last query against the oracle on the rows they address
+        few = ka.Batch(ctx, s.queries[:20])
+        r5 = s.group.search(few, 0.0001)
+        assert len(r5.hits) == 20 * w.num_samples
+        assert np.array_equal(r5.hits["query"], np.repeat(np.arange(20, dtype=np.uint32), w.num_samples))
+        assert np.array_equal(r5.hits["column"], np.tile(np.arange(w.num_samples, dtype=np.uint32), 20))
+        _check_sampled(ka, oracle, s, r5, [0, 19], 0.0001)
+        few.close()
         s.batch.close()
         s.group.close()
 
