@@ -55,19 +55,23 @@ try:
         for i, s in enumerate(queries):
             fh.write(">query_%d\n%s\n" % (i, s))
 
-    def run(exe, env=None):
+    def run(exe, env=None, reps=2):
         best, out = None, None
-        for _ in range(2):
+        for _ in range(reps):
             t0 = time.perf_counter()
             r = subprocess.run([exe, "-d", os.path.join(tmp, "db"), "-i", q, "--o.csv"], capture_output=True, env=env)
             dt = time.perf_counter() - t0
             assert r.returncode == 0, r.stderr.decode()
             best = dt if best is None else min(best, dt)
             out = r.stdout.decode()
+            inside = [l.split()[1] for l in r.stderr.decode().splitlines() if "from the start of main" in l]
+            if inside:          # KWAGE_VERBOSE: how much of the wall time lies outside main (program start, exit)
+                init = [l for l in r.stderr.decode().splitlines() if ": init " in l][0]
+                print("   wall %.3f s, inside main %s s (%s)" % (dt, inside[0], init[init.index("init"):init.index(", search")]))
         return best, out
 
     cores = min(os.cpu_count() or 1, 16)
-    t_gpu, out_gpu = run(native.KWAGE_BIN)
+    t_gpu, out_gpu = run(native.KWAGE_BIN, dict(os.environ, KWAGE_VERBOSE="1"), reps=5)
     r = subprocess.run([native.KWAGE_BIN, "-d", os.path.join(tmp, "db"), "-i", q, "--o.csv", "-o", os.path.join(tmp, "o.csv")], capture_output=True, env=dict(os.environ, KWAGE_VERBOSE="1"))
     print(r.stderr.decode().strip())
     r = subprocess.run([native.KWAGE_BIN, "-d", os.path.join(tmp, "db"), "-i", q, "--o.csv", "-o", os.path.join(tmp, "o2.csv")], capture_output=True,
