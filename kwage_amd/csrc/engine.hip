@@ -1393,6 +1393,9 @@ struct SdmaPipe {
 			const uint64_t wr = std::min(win_rows, g->nrows - r0);
 			const uint64_t off = DB_HEADER_BYTES + r0*width, off0 = off/page*page;
 			const size_t maplen = (size_t)(off - off0 + wr*width);
+			// pages that are not in the page cache yet: have the kernel read the next two windows while this one is pinned
+			// and copied (the lock below faults pages in one by one, at half the rate of a plain sequential read)
+			(void)posix_fadvise(src.fd, (off_t)(off0 + maplen), (off_t)(2*win_rows*width), POSIX_FADV_WILLNEED);
 			void *base = mmap(nullptr, maplen, PROT_READ, MAP_PRIVATE, src.fd, (off_t)off0);      // (the lock faults the pages in)
 			if(base == MAP_FAILED){ return KWAGE_OK; }
 			void *dev_view = nullptr;
@@ -1630,6 +1633,8 @@ extern "C" int kwage_group_add_db_files(kwage_group *g, const char *const *paths
 			ptrs[cnt] = &src;
 			++cnt;
 			if(g->d_row_map){ continue; }                // sparse group: gangs of any files
+			// whole-file loading: start reading the head of every file of the gang now (no-op for pages already cached)
+			if(src.fd >= 0){ (void)posix_fadvise(src.fd, 0, (off_t)(512ull << 20), POSIX_FADV_WILLNEED); }
 			if(!direct_loadable(src)){ break; }          // this file ends the gang and is staged on its own
 			n_direct = cnt;
 		}
