@@ -67,8 +67,14 @@ def test_query_file_larger_than_the_memory_the_cli_may_use(oracle, tmp_path):
     assert rc == 0, err
     print(err0, err)
     # 14 times the reads must not cost memory: a query set held in RAM would add 180 MB of bases (plus a
-    # std::string per read); streaming adds nothing but allocator slack
-    assert rss_big - rss_small < 40 << 20, (rss_small >> 20, rss_big >> 20, err0, err)
+    # std::string per read, > 250 MB in all); streaming adds nothing but allocator slack.  What the HIP runtime maps at
+    # start-up differs by tens of MB from process to process (the "device 0 ready" line), so the growth of each run over
+    # its own start-up is compared, not the absolute peaks.
+    def at_start(stderr_text):
+        line = [l for l in stderr_text.splitlines() if "ready:" in l][0]
+        return int(line.split("ready:")[1].split()[0]) << 20
+    grow_small, grow_big = rss_small - at_start(err0), rss_big - at_start(err)
+    assert grow_big - grow_small < 64 << 20, (grow_small >> 20, grow_big >> 20, err0, err)
 
     # and the report is right: exactly the planted reads, each found in exactly the planted samples
     rep = oracle.parse_csv(out)
