@@ -420,6 +420,8 @@ extern "C" int kwage_repack_db(kwage_ctx *ctx, const char *out_path, const char 
 	std::vector<unsigned char> recs;
 	uint64_t pos = info_start + 8ull*total_cols;
 	for(uint32_t i = 0; i < n; ++i){
+		std::string meta_err;
+		if(!info[i].load(meta_err)){ fclose(fout); return fail(KWAGE_ERR_IO, "kwage_repack_db: %s", meta_err.c_str()); }
 		for(uint32_t j = 0; j < src[i].header.num_filter; ++j){
 			const uint64_t l = info[i].info_loc[j];
 			if(l < info[i].tail_start || l >= info[i].tail_start + info[i].tail.size()){ fclose(fout); return fail(KWAGE_ERR_FORMAT, "%s: bad metadata index", in_paths[i]); }

@@ -226,34 +226,51 @@ void pack_filter_info(const FilterInfo &fi, std::vector<unsigned char> &out)
 }
 
 // ---- database metadata ----------------------------------------------------------------------
-bool DbInfo::open(const std::string &path, std::string &err)
+bool DbInfo::open(const std::string &file, std::string &err)
 {
-	std::ifstream fin(path.c_str(), std::ios::binary);
-	if(!fin){ err = "Unable to open database file " + path + " for reading"; return false; }
+	std::ifstream fin(file.c_str(), std::ios::binary);
+	if(!fin){ err = "Unable to open database file " + file + " for reading"; return false; }
 	unsigned char hb[DB_HEADER_BYTES];
 	fin.read((char*)hb, DB_HEADER_BYTES);
-	if(!fin){ err = path + ": Unable to read header"; return false; }
+	if(!fin){ err = file + ": Unable to read header"; return false; }
 	unpack_db_header(hb, &header);
 	fin.seekg(0, std::ios::end);
 	const uint64_t fsize = (uint64_t)fin.tellg();
 	if(header.info_start > fsize || fsize - header.info_start < 8ull*header.num_filter){
-		err = path + ": metadata index lies outside the file";
+		err = file + ": metadata index lies outside the file";
 		return false;
 	}
-	// info_loc[N] then the FilterInfo records (build_db.cpp:371-416): read the tail once
+	path = file;
 	tail_start = header.info_start;
-	tail.resize(fsize - tail_start);
-	fin.seekg((std::streamoff)tail_start);
-	fin.read((char*)tail.data(), (std::streamsize)tail.size());
-	if(!fin){ err = path + ": Unable to read metadata"; return false; }
-	info_loc.resize(header.num_filter);
-	for(uint32_t j = 0; j < header.num_filter; ++j){ info_loc[j] = rd64(tail.data() + 8ull*j); }
+	tail_bytes = fsize - tail_start;
+	return true;
+}
+
+// info_loc[N] then the FilterInfo records (build_db.cpp:371-416): the tail of the file, read once
+bool DbInfo::load(std::string &err) const
+{
+	std::lock_guard<std::mutex> lk(once);
+	if(state == 0){
+		state = -1;
+		std::ifstream fin(path.c_str(), std::ios::binary);
+		tail.resize(tail_bytes);
+		if(fin){ fin.seekg((std::streamoff)tail_start); fin.read((char*)tail.data(), (std::streamsize)tail.size()); }
+		if(fin && tail.size() >= 8ull*header.num_filter){
+			info_loc.resize(header.num_filter);
+			for(uint32_t j = 0; j < header.num_filter; ++j){ info_loc[j] = rd64(tail.data() + 8ull*j); }
+			state = 1;
+		}
+		else{ tail.clear(); }
+	}
+	if(state != 1){ err = path + ": Unable to read metadata"; return false; }
 	return true;
 }
 
 bool DbInfo::info(uint32_t column, FilterInfo &fi) const
 {
 	if(column >= header.num_filter){ return false; }
+	std::string err;
+	if(!load(err)){ return false; }
 	const uint64_t loc = info_loc[column];          // kwage.cpp:505-515
 	if(loc < tail_start || loc >= tail_start + tail.size()){ return false; }
 	return parse_filter_info(tail.data() + (loc - tail_start), tail.size() - (loc - tail_start), fi);

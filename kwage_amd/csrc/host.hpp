@@ -3,6 +3,7 @@
 #define KWAGE_AMD_HOST_HPP
 
 #include <cstdint>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -38,14 +39,21 @@ bool str_to_accession(const std::string &s, uint64_t &out);
 std::string accession_to_str(uint64_t acc);
 bool find_file_extension(const std::string &path, const char *ext);
 
-// info_loc[] + FilterInfo records of one `.db` file, read once.
+// info_loc[] + FilterInfo records of one `.db` file.  open() reads the header and checks where the metadata lies; the
+// metadata itself is read on first use, once: a database of a million samples carries a GB of it, a report touches the
+// records of the samples that were hit (the reference seeks to them one by one, kwage.cpp:505-515).
 struct DbInfo {
 	kwage_db_header header{};
-	uint64_t tail_start = 0;
-	std::vector<unsigned char> tail;
-	std::vector<uint64_t> info_loc;
+	uint64_t tail_start = 0, tail_bytes = 0;
+	std::string path;
+	mutable std::vector<unsigned char> tail;
+	mutable std::vector<uint64_t> info_loc;
 	bool open(const std::string &path, std::string &err);
+	bool load(std::string &err) const;                  // thread-safe; what info() does first
 	bool info(uint32_t column, FilterInfo &fi) const;
+private:
+	mutable std::mutex once;
+	mutable int state = 0;                               // 0 not read yet, 1 read, -1 unreadable
 };
 
 // Reader of the bit-slice block of a `.db` file, raw (compression 0, the only layout the reference

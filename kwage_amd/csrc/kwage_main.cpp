@@ -827,7 +827,7 @@ int main(int argc, char *argv[])
 		mutex merge_lock;
 		vector<string> worker_error(ndev);
 		const double t_start = now_s();
-		if(env_u64("KWAGE_VERBOSE", 0)){ cerr << "[kwage] command line, headers and metadata of " << files.size() << " files, query preview: " << (t_start - t_main) << " s" << endl; }
+		if(env_u64("KWAGE_VERBOSE", 0)){ cerr << "[kwage] command line, headers of " << files.size() << " files, query preview: " << (t_start - t_main) << " s" << endl; }
 
 		auto worker = [&](size_t di) {
 			try{
