@@ -120,6 +120,12 @@ int kwage_group_add_db_file(kwage_group *g, const char *path, uint64_t *first_co
 int kwage_group_add_db_files(kwage_group *g, const char *const *paths, uint32_t n, uint64_t *first_columns,
                              uint32_t *num_filters);
 
+/* Loading progress: while files are loaded through `ctx`, the library adds the bytes of every database file it has
+ * passed (whole files, in the order they were given) to *bytes_passed.  The word may lie in memory shared with another
+ * process: the CLI's page-cache reader, a child forked before the GPU is touched, keeps a bounded distance ahead of it
+ * when the files are not in the page cache.  NULL switches the reporting off (the default). */
+void kwage_set_load_progress(kwage_ctx *ctx, volatile uint64_t *bytes_passed);
+
 /* Append `num_columns` synthetic columns: i.i.d. Bernoulli(density_q8/256) bits from a
  * counter-based generator keyed by (seed, row, 64-bit word index) -- generated ON the device. */
 int kwage_group_add_random_columns(kwage_group *g, uint64_t num_columns, uint64_t seed,

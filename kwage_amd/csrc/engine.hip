@@ -135,6 +135,7 @@ struct kwage_ctx {
 	struct LockedWindow { void *base; size_t len; hipEvent_t done; bool owns_event; };     // the windows of one launch share its event; the last one owns it
 	std::deque<LockedWindow> locked;
 	std::vector<hipEvent_t> spare_events;
+	volatile uint64_t *load_progress = nullptr;      // kwage_set_load_progress
 };
 
 namespace {
@@ -990,6 +991,11 @@ extern "C" void kwage_shutdown(kwage_ctx *ctx)
 	delete ctx;
 }
 
+extern "C" void kwage_set_load_progress(kwage_ctx *ctx, volatile uint64_t *bytes_passed)
+{
+	if(ctx){ ctx->load_progress = bytes_passed; }
+}
+
 extern "C" int kwage_mem_info(kwage_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes)
 {
 	if(!ctx){ return fail(KWAGE_ERR_ARG, "kwage_mem_info: ctx is NULL"); }
@@ -1412,6 +1418,7 @@ struct SdmaPipe {
 			}
 			windows.push_back(Window{base, maplen, issued});
 			++issued;
+			if(ctx->load_progress){ __atomic_fetch_add(ctx->load_progress, wr*width, __ATOMIC_RELAXED); }      // pinned: no longer the reader's business
 			r0 += wr;
 			*rows_done = r0;
 			if(issued - finished >= 2){ if((rc = finish_one())){ return rc; } }       // one copy stays in flight while the next window is pinned
@@ -1650,6 +1657,7 @@ extern "C" int kwage_group_add_db_files(kwage_group *g, const char *const *paths
 			if((rc = load_gang_direct(g, ptrs, byte0, n_direct, &rows_done))){ return rc; }
 		}
 		for(uint32_t k = 0; k < cnt; ++k){
+			const uint64_t progress_before = g->ctx->load_progress ? __atomic_load_n(g->ctx->load_progress, __ATOMIC_RELAXED) : 0;
 			uint64_t from = (k < n_direct) ? rows_done : 0;
 			if(from == 0 && pipe.usable && srcs[k].header.compression == KWAGE_COMPRESSION_NONE){
 				if((rc = pipe.add_file(srcs[k], byte0[k], &from))){ return rc; }
@@ -1658,6 +1666,13 @@ extern "C" int kwage_group_add_db_files(kwage_group *g, const char *const *paths
 			else if(pipe.usable){ if((rc = pipe.flush())){ return rc; } }
 			if(from < g->nrows){
 				if((rc = load_source_rows_staged(g, srcs[k], paths[i0 + k], byte0[k], from))){ return rc; }
+			}
+			if(g->ctx->load_progress){       // the whole file has been passed now (windows reported themselves as they were pinned)
+				struct stat st;
+				if(fstat(srcs[k].fd, &st) == 0 && st.st_size > 0){
+					const uint64_t now = __atomic_load_n(g->ctx->load_progress, __ATOMIC_RELAXED), end = progress_before + (uint64_t)st.st_size;
+					if(end > now){ __atomic_fetch_add(g->ctx->load_progress, end - now, __ATOMIC_RELAXED); }
+				}
 			}
 		}
 		i0 += cnt;

@@ -19,6 +19,8 @@
 //                     parameter groups (filter sizes) that fit together are resident together and the query files
 //                     are read once per pass; a larger database takes several passes over whole files
 //   KWAGE_ONE_UNIT_PER_PASS  1 = one parameter group per pass (measurement: the schedule of earlier versions)
+//   KWAGE_CACHE_READER  threads of the page-cache reader, a child process that reads database files which are not in
+//                     the page cache ahead of the loader (default 4; 0 = none); KWAGE_CACHE_READER_AHEAD_MB (8192)
 //   KWAGE_SPARSE      how a SMALL query set (everything fits one batch of KWAGE_SPARSE_BASES, default 4 Mi bases) is
 //                     searched: "auto" (default) loads only the slices the queries address when they address at most
 //                     1/8 of a group's rows -- I/O proportional to the queries, like the reference's seek + read per
@@ -43,7 +45,14 @@
 #include <thread>
 #include <vector>
 
+#include <atomic>
 #include <dirent.h>
+#include <fcntl.h>
+#include <signal.h>
+#include <sys/mman.h>
+#include <sys/prctl.h>
+#include <sys/wait.h>
+#include <unistd.h>
 #include <getopt.h>
 #include <sys/stat.h>
 
@@ -693,6 +702,105 @@ struct JsonReport : Report {
 	void end() override { if(js){ js->finish(); } to.flush(); to.out.flush(); }
 };
 
+// =====================================================================================================
+// page-cache reader
+// =====================================================================================================
+// Database files that are not in the page cache are read at half the rate the disk gives when the loader's own thread
+// faults their pages in while pinning them, and reading and copying then run in turn (profiles/r02_cold_load.txt).
+// Helper THREADS made it worse -- they contend with the loader for the process's address-space lock -- so the reading
+// ahead is done by a child PROCESS, forked before anything has touched the GPU: it walks the files in the loader's
+// order, never more than `lookahead` bytes ahead of what the loader reports as passed (kwage_set_load_progress into a
+// word both processes share), asks mincore() whether a 64 MiB piece is resident already (a warm database costs a
+// system call per piece) and reads it if not, several pieces at a time.
+struct ReaderShared {
+	volatile uint64_t passed;       // bytes of the file sequence the loader is done with
+	volatile int go, stop;
+};
+
+struct CacheReader {
+	ReaderShared *shared = nullptr;
+	pid_t child = -1;
+
+	static void child_main(ReaderShared *sh, const vector<string> &paths, unsigned nthreads, uint64_t lookahead)
+	{
+		prctl(PR_SET_PDEATHSIG, SIGKILL);          // never outlive the search
+		if(getppid() == 1){ _exit(0); }
+		while(!sh->go && !sh->stop){ usleep(500); }
+		struct Piece { const string *path; uint64_t offset, length, start; };
+		vector<Piece> pieces;
+		uint64_t total = 0;
+		const uint64_t piece_bytes = 64ull << 20;
+		for(const string &path : paths){
+			struct stat st;
+			if(stat(path.c_str(), &st) != 0 || st.st_size <= 0){ continue; }
+			for(uint64_t off = 0; off < (uint64_t)st.st_size; off += piece_bytes){
+				pieces.push_back(Piece{&path, off, min<uint64_t>(piece_bytes, (uint64_t)st.st_size - off), total + off});
+			}
+			total += (uint64_t)st.st_size;
+		}
+		atomic<size_t> next{0};
+		auto run = [&]() {
+			const long page = sysconf(_SC_PAGESIZE);
+			vector<unsigned char> resident;
+			vector<char> buf(4u << 20);
+			for(;;){
+				const size_t i = next.fetch_add(1);
+				if(i >= pieces.size()){ return; }
+				const Piece &p = pieces[i];
+				while(!sh->stop && p.start > sh->passed + lookahead){ usleep(300); }
+				if(sh->stop){ return; }
+				if(p.start + p.length <= sh->passed){ continue; }          // the loader has been here already
+				const int fd = open(p.path->c_str(), O_RDONLY);
+				if(fd < 0){ continue; }
+				bool cold = true;
+				void *m = mmap(nullptr, (size_t)p.length, PROT_READ, MAP_SHARED, fd, (off_t)p.offset);
+				if(m != MAP_FAILED){
+					const size_t npages = (size_t)((p.length + page - 1)/page);
+					resident.assign(npages, 0);
+					size_t present = 0;
+					if(mincore(m, (size_t)p.length, resident.data()) == 0){ for(unsigned char r : resident){ present += r & 1; } }
+					cold = present < npages;
+					(void)munmap(m, (size_t)p.length);
+				}
+				for(uint64_t done = 0; cold && done < p.length && !sh->stop; ){
+					const ssize_t got = pread(fd, buf.data(), (size_t)min<uint64_t>(buf.size(), p.length - done), (off_t)(p.offset + done));
+					if(got <= 0){ break; }
+					done += (uint64_t)got;
+				}
+				close(fd);
+			}
+		};
+		vector<thread> pool;
+		for(unsigned t = 1; t < nthreads; ++t){ pool.emplace_back(run); }
+		run();
+		for(thread &t : pool){ t.join(); }
+		_exit(0);
+	}
+
+	// Call before the first HIP call of the process, and before any thread is started.
+	void start(const vector<string> &ordered_paths, unsigned nthreads, uint64_t lookahead)
+	{
+		void *m = mmap(nullptr, sizeof(ReaderShared), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+		if(m == MAP_FAILED){ return; }
+		shared = new (m) ReaderShared();
+		shared->passed = 0; shared->go = 0; shared->stop = 0;
+		cout.flush(); cerr.flush();
+		child = fork();
+		if(child == 0){ child_main(shared, ordered_paths, nthreads, lookahead); _exit(0); }
+		if(child < 0){ (void)munmap(m, sizeof(ReaderShared)); shared = nullptr; }
+	}
+	void release(bool dense) { if(shared){ if(dense){ shared->go = 1; } else { shared->stop = 1; } } }
+	void finish()
+	{
+		if(!shared){ return; }
+		shared->stop = 1;
+		if(child > 0){ int status = 0; (void)waitpid(child, &status, 0); child = -1; }
+		(void)munmap((void*)shared, sizeof(ReaderShared));
+		shared = nullptr;
+	}
+	~CacheReader() { finish(); }
+};
+
 double now_s() { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // resident set size of this process in MB, now and at its peak (KWAGE_VERBOSE)
@@ -794,6 +902,16 @@ int main(int argc, char *argv[])
 		const uint64_t max_group_bytes = env_u64("KWAGE_MAX_GROUP_BYTES", 0);       // 0 = what is free on the device
 		const bool verbose = env_u64("KWAGE_VERBOSE", 0) != 0;
 
+		// The page-cache reader (one device only: the workers of several devices load their shares side by side): forked
+		// here, before the first HIP call and before any thread exists; it waits until the plan says whole files are read.
+		CacheReader reader;
+		const unsigned reader_threads = (unsigned)min<uint64_t>(env_u64("KWAGE_CACHE_READER", 4), 16);
+		vector<string> load_order;
+		if(ndev == 1 && reader_threads){
+			for(const auto &grp_entry : groups){ for(uint32_t fi : grp_entry.second){ load_order.push_back(files[fi].path); } }
+			reader.start(load_order, reader_threads, env_u64("KWAGE_CACHE_READER_AHEAD_MB", 8192) << 20);
+		}
+
 		// A small query set is read ONCE, up front, and reused for every group and pass; it is also what makes the sparse
 		// path possible (the rows to fetch must be known before the files are read).
 		const string sparse_mode = getenv("KWAGE_SPARSE") ? getenv("KWAGE_SPARSE") : "auto";
@@ -823,6 +941,9 @@ int main(int argc, char *argv[])
 			}
 		}
 
+		// whole files are certain to be read when no sparse group can come about: the reader may start during HIP initialisation
+		if(!small_set || sparse_mode == "0"){ reader.release(true); }
+
 		Findings from_command_line, from_files;
 		mutex merge_lock;
 		vector<string> worker_error(ndev);
@@ -834,6 +955,7 @@ int main(int argc, char *argv[])
 				kwage_ctx *ctx = nullptr;
 				check(kwage_init(devices[di], &ctx));
 				if(verbose){ lock_guard<mutex> lk(merge_lock); cerr << "[kwage] device " << devices[di] << " ready: " << rss_mb() << endl; }
+				if(reader.shared){ kwage_set_load_progress(ctx, &reader.shared->passed); }
 				double t_load = 0, t_search = 0, t_free = 0, gb_loaded = 0;
 				const double t_init = now_s() - t_start;
 				Findings local_cmdline, local_files;
@@ -915,6 +1037,11 @@ int main(int argc, char *argv[])
 					}
 				}
 
+				{       // whole files will be read (no unit fetches addressed slices only): let the page-cache reader run ahead
+					bool any = false, dense = true;
+					for(const vector<UnitPlan> &pass : passes){ for(const UnitPlan &u : pass){ any = true; dense = dense && !u.sparse_rows; } }
+					reader.release(any && dense);
+				}
 				for(const vector<UnitPlan> &pass : passes){
 					if(pass.empty()){ continue; }
 					// the query files of this pass are read ahead from now on, beside the loading
@@ -983,6 +1110,8 @@ int main(int argc, char *argv[])
 						cerr << "[kwage] device " << devices[di] << " pass of " << resident.size() << " unit(s) searched" << endl;
 					}
 				}
+				kwage_set_load_progress(ctx, nullptr);
+				if(ndev == 1){ reader.finish(); }          // everything is loaded: the reader has nothing left to do
 				const double t_down = now_s();
 				kwage_shutdown(ctx);
 				lock_guard<mutex> lk(merge_lock);        // as the reference's `omp critical` section, kwage.cpp:154-177

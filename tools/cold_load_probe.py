@@ -65,8 +65,10 @@ try:
                 pass
     dt = time.perf_counter() - t0
     print("read again (page cache): %.2f s = %.2f GB/s" % (dt, gb / dt))
-    for label, extra in (("default (locked mappings + copy engine)", {}), ("pread into pinned buffers (KWAGE_LOAD_MMAP=0)", {"KWAGE_LOAD_MMAP": "0"}),
-                         ("default (locked mappings + copy engine)", {}), ("pread into pinned buffers (KWAGE_LOAD_MMAP=0)", {"KWAGE_LOAD_MMAP": "0"})):
+    for label, extra in (("default (reader process, 4 threads)", {}), ("no reader process (KWAGE_CACHE_READER=0)", {"KWAGE_CACHE_READER": "0"}),
+                         ("reader process, 1 thread", {"KWAGE_CACHE_READER": "1"}), ("reader process, 8 threads", {"KWAGE_CACHE_READER": "8"}),
+                         ("pread path, no reader (KWAGE_LOAD_MMAP=0)", {"KWAGE_LOAD_MMAP": "0", "KWAGE_CACHE_READER": "0"}),
+                         ("default (reader process, 4 threads)", {}), ("no reader process (KWAGE_CACHE_READER=0)", {"KWAGE_CACHE_READER": "0"})):
         for state in ("cold", "warm"):
             if state == "cold":
                 evict()
