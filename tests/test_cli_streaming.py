@@ -133,3 +133,27 @@ def test_query_files_are_read_once_in_a_single_pass(oracle, tmp_path, golden_dir
         t.join(timeout=10)
         assert got.returncode == 0, got.stderr.decode()
         assert got.stdout == want.stdout, env_extra
+
+
+def test_page_cache_reader_process_changes_nothing_but_the_loading(tmp_path, golden_dir):
+    """The CLI's page-cache reader (a child forked before the GPU is touched) with 0, 1 and 4 threads, on database files
+    evicted from the page cache, whole-file loading forced: identical reports, exit status 0, and the child is gone
+    when the program ends (its stdout pipe closes: subprocess.run returns)."""
+    import shutil
+    from kwage_amd import native
+    base = os.path.join(golden_dir, "multi")
+    dbs = str(tmp_path / "dbs")
+    shutil.copytree(os.path.join(base, "dbs"), dbs)
+    argv = [native.KWAGE_BIN, "-d", dbs, "-i", os.path.join(base, "reads.fastq"), "-t", "0.7", "--o.json"]
+    outs = []
+    for threads in ("0", "1", "4"):
+        for root, _, names in os.walk(dbs):
+            for n in names:
+                fd = os.open(os.path.join(root, n), os.O_RDONLY)
+                os.fsync(fd)
+                os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+                os.close(fd)
+        r = subprocess.run(argv, capture_output=True, env=dict(os.environ, KWAGE_CACHE_READER=threads, KWAGE_SPARSE="0", KWAGE_CACHE_READER_AHEAD_MB="1"), timeout=120)
+        assert r.returncode == 0, r.stderr.decode()
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 100
