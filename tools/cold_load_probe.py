@@ -68,6 +68,8 @@ try:
     for label, extra in (("default (reader process, 4 threads)", {}), ("no reader process (KWAGE_CACHE_READER=0)", {"KWAGE_CACHE_READER": "0"}),
                          ("reader process, 1 thread", {"KWAGE_CACHE_READER": "1"}), ("reader process, 8 threads", {"KWAGE_CACHE_READER": "8"}),
                          ("pread path, no reader (KWAGE_LOAD_MMAP=0)", {"KWAGE_LOAD_MMAP": "0", "KWAGE_CACHE_READER": "0"}),
+                         ("pread path + reader process", {"KWAGE_LOAD_MMAP": "0"}),
+                         ("hipHostRegister path + reader process (KWAGE_LOAD_SDMA=0)", {"KWAGE_LOAD_SDMA": "0"}),
                          ("default (reader process, 4 threads)", {}), ("no reader process (KWAGE_CACHE_READER=0)", {"KWAGE_CACHE_READER": "0"})):
         for state in ("cold", "warm"):
             if state == "cold":
