@@ -902,14 +902,29 @@ int main(int argc, char *argv[])
 		const uint64_t max_group_bytes = env_u64("KWAGE_MAX_GROUP_BYTES", 0);       // 0 = what is free on the device
 		const bool verbose = env_u64("KWAGE_VERBOSE", 0) != 0;
 
-		// The page-cache reader (one device only: the workers of several devices load their shares side by side): forked
-		// here, before the first HIP call and before any thread exists; it waits until the plan says whole files are read.
-		CacheReader reader;
+		// A device's share of a group: a file belongs to the device that owns its middle column.
+		auto share_of = [&](const vector<uint32_t> &group_files, size_t di) {
+			uint64_t total = 0;
+			for(uint32_t fi : group_files){ total += files[fi].header.num_filter; }
+			vector<uint32_t> members;
+			uint64_t before = 0;
+			for(uint32_t fi : group_files){
+				const uint64_t nf = files[fi].header.num_filter;
+				const size_t owner = min<size_t>(ndev - 1, (size_t)(((long double)before + nf/2.0L)*ndev/max<uint64_t>(total, 1)));
+				if(owner == di){ members.push_back(fi); }
+				before += nf;
+			}
+			return members;
+		};
+
+		// The page-cache readers, one per device (each follows the loading of its device's share): forked here, before
+		// the first HIP call and before any thread exists; they wait until the plan says whole files are read.
+		vector<CacheReader> readers(ndev);
+		vector<vector<string> > load_order(ndev);
 		const unsigned reader_threads = (unsigned)min<uint64_t>(env_u64("KWAGE_CACHE_READER", 4), 16);
-		vector<string> load_order;
-		if(ndev == 1 && reader_threads){
-			for(const auto &grp_entry : groups){ for(uint32_t fi : grp_entry.second){ load_order.push_back(files[fi].path); } }
-			reader.start(load_order, reader_threads, env_u64("KWAGE_CACHE_READER_AHEAD_MB", 8192) << 20);
+		for(size_t di = 0; di < ndev && reader_threads; ++di){
+			for(const auto &grp_entry : groups){ for(uint32_t fi : share_of(grp_entry.second, di)){ load_order[di].push_back(files[fi].path); } }
+			readers[di].start(load_order[di], reader_threads, env_u64("KWAGE_CACHE_READER_AHEAD_MB", 8192) << 20);
 		}
 
 		// A small query set is read ONCE, up front, and reused for every group and pass; it is also what makes the sparse
@@ -942,7 +957,7 @@ int main(int argc, char *argv[])
 		}
 
 		// whole files are certain to be read when no sparse group can come about: the reader may start during HIP initialisation
-		if(!small_set || sparse_mode == "0"){ reader.release(true); }
+		if(!small_set || sparse_mode == "0"){ for(CacheReader &r : readers){ r.release(true); } }
 
 		Findings from_command_line, from_files;
 		mutex merge_lock;
@@ -955,6 +970,7 @@ int main(int argc, char *argv[])
 				kwage_ctx *ctx = nullptr;
 				check(kwage_init(devices[di], &ctx));
 				if(verbose){ lock_guard<mutex> lk(merge_lock); cerr << "[kwage] device " << devices[di] << " ready: " << rss_mb() << endl; }
+				CacheReader &reader = readers[di];
 				if(reader.shared){ kwage_set_load_progress(ctx, &reader.shared->passed); }
 				double t_load = 0, t_search = 0, t_free = 0, gb_loaded = 0;
 				const double t_init = now_s() - t_start;
@@ -980,17 +996,7 @@ int main(int argc, char *argv[])
 				uint64_t pass_left = budget;
 				const bool one_unit_per_pass = env_u64("KWAGE_ONE_UNIT_PER_PASS", 0) != 0;      // measurement hook: the schedule before units shared passes
 				for(const auto &grp_entry : groups){
-					// this device's share: a file belongs to the device that owns its middle column
-					uint64_t total = 0;
-					for(uint32_t fi : grp_entry.second){ total += files[fi].header.num_filter; }
-					vector<uint32_t> members;
-					uint64_t before = 0;
-					for(uint32_t fi : grp_entry.second){
-						const uint64_t nf = files[fi].header.num_filter;
-						const size_t owner = min<size_t>(ndev - 1, (size_t)(((long double)before + nf/2.0L)*ndev/max<uint64_t>(total, 1)));
-						if(owner == di){ members.push_back(fi); }
-						before += nf;
-					}
+					const vector<uint32_t> members = share_of(grp_entry.second, di);
 					if(members.empty()){ continue; }
 					kwage_params p;
 					p.kmer_len = grp_entry.first.kmer_len;
@@ -1111,7 +1117,7 @@ int main(int argc, char *argv[])
 					}
 				}
 				kwage_set_load_progress(ctx, nullptr);
-				if(ndev == 1){ reader.finish(); }          // everything is loaded: the reader has nothing left to do
+				reader.finish();          // everything is loaded: the reader has nothing left to do
 				const double t_down = now_s();
 				kwage_shutdown(ctx);
 				lock_guard<mutex> lk(merge_lock);        // as the reference's `omp critical` section, kwage.cpp:154-177

@@ -146,14 +146,14 @@ def test_page_cache_reader_process_changes_nothing_but_the_loading(tmp_path, gol
     shutil.copytree(os.path.join(base, "dbs"), dbs)
     argv = [native.KWAGE_BIN, "-d", dbs, "-i", os.path.join(base, "reads.fastq"), "-t", "0.7", "--o.json"]
     outs = []
-    for threads in ("0", "1", "4"):
+    for threads, devices in (("0", "0"), ("1", "0"), ("4", "0"), ("2", "0,0")):       # the last: one reader per device context
         for root, _, names in os.walk(dbs):
             for n in names:
                 fd = os.open(os.path.join(root, n), os.O_RDONLY)
                 os.fsync(fd)
                 os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
                 os.close(fd)
-        r = subprocess.run(argv, capture_output=True, env=dict(os.environ, KWAGE_CACHE_READER=threads, KWAGE_SPARSE="0", KWAGE_CACHE_READER_AHEAD_MB="1"), timeout=120)
+        r = subprocess.run(argv, capture_output=True, env=dict(os.environ, KWAGE_CACHE_READER=threads, KWAGE_DEVICES=devices, KWAGE_SPARSE="0", KWAGE_CACHE_READER_AHEAD_MB="1"), timeout=120)
         assert r.returncode == 0, r.stderr.decode()
         outs.append(r.stdout)
-    assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 100
+    assert outs[0] == outs[1] == outs[2] == outs[3] and len(outs[0]) > 100
