@@ -162,6 +162,32 @@ void hits_are_filed_under_their_queries()
 	for(const auto &kv : got.by_query){ EXPECT(a.by_query[kv.first].size() == 2*kv.second.size()); }
 }
 
+void page_cache_reader_starts_stops_and_is_reaped()
+{
+	char dir[] = "/tmp/kwage_reader_unit_XXXXXX";
+	EXPECT(mkdtemp(dir) != nullptr);
+	vector<string> paths;
+	for(int f = 0; f < 3; ++f){
+		paths.push_back(string(dir) + "/f" + to_string(f) + ".bin");
+		ofstream o(paths.back().c_str(), ios::binary);
+		const string block(1 << 20, (char)('a' + f));
+		for(int i = 0; i < 3; ++i){ o << block; }
+	}
+	for(int mode = 0; mode < 3; ++mode){
+		CacheReader r;
+		r.start(paths, 2, 1 << 20);
+		EXPECT(r.shared != nullptr && r.child > 0);
+		if(mode == 1){ r.release(true); usleep(50000); }                          // reads (or finds resident) everything within its look-ahead
+		if(mode == 2){ r.release(true); r.shared->passed = 9u << 20; usleep(50000); }       // the loader has passed everything: nothing to do
+		r.finish();                                                                // mode 0: never released -- must still end at once
+		EXPECT(r.shared == nullptr && r.child == -1);
+		int status = 0;
+		EXPECT(waitpid(-1, &status, WNOHANG) == -1);                              // no child left behind
+	}
+	for(const string &p : paths){ remove(p.c_str()); }
+	rmdir(dir);
+}
+
 }  // namespace
 
 int main()
@@ -171,6 +197,7 @@ int main()
 	read_ahead_can_be_dropped_early();
 	integers_and_percentages_match_printf();
 	hits_are_filed_under_their_queries();
+	page_cache_reader_starts_stops_and_is_reaped();
 	printf("%d failure(s)\n", failures);
 	return failures ? 1 : 0;
 }

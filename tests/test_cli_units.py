@@ -1,5 +1,6 @@
 """Host-side pieces of the CLI that need no GPU -- the read-ahead query source (order, error hand-over, early
-destruction), the filing of hits under their queries, the report writers' number formatting against printf --
+destruction), the filing of hits under their queries, the report writers' number formatting against printf, the page-cache reader
+process (starts, respects its look-ahead, stops, is reaped) --
 compiled from the CLI's own translation unit under AddressSanitizer + UndefinedBehaviorSanitizer."""
 import os
 import shutil
