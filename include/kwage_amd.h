@@ -188,6 +188,11 @@ typedef struct {
 	                                 * "count_narrow_kernel<7,1,4>", "...+segments"; "" if none.  Owned by the result. */
 } kwage_result;
 
+/* Order `n` hit records by (query, column) in place, on the host (LSD radix sort on the 64-bit key; no device is
+ * touched).  What a caller that gathers the unsorted device-resident lists of several shards needs after adding each
+ * shard's column base (kwage_amd/distributed.py). */
+void kwage_sort_hits(kwage_hit *hits, uint64_t n);
+
 int kwage_search(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
                  kwage_result **out);
 void kwage_result_free(kwage_result *r);

@@ -1976,6 +1976,11 @@ int build_result(Slot *sl, kwage_group *g, kwage_batch *b, const SearchOutcome &
 
 }  // namespace
 
+extern "C" void kwage_sort_hits(kwage_hit *hits, uint64_t n)
+{
+	if(hits && n > 1){ sort_hits(hits, (size_t)n); }
+}
+
 struct kwage_pending { Slot *sl; };
 
 extern "C" int kwage_search_submit(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags, kwage_pending **out)

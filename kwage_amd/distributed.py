@@ -85,19 +85,22 @@ def gatherv_hits(local_hits, dist, rank: int, world: int, dst: int = 0, device=N
 
 def merge_hits(parts: Sequence[np.ndarray], column_base: Sequence[int]) -> np.ndarray:
     """Concatenate per-rank [n,3] (query, local column, num_match) records into global columns,
-    sorted by (query, column).  Column ranges are disjoint, so this is a plain concatenation."""
+    sorted by (query, column).  Column ranges are disjoint, so this is a plain concatenation; the order is made by the
+    library's host radix sort (kwage_sort_hits: 1.2 M records in tens of ms where numpy's lexsort takes 0.4 s -- more
+    than a C3 search step)."""
     rows = []
     for r, p in enumerate(parts):
-        p = np.asarray(p, dtype=np.int64).reshape(-1, 3)
+        p = np.asarray(p).reshape(-1, 3)
         if len(p):
-            q = p.copy()
-            q[:, 1] += int(column_base[r])
+            q = p.astype(np.uint32)           # a copy: the caller's buffer is left alone
+            q[:, 1] += np.uint32(int(column_base[r]))
             rows.append(q)
     if not rows:
         return np.zeros((0, 3), dtype=np.int64)
-    allh = np.concatenate(rows)
-    order = np.lexsort((allh[:, 1], allh[:, 0]))
-    return allh[order]
+    allh = np.ascontiguousarray(np.concatenate(rows))
+    from . import native
+    native.lib().kwage_sort_hits(allh.ctypes.data, len(allh))
+    return allh.astype(np.int64)
 
 
 def merge_hits_torch(parts, column_base):

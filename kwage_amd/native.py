@@ -102,6 +102,7 @@ _SIGNATURES = [
     ("kwage_shutdown", None, [_P]),
     ("kwage_mem_info", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("kwage_set_load_progress", None, [_P, C.POINTER(C.c_uint64)]),
+    ("kwage_sort_hits", None, [C.c_void_p, C.c_uint64]),
     ("kwage_sync", C.c_int, [_P]),
     ("kwage_group_create", C.c_int, [_P, C.POINTER(Params), C.c_uint64, C.POINTER(_P)]),
     ("kwage_group_destroy", None, [_P]),
