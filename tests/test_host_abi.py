@@ -144,6 +144,28 @@ def test_query_threshold(L, oracle):
             assert L.kwage_query_threshold(C.c_float(t), n) == oracle.query_threshold(t, n)
 
 
+def test_sort_hits_orders_by_query_then_column(L):
+    """kwage_sort_hits (host, no device): every size around the switch from std::sort to the radix sort, keys that
+    differ in one digit only, values at both ends of 32 bits; against numpy's lexsort, the payload carried along."""
+    rng = np.random.default_rng(12)
+    for n in (0, 1, 2, 255, 256, 257, 5000, 300_000):
+        for spread in ("wide", "narrow", "extreme"):
+            if spread == "wide":
+                q, c = rng.integers(0, 1 << 20, n), rng.integers(0, 1 << 17, n)
+            elif spread == "narrow":
+                q, c = rng.integers(7, 9, n), rng.integers(0, 3, n) << 11        # one varying digit in each field
+            else:
+                q, c = rng.choice([0, 1, 0xFFFFFFFE, 0xFFFFFFFF], n), rng.choice([0, 0x7FF, 0x800, 0xFFFFFFFF], n)
+            h = np.stack([q, c, np.arange(n)], axis=1).astype(np.uint32)
+            want = h[np.lexsort((np.arange(n), h[:, 1], h[:, 0]))]
+            got = np.ascontiguousarray(h.copy())
+            L.kwage_sort_hits(got.ctypes.data, n)
+            assert np.array_equal(got[:, :2], want[:, :2]), (n, spread)
+            # equal keys may come in any order: compare the payloads as multisets per key
+            assert sorted(map(tuple, got.tolist())) == sorted(map(tuple, want.tolist())), (n, spread)
+    L.kwage_sort_hits(None, 0)
+
+
 def test_cli_usage_and_validation_without_gpu():
     """Option handling mirrors options.cpp:39-192 and needs no device."""
     import subprocess
