@@ -526,6 +526,7 @@ bool SeqFile::open(const std::string &path, std::string &err)
 	if(type == 2){ err = "SequenceIterator: Unknown file type"; return false; }
 	fin = gzopen(path.c_str(), "r");      // plain and gzip files alike, parse_sequence.cpp:40
 	if(!fin){ err = "Error opening: " + path; return false; }
+	(void)gzbuffer((gzFile)fin, 1u << 20);      // zlib's own input buffer is 8 KiB by default: one read() per 8 KiB of a .gz file
 	return true;
 }
 
