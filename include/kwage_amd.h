@@ -68,6 +68,13 @@ int kwage_mem_info(kwage_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
 /* Block until everything queued on the context's stream has finished. */
 int kwage_sync(kwage_ctx *ctx);
 
+/* Kernel-selection knobs of a context ("walk", "walk_waves", "force_segs", "count_walk", "and_vec", ...: the table in
+ * kwage_amd/csrc/engine.hip).  Their values are read ONCE, when the context is created, from the environment
+ * (KWAGE_<NAME IN CAPITALS>); afterwards only these calls change them -- nothing on the search path looks at the
+ * environment.  For tests and tuning tools: no knob changes any result.  Not while a search is pending. */
+int kwage_ctx_set_tuning(kwage_ctx *ctx, const char *name, int64_t value);
+int kwage_ctx_get_tuning(kwage_ctx *ctx, const char *name, int64_t *value);
+
 /* ------------------------------------------------------------------------------------
  * Database group: all columns (samples) that share (kmer_len, num_hash, log_2_filter_len,
  * hash_func), concatenated into ONE wide row-major bit matrix resident in HBM.
@@ -113,10 +120,11 @@ int kwage_group_add_db_file(kwage_group *g, const char *path, uint64_t *first_co
                             uint32_t *num_filter);
 
 /* The same for `n` files, columns in the order given; first_columns / num_filters (n entries each, may be
- * NULL) receive what kwage_group_add_db_file reports per file.  Prefer this when a group has many files:
- * up to 16 raw files at a time are copied side by side, so that every row of the resident matrix is
- * written in pieces of KiB instead of one 256-byte file row at a time (a 105 GB matrix of 392 files loads
- * PCIe-bound instead of DRAM-page bound). */
+ * NULL) receive what kwage_group_add_db_file reports per file.  Prefer this when a group has many files: raw
+ * files go file by file through ONE copy-engine pipeline that stays busy across file boundaries (windows of a
+ * file are locked in the page cache, copied by SDMA into staging buffers and scattered into the matrix while the
+ * next window is being locked: 45-54 GB/s).  Opt-in alternative, KWAGE_LOAD_DIRECT=1: no staging, up to 16 raw
+ * files at a time copied side by side by one kernel -- measured slower on a 105 GB matrix of 392 files. */
 int kwage_group_add_db_files(kwage_group *g, const char *const *paths, uint32_t n, uint64_t *first_columns,
                              uint32_t *num_filters);
 
@@ -222,6 +230,17 @@ int kwage_search_device_submit(kwage_group *g, kwage_batch *b, float threshold, 
                                void *hits_dev, uint64_t capacity, void *count_dev, kwage_pending **out);
 /* search_kernel_ms (may be NULL): HIP-event duration of the gather kernel(s) when KWAGE_SEARCH_TIMING was set. */
 int kwage_search_device_collect(kwage_pending *p, uint64_t *n_hits, void *num_query_kmer_dev, float *search_kernel_ms);
+
+/* Append mode, for hosts whose result list spans several groups or shards -- the reference appends the matches of every
+ * database file to one list per query (kwage.cpp:154-177): *count_dev (a device uint64, required) IS the list's hit
+ * counter.  The search appends its records behind the ones already counted there instead of starting at record 0,
+ * `column_base` is added to every reported column (each group / shard gets its own range of global column numbers),
+ * and reset_count != 0 zeroes the counter in stream order before this search (the first search of a new list).
+ * kwage_search_device_collect then reports the RUNNING total; records beyond `capacity` are counted, not stored
+ * (grow the buffer and redo the list).  The searches of one context run in submission order. */
+int kwage_search_device_append_submit(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
+                                      void *hits_dev, uint64_t capacity, void *count_dev, uint32_t column_base,
+                                      int reset_count, kwage_pending **out);
 
 /* K-mer stage alone (word.h:73-104 + kwage.cpp:362-366 + hash.cpp:176-234 on the device):
  * for query i writes its distinct canonical k-mers to kmers[kmer_offsets[i] ...] (unordered)

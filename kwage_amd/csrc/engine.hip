@@ -112,14 +112,61 @@ struct Slot {
 	char kernel_name[64] = "";          // the gather kernel launch_search_stage picked, with its template shape
 	// and_walk_kernel's meeting place for (query, tile) pairs cut by a wave-share boundary: all zero between searches
 	DevBuf walk_or, walk_done;
+	// count_walk_kernel's: partial counters of cut pairs (overwritten before they are read) and their k-mer counters (zero between searches)
+	DevBuf cwalk_slab, cwalk_done;
 	uint64_t staged_hits = 0;
 	kwage_hit *ext_hits = nullptr;      // caller-owned device buffer (kwage_search_device) or null
 	uint64_t ext_cap = 0;
 	uint64_t *ext_count = nullptr;      // optional device word that receives the hit count in stream order
+	// append mode (kwage_search_device_append_submit): *ext_count IS the hit counter -- not zeroed unless asked, so the
+	// searches of several groups fill one list -- and col_base is added to every reported column
+	bool append = false, append_reset = false;
+	uint32_t col_base = 0;
+};
+
+// Kernel-selection knobs.  They are parsed ONCE, from the environment, when a context is created, and changed afterwards
+// only through kwage_ctx_set_tuning (tests and tuning tools): nothing on the search path reads the environment.
+struct Tuning {
+	int64_t walk = 4;               // KWAGE_WALK: and_walk_kernel's rows in flight (4 or 2); 0 = always the tiled kernel
+	int64_t walk_min_rows = -1;     // KWAGE_WALK_MIN_ROWS: batches with fewer rows use the tiled kernel (-1: 64 rows per wave of the chip)
+	int64_t walk_max_kib = 16;      // KWAGE_WALK_MAX_KIB: widest row the walk form takes
+	int64_t walk_early_exit = 0;    // KWAGE_WALK_EARLY_EXIT: use the walk form with early exit too (the tiled kernel stops sooner)
+	int64_t walk_waves = 0;         // KWAGE_WALK_WAVES: exactly this many waves (tests: shares of every size); 0 = from the CU count
+	int64_t walk_fences = 0;        // KWAGE_WALK_FENCES: agent-scope fences around the cut-pair count (measurement only)
+	int64_t and_vec = 0;            // KWAGE_AND_CFG="vec,unroll,nt[,ldsKB[,block waves]]": shape of the tiled AND kernel (0 = by row width)
+	int64_t and_unroll = 8;
+	int64_t and_nt = 1;
+	int64_t and_lds_kb = 0;         //   dynamic LDS per workgroup caps the waves per CU (tuning only)
+	int64_t and_block_waves = SEARCH_THREADS/WAVE;
+	int64_t narrow = 1;             // KWAGE_NARROW: several queries per wave for rows <= 512 B
+	int64_t force_segs = 0;         // KWAGE_FORCE_SEGS: cut every query's k-mer list into this many segments (tests)
+	int64_t count_walk = 1;         // KWAGE_COUNT_WALK: the persistent count kernel where it applies
+	int64_t count_walk_wpc = 16;    // KWAGE_COUNT_WALK_WPC: its waves per CU
+	int64_t count_walk_waves = 0;   // KWAGE_COUNT_WALK_WAVES: exactly this many waves (tests)
+	int64_t count_walk_min_rows = -1;   // KWAGE_COUNT_WALK_MIN_ROWS
+	int64_t count_walk_max_parts = 8;   // KWAGE_COUNT_WALK_MAX_PARTS: longest chain of parts one wave adds up; longer queries use segments
+	int64_t count_narrow_kps = 8;   // KWAGE_COUNT_NARROW_KPS: k-mers per step of the narrow count kernel (8 or 4)
+	int64_t hit_sort_host = 0;      // KWAGE_HIT_SORT=host: order long hit lists on the host (A/B runs, the fallback)
+	int64_t hit_copy_piece_kb = 0;  // KWAGE_HIT_COPY_PIECE_KB: piece size of the copy-back of a long hit list (0 = default)
+	int64_t shared_table_log2 = 0;  // KWAGE_SHARED_TABLE_LOG2: at least this many slots in a sample's shared distinct set (tests)
+};
+
+struct TuningName { const char *name; int64_t Tuning::*field; };
+static const TuningName TUNING_NAMES[] = {
+	{"walk", &Tuning::walk}, {"walk_min_rows", &Tuning::walk_min_rows}, {"walk_max_kib", &Tuning::walk_max_kib},
+	{"walk_early_exit", &Tuning::walk_early_exit}, {"walk_waves", &Tuning::walk_waves}, {"walk_fences", &Tuning::walk_fences},
+	{"and_vec", &Tuning::and_vec}, {"and_unroll", &Tuning::and_unroll}, {"and_nt", &Tuning::and_nt}, {"and_lds_kb", &Tuning::and_lds_kb},
+	{"and_block_waves", &Tuning::and_block_waves}, {"narrow", &Tuning::narrow}, {"force_segs", &Tuning::force_segs},
+	{"count_walk", &Tuning::count_walk}, {"count_walk_wpc", &Tuning::count_walk_wpc}, {"count_walk_waves", &Tuning::count_walk_waves},
+	{"count_walk_min_rows", &Tuning::count_walk_min_rows}, {"count_walk_max_parts", &Tuning::count_walk_max_parts},
+	{"count_narrow_kps", &Tuning::count_narrow_kps},
+	{"hit_sort_host", &Tuning::hit_sort_host}, {"hit_copy_piece_kb", &Tuning::hit_copy_piece_kb}, {"shared_table_log2", &Tuning::shared_table_log2},
 };
 
 struct kwage_ctx {
 	int device = -1;
+	int ncu = 0;                        // compute units of the device (persistent grids are sized from it)
+	Tuning tune;
 	hipStream_t stream = nullptr;       // == slot[0].stream; loading, building and the synchronous calls use it
 	Slot slot[2];
 	DevBuf kmers;                       // kwage_hash_batch output
@@ -439,27 +486,57 @@ int launch_kmer_stage(Slot *sl, const kwage_params &p, kwage_batch *b, float thr
 static const uint32_t WALK_MIN_ROWS_PER_WAVE = 64;   // and_walk_kernel: below this share per wave the tiled kernel is used
 static const uint32_t WALK_WAVES_PER_CU = 8;         // 2 workgroups: 2048 waves measured 1-2 % faster than 4096 (half the cut pairs)
 
-static int g_and_lds_bytes = 0;     // tuning only: dynamic LDS per workgroup caps waves per CU
-static int g_and_block_waves = SEARCH_THREADS/WAVE;   // tuning only: waves per workgroup of and_kernel
-
 uint32_t search_blocks(const SearchArgs &a)
 {
 	const uint64_t tiles = (uint64_t)a.n_queries*a.segs*a.chunks;
 	return (uint32_t)((tiles + 3)/4);
 }
 
+// Shape of the tiled AND kernel: VEC 16-byte vectors per lane, UNROLL rows in flight, nontemporal loads, and (tuning
+// only) dynamic LDS per workgroup and waves per workgroup.  Defaults come from measurements on MI355X.
+struct AndCfg { int vec, unroll, nt, lds_bytes, block_waves; };
+
+AndCfg and_config(const Tuning &t, uint32_t units_per_row)
+{
+	AndCfg c;
+	c.vec = (t.and_vec == 1 || t.and_vec == 2 || t.and_vec == 4) ? (int)t.and_vec : ((units_per_row >= 4*WAVE) ? 2 : 1);
+	c.unroll = (t.and_unroll == 4 || t.and_unroll == 16 || t.and_unroll == 32) ? (int)t.and_unroll : 8;
+	if((c.unroll == 16 && c.vec == 4) || (c.unroll == 32 && c.vec != 1)){ c.unroll = 8; }       // shapes that are not instantiated
+	c.nt = t.and_nt ? 1 : 0;      // +4-10 % on MI355X: each row byte is consumed once per (query, tile)
+	c.lds_bytes = (t.and_lds_kb > 0 && t.and_lds_kb <= 160) ? (int)t.and_lds_kb*1024 : 0;
+	c.block_waves = (t.and_block_waves == 1 || t.and_block_waves == 2) ? (int)t.and_block_waves : SEARCH_THREADS/WAVE;
+	return c;
+}
+
 template <int VEC, int UNROLL, bool NT>
-void launch_and(const SearchArgs &a, hipStream_t s)
+void launch_and(const SearchArgs &a, hipStream_t s, const AndCfg &c)
 {
 	const uint64_t tiles = (uint64_t)a.n_queries*a.segs*a.chunks;
-	const uint32_t bw = (uint32_t)g_and_block_waves;
+	const uint32_t bw = (uint32_t)c.block_waves;
 	const dim3 grid((uint32_t)((tiles + bw - 1)/bw)), block(bw*WAVE);
 	if(a.segs > 1){
-		hipLaunchKernelGGL((and_kernel<VEC, UNROLL, NT, true>), grid, block, (size_t)g_and_lds_bytes, s, a);
+		hipLaunchKernelGGL((and_kernel<VEC, UNROLL, NT, true>), grid, block, (size_t)c.lds_bytes, s, a);
 	}
 	else{
-		hipLaunchKernelGGL((and_kernel<VEC, UNROLL, NT, false>), grid, block, (size_t)g_and_lds_bytes, s, a);
+		hipLaunchKernelGGL((and_kernel<VEC, UNROLL, NT, false>), grid, block, (size_t)c.lds_bytes, s, a);
 	}
+}
+
+template <int VEC, bool NT>
+void launch_and_u(const SearchArgs &a, hipStream_t s, const AndCfg &c)
+{
+	if(c.unroll == 4){ launch_and<VEC, 4, NT>(a, s, c); }
+	else if(c.unroll == 16 && VEC < 4){ launch_and<VEC, 16, NT>(a, s, c); }
+	else if(c.unroll == 32 && VEC == 1){ launch_and<VEC, 32, NT>(a, s, c); }
+	else{ launch_and<VEC, 8, NT>(a, s, c); }
+}
+
+template <bool NT>
+void launch_and_v(const SearchArgs &a, hipStream_t s, const AndCfg &c)
+{
+	if(c.vec == 1){ launch_and_u<1, NT>(a, s, c); }
+	else if(c.vec == 2){ launch_and_u<2, NT>(a, s, c); }
+	else{ launch_and_u<4, NT>(a, s, c); }
 }
 
 template <int PLANES, int NH>
@@ -473,18 +550,25 @@ void launch_count(const SearchArgs &a, hipStream_t s)
 	}
 }
 
-template <int PLANES, int G>
+template <int PLANES, int G, int KPS>
 void launch_count_narrow(const SearchArgs &a, hipStream_t s)
 {
 	const uint64_t waves = ((uint64_t)a.n_queries + G - 1)/G;
 	const dim3 grid((uint32_t)((waves + 3)/4)), block(SEARCH_THREADS);
 	switch(a.num_hash){
-		case 1: hipLaunchKernelGGL((count_narrow_kernel<PLANES, 1, G>), grid, block, 0, s, a); break;
-		case 2: hipLaunchKernelGGL((count_narrow_kernel<PLANES, 2, G>), grid, block, 0, s, a); break;
-		case 3: hipLaunchKernelGGL((count_narrow_kernel<PLANES, 3, G>), grid, block, 0, s, a); break;
-		case 4: hipLaunchKernelGGL((count_narrow_kernel<PLANES, 4, G>), grid, block, 0, s, a); break;
-		default: hipLaunchKernelGGL((count_narrow_kernel<PLANES, 5, G>), grid, block, 0, s, a); break;
+		case 1: hipLaunchKernelGGL((count_narrow_kernel<PLANES, 1, G, KPS>), grid, block, 0, s, a); break;
+		case 2: hipLaunchKernelGGL((count_narrow_kernel<PLANES, 2, G, KPS>), grid, block, 0, s, a); break;
+		case 3: hipLaunchKernelGGL((count_narrow_kernel<PLANES, 3, G, KPS>), grid, block, 0, s, a); break;
+		case 4: hipLaunchKernelGGL((count_narrow_kernel<PLANES, 4, G, KPS>), grid, block, 0, s, a); break;
+		default: hipLaunchKernelGGL((count_narrow_kernel<PLANES, 5, G, KPS>), grid, block, 0, s, a); break;
 	}
+}
+
+template <int PLANES, int G>
+void launch_count_narrow_k(const SearchArgs &a, hipStream_t s, int kps)
+{
+	if(kps == 4){ launch_count_narrow<PLANES, G, 4>(a, s); }
+	else{ launch_count_narrow<PLANES, G, 8>(a, s); }
 }
 
 template <int PLANES>
@@ -519,6 +603,19 @@ void launch_count_planes(uint32_t planes, const SearchArgs &a, hipStream_t s)
 }
 
 template <int PLANES>
+void launch_count_walk_nh(const SearchArgs &a, const CountWalkArgs &wa, uint32_t wgs, hipStream_t s)
+{
+	const dim3 grid(wgs), block(SEARCH_THREADS);
+	switch(a.num_hash){
+		case 1: hipLaunchKernelGGL((count_walk_kernel<PLANES, 1>), grid, block, 0, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr); break;
+		case 2: hipLaunchKernelGGL((count_walk_kernel<PLANES, 2>), grid, block, 0, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr); break;
+		case 3: hipLaunchKernelGGL((count_walk_kernel<PLANES, 3>), grid, block, 0, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr); break;
+		case 4: hipLaunchKernelGGL((count_walk_kernel<PLANES, 4>), grid, block, 0, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr); break;
+		default: hipLaunchKernelGGL((count_walk_kernel<PLANES, 5>), grid, block, 0, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr); break;
+	}
+}
+
+template <int PLANES>
 int launch_count_combine(const SearchArgs &a, uint32_t seg_planes, hipStream_t s)
 {
 	const size_t lds = (size_t)(COMBINE_WAVES/2)*PLANES*WAVE*16;
@@ -529,51 +626,10 @@ int launch_count_combine(const SearchArgs &a, uint32_t seg_planes, hipStream_t s
 	return KWAGE_OK;
 }
 
-// Shape of the AND kernel: VEC 16-byte vectors per lane, UNROLL rows in flight, nontemporal loads.
-// Defaults come from measurements on MI355X; KWAGE_AND_CFG="vec,unroll,nt[,ldsKB]"
-// overrides them for tuning runs (read on every launch so one process can sweep variants).
-struct AndCfg { int vec, unroll, nt; };
-
-AndCfg and_config(uint32_t units_per_row)
-{
-	AndCfg c;
-	c.vec = (units_per_row >= 4*WAVE) ? 2 : 1;
-	c.unroll = 8;
-	c.nt = 1;      // +4-10 % on MI355X: each row byte is consumed once per (query, tile)
-	const char *e = getenv("KWAGE_AND_CFG");
-	if(e){
-		int v = 0, u = 0, n = 0, l = 0, w = 0;
-		const int got = sscanf(e, "%d,%d,%d,%d,%d", &v, &u, &n, &l, &w);
-		if(got >= 3 && (v == 1 || v == 2 || v == 4) && (u == 4 || u == 8 || u == 16 || u == 32)){
-			c.vec = v; c.unroll = u; c.nt = n ? 1 : 0;
-			g_and_lds_bytes = (got >= 4 && l > 0 && l <= 160) ? l*1024 : 0;
-			g_and_block_waves = (got >= 5 && (w == 1 || w == 2 || w == 4)) ? w : SEARCH_THREADS/WAVE;
-		}
-	}
-	return c;
-}
-
-template <int VEC, bool NT>
-void launch_and_u(const SearchArgs &a, hipStream_t s, int unroll)
-{
-	if(unroll == 4){ launch_and<VEC, 4, NT>(a, s); }
-	else if(unroll == 16 && VEC < 4){ launch_and<VEC, 16, NT>(a, s); }
-	else if(unroll == 32 && VEC == 1){ launch_and<VEC, 32, NT>(a, s); }
-	else{ launch_and<VEC, 8, NT>(a, s); }
-}
-
-template <bool NT>
-void launch_and_v(const SearchArgs &a, hipStream_t s, const AndCfg &c)
-{
-	if(c.vec == 1){ launch_and_u<1, NT>(a, s, c.unroll); }
-	else if(c.vec == 2){ launch_and_u<2, NT>(a, s, c.unroll); }
-	else{ launch_and_u<4, NT>(a, s, c.unroll); }
-}
-
 // How many segments to cut each query's k-mer list into: none while the launch already has
 // enough waves to fill the chip; otherwise enough to reach ~TARGET_TILES waves (about 8 per CU, ~2x the bytes in flight that cover HBM latency), but never segments
-// shorter than MIN_SEG_KMERS k-mers.  KWAGE_FORCE_SEGS=<n> forces n (tests).
-void choose_segments(SearchArgs &a, uint64_t max_kmers, uint64_t max_segs)
+// shorter than MIN_SEG_KMERS k-mers.  The force_segs knob forces a count (tests).
+void choose_segments(SearchArgs &a, uint64_t max_kmers, uint64_t max_segs, int64_t force_segs)
 {
 	static const uint64_t TARGET_TILES = 2048, MIN_SEG_KMERS = 64;
 	const uint64_t MAX_SEGS = max_segs;
@@ -581,8 +637,7 @@ void choose_segments(SearchArgs &a, uint64_t max_kmers, uint64_t max_segs)
 	a.seg_kmers = (uint32_t)std::max<uint64_t>(max_kmers, 1);
 	if(a.n_queries > 65535){ return; }      // the combine kernels index queries with gridDim.y
 	uint64_t want = 1;
-	const char *f = getenv("KWAGE_FORCE_SEGS");
-	if(f && atoi(f) > 0){ want = (uint64_t)atoi(f); }
+	if(force_segs > 0){ want = (uint64_t)force_segs; }
 	else{
 		const uint64_t tiles = (uint64_t)a.n_queries*a.chunks;
 		if(tiles >= TARGET_TILES || max_kmers < 2*MIN_SEG_KMERS){ return; }
@@ -594,10 +649,22 @@ void choose_segments(SearchArgs &a, uint64_t max_kmers, uint64_t max_segs)
 	a.segs = (uint32_t)((max_kmers + a.seg_kmers - 1)/a.seg_kmers);
 }
 
+// A scratch buffer the kernels leave all zero: cleared when it is (re)allocated, never per search.
+int reserve_zeroed(DevBuf &buf, uint64_t bytes, hipStream_t s)
+{
+	if(bytes <= buf.cap){ return KWAGE_OK; }
+	int rc = buf.reserve(bytes);
+	if(rc){ return rc; }
+	HIP_TRY(hipMemsetAsync(buf.p, 0, buf.cap, s));
+	return KWAGE_OK;
+}
+
 // Launch the gather+reduce kernel(s) for the current batch.
 int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
-                        kwage_hit *d_hits, uint64_t cap)
+                        kwage_hit *d_hits, uint64_t cap, unsigned long long *hit_count)
 {
+	const Tuning &tn = g->ctx->tune;
+	const uint64_t ncu = (uint64_t)std::max(g->ctx->ncu, 1);
 	SearchArgs a;
 	a.db = g->d_bits;
 	a.stride = g->stride;
@@ -611,19 +678,19 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 	a.n_queries = b->n;
 	a.hits = d_hits;
 	a.cap = cap;
-	a.hit_count = (unsigned long long*)sl->d_counters;
+	a.hit_count = hit_count;
 	a.early_exit = (flags & KWAGE_SEARCH_EARLY_EXIT) ? 1 : 0;
 	a.partial = nullptr;
+	a.col_base = sl->col_base;
 	int rc;
 
 	if(threshold == 1.0f){
-		const AndCfg cfg = and_config(a.units_per_row);
+		const AndCfg cfg = and_config(tn, a.units_per_row);
 		a.chunks = (a.units_per_row + WAVE*cfg.vec - 1)/(WAVE*cfg.vec);
-		choose_segments(a, b->max_pos, 4096);
+		choose_segments(a, b->max_pos, 4096, tn.force_segs);
 		if((uint64_t)a.n_queries*a.segs*a.chunks/4 + 1 > 0x7FFFFFFFull){ return fail(KWAGE_ERR_ARG, "batch too large for one launch"); }
-		// narrow rows: several queries per wave (tools/bench_narrow.py); KWAGE_NARROW=0 disables it
-		static const bool narrow_ok = []() { const char *e = getenv("KWAGE_NARROW"); return !(e && atoi(e) == 0); }();
-		if(narrow_ok && a.segs == 1 && a.units_per_row <= 32 && a.n_queries >= 64){
+		// narrow rows: several queries per wave (tools/bench_narrow.py)
+		if(tn.narrow && a.segs == 1 && a.units_per_row <= 32 && a.n_queries >= 64){
 			const uint32_t G = (a.units_per_row <= 4) ? 16 : (a.units_per_row <= 8) ? 8 : (a.units_per_row <= 16) ? 4 : 2;
 			const uint64_t waves = ((uint64_t)a.n_queries + G - 1)/G;
 			const dim3 grid((uint32_t)((waves + 3)/4)), block(SEARCH_THREADS);
@@ -640,32 +707,23 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 		// rows of 3..16 KiB: the walk form (a persistent grid, every wave walks an equal share of the batch's row
 		// list over the whole width of a column tile; kernels.hpp and_walk_kernel).  Worth it once every wave of
 		// the chip gets a few dozen rows; smaller batches stay with the tiled kernel and its row-list segments.
-		// KWAGE_WALK=0 keeps the tiled kernel, KWAGE_WALK=2 selects two rows in flight instead of four;
-		// KWAGE_WALK_MIN_ROWS / KWAGE_WALK_MAX_KIB move the limits (tests force the walk form on tiny inputs).
-		// (read per call, like KWAGE_AND_CFG: tools/tune_walk.py switches them inside one process)
-		const char *we = getenv("KWAGE_WALK"), *wr = getenv("KWAGE_WALK_MIN_ROWS");
-		const int walk_unroll = we ? atoi(we) : 4;
-		const uint64_t walk_min_rows = wr ? strtoull(wr, nullptr, 10) : (uint64_t)WALK_MIN_ROWS_PER_WAVE*256*WALK_WAVES_PER_CU;
+		const int walk_unroll = (int)tn.walk;
+		const uint64_t walk_min_rows = (tn.walk_min_rows >= 0) ? (uint64_t)tn.walk_min_rows : (uint64_t)WALK_MIN_ROWS_PER_WAVE*256*WALK_WAVES_PER_CU;
 		const uint32_t kib = (a.units_per_row + WAVE - 1)/WAVE;
-		// (the kernel handles wider rows as several balanced column tiles -- KWAGE_WALK_MAX_KIB raises the limit --
+		// (the kernel handles wider rows as several balanced column tiles -- the walk_max_kib knob raises the limit --
 		// but 125 KB rows measured no gain over the tiled kernel)
-		const char *wk = getenv("KWAGE_WALK_MAX_KIB");
-		const uint32_t walk_max_kib = wk ? (uint32_t)atoi(wk) : 16u;
+		const uint32_t walk_max_kib = (uint32_t)std::max<int64_t>(tn.walk_max_kib, 0);
 		const uint32_t coltiles = (kib + 15)/16, walk_ch = (kib + coltiles - 1)/coltiles;     // balanced tiles of <= 16 KiB
 		// With early exit the tiled kernel wins: a tile that holds no candidate column stops after a few rows even
 		// when another tile of the same query holds a hit, whereas a walking wave covers the hit column's whole row
-		// width and never stops (C2 with early exit: 0.64 ms tiled, 1.29 ms walk).  KWAGE_WALK_EARLY_EXIT=1 overrides.
-		const char *wx = getenv("KWAGE_WALK_EARLY_EXIT");
-		const bool walk_ee_ok = !a.early_exit || (wx && atoi(wx) != 0);
+		// width and never stops (C2 with early exit: 0.64 ms tiled, 1.29 ms walk).
+		const bool walk_ee_ok = !a.early_exit || tn.walk_early_exit;
 		const uint64_t walk_slots = (uint64_t)coltiles*b->total_pos;
 		if(walk_unroll && walk_ee_ok && kib >= 3 && kib <= walk_max_kib && walk_slots*a.num_hash >= walk_min_rows && walk_slots > 0){
 			// WALK_WAVES_PER_CU waves per CU, all resident at once (__launch_bounds__(256, 4) allows twice as many),
 			// fewer when the batch is small: a wave should have WALK_MIN_ROWS_PER_WAVE rows to walk
-			int ncu = 0;
-			(void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, g->ctx->device);
-			const char *ww = getenv("KWAGE_WALK_WAVES");                     // tuning / tests: exactly this many waves
-			const uint64_t chip_waves = (uint64_t)std::max(ncu, 1)*WALK_WAVES_PER_CU;
-			const uint64_t want_waves = (ww && atoi(ww) > 0) ? std::min<uint64_t>((uint64_t)atoi(ww), walk_slots)
+			const uint64_t chip_waves = ncu*WALK_WAVES_PER_CU;
+			const uint64_t want_waves = (tn.walk_waves > 0) ? std::min<uint64_t>((uint64_t)tn.walk_waves, walk_slots)
 				: std::max<uint64_t>(1, std::min<uint64_t>(chip_waves, walk_slots*a.num_hash/WALK_MIN_ROWS_PER_WAVE));
 			const uint32_t wgs = (uint32_t)((want_waves + 3)/4);
 			const uint64_t waves = (uint64_t)wgs*4;
@@ -673,19 +731,12 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 			wa.total_slots = walk_slots;
 			wa.per_wave = (walk_slots + waves - 1)/waves;
 			wa.coltiles = coltiles;
-			// cut-pair slots: one per wave, 16 KiB each whatever CH is, zeroed when (re)allocated -- the kernel leaves them zero
-			const uint64_t or_bytes = waves*16*1024, done_bytes = waves*2*sizeof(uint32_t);
-			if(or_bytes > sl->walk_or.cap){
-				if((rc = sl->walk_or.reserve(or_bytes))){ return rc; }
-				HIP_TRY(hipMemsetAsync(sl->walk_or.p, 0, sl->walk_or.cap, sl->stream));
-			}
-			if(done_bytes > sl->walk_done.cap){
-				if((rc = sl->walk_done.reserve(done_bytes))){ return rc; }
-				HIP_TRY(hipMemsetAsync(sl->walk_done.p, 0, sl->walk_done.cap, sl->stream));
-			}
+			// cut-pair slots: one per wave, 16 KiB each whatever CH is; the kernel leaves them zero
+			if((rc = reserve_zeroed(sl->walk_or, waves*16*1024, sl->stream))){ return rc; }
+			if((rc = reserve_zeroed(sl->walk_done, waves*2*sizeof(uint32_t), sl->stream))){ return rc; }
 			wa.orbuf = (uint32_t*)sl->walk_or.p;
 			wa.done = (uint32_t*)sl->walk_done.p;
-			{ const char *wf = getenv("KWAGE_WALK_FENCES"); wa.full_fences = (wf && atoi(wf) != 0) ? 1 : 0; }
+			wa.full_fences = tn.walk_fences ? 1 : 0;
 			a.segs = 1;
 			a.chunks = coltiles;
 			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_walk_kernel<%u,%d>", walk_ch, walk_unroll == 2 ? 2 : 4);
@@ -709,10 +760,7 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 			HIP_TRY(hipMemsetAsync(sl->partial.p, 0xFF, bytes, sl->stream));
 			a.partial = (uint32_t*)sl->partial.p;
 		}
-		{
-			const int eff_unroll = (cfg.unroll == 4) ? 4 : (cfg.unroll == 16 && cfg.vec < 4) ? 16 : (cfg.unroll == 32 && cfg.vec == 1) ? 32 : 8;     // launch_and_u
-			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_kernel<%d,%d,%s>%s", cfg.vec, eff_unroll, cfg.nt ? "nt" : "t", a.segs > 1 ? "+segments" : "");
-		}
+		snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_kernel<%d,%d,%s>%s", cfg.vec, cfg.unroll, cfg.nt ? "nt" : "t", a.segs > 1 ? "+segments" : "");
 		if(cfg.nt){ launch_and_v<true>(a, sl->stream, cfg); }
 		else{ launch_and_v<false>(a, sl->stream, cfg); }
 		if(a.segs > 1){
@@ -723,10 +771,48 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 		a.chunks = (a.units_per_row + WAVE - 1)/WAVE;
 		// counter planes: enough bits for the largest possible num_query_kmer of the batch
 		const uint32_t planes = planes_for(b->max_pos);
+		const bool narrow = tn.narrow && a.units_per_row <= 32 && a.units_per_row > 8 && a.n_queries >= 64 && planes <= 14;
+		// The persistent form (count_walk_kernel): equal shares of the batch's (query, KiB tile, position) list per wave,
+		// pairs cut by a share boundary finished through memory.  Taken when the batch gives every wave of the launch a
+		// few dozen rows, no early exit is asked for (a persistent wave has no tile of its own to give up) and no pair
+		// is spread over more than count_walk_max_parts waves (the wave that completes a pair adds the parts up one after
+		// the other; longer queries go through the segment slab and its tree combine below).
+		if(tn.count_walk && !a.early_exit && !narrow && tn.force_segs <= 0 && b->total_pos > 0){
+			const uint64_t slots = (uint64_t)a.chunks*b->total_pos;
+			const uint64_t min_rows = (tn.count_walk_min_rows >= 0) ? (uint64_t)tn.count_walk_min_rows : (uint64_t)WALK_MIN_ROWS_PER_WAVE*ncu*(uint64_t)std::max<int64_t>(tn.count_walk_wpc, 1);
+			const uint64_t chip_waves = ncu*(uint64_t)std::max<int64_t>(tn.count_walk_wpc, 1);
+			const uint64_t want_waves = (tn.count_walk_waves > 0) ? std::min<uint64_t>((uint64_t)tn.count_walk_waves, slots)
+				: std::max<uint64_t>(1, std::min<uint64_t>(chip_waves, slots*a.num_hash/WALK_MIN_ROWS_PER_WAVE));
+			const uint32_t wgs = (uint32_t)((want_waves + 3)/4);
+			const uint64_t waves = (uint64_t)wgs*4;
+			const uint64_t per_wave = (slots + waves - 1)/waves;
+			const uint64_t max_parts = (b->max_pos + per_wave - 1)/per_wave + 1;
+			if(slots*a.num_hash >= min_rows && max_parts <= (uint64_t)std::max<int64_t>(tn.count_walk_max_parts, 2)){
+				CountWalkArgs wa;
+				wa.total_slots = slots;
+				wa.per_wave = per_wave;
+				wa.coltiles = a.chunks;
+				if((rc = sl->cwalk_slab.reserve(waves*2*planes*1024))){ return rc; }
+				if((rc = reserve_zeroed(sl->cwalk_done, waves*sizeof(uint32_t), sl->stream))){ return rc; }
+				wa.slab = (uint32_t*)sl->cwalk_slab.p;
+				wa.done = (uint32_t*)sl->cwalk_done.p;
+				a.segs = 1;
+				snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_walk_kernel<%u,%u>", planes, std::min(a.num_hash, 5u));
+				switch(planes){
+					case 7: launch_count_walk_nh<7>(a, wa, wgs, sl->stream); break;
+					case 10: launch_count_walk_nh<10>(a, wa, wgs, sl->stream); break;
+					case 14: launch_count_walk_nh<14>(a, wa, wgs, sl->stream); break;
+					case 20: launch_count_walk_nh<20>(a, wa, wgs, sl->stream); break;
+					default: launch_count_walk_nh<32>(a, wa, wgs, sl->stream); break;
+				}
+				HIP_TRY(hipGetLastError());
+				return KWAGE_OK;
+			}
+		}
 		// Long queries: segments of the k-mer list are counted by different waves into a slab of partial counters
 		// and added by count_combine_kernel (a tree per (query, 64 units)); a segment's counters need only the
 		// planes its own k-mer count can reach.
-		choose_segments(a, b->max_pos, 1024);
+		choose_segments(a, b->max_pos, 1024, tn.force_segs);
 		uint32_t seg_planes = (a.segs > 1) ? planes_for(a.seg_kmers) : planes;
 		// keep the slab of partial counters bounded (1 GiB)
 		while(a.segs > 1 && (uint64_t)a.n_queries*a.segs*seg_planes*g->stride > (1ull << 30)){
@@ -740,19 +826,19 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 			if((rc = sl->partial.reserve((uint64_t)a.n_queries*a.segs*seg_planes*g->stride))){ return rc; }
 			a.partial = (uint32_t*)sl->partial.p;
 		}
-		static const bool narrow_ok = []() { const char *e = getenv("KWAGE_NARROW"); return !(e && atoi(e) == 0); }();
-		if(narrow_ok && a.segs == 1 && a.units_per_row <= 32 && a.units_per_row > 8 && a.n_queries >= 64 && planes <= 14){
+		if(narrow && a.segs == 1){
 			// one reference file (<= 2048 columns = 16 units) or two: 4 resp. 2 queries per wave
-			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_narrow_kernel<%u,%u,%d>", planes, a.num_hash, a.units_per_row <= 16 ? 4 : 2);
+			const int kps = (tn.count_narrow_kps == 4) ? 4 : 8;
+			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_narrow_kernel<%u,%u,%d,%d>", planes, a.num_hash, a.units_per_row <= 16 ? 4 : 2, kps);
 			if(a.units_per_row <= 16){
-				if(planes == 7){ launch_count_narrow<7, 4>(a, sl->stream); }
-				else if(planes == 10){ launch_count_narrow<10, 4>(a, sl->stream); }
-				else{ launch_count_narrow<14, 4>(a, sl->stream); }
+				if(planes == 7){ launch_count_narrow_k<7, 4>(a, sl->stream, kps); }
+				else if(planes == 10){ launch_count_narrow_k<10, 4>(a, sl->stream, kps); }
+				else{ launch_count_narrow_k<14, 4>(a, sl->stream, kps); }
 			}
 			else{
-				if(planes == 7){ launch_count_narrow<7, 2>(a, sl->stream); }
-				else if(planes == 10){ launch_count_narrow<10, 2>(a, sl->stream); }
-				else{ launch_count_narrow<14, 2>(a, sl->stream); }
+				if(planes == 7){ launch_count_narrow_k<7, 2>(a, sl->stream, kps); }
+				else if(planes == 10){ launch_count_narrow_k<10, 2>(a, sl->stream, kps); }
+				else{ launch_count_narrow_k<14, 2>(a, sl->stream, kps); }
 			}
 			HIP_TRY(hipGetLastError());
 			return KWAGE_OK;
@@ -810,14 +896,20 @@ int enqueue_search_and_copy(Slot *sl)
 		// k-mer stage enqueued before and the copy-back enqueued after are what overlaps.
 		Slot *other = (sl == &g->ctx->slot[0]) ? &g->ctx->slot[1] : &g->ctx->slot[0];
 		if(other->search_done_valid){ HIP_TRY(hipStreamWaitEvent(sl->stream, other->search_done, 0)); }
+		if(sl->append && sl->append_reset){ HIP_TRY(hipMemsetAsync(sl->ext_count, 0, sizeof(uint64_t), sl->stream)); }      // a new list starts here
 		if(timing){ HIP_TRY(hipEventRecord(sl->ev[2], sl->stream)); }
-		if((rc = launch_search_stage(sl, g, b, sl->threshold, sl->flags, d_hits, cap))){ return rc; }
+		unsigned long long *hit_count = sl->append ? (unsigned long long*)sl->ext_count : (unsigned long long*)sl->d_counters;
+		if((rc = launch_search_stage(sl, g, b, sl->threshold, sl->flags, d_hits, cap, hit_count))){ return rc; }
 		if(timing){ HIP_TRY(hipEventRecord(sl->ev[3], sl->stream)); }
 		HIP_TRY(hipEventRecord(sl->search_done, sl->stream));
 		sl->search_done_valid = true;
 		++sl->launches;
 	}
-	if(sl->ext_count){      // the caller's exchange buffer carries its own record count (no host round trip)
+	else if(sl->append && sl->append_reset){ HIP_TRY(hipMemsetAsync(sl->ext_count, 0, sizeof(uint64_t), sl->stream)); }      // nothing to search: an empty list all the same
+	if(sl->append){         // the running total of the caller's list comes back with the head of the result block
+		HIP_TRY(hipMemcpyAsync(sl->d_counters, sl->ext_count, sizeof(uint64_t), hipMemcpyDeviceToDevice, sl->stream));
+	}
+	else if(sl->ext_count){      // the caller's exchange buffer carries its own record count (no host round trip)
 		HIP_TRY(hipMemcpyAsync(sl->ext_count, sl->d_counters, sizeof(uint64_t), hipMemcpyDeviceToDevice, sl->stream));
 	}
 	sl->staged_hits = own ? std::min<uint64_t>(SPEC_HITS, cap) : 0;
@@ -829,7 +921,8 @@ int enqueue_search_and_copy(Slot *sl)
 
 // First half of a search: validate, lay out the slot, enqueue the whole device pipeline. Returns at once.
 int submit_search(Slot *sl, kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
-                  kwage_hit *ext_hits, uint64_t ext_cap, uint64_t *ext_count = nullptr)
+                  kwage_hit *ext_hits, uint64_t ext_cap, uint64_t *ext_count = nullptr,
+                  bool append = false, bool append_reset = false, uint32_t col_base = 0)
 {
 	kwage_ctx *ctx = g->ctx;
 	int rc;
@@ -851,6 +944,7 @@ int submit_search(Slot *sl, kwage_group *g, kwage_batch *b, float threshold, uin
 	if((rc = sl->rows.reserve(std::max<uint64_t>(b->total_pos*g->params.num_hash, 1)*sizeof(uint32_t)))){ return rc; }
 	sl->g = g; sl->b = b; sl->threshold = threshold; sl->flags = flags;
 	sl->ext_hits = ext_hits; sl->ext_cap = ext_cap; sl->ext_count = ext_count;
+	sl->append = append; sl->append_reset = append_reset; sl->col_base = col_base;
 	sl->launches = 0;
 
 	const bool timing_kmer = (flags & KWAGE_SEARCH_TIMING) && (flags & KWAGE_SEARCH_TIMING_KMER);
@@ -916,6 +1010,51 @@ Slot *free_slot(kwage_ctx *ctx)
 
 }  // namespace
 
+namespace {
+
+// The knobs' values at context creation: KWAGE_<NAME> for every name of TUNING_NAMES, plus the two historic spellings
+// KWAGE_AND_CFG="vec,unroll,nt[,ldsKB[,block waves]]" and KWAGE_HIT_SORT=host.
+void tuning_from_environment(Tuning *t)
+{
+	for(const TuningName &tn : TUNING_NAMES){
+		std::string env = "KWAGE_";
+		for(const char *c = tn.name; *c; ++c){ env += (char)toupper((unsigned char)*c); }
+		const char *e = getenv(env.c_str());
+		if(e && *e){ t->*(tn.field) = strtoll(e, nullptr, 10); }
+	}
+	if(const char *e = getenv("KWAGE_AND_CFG")){
+		int v = 0, u = 0, n = 0, l = 0, w = 0;
+		const int got = sscanf(e, "%d,%d,%d,%d,%d", &v, &u, &n, &l, &w);
+		if(got >= 3){
+			t->and_vec = v; t->and_unroll = u; t->and_nt = n;
+			t->and_lds_kb = (got >= 4) ? l : 0;
+			t->and_block_waves = (got >= 5) ? w : SEARCH_THREADS/WAVE;
+		}
+	}
+	if(const char *e = getenv("KWAGE_HIT_SORT")){ t->hit_sort_host = !strcmp(e, "host") ? 1 : 0; }
+}
+
+}  // namespace
+
+extern "C" int kwage_ctx_set_tuning(kwage_ctx *ctx, const char *name, int64_t value)
+{
+	if(!ctx || !name){ return fail(KWAGE_ERR_ARG, "kwage_ctx_set_tuning: NULL argument"); }
+	for(int i = 0; i < 2; ++i){ if(ctx->slot[i].busy){ return fail(KWAGE_ERR_STATE, "kwage_ctx_set_tuning: a search is pending on this context"); } }
+	for(const TuningName &tn : TUNING_NAMES){
+		if(!strcmp(tn.name, name)){ ctx->tune.*(tn.field) = value; return KWAGE_OK; }
+	}
+	return fail(KWAGE_ERR_ARG, "kwage_ctx_set_tuning: no knob named '%s'", name);
+}
+
+extern "C" int kwage_ctx_get_tuning(kwage_ctx *ctx, const char *name, int64_t *value)
+{
+	if(!ctx || !name || !value){ return fail(KWAGE_ERR_ARG, "kwage_ctx_get_tuning: NULL argument"); }
+	for(const TuningName &tn : TUNING_NAMES){
+		if(!strcmp(tn.name, name)){ *value = ctx->tune.*(tn.field); return KWAGE_OK; }
+	}
+	return fail(KWAGE_ERR_ARG, "kwage_ctx_get_tuning: no knob named '%s'", name);
+}
+
 namespace kwage {
 hipStream_t ctx_stream(kwage_ctx *ctx) { return ctx->stream; }
 int ctx_device(kwage_ctx *ctx) { return ctx->device; }
@@ -952,6 +1091,8 @@ extern "C" int kwage_init(int device, kwage_ctx **out)
 	kwage_ctx *ctx = new (std::nothrow) kwage_ctx();
 	if(!ctx){ return fail(KWAGE_ERR_DEVICE, "out of host memory"); }
 	ctx->device = device;
+	ctx->ncu = prop.multiProcessorCount;
+	tuning_from_environment(&ctx->tune);
 	for(int k = 0; k < 2; ++k){
 		Slot *sl = &ctx->slot[k];
 		// (a lowest-priority stream was tried so that a caller's small kernels get in between the gather
@@ -977,7 +1118,7 @@ extern "C" void kwage_shutdown(kwage_ctx *ctx)
 		if(sl->stream){ (void)hipStreamSynchronize(sl->stream); }
 		sl->rows.release(); sl->tables.release(); sl->result.release();
 		sl->partial.release(); sl->h_stage.release(); sl->sort_scratch.release();
-		sl->walk_or.release(); sl->walk_done.release();
+		sl->walk_or.release(); sl->walk_done.release(); sl->cwalk_slab.release(); sl->cwalk_done.release();
 		for(int i = 0; i < 4; ++i){ if(sl->ev[i]){ (void)hipEventDestroy(sl->ev[i]); } }
 		if(sl->search_done){ (void)hipEventDestroy(sl->search_done); }
 		if(sl->stream){ (void)hipStreamDestroy(sl->stream); }
@@ -1666,6 +1807,10 @@ extern "C" int kwage_group_add_db_files(kwage_group *g, const char *const *paths
 			else if(pipe.usable){ if((rc = pipe.flush())){ return rc; } }
 			if(from < g->nrows){
 				if((rc = load_source_rows_staged(g, srcs[k], paths[i0 + k], byte0[k], from))){ return rc; }
+				// its mapped path returns with copies and scatter kernels still in flight on the staging buffers the
+				// copy-engine pipeline shares (and records no load_done event): nothing of it may be left when the pipe
+				// writes into them again
+				if(pipe.usable){ HIP_TRY(hipStreamSynchronize(g->ctx->stream)); }
 			}
 			if(g->ctx->load_progress){       // the whole file has been passed now (windows reported themselves as they were pinned)
 				struct stat st;
@@ -1912,15 +2057,15 @@ int build_result(Slot *sl, kwage_group *g, kwage_batch *b, const SearchOutcome &
 		// A large hit list is sorted where it lies (hit_sort.hip) and then fetched whole, in pieces through the two
 		// halves of the pinned staging buffer: piece i+1 crosses PCIe while piece i is copied into the result.
 		uint64_t scratch = 0;
-		const char *where = getenv("KWAGE_HIT_SORT");      // "host": the sort of round 1, kept for A/B runs and as the fallback
+		const bool host_sort = g->ctx->tune.hit_sort_host != 0;      // the sort of round 1, kept for A/B runs and as the fallback
 		const uint64_t column_span = g->stride*8;      // no hit carries a column beyond the row (files are padded apart: more than num_columns)
-		bool on_device = !(where && !strcmp(where, "host"))
+		bool on_device = !host_sort
 		                 && hit_sort_scratch_bytes(so.n_hits, b->n, column_span, &scratch) == KWAGE_OK
 		                 && sl->sort_scratch.reserve(scratch) == KWAGE_OK
 		                 && sort_hits_on_device(sl->stream, sl->d_hits, so.n_hits, b->n, column_span, sl->sort_scratch.p, sl->sort_scratch.cap) == KWAGE_OK;
 		if(!on_device){
 			(void)hipGetLastError();
-			if(!(where && !strcmp(where, "host"))){      // never silently: the list is still ordered, by the host, and that is slower
+			if(!host_sort){      // never silently: the list is still ordered, by the host, and that is slower
 				fprintf(stderr, "[kwage_amd] no room for the device hit sort's buffers (%llu bytes) beside the database: %llu hits ordered by the host\n",
 				        (unsigned long long)scratch, (unsigned long long)so.n_hits);
 			}
@@ -1978,7 +2123,13 @@ int build_result(Slot *sl, kwage_group *g, kwage_batch *b, const SearchOutcome &
 
 extern "C" void kwage_sort_hits(kwage_hit *hits, uint64_t n)
 {
-	if(hits && n > 1){ sort_hits(hits, (size_t)n); }
+	if(!hits || n < 2){ return; }
+	try{ sort_hits(hits, (size_t)n); }
+	catch(const std::bad_alloc &){      // no room for the radix sort's two copies of the list: order it in place
+		std::sort(hits, hits + n, [](const kwage_hit &x, const kwage_hit &y){
+			return (x.query != y.query) ? (x.query < y.query) : (x.column < y.column);
+		});
+	}
 }
 
 struct kwage_pending { Slot *sl; };
@@ -2050,6 +2201,28 @@ extern "C" int kwage_search_device_submit(kwage_group *g, kwage_batch *b, float 
 	if(!sl){ return fail(KWAGE_ERR_STATE, "kwage_search_device_submit: two searches are already pending on this context"); }
 	static kwage_hit dummy;          // non-null marker for "caller-owned buffer" when capacity is 0
 	int rc = submit_search(sl, g, b, threshold, flags, capacity ? (kwage_hit*)hits_dev : &dummy, capacity, (uint64_t*)count_dev);
+	if(rc){ return rc; }
+	kwage_pending *p = new (std::nothrow) kwage_pending();
+	if(!p){ SearchOutcome so; (void)collect_search(sl, &so); return fail(KWAGE_ERR_DEVICE, "out of host memory"); }
+	p->sl = sl;
+	*out = p;
+	return KWAGE_OK;
+}
+
+extern "C" int kwage_search_device_append_submit(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
+                                                 void *hits_dev, uint64_t capacity, void *count_dev, uint32_t column_base,
+                                                 int reset_count, kwage_pending **out)
+{
+	if(!g || !b || !out || !count_dev || (capacity && !hits_dev)){ return fail(KWAGE_ERR_ARG, "kwage_search_device_append_submit: NULL argument"); }
+	*out = nullptr;
+	if((uint64_t)column_base + g->stride*8 > 0x100000000ull){
+		return fail(KWAGE_ERR_ARG, "kwage_search_device_append_submit: column base %u + the group's column span exceeds 32 bits", column_base);
+	}
+	Slot *sl = free_slot(g->ctx);
+	if(!sl){ return fail(KWAGE_ERR_STATE, "kwage_search_device_append_submit: two searches are already pending on this context"); }
+	static kwage_hit dummy;          // non-null marker for "caller-owned buffer" when capacity is 0
+	int rc = submit_search(sl, g, b, threshold, flags, capacity ? (kwage_hit*)hits_dev : &dummy, capacity, (uint64_t*)count_dev,
+	                       true, reset_count != 0, column_base);
 	if(rc){ return rc; }
 	kwage_pending *p = new (std::nothrow) kwage_pending();
 	if(!p){ SearchOutcome so; (void)collect_search(sl, &so); return fail(KWAGE_ERR_DEVICE, "out of host memory"); }
@@ -2134,8 +2307,8 @@ int run_shared_kmer_pass(kwage_ctx *ctx, const kwage_params &p, kwage_batch *b, 
 	if((rc = layout_result(sl, b->n, 0, false))){ return rc; }
 	uint32_t lg = 10;
 	while((1ull << lg) < 2*std::max<uint64_t>(b->total_pos, 1)){ ++lg; }
-	// (KWAGE_SHARED_TABLE_LOG2 raises the table size: tests exercise the >= 2^32-slot arithmetic on small inputs)
-	if(const char *e = getenv("KWAGE_SHARED_TABLE_LOG2")){ lg = std::max<uint32_t>(lg, (uint32_t)atoi(e)); }
+	// (the shared_table_log2 knob raises the table size: tests exercise the >= 2^32-slot arithmetic on small inputs)
+	if(ctx->tune.shared_table_log2 > 0){ lg = std::max<uint32_t>(lg, (uint32_t)ctx->tune.shared_table_log2); }
 	if(lg > 36){ return fail(KWAGE_ERR_ARG, "too many k-mer positions for one sample"); }
 	if((rc = sl->tables.reserve((1ull << lg)*sizeof(uint64_t)))){ return rc; }
 	HIP_TRY(hipMemsetAsync(sl->tables.p, 0xFF, (1ull << lg)*sizeof(uint64_t), ctx->stream));

@@ -264,6 +264,9 @@ struct SearchArgs {
 	uint32_t segs;
 	uint32_t seg_kmers;
 	uint32_t *partial;              // AND: u32 [query][units*4] masks; count: u32x4 [query][seg][plane][unit]
+	// added to every reported column: a host that appends the hits of several groups / shards to ONE list gives each
+	// its own range of global column numbers (kwage_search_device_append_submit)
+	uint32_t col_base;
 };
 
 // 16 bytes of columns as a clang vector: bitwise operators apply lane-wise, and the nontemporal
@@ -328,7 +331,7 @@ __device__ __forceinline__ unsigned long long reserve_hits_wg(const SearchArgs &
 __device__ __forceinline__ void store_hit(const SearchArgs &a, unsigned long long slot, uint32_t q, uint32_t col, uint32_t nm)
 {
 	if(slot < a.cap){
-		kwage_hit h; h.query = q; h.column = col; h.num_match = nm;
+		kwage_hit h; h.query = q; h.column = col + a.col_base; h.num_match = nm;
 		a.hits[slot] = h;
 	}
 }
@@ -742,6 +745,98 @@ __device__ __forceinline__ void emit_count_hits(const SearchArgs &a, uint32_t q,
 	}
 }
 
+// Add two bit-sliced counters: acc (PLANES planes) += b (the first nb planes of `b`, the rest zero).
+template <int PLANES, typename LOADB>
+__device__ __forceinline__ void planes_accumulate(u32x4 (&acc)[PLANES], int nb, LOADB loadb)
+{
+	u32x4 carry = (u32x4)(0u);
+#pragma unroll
+	for(int p = 0; p < PLANES; ++p){
+		const u32x4 b = (p < nb) ? loadb(p) : (u32x4)(0u);
+		const u32x4 x = acc[p] ^ b;
+		const u32x4 cnext = (acc[p] & b) | (carry & x);
+		acc[p] = x ^ carry;
+		carry = cnext;
+	}
+}
+
+// Four 1-bit vectors into the bit-sliced counters: a carry-save tree, so that the ripple through the upper planes
+// runs once per four k-mers (planes 0 and 1 are the CSA residues).
+template <int PLANES>
+__device__ __forceinline__ void planes_add4(u32x4 (&plane)[PLANES], u32x4 m0, u32x4 m1, u32x4 m2, u32x4 m3)
+{
+	if(PLANES >= 3){
+		u32x4 twoA, twoB, four, s;
+		csa(s, twoA, plane[0], m0, m1);
+		csa(plane[0], twoB, s, m2, m3);
+		csa(plane[1], four, plane[1], twoA, twoB);
+		planes_add<PLANES>(plane, four, 2);
+	}
+	else{
+		planes_add<PLANES>(plane, m0, 0);
+		planes_add<PLANES>(plane, m1, 0);
+		planes_add<PLANES>(plane, m2, 0);
+		planes_add<PLANES>(plane, m3, 0);
+	}
+}
+
+// Eight at once (7 CSAs, then one ripple from plane 3): the narrow kernels keep eight k-mers' rows in flight per wave.
+template <int PLANES>
+__device__ __forceinline__ void planes_add8(u32x4 (&plane)[PLANES], const u32x4 (&m)[8])
+{
+	static_assert(PLANES >= 4, "planes_add8 needs four planes");
+	u32x4 s1, s2, s3, c1, c2, c3, c4, t1, f1, f2, e1;
+	csa(s1, c1, m[0], m[1], m[2]);
+	csa(s2, c2, m[3], m[4], m[5]);
+	csa(s3, c3, m[6], m[7], plane[0]);
+	csa(plane[0], c4, s1, s2, s3);
+	csa(t1, f1, c1, c2, c3);
+	csa(plane[1], f2, t1, c4, plane[1]);
+	csa(plane[2], e1, f1, f2, plane[2]);
+	planes_add<PLANES>(plane, e1, 3);
+}
+
+// The counting loop of one (query, 1 KiB column tile): k-mers [0, nk) of the row list `rq` ([k-mer][NH] row indices),
+// kmer_match = AND over the NH hash rows (kwage.cpp:409-422), added into the lane's bit-sliced counters
+// (increment_count, bloom.h:291-330).  Four k-mers per step: 4*NH row loads in flight.  (Eight per step -- 94 VGPRs, 5
+// waves/SIMD -- measured the same with one and two hash functions at C2's shape: 1.916 vs 1.921 ms, 3.752 vs 3.755 ms,
+// round 2; not kept.)  `stop(done)` is asked every 64 k-mers whether the tile can be given up (early exit); returns
+// false when it was.
+template <int PLANES, int NH, typename STOP>
+__device__ __forceinline__ bool count_kmers(const uint8_t *db, uint64_t stride, const uint32_t *rq, uint32_t nk, uint32_t unit,
+                                            u32x4 (&plane)[PLANES], STOP stop)
+{
+	constexpr int KPS = 4;
+	uint32_t i = 0;
+	for(; i + KPS <= nk; i += KPS){
+		u32x4 m[KPS];
+#pragma unroll
+		for(int u = 0; u < KPS; ++u){
+			u32x4 x[NH];
+#pragma unroll
+			for(int h = 0; h < NH; ++h){
+				const uint32_t r = rq[(i + u)*NH + h];
+				x[h] = load16<true>(reinterpret_cast<const u32x4*>(db + (uint64_t)r*stride) + unit);
+			}
+			m[u] = x[0];
+#pragma unroll
+			for(int h = 1; h < NH; ++h){ m[u] &= x[h]; }    // kmer_match &= slice
+		}
+		planes_add4<PLANES>(plane, m[0], m[1], m[2], m[3]);
+		if(((i + KPS) & 63u) == 0 && stop(i + KPS)){ return false; }
+	}
+	for(; i < nk; ++i){
+		u32x4 mm = ~(u32x4)(0u);
+#pragma unroll
+		for(int h = 0; h < NH; ++h){
+			const uint32_t r = rq[i*NH + h];
+			mm &= load16<true>(reinterpret_cast<const u32x4*>(db + (uint64_t)r*stride) + unit);
+		}
+		planes_add<PLANES>(plane, mm, 0);
+	}
+	return true;
+}
+
 template <int PLANES, int NH, bool SEG>
 __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 {
@@ -770,60 +865,17 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 #pragma unroll
 	for(int p = 0; p < PLANES; ++p){ plane[p] = (u32x4)(0u); }
 
-	// KPS = four k-mers per step: 4*NH row loads in flight, then a carry-save tree so that the ripple through the
-	// upper planes happens once per four k-mers (planes 0,1 are the CSA residues).  (Eight per step -- 94 VGPRs, 5
-	// waves/SIMD -- measured the same with one and two hash functions at C2's shape: 1.916 vs 1.921 ms, 3.752 vs
-	// 3.755 ms, tools/ab_count_kps.py in round 2; not kept.)
-	constexpr int KPS = 4;
-	uint32_t i = 0;
-	for(; i + KPS <= nk; i += KPS){
-		u32x4 m[KPS];
-#pragma unroll
-		for(int u = 0; u < KPS; ++u){
-			u32x4 x[NH];
-#pragma unroll
-			for(int h = 0; h < NH; ++h){
-				const uint32_t r = rq[(i + u)*NH + h];
-				x[h] = load16<true>(reinterpret_cast<const u32x4*>(a.db + (uint64_t)r*a.stride) + unit);
-			}
-			m[u] = x[0];
-#pragma unroll
-			for(int h = 1; h < NH; ++h){ m[u] &= x[h]; }    // kmer_match &= slice
-		}
-#pragma unroll
-		for(int g4 = 0; g4 < KPS; g4 += 4){
-			if(PLANES >= 3){
-				u32x4 twoA, twoB, four, s;
-				csa(s, twoA, plane[0], m[g4 + 0], m[g4 + 1]);
-				csa(plane[0], twoB, s, m[g4 + 2], m[g4 + 3]);
-				csa(plane[1], four, plane[1], twoA, twoB);
-				planes_add<PLANES>(plane, four, 2);
-			}
-			else{
-#pragma unroll
-				for(int u = 0; u < 4; ++u){ planes_add<PLANES>(plane, m[g4 + u], 0); }
-			}
-		}
-		// kwage.cpp:478-481 per tile: stop once no column of the tile can still reach the threshold
-		// even if every remaining k-mer matched (max count + remaining < threshold)
-		if(!SEG && a.early_exit && ((i + KPS) & 63u) == 0){
-			const uint32_t remaining = nk - (i + KPS);
-			const uint32_t thr = a.qthr[q];
-			if(thr > remaining){
-				const u32x4 can = planes_ge<PLANES>(plane, thr - remaining);
-				if(!__any((can.x | can.y | can.z | can.w) != 0)){ return; }
-			}
-		}
-	}
-	for(; i < nk; ++i){
-		u32x4 mm = ~(u32x4)(0u);
-#pragma unroll
-		for(int h = 0; h < NH; ++h){
-			const uint32_t r = rq[i*NH + h];
-			mm &= load16<true>(reinterpret_cast<const u32x4*>(a.db + (uint64_t)r*a.stride) + unit);
-		}
-		planes_add<PLANES>(plane, mm, 0);
-	}
+	// kwage.cpp:478-481 per tile: stop once no column of the tile can still reach the threshold even if every
+	// remaining k-mer matched (max count + remaining < threshold)
+	const bool whole = count_kmers<PLANES, NH>(a.db, a.stride, rq, nk, unit, plane, [&](uint32_t done) -> bool {
+		if(SEG || !a.early_exit){ return false; }
+		const uint32_t remaining = nk - done;
+		const uint32_t thr = a.qthr[q];
+		if(thr <= remaining){ return false; }
+		const u32x4 can = planes_ge<PLANES>(plane, thr - remaining);
+		return !__any((can.x | can.y | can.z | can.w) != 0);
+	});
+	if(!whole){ return; }
 
 	if(SEG){
 		// partial counters of this segment -> slab [query][segment][plane][unit]
@@ -838,9 +890,113 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 	}
 }
 
+// The same counts from a PERSISTENT, statically balanced grid (and_walk_kernel's idea for the threshold < 1 path):
+// the tiled kernel above has one wave per (query, 1 KiB column tile), and at C2's shape those 13 000 waves are 1.6x what
+// the chip holds -- the last round runs on a part-filled chip (0.93 of the box's stream read against 0.99 for the AND
+// walk on the same matrix).  Here the launch has a fixed number of waves per CU and the batch's slot list -- for every
+// query and column tile its positions, query-major, exactly and_walk_kernel's -- is cut into equal contiguous shares.
+// Counters do not fit a wave's registers for more than one KiB of columns, so a wave walks its share one (query, KiB
+// tile) part at a time:
+//   - a part that is a whole pair is thresholded and emitted at once;
+//   - a pair CUT by a share boundary is finished through memory: every wave that holds a part stores its partial
+//     counters in its own block of `slab` -- block [w][0] for a part that began in an earlier wave, [w][1] for one
+//     that goes on in the next -- and adds its k-mer count to the pair's counter (done[wave that holds the pair's
+//     first position]: only the last pair that starts in a share can be cut, so no two cut pairs share one); the
+//     wave whose add completes the pair's nkmer adds the other parts' blocks to its own counters (ripple-carry
+//     adders across the planes), emits, and leaves the counter ZERO again.
+// Everything the protocol exchanges goes through device-scope stores / atomics and loads (the XCDs' L2s are not
+// coherent with one another for plain accesses), ordered by waiting for the stores' acknowledgements (vmcnt).
+struct CountWalkArgs {
+	uint64_t total_slots;           // column tiles per row x positions of the batch
+	uint64_t per_wave;              // slots per wave
+	uint32_t coltiles;              // 1 KiB column tiles per row
+	uint32_t *slab;                 // [waves][2][PLANES][4][64] partial counters of cut pairs
+	uint32_t *done;                 // [waves] k-mers folded into the cut pair that starts in the wave's share; zero between searches
+};
+
+template <int PLANES, int NH>
+__global__ __launch_bounds__(SEARCH_THREADS) void count_walk_kernel(SearchArgs a, CountWalkArgs wa, const uint32_t *__restrict__ rows,
+                                                                    const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ nkmer,
+                                                                    const uint32_t *__restrict__ qthr)
+{
+	const uint32_t lane = threadIdx.x & (WAVE - 1);
+	const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x*(SEARCH_THREADS/WAVE) + (threadIdx.x >> 6));
+	uint64_t s = (uint64_t)gw*wa.per_wave;
+	const uint64_t s1 = min(wa.total_slots, s + wa.per_wave);
+	if(s >= s1){ return; }
+	const uint32_t ct = wa.coltiles;
+
+	// the query that holds slot s: the largest q with ct*pos_off[q] <= s
+	uint32_t q = 0;
+	{
+		uint32_t hi = a.n_queries;
+		while(hi - q > 1){
+			const uint32_t mid = q + (hi - q)/2;
+			if((uint64_t)ct*pos_off[mid] <= s){ q = mid; } else { hi = mid; }
+		}
+	}
+
+	while(s < s1){
+		const uint64_t p0 = pos_off[q];
+		const uint64_t npos = pos_off[q + 1] - p0;
+		if(npos == 0){ ++q; continue; }
+		const uint64_t rem = s - (uint64_t)ct*p0;
+		const uint32_t c = __builtin_amdgcn_readfirstlane((uint32_t)(rem / npos));
+		const uint32_t j0 = __builtin_amdgcn_readfirstlane((uint32_t)(rem % npos));
+		const uint32_t take = (uint32_t)min(npos - j0, s1 - s);
+		const uint32_t j1 = j0 + take;
+		const uint32_t n = nkmer[q];
+		const uint32_t jv1 = min(j1, n);                     // positions past the distinct k-mers hold no rows
+		if(j0 < jv1){
+			const uint32_t u0 = c*WAVE + lane;
+			const bool live = (u0 < a.units_per_row);
+			const uint32_t unit = live ? u0 : (a.units_per_row - 1);
+			u32x4 plane[PLANES];
+#pragma unroll
+			for(int p = 0; p < PLANES; ++p){ plane[p] = (u32x4)(0u); }
+			count_kmers<PLANES, NH>(a.db, a.stride, rows + (p0 + j0)*NH, jv1 - j0, unit, plane, [](uint32_t) -> bool { return false; });
+
+			bool emit = true;
+			if(j0 != 0 || jv1 != n){
+				const uint64_t pair_start = (uint64_t)ct*p0 + (uint64_t)c*npos;        // slot of the pair's position 0
+				const uint32_t first_w = (uint32_t)(pair_start / wa.per_wave);
+				uint32_t *mine = wa.slab + ((uint64_t)gw*2 + (j0 != 0 ? 0 : 1))*(PLANES*4*WAVE) + lane;
+#pragma unroll
+				for(int p = 0; p < PLANES; ++p){
+#pragma unroll
+					for(int d = 0; d < 4; ++d){ __hip_atomic_store(mine + (p*4 + d)*WAVE, plane[p][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+				}
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores are performed before the count says so
+				uint32_t old = 0;
+				if(lane == 0){ old = __hip_atomic_fetch_add(wa.done + first_w, jv1 - j0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+				old = __builtin_amdgcn_readfirstlane(old);
+				emit = false;
+				if(old + (jv1 - j0) == n){                            // this part completes the pair: add the others
+					const uint32_t last_w = (uint32_t)((pair_start + n - 1) / wa.per_wave);
+					for(uint32_t w = first_w; w <= last_w; ++w){
+						if(w == gw){ continue; }
+						const uint32_t *theirs = wa.slab + ((uint64_t)w*2 + (w == first_w ? 1 : 0))*(PLANES*4*WAVE) + lane;
+						planes_accumulate<PLANES>(plane, PLANES, [&](int p) -> u32x4 {
+							u32x4 v;
+#pragma unroll
+							for(int d = 0; d < 4; ++d){ v[d] = __hip_atomic_load(theirs + (p*4 + d)*WAVE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+							return v;
+						});
+					}
+					if(lane == 0){ __hip_atomic_store(wa.done + first_w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+					emit = true;
+				}
+			}
+			if(emit){ emit_count_hits<PLANES>(a, q, unit, plane, qthr[q], live); }
+		}
+		s += take;
+		if(j1 == npos && c + 1 == ct){ ++q; }
+	}
+}
+
 // Narrow databases, count path: G queries per wave (see and_narrow_kernel).  A shorter k-mer list is padded
 // with all-zero matches (counting is not idempotent, so padded steps must add nothing).
-template <int PLANES, int NH, int G>
+template <int PLANES, int NH, int G, int KPS>
 __global__ __launch_bounds__(SEARCH_THREADS) void count_narrow_kernel(SearchArgs a)
 {
 	constexpr uint32_t LG = WAVE/G;
@@ -859,10 +1015,12 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_narrow_kernel(SearchArgs
 #pragma unroll
 	for(int p = 0; p < PLANES; ++p){ plane[p] = (u32x4)(0u); }
 
-	for(uint32_t i = 0; active && __any(i < nk); i += 4){
-		u32x4 m[4];
+	// eight k-mers per step: a narrow launch has few waves (10 k queries of 1 kb against one 2048-column file: 2500, ten per
+	// CU), so the bytes in flight come from the loads per wave (4 per step measured 4.2 TB/s where the AND form's 8 reach 5.7)
+	for(uint32_t i = 0; active && __any(i < nk); i += KPS){
+		u32x4 m[KPS];
 #pragma unroll
-		for(int u = 0; u < 4; ++u){
+		for(int u = 0; u < KPS; ++u){
 			const bool real = (i + u < nk);
 			const uint32_t kk = real ? (i + u) : (nk - 1);
 			u32x4 x = load16<true>(reinterpret_cast<const u32x4*>(a.db + (uint64_t)rq[kk*NH]*a.stride) + unit);
@@ -872,29 +1030,11 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_narrow_kernel(SearchArgs
 			}
 			m[u] = real ? x : (u32x4)(0u);
 		}
-		u32x4 twoA, twoB, four, s;
-		csa(s, twoA, plane[0], m[0], m[1]);
-		csa(plane[0], twoB, s, m[2], m[3]);
-		csa(plane[1], four, plane[1], twoA, twoB);
-		planes_add<PLANES>(plane, four, 2);
+		if(KPS == 8){ planes_add8<PLANES>(plane, reinterpret_cast<const u32x4 (&)[8]>(m)); }
+		else{ planes_add4<PLANES>(plane, m[0], m[1], m[2], m[3]); }
 	}
 	__shared__ WgHitScratch wg_scratch;
 	emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q], active, &wg_scratch);      // every wave of the workgroup gets here, exactly once
-}
-
-// Add two bit-sliced counters: acc (PLANES planes) += b (the first nb planes of `b`, the rest zero).
-template <int PLANES, typename LOADB>
-__device__ __forceinline__ void planes_accumulate(u32x4 (&acc)[PLANES], int nb, LOADB loadb)
-{
-	u32x4 carry = (u32x4)(0u);
-#pragma unroll
-	for(int p = 0; p < PLANES; ++p){
-		const u32x4 b = (p < nb) ? loadb(p) : (u32x4)(0u);
-		const u32x4 x = acc[p] ^ b;
-		const u32x4 cnext = (acc[p] & b) | (carry & x);
-		acc[p] = x ^ carry;
-		carry = cnext;
-	}
 }
 
 // Second pass of the segmented count: add the per-segment bit-sliced counters (ripple-carry adders across

@@ -821,12 +821,40 @@ uint64_t env_u64(const char *name, uint64_t fallback)
 	return e ? strtoull(e, nullptr, 10) : fallback;
 }
 
-vector<int> chosen_devices()
+// The number of visible devices WITHOUT starting the HIP runtime in this process: the page-cache readers are forked
+// after the devices have been chosen, and a process in which HIP is up (runtime threads, the open KFD) must not be
+// forked.  A short-lived child asks the runtime and reports over a pipe.  -1: could not be done.
+int device_count_in_child()
+{
+	int fd[2];
+	if(pipe(fd) != 0){ return -1; }
+	const pid_t pid = fork();
+	if(pid < 0){ close(fd[0]); close(fd[1]); return -1; }
+	if(pid == 0){
+		close(fd[0]);
+		const int n = kwage_device_count();
+		const ssize_t w = write(fd[1], &n, sizeof(n));
+		_exit(w == (ssize_t)sizeof(n) ? 0 : 1);
+	}
+	close(fd[1]);
+	int n = -1;
+	if(read(fd[0], &n, sizeof(n)) != (ssize_t)sizeof(n)){ n = -1; }
+	close(fd[0]);
+	int status = 0;
+	(void)waitpid(pid, &status, 0);
+	return n;
+}
+
+// *hip_is_up: the device count had to come from a HIP call in THIS process (no page-cache reader may be forked then)
+vector<int> chosen_devices(bool *hip_is_up)
 {
 	vector<int> devices;
+	*hip_is_up = false;
 	if(const char *dl = getenv("KWAGE_DEVICES")){
 		if(string(dl) == "all"){
-			for(int d = 0; d < kwage_device_count(); ++d){ devices.push_back(d); }
+			int n = device_count_in_child();
+			if(n < 0){ n = kwage_device_count(); *hip_is_up = true; }
+			for(int d = 0; d < n; ++d){ devices.push_back(d); }
 		}
 		else{
 			stringstream ss(dl);
@@ -895,7 +923,8 @@ int main(int argc, char *argv[])
 		// KWAGE_DEVICES="all" | "0,1,..." shards every group's files (whole files, contiguous, balanced by column
 		// count) over several GPUs, one host thread + one kwage_ctx per GPU -- the reference's only parallel axis is
 		// the same one (OpenMP over files, kwage.cpp:76-87).  Every worker streams the query files itself.
-		const vector<int> devices = chosen_devices();
+		bool hip_is_up = false;
+		const vector<int> devices = chosen_devices(&hip_is_up);
 		const size_t ndev = devices.size();
 		const uint32_t flags = env_u64("KWAGE_EARLY_EXIT", 1) ? KWAGE_SEARCH_EARLY_EXIT : 0u;
 		const uint64_t max_batch_bases = env_u64("KWAGE_BATCH_BASES", 64ull << 20);
@@ -921,7 +950,7 @@ int main(int argc, char *argv[])
 		// the first HIP call and before any thread exists; they wait until the plan says whole files are read.
 		vector<CacheReader> readers(ndev);
 		vector<vector<string> > load_order(ndev);
-		const unsigned reader_threads = (unsigned)min<uint64_t>(env_u64("KWAGE_CACHE_READER", 4), 16);
+		const unsigned reader_threads = hip_is_up ? 0u : (unsigned)min<uint64_t>(env_u64("KWAGE_CACHE_READER", 4), 16);
 		for(size_t di = 0; di < ndev && reader_threads; ++di){
 			for(const auto &grp_entry : groups){ for(uint32_t fi : share_of(grp_entry.second, di)){ load_order[di].push_back(files[fi].path); } }
 			readers[di].start(load_order[di], reader_threads, env_u64("KWAGE_CACHE_READER_AHEAD_MB", 8192) << 20);

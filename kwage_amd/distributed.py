@@ -93,6 +93,8 @@ def merge_hits(parts: Sequence[np.ndarray], column_base: Sequence[int]) -> np.nd
         p = np.asarray(p).reshape(-1, 3)
         if len(p):
             q = p.astype(np.uint32)           # a copy: the caller's buffer is left alone
+            if int(column_base[r]) + int(q[:, 1].max()) >= 1 << 32:
+                raise OverflowError("merge_hits: column base %d + local column %d does not fit 32 bits" % (int(column_base[r]), int(q[:, 1].max())))
             q[:, 1] += np.uint32(int(column_base[r]))
             rows.append(q)
     if not rows:

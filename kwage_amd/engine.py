@@ -50,6 +50,32 @@ class Context:
     def sync(self) -> None:
         check(lib().kwage_sync(self._h))
 
+    def set_tuning(self, name: str, value: int) -> None:
+        """One kernel-selection knob of this context (kwage_ctx_set_tuning; tests and tuning tools)."""
+        check(lib().kwage_ctx_set_tuning(self._h, name.encode(), int(value)))
+
+    def get_tuning(self, name: str) -> int:
+        v = C.c_int64()
+        check(lib().kwage_ctx_get_tuning(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
+
+    def tuning(self, **knobs):
+        """`with ctx.tuning(walk_waves=17, walk_min_rows=1): ...` -- the knobs are set inside the block and put back
+        after it."""
+        ctx = self
+
+        class _Scope:
+            def __enter__(self):
+                self.old = {k: ctx.get_tuning(k) for k in knobs}
+                for k, v in knobs.items():
+                    ctx.set_tuning(k, v)
+                return ctx
+
+            def __exit__(self, *exc):
+                for k, v in self.old.items():
+                    ctx.set_tuning(k, v)
+        return _Scope()
+
 
 class Group:
     """HBM-resident bit matrix of all columns sharing (kmer_len, num_hash, log_2_filter_len, hash_func)."""
@@ -59,6 +85,7 @@ class Group:
         self.ctx = ctx
         self.params = Params(kmer_len, num_hash, log_2_filter_len, hash_func)
         self._h = C.c_void_p()
+        self._nrows = 1 << log_2_filter_len          # rows an add_columns() image must hold
         check(lib().kwage_group_create(ctx._h, C.byref(self.params), column_capacity, C.byref(self._h)))
 
     @classmethod
@@ -71,6 +98,7 @@ class Group:
         g.ctx = ctx
         g.params = Params(kmer_len, num_hash, log_2_filter_len, hash_func)
         g._h = C.c_void_p()
+        g._nrows = int(rows.size)                     # a sparse group's images hold the listed rows only
         check(lib().kwage_group_create_sparse(ctx._h, C.byref(g.params), column_capacity, rows.ctypes.data, rows.size, C.byref(g._h)))
         return g
 
@@ -80,8 +108,10 @@ class Group:
             self._h = C.c_void_p()
 
     def add_columns(self, rows: np.ndarray, num_filter: int) -> int:
-        """rows: uint8 [2^L, >= ceil(num_filter/8)] host image of a file's bit-slice block."""
+        """rows: uint8 [2^L (a sparse group: its listed rows), >= ceil(num_filter/8)] host image of a file's bit-slice block."""
         assert rows.dtype == np.uint8 and rows.ndim == 2 and rows.strides[1] == 1
+        # the library reads exactly this many rows of host_row_stride bytes from the pointer
+        assert rows.shape[0] == self._nrows and rows.shape[1] >= (num_filter + 7) // 8, (rows.shape, self._nrows, num_filter)
         first = C.c_uint64()
         check(lib().kwage_group_add_columns(self._h, rows.ctypes.data, rows.strides[0], num_filter, C.byref(first)))
         return first.value
@@ -92,7 +122,7 @@ class Group:
         return first.value, nf.value
 
     def add_db_files(self, paths: Sequence[str]) -> List[Tuple[int, int]]:
-        """Several files at once (columns in the order given): raw files are loaded 16 at a time, side by side."""
+        """Several files at once (columns in the order given): raw files stream through one copy-engine pipeline."""
         n = len(paths)
         arr = (C.c_char_p * n)(*[p.encode() for p in paths])
         first, nf = (C.c_uint64 * n)(), (C.c_uint32 * n)()

@@ -104,6 +104,8 @@ _SIGNATURES = [
     ("kwage_set_load_progress", None, [_P, C.POINTER(C.c_uint64)]),
     ("kwage_sort_hits", None, [C.c_void_p, C.c_uint64]),
     ("kwage_sync", C.c_int, [_P]),
+    ("kwage_ctx_set_tuning", C.c_int, [_P, C.c_char_p, C.c_int64]),
+    ("kwage_ctx_get_tuning", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
     ("kwage_group_create", C.c_int, [_P, C.POINTER(Params), C.c_uint64, C.POINTER(_P)]),
     ("kwage_group_destroy", None, [_P]),
     ("kwage_group_create_sparse", C.c_int, [_P, C.POINTER(Params), C.c_uint64, _P, C.c_uint64, C.POINTER(_P)]),
@@ -129,6 +131,7 @@ _SIGNATURES = [
     ("kwage_search_collect", C.c_int, [_P, C.POINTER(C.POINTER(Result))]),
     ("kwage_search_device", C.c_int, [_P, _P, C.c_float, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64), _P]),
     ("kwage_search_device_submit", C.c_int, [_P, _P, C.c_float, C.c_uint32, _P, C.c_uint64, _P, C.POINTER(_P)]),
+    ("kwage_search_device_append_submit", C.c_int, [_P, _P, C.c_float, C.c_uint32, _P, C.c_uint64, _P, C.c_uint32, C.c_int, C.POINTER(_P)]),
     ("kwage_search_device_collect", C.c_int, [_P, C.POINTER(C.c_uint64), _P, C.POINTER(C.c_float)]),
     ("kwage_hash_batch", C.c_int, [_P, C.POINTER(Params), _P, _P, _P, _P, _P]),
     ("kwage_stream_read_gbps", C.c_int, [_P, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),

@@ -117,15 +117,15 @@ def test_distinct_kmer_count_and_long_sequences(oracle):
 def test_distinct_set_with_2_pow_32_slots_or_more(oracle, lg, monkeypatch):
     """A sample above ~1 G k-mer positions (a human or plant assembly) gets ONE shared distinct set of 2^32 slots or
     more; the probe arithmetic must be 64-bit there (a 32-bit mask wraps to 0 or 1 and the k-mer stage never
-    returns).  KWAGE_SHARED_TABLE_LOG2 forces such a table (34 / 69 GB of HBM) under a small input."""
+    returns).  The shared_table_log2 knob forces such a table (34 / 69 GB of HBM) under a small input."""
     import kwage_amd as ka
     rng = np.random.default_rng(lg)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     chrom = acgt[rng.integers(0, 4, size=50_000)].tobytes().decode()
     seqs = [chrom, chrom[100:9000], "ACGT" * 30]
     exp = len(np.unique(np.concatenate([oracle.unique_kmers(s, 31) for s in seqs])))
-    monkeypatch.setenv("KWAGE_SHARED_TABLE_LOG2", str(lg))
     with ka.Context(0) as ctx:
+        ctx.set_tuning("shared_table_log2", lg)
         free, _ = ctx.mem_info()
         if free < (8 << lg) + (4 << 30):
             pytest.skip("not enough free HBM for a 2^%d-slot table" % lg)

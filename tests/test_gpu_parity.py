@@ -182,9 +182,8 @@ def test_hit_buffer_growth(ka, ctx, oracle, n_queries, monkeypatch):
     seqs = [rand_seq(rng, 60) for _ in range(n_queries)]
     b = ka.Batch(ctx, seqs)
     r = g.search(b, 0.001)
-    monkeypatch.setenv("KWAGE_HIT_SORT", "host")
-    assert np.array_equal(g.search(b, 0.001).hits, r.hits)      # the host's sort of the same list
-    monkeypatch.delenv("KWAGE_HIT_SORT")
+    with ctx.tuning(hit_sort_host=1):
+        assert np.array_equal(g.search(b, 0.001).hits, r.hits)      # the host's sort of the same list
     assert len(r.hits) == n_cols * len(seqs) and r.search_kernel_launches == 2
     assert np.array_equal(r.hits["query"], np.repeat(np.arange(len(seqs), dtype=np.uint32), n_cols))
     assert np.array_equal(r.hits["column"][:n_cols], np.arange(n_cols, dtype=np.uint32))
@@ -216,8 +215,8 @@ def test_device_hit_sort_key_widths(ka, ctx, n_cols, n_queries, monkeypatch):
     assert len(r.hits) == len(live) * n_cols > 8192
     assert np.array_equal(r.hits["query"], np.repeat(live, n_cols))
     assert np.array_equal(r.hits["column"], np.tile(np.arange(n_cols, dtype=np.uint32), len(live)))
-    monkeypatch.setenv("KWAGE_HIT_SORT", "host")
-    assert np.array_equal(g.search(b, 0.0001).hits, r.hits)
+    with ctx.tuning(hit_sort_host=1):
+        assert np.array_equal(g.search(b, 0.0001).hits, r.hits)
     b.close()
     g.close()
 
@@ -240,8 +239,8 @@ def test_device_hit_sort_with_files_padded_apart(ka, ctx, monkeypatch):
     assert len(r.hits) == len(seqs) * len(columns) > 8192
     assert np.array_equal(r.hits["query"], np.repeat(np.arange(len(seqs), dtype=np.uint32), len(columns)))
     assert np.array_equal(r.hits["column"], np.tile(columns, len(seqs)))
-    monkeypatch.setenv("KWAGE_HIT_SORT", "host")
-    assert np.array_equal(g.search(b, 0.0001).hits, r.hits)
+    with ctx.tuning(hit_sort_host=1):
+        assert np.array_equal(g.search(b, 0.0001).hits, r.hits)
     b.close()
     g.close()
 
@@ -387,22 +386,24 @@ def test_long_queries_are_segmented(ka, ctx, oracle, num_hash, monkeypatch):
     g.add_columns(image, n_cols)
     g.finalize()
     b = ka.Batch(ctx, seqs)
-    for force in (None, "1", "7", "64"):
-        if force is None:
-            monkeypatch.delenv("KWAGE_FORCE_SEGS", raising=False)     # natural choice: few tiles -> segments
-        else:
-            monkeypatch.setenv("KWAGE_FORCE_SEGS", force)
-        for threshold in (1.0, 0.97, 0.5):
-            thr32 = float(np.float32(threshold))
-            for flags in (0, ka.SEARCH_EARLY_EXIT):
-                r = g.search(b, threshold, flags)
-                per_q = r.per_query()
-                for i, s in enumerate(seqs):
-                    kmers = oracle.unique_kmers(s, k)
-                    exp, _ = oracle.search_image(image, image.shape[1], k, num_hash, L, n_cols, kmers, thr32)
-                    assert per_q[i] == exp, (force, threshold, flags, i, len(per_q[i]), len(exp))
-                if threshold == 1.0:
-                    assert {5, 2999} <= {c for c, _ in per_q[0]}
+    # (0 = the natural choice: few tiles -> segments; "cw" = the persistent count kernel with a pair spread over
+    # up to 40 waves instead of the segment slab)
+    for force in (0, 1, 7, 64, "cw"):
+        knobs = dict(force_segs=0, count_walk_min_rows=1, count_walk_waves=1500, count_walk_max_parts=64) if force == "cw" else dict(force_segs=force)
+        with ctx.tuning(**knobs):
+            for threshold in (1.0, 0.97, 0.5):
+                thr32 = float(np.float32(threshold))
+                for flags in (0, ka.SEARCH_EARLY_EXIT):
+                    r = g.search(b, threshold, flags)
+                    if force == "cw" and threshold < 1.0 and not flags:
+                        assert r.search_kernel.startswith("count_walk_kernel<"), r.search_kernel
+                    per_q = r.per_query()
+                    for i, s in enumerate(seqs):
+                        kmers = oracle.unique_kmers(s, k)
+                        exp, _ = oracle.search_image(image, image.shape[1], k, num_hash, L, n_cols, kmers, thr32)
+                        assert per_q[i] == exp, (force, threshold, flags, i, len(per_q[i]), len(exp))
+                    if threshold == 1.0:
+                        assert {5, 2999} <= {c for c, _ in per_q[0]}
     b.close()
     g.close()
 
@@ -670,7 +671,7 @@ def test_pipelined_device_search_and_counted_exchange(ka, ctx):
 
 
 @pytest.mark.parametrize("n_cols", [16500, 40000, 100000, 131072, 131073, 300000])
-def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, monkeypatch):
+def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, request):
     """Rows of >= 3 KiB take and_walk_kernel when the batch is large (a persistent grid, every wave walks an
     equal share of the batch's positions over a column tile's whole width; pairs cut by a share boundary meet
     in memory): ragged query lengths so that shares start and end inside, between and across queries, empty and
@@ -678,8 +679,9 @@ def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, monkeypatch):
     column tiles whose last chunk lies wholly past the row end, 300000 columns three tiles (by default rows wider
     than 16 KiB and batches below 256k rows stay with the tiled kernel: both limits are moved here).  Every case
     with the natural number of waves and with shares of a handful of positions."""
-    monkeypatch.setenv("KWAGE_WALK_MAX_KIB", "64")
-    monkeypatch.setenv("KWAGE_WALK_MIN_ROWS", "1")
+    scope = ctx.tuning(walk_max_kib=64, walk_min_rows=1, walk_waves=0, walk_early_exit=0, walk=4)      # (knobs of the module's shared context)
+    scope.__enter__()
+    request.addfinalizer(lambda: scope.__exit__(None, None, None))
     rng = np.random.default_rng(n_cols)
     k, nh, L = 31, 2, 10
     image = _make_random_db(rng, L, n_cols, 0.9)
@@ -703,26 +705,38 @@ def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, monkeypatch):
     b = ka.Batch(ctx, seqs)
     exp = [oracle.search_image(image, image.shape[1], k, nh, L, n_cols, oracle.unique_kmers(s, k), 1.0)[0] for s in seqs]
     first = None
-    for waves in (None, "5", "3001", "16384"):
-        if waves is None:
-            monkeypatch.delenv("KWAGE_WALK_WAVES", raising=False)
-        else:
-            monkeypatch.setenv("KWAGE_WALK_WAVES", waves)
-        for flags, ee in ((0, "0"), (ka.SEARCH_EARLY_EXIT, "1"), (ka.SEARCH_EARLY_EXIT, "0")):
-            monkeypatch.setenv("KWAGE_WALK_EARLY_EXIT", ee)      # with early exit the host prefers the tiled kernel unless told otherwise
+    for waves in (0, 5, 3001, 16384):
+        ctx.set_tuning("walk_waves", waves)
+        for flags, ee in ((0, 0), (ka.SEARCH_EARLY_EXIT, 1), (ka.SEARCH_EARLY_EXIT, 0)):
+            ctx.set_tuning("walk_early_exit", ee)      # with early exit the host prefers the tiled kernel unless told otherwise
             r = g.search(b, 1.0, flags)
-            assert r.search_kernel.startswith("and_kernel<" if (flags and ee == "0") else "and_walk_kernel<"), r.search_kernel
+            assert r.search_kernel.startswith("and_kernel<" if (flags and ee == 0) else "and_walk_kernel<"), r.search_kernel
             if first is None:
                 first = r
                 assert r.per_query() == exp, (n_cols, flags, waves)           # against the oracle once ...
             else:                                                            # ... then hit list against hit list (millions of records)
                 assert np.array_equal(r.hits, first.hits) and np.array_equal(r.num_query_kmer, first.num_query_kmer), (n_cols, flags, waves)
-    monkeypatch.delenv("KWAGE_WALK_WAVES", raising=False)
-    monkeypatch.setenv("KWAGE_WALK", "0")
+    ctx.set_tuning("walk_waves", 0)
+    ctx.set_tuning("walk", 0)
     r = g.search(b, 1.0, 0)
     assert r.search_kernel.startswith("and_kernel<") and np.array_equal(r.hits, first.hits)
     planted = [e for s, e in zip(seqs, exp) if len(s) >= 31 and s in genome]
     assert planted and all({c for c, _ in e} >= set(cols) for e in planted)
+    # The count path's persistent form (count_walk_kernel) on the same ragged batch: shares of a handful of positions,
+    # of thousands, and more waves than the chip holds; twice per case (the kernel must leave its pair counters zero);
+    # against the tiled count kernel's list, which is checked against the oracle once.
+    for thr in (0.9, 0.5):
+        with ctx.tuning(count_walk=0):
+            ref = g.search(b, thr, 0)
+        assert ref.search_kernel.startswith("count_kernel<"), ref.search_kernel
+        thr32 = float(np.float32(thr))
+        assert ref.per_query() == [oracle.search_image(image, image.shape[1], k, nh, L, n_cols, oracle.unique_kmers(s, k), thr32)[0] for s in seqs]
+        for waves in (0, 7, 3001, 30000):
+            with ctx.tuning(count_walk_waves=waves, count_walk_min_rows=1, count_walk_max_parts=1 << 20):
+                for rep in range(2):
+                    r = g.search(b, thr, 0)
+                    assert r.search_kernel.startswith("count_walk_kernel<"), r.search_kernel
+                    assert np.array_equal(r.hits, ref.hits) and np.array_equal(r.num_query_kmer, ref.num_query_kmer), (n_cols, thr, waves, rep)
     b.close()
     g.close()
 

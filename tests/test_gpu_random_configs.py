@@ -62,34 +62,33 @@ def test_random_configuration(oracle, seed, monkeypatch):
                 kmers = oracle.unique_kmers(s, k)
                 e, _ = oracle.search_image(image, image.shape[1], k, nh, L, n_cols, kmers, thr32)
                 exp.append((len(kmers), e))
-            for flags, force in ((0, None), (ka.SEARCH_EARLY_EXIT, None), (0, str(int(rng.choice([2, 5, 33, 300])))), (ka.SEARCH_EARLY_EXIT, "3")):
-                if force is None:
-                    monkeypatch.delenv("KWAGE_FORCE_SEGS", raising=False)
-                else:
-                    monkeypatch.setenv("KWAGE_FORCE_SEGS", force)
+            for flags, force in ((0, 0), (ka.SEARCH_EARLY_EXIT, 0), (0, int(rng.choice([2, 5, 33, 300]))), (ka.SEARCH_EARLY_EXIT, 3)):
+                ctx.set_tuning("force_segs", force)
                 r = g.search(b, thr, flags)
                 per_q = r.per_query()
                 for i, (nk, e) in enumerate(exp):
                     assert r.num_query_kmer[i] == nk, (seed, thr, i)
                     assert per_q[i] == e, (seed, k, nh, L, n_cols, thr, flags, force, i, len(per_q[i]), len(e))
+            ctx.set_tuning("force_segs", 0)
+            if thr < 1.0 and n_cols > 256:
+                # the persistent form of the count path (normally for batches that give every wave of the chip a few dozen
+                # rows): shares of a few positions / hundreds / more waves than the chip holds, long queries spread over
+                # dozens of waves each; twice per case (the kernel must leave its pair counters zero)
+                for waves in (0, int(rng.choice([3, 11, 64])), int(rng.choice([700, 2048, 9000]))):
+                    with ctx.tuning(count_walk_min_rows=1, count_walk_waves=waves, count_walk_max_parts=1 << 20, narrow=0):
+                        for _ in range(2):
+                            r = g.search(b, thr, 0)
+                            assert r.search_kernel.startswith("count_walk_kernel<"), r.search_kernel
+                            assert [(int(n), e) for n, e in zip(r.num_query_kmer, r.per_query())] == exp, (seed, n_cols, thr, waves)
             if thr == 1.0 and n_cols > 16384:
                 # the walk form of the AND kernel (normally for batches of >= 256k rows and rows of 3..16 KiB), both
                 # unrolls, with the batch's positions cut into few / many / very many wave shares: the long queries
                 # are then finished through the cut-pair slots by dozens of waves each
-                monkeypatch.setenv("KWAGE_WALK_MIN_ROWS", "1")
-                monkeypatch.setenv("KWAGE_WALK_MAX_KIB", "64")
-                monkeypatch.setenv("KWAGE_WALK_EARLY_EXIT", "1")
-                for unroll, flags, waves in (("4", 0, None), ("2", ka.SEARCH_EARLY_EXIT, "7"), ("4", 0, "1000"), ("2", 0, "4096")):
-                    monkeypatch.setenv("KWAGE_WALK", unroll)
-                    if waves is None:
-                        monkeypatch.delenv("KWAGE_WALK_WAVES", raising=False)
-                    else:
-                        monkeypatch.setenv("KWAGE_WALK_WAVES", waves)
-                    for _ in range(2):         # twice: the kernel must leave its cut-pair slots clean
-                        r = g.search(b, thr, flags)
-                        assert r.search_kernel.startswith("and_walk_kernel<")
-                        assert [(int(n), e) for n, e in zip(r.num_query_kmer, r.per_query())] == exp, (seed, n_cols, unroll, waves)
-                for v in ("KWAGE_WALK_MIN_ROWS", "KWAGE_WALK_MAX_KIB", "KWAGE_WALK", "KWAGE_WALK_EARLY_EXIT", "KWAGE_WALK_WAVES"):
-                    monkeypatch.delenv(v, raising=False)
+                for unroll, flags, waves in ((4, 0, 0), (2, ka.SEARCH_EARLY_EXIT, 7), (4, 0, 1000), (2, 0, 4096)):
+                    with ctx.tuning(walk_min_rows=1, walk_max_kib=64, walk_early_exit=1, walk=unroll, walk_waves=waves):
+                        for _ in range(2):         # twice: the kernel must leave its cut-pair slots clean
+                            r = g.search(b, thr, flags)
+                            assert r.search_kernel.startswith("and_walk_kernel<")
+                            assert [(int(n), e) for n, e in zip(r.num_query_kmer, r.per_query())] == exp, (seed, n_cols, unroll, waves)
         b.close()
         g.close()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sweep and_kernel shapes (KWAGE_AND_CFG=vec,unroll,nt) on one resident workload, interleaved
+"""Sweep and_kernel shapes (the and_vec / and_unroll / and_nt / and_lds_kb / and_block_waves knobs) on one resident workload, interleaved
 rounds in ONE process (cdna_hip_programming.md section 5.4 rule 24).  Prints median/min kernel ms
 and algorithmic GB/s per variant.   python tools/tune_and.py [workload] [rounds]"""
 import os
@@ -16,12 +16,14 @@ rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 variants = [(2, 8, 1, 0, 4), (2, 8, 1, 0, 2), (2, 8, 1, 0, 1), (1, 8, 1, 0, 4), (1, 8, 1, 0, 1), (1, 16, 1, 0, 1),
             (2, 16, 1, 0, 4), (2, 16, 1, 0, 1), (4, 8, 1, 0, 4), (4, 8, 1, 0, 1), (2, 8, 0, 0, 4)]
 ctx = ka.Context(0)
+ctx.set_tuning("walk", 0)      # the tiled kernel is what is swept
 s = synth.build(ctx, synth.WORKLOADS[wl])
 ms = {v: [] for v in variants}
 ref = None
 for r in range(rounds):
     for v in variants:
-        os.environ["KWAGE_AND_CFG"] = "%d,%d,%d,%d,%d" % v
+        for name, x in zip(("and_vec", "and_unroll", "and_nt", "and_lds_kb", "and_block_waves"), v):
+            ctx.set_tuning(name, x)
         res = s.group.search(s.batch, s.workload.threshold, ka.SEARCH_TIMING)
         key = (len(res.hits), int(res.hits["column"].astype(np.uint64).sum()), int(res.hits["query"].astype(np.uint64).sum()))
         ref = ref or key

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Generic in-process A/B: values of one environment variable that the engine reads per call, interleaved
-rounds on one resident workload.   python tools/tune_env.py VAR v1,v2,... [workload] [rounds]"""
+"""Generic in-process A/B: values of one kernel-selection knob of the context (kwage_ctx_set_tuning), interleaved
+rounds on one resident workload.   python tools/tune_knob.py KNOB v1,v2,... [workload] [rounds] [other_knob=value ...]"""
 import os
 import sys
 
@@ -14,12 +14,14 @@ var, values = sys.argv[1], sys.argv[2].split(",")
 wl = sys.argv[3] if len(sys.argv) > 3 else "c2"
 rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 9
 ctx = ka.Context(0)
+for kv in sys.argv[5:]:
+    ctx.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
 s = synth.build(ctx, synth.WORKLOADS[wl])
 ms = {v: [] for v in values}
 ref = None
 for r in range(rounds):
     for v in values:
-        os.environ[var] = v
+        ctx.set_tuning(var, int(v))
         res = s.group.search(s.batch, s.workload.threshold, ka.SEARCH_TIMING)
         key = (len(res.hits), int(res.hits["column"].astype(np.uint64).sum()), int(res.hits["num_match"].astype(np.uint64).sum()))
         ref = ref or key

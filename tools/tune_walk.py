@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""and_walk_kernel (KWAGE_WALK=unroll) against the tiled and_kernel (KWAGE_WALK=0) on one resident workload,
+"""and_walk_kernel (the walk knob = rows in flight) against the tiled and_kernel (walk = 0) on one resident workload,
 interleaved rounds in ONE process (the same 105 GB allocation: separate processes differ by +-3 % from
 physical placement alone).   python tools/tune_walk.py [workload] [rounds] [values]"""
 import os
@@ -20,7 +20,7 @@ ms = {v: [] for v in values}
 ref = None
 for r in range(rounds):
     for v in values:
-        os.environ["KWAGE_WALK"] = v
+        ctx.set_tuning("walk", int(v))
         res = s.group.search(s.batch, s.workload.threshold, ka.SEARCH_TIMING)
         key = (len(res.hits), int(res.hits["column"].astype(np.uint64).sum()), int(res.hits["query"].astype(np.uint64).sum()))
         ref = ref or key
@@ -30,4 +30,4 @@ ab = res.algorithmic_bytes
 print("workload %s  algorithmic bytes/launch %.3f GB, %d rounds" % (wl, ab / 1e9, rounds))
 for v in sorted(values, key=lambda v: np.median(ms[v][1:])):
     m = np.array(ms[v][1:])
-    print("KWAGE_WALK=%s  median %.4f ms  min %.4f ms  max %.4f ms -> %.0f GB/s (median)" % (v, np.median(m), m.min(), m.max(), ab / np.median(m) / 1e6))
+    print("walk=%s  median %.4f ms  min %.4f ms  max %.4f ms -> %.0f GB/s (median)" % (v, np.median(m), m.min(), m.max(), ab / np.median(m) / 1e6))
