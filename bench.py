@@ -256,23 +256,25 @@ def rank_main(args):
     flags = ka.SEARCH_TIMING | (ka.SEARCH_EARLY_EXIT if args.early_exit else 0)
     threshold = w.threshold
 
-    ss = None
+    members = multi or [s]             # the groups this rank holds: one, or C5's eight filter sizes
+    n_groups = len(members)
+    ss = hx = None
+    bases, total_columns = [0] * n_groups, None
     if sharded:
-        from kwage_amd.distributed import PipelinedDeviceSearcher, ShardedSearch, device_tensor_search_fn
+        from kwage_amd.distributed import HitExchange, ShardedSearch, StepPipeline, device_tensor_search_fn, global_column_bases, hits_checksum
         dev = "cuda:%d" % local_rank
-        ss = [ShardedSearch(dist, rank, world, int(m.group.column_span),
-                            device_tensor_search_fn(m.group, flags, dev), device=cdev)
-              for m in (multi or [s])]
+        # global column numbers: group after group, inside a group rank after rank (one all_gather of the spans)
+        bases, _, total_columns = global_column_bases(dist, rank, world, [int(m.group.column_span) for m in members], cdev)
+        hx = HitExchange(dist, rank, world)
+        # the synchronous form (one padded gather per group and step): the fallback if the pipelined search fails somewhere
+        ss = [ShardedSearch(dist, rank, world, int(m.group.column_span), device_tensor_search_fn(m.group, flags, dev), device=cdev)
+              for m in members]
 
     def step():
-        """One pass of the hot path; returns (result-or-None, search_kernel_ms, hits delivered to rank 0)."""
-        if not sharded and multi is not None:
-            rs = [m.group.search(s.batch, threshold, flags) for m in multi]
-            return rs, sum(r.search_kernel_ms for r in rs), sum(len(r.hits) for r in rs)
+        """One synchronous pass of the hot path; returns (results-or-None, search_kernel_ms, hits delivered to rank 0)."""
         if not sharded:
-            r = s.group.search(s.batch, threshold, flags)
-            return r, r.search_kernel_ms, len(r.hits)
-        # multi-GPU: hits stay in HBM, ONE gatherv over RCCL, rank 0 concatenates + sorts
+            rs = [m.group.search(s.batch, threshold, flags) for m in members]
+            return rs, sum(r.search_kernel_ms for r in rs), sum(len(r.hits) for r in rs)
         total = 0
         for one in ss:          # one group after the other; each ends in ONE gatherv of its hit list
             merged, _ = one.search(s.batch, threshold)
@@ -289,41 +291,39 @@ def rank_main(args):
     for _ in range(args.warmup):
         step()
     pipe = None
-    pipeline_note = "on" if not sharded else "n/a"
+    pipeline_note = "on"
     kernel_ms = []
+    exchange_check = None
 
     trace = [] if os.environ.get("KWAGE_BENCH_TRACE") == "1" else None
 
-    def local_collect(pipe, tk):
+    def local_finish():
+        """Complete the oldest step of this rank's pipeline -> (its exchange buffer, n_hits)."""
         t_a = time.perf_counter()
-        buf, n = pipe.collect_counted(tk)
+        buf, n = pipe.finish()
         if trace is not None:
             trace.append((time.perf_counter() - t_a, t_a))
         kernel_ms.append(pipe.last_kernel_ms)
         if backend != "nccl":                    # gloo rehearsal: the same exchange on host tensors
-            buf = buf[:max(n, ss[0].capacity) + 1].cpu()
+            buf = buf[:n + 1].cpu()
         return buf, n
 
-    def exchange(pipe, tk):
-        buf, n = local_collect(pipe, tk)
-        return ss[0].exchange_counted(buf, n)
-
-    if not sharded and multi is None:
+    if not sharded:
         # untimed: let the second search slot allocate its scratch too (the timed loop uses both)
-        p1 = s.group.submit(s.batch, threshold, flags)
-        p2 = s.group.submit(s.batch, threshold, flags)
+        p1 = members[0].group.submit(s.batch, threshold, flags)
+        p2 = members[-1].group.submit(s.batch, threshold, flags)
         p1.collect()
         p2.collect()
-    elif sharded and multi is None:
-        # untimed warm-up of both slots of the pipelined exchange.  Rank-LOCAL work first (submit + collect, may fail
-        # on one rank only, e.g. out of memory), then every rank learns whether all succeeded, and only then the
-        # first collective exchange: a rank that failed never leaves the others blocked inside an all_gather.
-        pipeline_note = "on"
+    else:
+        # untimed warm-up of both buffers of the step pipeline.  Rank-LOCAL work first (submit + collect, may fail on
+        # one rank only, e.g. out of memory), then every rank learns whether all succeeded, and only then the first
+        # collective exchange: a rank that failed never leaves the others blocked inside an all_gather.
         pending = []
         try:
-            pipe = PipelinedDeviceSearcher(s.group, flags, "cuda:%d" % local_rank)
-            t1, t2 = pipe.submit(s.batch, threshold), pipe.submit(s.batch, threshold)
-            pending = [local_collect(pipe, t1), local_collect(pipe, t2)]
+            pipe = StepPipeline([m.group for m in members], bases, flags, "cuda:%d" % local_rank)
+            pipe.begin(s.batch, threshold)
+            pipe.begin(s.batch, threshold)
+            pending = [local_finish(), local_finish()]
             ok = 1
         except Exception as exc:       # keep a number rather than none: fall back to the synchronous exchange
             print("[bench] pipelined search failed on rank %d (%r): falling back to the synchronous path" % (rank, exc), file=sys.stderr)
@@ -334,45 +334,81 @@ def rank_main(args):
             pipe, pipeline_note = None, "off (warm-up of the pipelined search failed on some rank)"
             ctx.sync()
         else:
+            merged = None
             for buf, n in pending:
-                ss[0].exchange_counted(buf, n)
+                merged = hx.exchange_step(buf, n)
+            # ---- untimed self-check of the exchange: what rank 0 holds after the gather is exactly what the ranks
+            # found -- every rank's record count and an order-independent checksum of its (query, global column,
+            # num_match) records against the merged list.
+            buf, n = pending[-1]
+            mine = np.array([n, hits_checksum(buf[1:1 + n].cpu().numpy())], dtype=np.uint64).view(np.int64)
+            t = torch.from_numpy(mine.copy()).to(cdev)
+            outs = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(outs, t)
+            per = [o.cpu().numpy().view(np.uint64) for o in outs]
+            good = 1
+            if rank == 0:
+                want_n = int(sum(int(x[0]) for x in per))
+                want_sum = int(sum(int(x[1]) for x in per) % (1 << 64))
+                key = (merged[:, 0].astype(np.uint64) << np.uint64(32)) | merged[:, 1].astype(np.uint64) if len(merged) else np.zeros(0, np.uint64)
+                ordered = bool(np.all(key[1:] > key[:-1])) if len(key) > 1 else True       # strictly ascending (query, column): sorted, no duplicate
+                in_range = bool(len(merged) == 0 or int(merged[:, 1].max()) < total_columns)
+                good = int(len(merged) == want_n and hits_checksum(merged) == want_sum and ordered and in_range)
+                exchange_check = {"ok": bool(good), "ranks": world, "hits": int(len(merged)), "hits_per_rank": [int(x[0]) for x in per],
+                                  "checksum": "%016x" % hits_checksum(merged), "sum_of_rank_checksums": "%016x" % want_sum,
+                                  "sorted_unique": ordered, "columns_in_range": in_range, "total_columns": int(total_columns)}
+            flag = torch.tensor([good], dtype=torch.int32, device=cdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if rank == 0:
+                    print(json.dumps({"metric": "exchange_check failed", "exchange_check": exchange_check}), flush=True)
+                sys.exit(3)
+
+    last_results = []
 
     def timed_steps(nsteps):
-        """nsteps passes, software-pipelined where the path allows; -> (last result or None, hits of the last step)."""
-        last, nhits = None, 0
-        if sharded and multi is None and pipe is not None:
-            # multi-GPU: the same software pipeline per rank -- step i+1's search is submitted before step i's hits
-            # are exchanged (one all_gather over RCCL) and merged on rank 0
-            tk = pipe.submit(s.batch, threshold)
+        """nsteps passes, software-pipelined; -> hits of the last step (as delivered to rank 0)."""
+        nhits = 0
+        if sharded and pipe is not None:
+            # multi-GPU: step i+1's searches are queued before step i's hits are exchanged (one small all_gather over
+            # RCCL; what does not fit goes to rank 0 alone) and merged on rank 0
+            pipe.begin(s.batch, threshold)
             for _ in range(nsteps - 1):
-                nxt = pipe.submit(s.batch, threshold)
-                merged = exchange(pipe, tk)
-                tk = nxt
-            merged = exchange(pipe, tk)
+                pipe.begin(s.batch, threshold)
+                merged = hx.exchange_step(*local_finish())
+            merged = hx.exchange_step(*local_finish())
             nhits = len(merged) if merged is not None else 0
-        elif not sharded and multi is None:
-            # K steps, software-pipelined through the two search slots of the context: step i+1 is submitted
-            # (its k-mer stage runs) before step i is collected (copy-back, sort); the gather kernels themselves
-            # run back to back, never side by side.  Every step is complete when the region ends.
-            pend = s.group.submit(s.batch, threshold, flags)
-            for _ in range(nsteps - 1):
-                nxt = s.group.submit(s.batch, threshold, flags)
-                last = pend.collect()
-                kernel_ms.append(last.search_kernel_ms)
-                pend = nxt
-            last = pend.collect()
-            kernel_ms.append(last.search_kernel_ms)
-            nhits = len(last.hits)
+        elif not sharded:
+            # The searches of all steps, group after group, stream through the two search slots of the context: search
+            # j+1 is submitted (its k-mer stage runs) before search j is collected (copy-back, sort); the gather kernels
+            # themselves run back to back, never side by side.  Every step is complete when the region ends.
+            from collections import deque
+            pend = deque()
+            acc = []
+
+            def collect_one():
+                acc.append(pend.popleft().collect())
+                if len(acc) == n_groups:
+                    kernel_ms.append(sum(r.search_kernel_ms for r in acc))
+                    last_results[:] = acc
+                    acc.clear()
+            for j in range(nsteps * n_groups):
+                pend.append(members[j % n_groups].group.submit(s.batch, threshold, flags))
+                if len(pend) == 2:
+                    collect_one()
+            while pend:
+                collect_one()
+            nhits = sum(len(r.hits) for r in last_results)
         else:
             for _ in range(nsteps):
-                last, ms, nhits = step()
+                _, ms, nhits = step()
                 kernel_ms.append(ms)
-        return last, nhits
+        return nhits
 
     sync_all()
     t0 = time.perf_counter()
     kernel_ms.clear()
-    last, nhits = timed_steps(args.steps)
+    nhits = timed_steps(args.steps)
     sync_all()
     dt = time.perf_counter() - t0
     if trace:     # host view of the pipeline: time blocked in collect, and collect-to-collect period
@@ -404,17 +440,13 @@ def rank_main(args):
         sustained = {"steps": n_sus, "seconds": round(dts, 3), "ms_per_step": round(dts / n_sus * 1e3, 4)}
 
     # work per step (identical on every rank: same queries, same column count)
-    probe = last if last is not None else [m.group.search(s.batch, threshold, flags) for m in (multi or [s])]
-    if isinstance(probe, list):
-        bit_tests_rank = int(sum(r.bit_tests for r in probe))
-        alg_bytes_rank = int(sum(r.algorithmic_bytes for r in probe))
-        probe = probe[0]
-    else:
-        bit_tests_rank = int(probe.bit_tests)
-        alg_bytes_rank = int(probe.algorithmic_bytes)
-    if sharded and (multi is not None or pipe is None):
+    probe = list(last_results) or [m.group.search(s.batch, threshold, flags) for m in members]
+    bit_tests_rank = int(sum(r.bit_tests for r in probe))
+    alg_bytes_rank = int(sum(r.algorithmic_bytes for r in probe))
+    probe = probe[0]
+    if sharded and pipe is None:
         # the synchronous sharded path does not return kernel times: measure them with three local searches
-        timed_kernel_ms = [sum(m.group.search(s.batch, threshold, flags).search_kernel_ms for m in (multi or [s])) for _ in range(3)]
+        timed_kernel_ms = [sum(m.group.search(s.batch, threshold, flags).search_kernel_ms for m in members) for _ in range(3)]
         sus_kernel_ms = []
 
     def stats(xs):
@@ -487,7 +519,12 @@ def rank_main(args):
             except Exception:
                 pass
             out["rccl"] = {"world": world, "backend": backend, "version": rv,
-                           "exchange": "one all_gather of [count | records] buffers per step" if pipe is not None else "one padded all_gather per group and step"}
+                           "exchange": ("one all_gather of [count | first %d records] per step for all %d group(s); longer lists: the rest to rank 0 only, exact sizes, one grouped send/recv" % (hx.spec, n_groups))
+                                       if pipe is not None else "one padded all_gather per group and step",
+                           "collectives": hx.stats["collectives"], "p2p_batches": hx.stats["p2p_batches"],
+                           "searches_per_step": n_groups}
+            if exchange_check is not None:
+                out["exchange_check"] = exchange_check
         if force_sharded:
             out["config"]["note"] = "KWAGE_BENCH_FORCE_SHARDED: multi-GPU code path on one rank"
         if world == 1 and not args.no_cpu_baseline:
@@ -498,7 +535,7 @@ def rank_main(args):
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
 
-    for m in (multi or [s]):
+    for m in members:
         m.batch.close()
         m.group.close()
     ctx.close()

@@ -112,8 +112,8 @@ struct Slot {
 	char kernel_name[64] = "";          // the gather kernel launch_search_stage picked, with its template shape
 	// and_walk_kernel's meeting place for (query, tile) pairs cut by a wave-share boundary: all zero between searches
 	DevBuf walk_or, walk_done;
-	// count_walk_kernel's: partial counters of cut pairs (overwritten before they are read) and their k-mer counters (zero between searches)
-	DevBuf cwalk_slab, cwalk_done;
+	// count_walk_kernel's: partial counters of cut pairs (overwritten before they are read) and the arrival counters of their trees (zero between searches)
+	DevBuf cwalk_slab, cwalk_arrived;
 	uint64_t staged_hits = 0;
 	kwage_hit *ext_hits = nullptr;      // caller-owned device buffer (kwage_search_device) or null
 	uint64_t ext_cap = 0;
@@ -141,10 +141,10 @@ struct Tuning {
 	int64_t narrow = 1;             // KWAGE_NARROW: several queries per wave for rows <= 512 B
 	int64_t force_segs = 0;         // KWAGE_FORCE_SEGS: cut every query's k-mer list into this many segments (tests)
 	int64_t count_walk = 1;         // KWAGE_COUNT_WALK: the persistent count kernel where it applies
-	int64_t count_walk_wpc = 16;    // KWAGE_COUNT_WALK_WPC: its waves per CU
+	int64_t count_walk_wpc = 8;     // KWAGE_COUNT_WALK_WPC: its waves per CU (8: 6335 GB/s at C2's shape, 12: 6271, 16: 6250, 20: 5876)
 	int64_t count_walk_waves = 0;   // KWAGE_COUNT_WALK_WAVES: exactly this many waves (tests)
-	int64_t count_walk_min_rows = -1;   // KWAGE_COUNT_WALK_MIN_ROWS
-	int64_t count_walk_max_parts = 8;   // KWAGE_COUNT_WALK_MAX_PARTS: longest chain of parts one wave adds up; longer queries use segments
+	int64_t count_walk_min_rows = -1;   // KWAGE_COUNT_WALK_MIN_ROWS: smaller batches use the tiled kernel (-1: 64 rows for one wave per CU)
+	int64_t count_walk_prefetch = 0;    // KWAGE_COUNT_WALK_PREFETCH: request the next four k-mers' rows before adding the current four
 	int64_t count_narrow_kps = 8;   // KWAGE_COUNT_NARROW_KPS: k-mers per step of the narrow count kernel (8 or 4)
 	int64_t hit_sort_host = 0;      // KWAGE_HIT_SORT=host: order long hit lists on the host (A/B runs, the fallback)
 	int64_t hit_copy_piece_kb = 0;  // KWAGE_HIT_COPY_PIECE_KB: piece size of the copy-back of a long hit list (0 = default)
@@ -158,7 +158,7 @@ static const TuningName TUNING_NAMES[] = {
 	{"and_vec", &Tuning::and_vec}, {"and_unroll", &Tuning::and_unroll}, {"and_nt", &Tuning::and_nt}, {"and_lds_kb", &Tuning::and_lds_kb},
 	{"and_block_waves", &Tuning::and_block_waves}, {"narrow", &Tuning::narrow}, {"force_segs", &Tuning::force_segs},
 	{"count_walk", &Tuning::count_walk}, {"count_walk_wpc", &Tuning::count_walk_wpc}, {"count_walk_waves", &Tuning::count_walk_waves},
-	{"count_walk_min_rows", &Tuning::count_walk_min_rows}, {"count_walk_max_parts", &Tuning::count_walk_max_parts},
+	{"count_walk_min_rows", &Tuning::count_walk_min_rows}, {"count_walk_prefetch", &Tuning::count_walk_prefetch},
 	{"count_narrow_kps", &Tuning::count_narrow_kps},
 	{"hit_sort_host", &Tuning::hit_sort_host}, {"hit_copy_piece_kb", &Tuning::hit_copy_piece_kb}, {"shared_table_log2", &Tuning::shared_table_log2},
 };
@@ -602,16 +602,28 @@ void launch_count_planes(uint32_t planes, const SearchArgs &a, hipStream_t s)
 	}
 }
 
-template <int PLANES>
+template <int PLANES, bool PF>
 void launch_count_walk_nh(const SearchArgs &a, const CountWalkArgs &wa, uint32_t wgs, hipStream_t s)
 {
 	const dim3 grid(wgs), block(SEARCH_THREADS);
 	switch(a.num_hash){
-		case 1: hipLaunchKernelGGL((count_walk_kernel<PLANES, 1>), grid, block, 0, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr); break;
-		case 2: hipLaunchKernelGGL((count_walk_kernel<PLANES, 2>), grid, block, 0, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr); break;
-		case 3: hipLaunchKernelGGL((count_walk_kernel<PLANES, 3>), grid, block, 0, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr); break;
-		case 4: hipLaunchKernelGGL((count_walk_kernel<PLANES, 4>), grid, block, 0, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr); break;
-		default: hipLaunchKernelGGL((count_walk_kernel<PLANES, 5>), grid, block, 0, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr); break;
+		case 1: hipLaunchKernelGGL((count_walk_kernel<PLANES, 1, PF>), grid, block, 0, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr); break;
+		case 2: hipLaunchKernelGGL((count_walk_kernel<PLANES, 2, PF>), grid, block, 0, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr); break;
+		case 3: hipLaunchKernelGGL((count_walk_kernel<PLANES, 3, PF>), grid, block, 0, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr); break;
+		case 4: hipLaunchKernelGGL((count_walk_kernel<PLANES, 4, PF>), grid, block, 0, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr); break;
+		default: hipLaunchKernelGGL((count_walk_kernel<PLANES, 5, PF>), grid, block, 0, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr); break;
+	}
+}
+
+template <bool PF>
+void launch_count_walk_planes(uint32_t planes, const SearchArgs &a, const CountWalkArgs &wa, uint32_t wgs, hipStream_t s)
+{
+	switch(planes){
+		case 7: launch_count_walk_nh<7, PF>(a, wa, wgs, s); break;
+		case 10: launch_count_walk_nh<10, PF>(a, wa, wgs, s); break;
+		case 14: launch_count_walk_nh<14, PF>(a, wa, wgs, s); break;
+		case 20: launch_count_walk_nh<20, PF>(a, wa, wgs, s); break;
+		default: launch_count_walk_nh<32, PF>(a, wa, wgs, s); break;
 	}
 }
 
@@ -773,38 +785,30 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 		const uint32_t planes = planes_for(b->max_pos);
 		const bool narrow = tn.narrow && a.units_per_row <= 32 && a.units_per_row > 8 && a.n_queries >= 64 && planes <= 14;
 		// The persistent form (count_walk_kernel): equal shares of the batch's (query, KiB tile, position) list per wave,
-		// pairs cut by a share boundary finished through memory.  Taken when the batch gives every wave of the launch a
-		// few dozen rows, no early exit is asked for (a persistent wave has no tile of its own to give up) and no pair
-		// is spread over more than count_walk_max_parts waves (the wave that completes a pair adds the parts up one after
-		// the other; longer queries go through the segment slab and its tree combine below).
+		// pairs cut by share boundaries added up as a tree through memory.  Taken whenever the batch gives a wave per CU
+		// its 64 rows and no early exit is asked for (a persistent wave has no tile of its own to give up): long queries
+		// need no segment slab and no combine pass then.  Early exit, tiny batches and forced segment counts go on below.
 		if(tn.count_walk && !a.early_exit && !narrow && tn.force_segs <= 0 && b->total_pos > 0){
 			const uint64_t slots = (uint64_t)a.chunks*b->total_pos;
-			const uint64_t min_rows = (tn.count_walk_min_rows >= 0) ? (uint64_t)tn.count_walk_min_rows : (uint64_t)WALK_MIN_ROWS_PER_WAVE*ncu*(uint64_t)std::max<int64_t>(tn.count_walk_wpc, 1);
+			const uint64_t min_rows = (tn.count_walk_min_rows >= 0) ? (uint64_t)tn.count_walk_min_rows : (uint64_t)WALK_MIN_ROWS_PER_WAVE*ncu;
 			const uint64_t chip_waves = ncu*(uint64_t)std::max<int64_t>(tn.count_walk_wpc, 1);
 			const uint64_t want_waves = (tn.count_walk_waves > 0) ? std::min<uint64_t>((uint64_t)tn.count_walk_waves, slots)
 				: std::max<uint64_t>(1, std::min<uint64_t>(chip_waves, slots*a.num_hash/WALK_MIN_ROWS_PER_WAVE));
 			const uint32_t wgs = (uint32_t)((want_waves + 3)/4);
 			const uint64_t waves = (uint64_t)wgs*4;
-			const uint64_t per_wave = (slots + waves - 1)/waves;
-			const uint64_t max_parts = (b->max_pos + per_wave - 1)/per_wave + 1;
-			if(slots*a.num_hash >= min_rows && max_parts <= (uint64_t)std::max<int64_t>(tn.count_walk_max_parts, 2)){
+			if(slots*a.num_hash >= min_rows){
 				CountWalkArgs wa;
 				wa.total_slots = slots;
-				wa.per_wave = per_wave;
+				wa.per_wave = (slots + waves - 1)/waves;
 				wa.coltiles = a.chunks;
 				if((rc = sl->cwalk_slab.reserve(waves*2*planes*1024))){ return rc; }
-				if((rc = reserve_zeroed(sl->cwalk_done, waves*sizeof(uint32_t), sl->stream))){ return rc; }
+				if((rc = reserve_zeroed(sl->cwalk_arrived, waves*CWALK_LEVELS*sizeof(uint32_t), sl->stream))){ return rc; }
 				wa.slab = (uint32_t*)sl->cwalk_slab.p;
-				wa.done = (uint32_t*)sl->cwalk_done.p;
+				wa.arrived = (uint32_t*)sl->cwalk_arrived.p;
 				a.segs = 1;
-				snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_walk_kernel<%u,%u>", planes, std::min(a.num_hash, 5u));
-				switch(planes){
-					case 7: launch_count_walk_nh<7>(a, wa, wgs, sl->stream); break;
-					case 10: launch_count_walk_nh<10>(a, wa, wgs, sl->stream); break;
-					case 14: launch_count_walk_nh<14>(a, wa, wgs, sl->stream); break;
-					case 20: launch_count_walk_nh<20>(a, wa, wgs, sl->stream); break;
-					default: launch_count_walk_nh<32>(a, wa, wgs, sl->stream); break;
-				}
+				snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_walk_kernel<%u,%u%s>", planes, std::min(a.num_hash, 5u), tn.count_walk_prefetch ? ",pf" : "");
+				if(tn.count_walk_prefetch){ launch_count_walk_planes<true>(planes, a, wa, wgs, sl->stream); }
+				else{ launch_count_walk_planes<false>(planes, a, wa, wgs, sl->stream); }
 				HIP_TRY(hipGetLastError());
 				return KWAGE_OK;
 			}
@@ -1118,7 +1122,7 @@ extern "C" void kwage_shutdown(kwage_ctx *ctx)
 		if(sl->stream){ (void)hipStreamSynchronize(sl->stream); }
 		sl->rows.release(); sl->tables.release(); sl->result.release();
 		sl->partial.release(); sl->h_stage.release(); sl->sort_scratch.release();
-		sl->walk_or.release(); sl->walk_done.release(); sl->cwalk_slab.release(); sl->cwalk_done.release();
+		sl->walk_or.release(); sl->walk_done.release(); sl->cwalk_slab.release(); sl->cwalk_arrived.release();
 		for(int i = 0; i < 4; ++i){ if(sl->ev[i]){ (void)hipEventDestroy(sl->ev[i]); } }
 		if(sl->search_done){ (void)hipEventDestroy(sl->search_done); }
 		if(sl->stream){ (void)hipStreamDestroy(sl->stream); }

@@ -890,31 +890,78 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 	}
 }
 
-// The same counts from a PERSISTENT, statically balanced grid (and_walk_kernel's idea for the threshold < 1 path):
-// the tiled kernel above has one wave per (query, 1 KiB column tile), and at C2's shape those 13 000 waves are 1.6x what
-// the chip holds -- the last round runs on a part-filled chip (0.93 of the box's stream read against 0.99 for the AND
-// walk on the same matrix).  Here the launch has a fixed number of waves per CU and the batch's slot list -- for every
-// query and column tile its positions, query-major, exactly and_walk_kernel's -- is cut into equal contiguous shares.
-// Counters do not fit a wave's registers for more than one KiB of columns, so a wave walks its share one (query, KiB
-// tile) part at a time:
+// The same loop with the NEXT four k-mers' rows requested before the current four are added up (16 more VGPRs): for the
+// persistent kernel below, whose few waves per CU leave nothing else to cover the adders' time.
+template <int PLANES, int NH>
+__device__ __forceinline__ void count_kmers_prefetch(const uint8_t *db, uint64_t stride, const uint32_t *rq, uint32_t nk, uint32_t unit,
+                                                     u32x4 (&plane)[PLANES])
+{
+	constexpr int KPS = 4;
+	auto fetch = [&](uint32_t i, u32x4 (&m)[KPS]) {
+#pragma unroll
+		for(int u = 0; u < KPS; ++u){
+			u32x4 x[NH];
+#pragma unroll
+			for(int h = 0; h < NH; ++h){
+				const uint32_t r = rq[(i + u)*NH + h];
+				x[h] = load16<true>(reinterpret_cast<const u32x4*>(db + (uint64_t)r*stride) + unit);
+			}
+			m[u] = x[0];
+#pragma unroll
+			for(int h = 1; h < NH; ++h){ m[u] &= x[h]; }
+		}
+	};
+	uint32_t i = 0;
+	if(nk >= KPS){
+		u32x4 cur[KPS], nxt[KPS];
+		fetch(0, cur);
+		for(i = KPS; i + KPS <= nk; i += KPS){
+			fetch(i, nxt);
+			planes_add4<PLANES>(plane, cur[0], cur[1], cur[2], cur[3]);
+#pragma unroll
+			for(int u = 0; u < KPS; ++u){ cur[u] = nxt[u]; }
+		}
+		planes_add4<PLANES>(plane, cur[0], cur[1], cur[2], cur[3]);
+	}
+	for(; i < nk; ++i){
+		u32x4 mm = ~(u32x4)(0u);
+#pragma unroll
+		for(int h = 0; h < NH; ++h){
+			const uint32_t r = rq[i*NH + h];
+			mm &= load16<true>(reinterpret_cast<const u32x4*>(db + (uint64_t)r*stride) + unit);
+		}
+		planes_add<PLANES>(plane, mm, 0);
+	}
+}
+
+// The same counts from a PERSISTENT, statically balanced grid (and_walk_kernel's idea for the threshold < 1 path).  The
+// tiled kernel above has one wave per (query, 1 KiB column tile): batch sizes whose waves are not a multiple of what the
+// chip holds end in a part-filled round, and a single long query needs the segment slab + combine pass.  Here the launch
+// has a fixed number of waves per CU and the batch's slot list -- for every query and column tile its positions,
+// query-major, exactly and_walk_kernel's -- is cut into equal contiguous shares.  Counters do not fit a wave's registers
+// for more than one KiB of columns, so a wave walks its share one (query, KiB tile) part at a time:
 //   - a part that is a whole pair is thresholded and emitted at once;
-//   - a pair CUT by a share boundary is finished through memory: every wave that holds a part stores its partial
-//     counters in its own block of `slab` -- block [w][0] for a part that began in an earlier wave, [w][1] for one
-//     that goes on in the next -- and adds its k-mer count to the pair's counter (done[wave that holds the pair's
-//     first position]: only the last pair that starts in a share can be cut, so no two cut pairs share one); the
-//     wave whose add completes the pair's nkmer adds the other parts' blocks to its own counters (ripple-carry
-//     adders across the planes), emits, and leaves the counter ZERO again.
+//   - a pair CUT by share boundaries lies in a run of consecutive waves first_w .. last_w (known to each of them from
+//     the pair's first slot, its k-mer count and the share size).  The parts are added up as a binary TREE over that
+//     run, "last arriver continues": a wave stores its partial counters in its own block of `slab` ([w][1] for the
+//     part that starts the pair, [w][0] for a part that began in an earlier wave), then arrives at the node it shares
+//     with its sibling subtree (one counter per (wave, level)); the first to arrive is done, the second adds the
+//     sibling's block to its registers (ripple-carry adders across the planes), zeroes the counter and climbs a level.
+//     Whoever climbs past the root holds the pair's counters and emits.  A pair cut once costs one store, one
+//     atomic and one load of PLANES KiB; a 1 Mb query spread over 80 waves is summed in 7 levels, not by one wave.
 // Everything the protocol exchanges goes through device-scope stores / atomics and loads (the XCDs' L2s are not
 // coherent with one another for plain accesses), ordered by waiting for the stores' acknowledgements (vmcnt).
+static constexpr uint32_t CWALK_LEVELS = 32;      // tree depth a 32-bit wave count can need
+
 struct CountWalkArgs {
 	uint64_t total_slots;           // column tiles per row x positions of the batch
 	uint64_t per_wave;              // slots per wave
 	uint32_t coltiles;              // 1 KiB column tiles per row
-	uint32_t *slab;                 // [waves][2][PLANES][4][64] partial counters of cut pairs
-	uint32_t *done;                 // [waves] k-mers folded into the cut pair that starts in the wave's share; zero between searches
+	uint32_t *slab;                 // [waves][2][PLANES][4][64] partial counters of cut pairs (overwritten before they are read)
+	uint32_t *arrived;              // [waves][CWALK_LEVELS] arrivals at the tree node (first wave of the node's subtree, level); zero between searches
 };
 
-template <int PLANES, int NH>
+template <int PLANES, int NH, bool PF>
 __global__ __launch_bounds__(SEARCH_THREADS) void count_walk_kernel(SearchArgs a, CountWalkArgs wa, const uint32_t *__restrict__ rows,
                                                                     const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ nkmer,
                                                                     const uint32_t *__restrict__ qthr)
@@ -954,37 +1001,42 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_walk_kernel(SearchArgs a
 			u32x4 plane[PLANES];
 #pragma unroll
 			for(int p = 0; p < PLANES; ++p){ plane[p] = (u32x4)(0u); }
-			count_kmers<PLANES, NH>(a.db, a.stride, rows + (p0 + j0)*NH, jv1 - j0, unit, plane, [](uint32_t) -> bool { return false; });
+			if(PF){ count_kmers_prefetch<PLANES, NH>(a.db, a.stride, rows + (p0 + j0)*NH, jv1 - j0, unit, plane); }
+			else{ count_kmers<PLANES, NH>(a.db, a.stride, rows + (p0 + j0)*NH, jv1 - j0, unit, plane, [](uint32_t) -> bool { return false; }); }
 
 			bool emit = true;
 			if(j0 != 0 || jv1 != n){
+				// the run of waves that hold a part of this pair, and this wave's place in it
 				const uint64_t pair_start = (uint64_t)ct*p0 + (uint64_t)c*npos;        // slot of the pair's position 0
 				const uint32_t first_w = (uint32_t)(pair_start / wa.per_wave);
-				uint32_t *mine = wa.slab + ((uint64_t)gw*2 + (j0 != 0 ? 0 : 1))*(PLANES*4*WAVE) + lane;
+				const uint32_t parts = (uint32_t)((pair_start + n - 1) / wa.per_wave) - first_w + 1;
+				uint32_t rep = gw - first_w;                                           // first wave (relative) of the subtree whose sum this wave holds
+				for(uint32_t stride = 1, level = 0; stride < parts; stride <<= 1, ++level){
+					const uint32_t parent = rep & ~(2*stride - 1);
+					if(rep == parent && rep + stride >= parts){ continue; }              // no sibling at this level: the subtree moves up as it is
+					// the block of a subtree's first wave holds the subtree's sum ([..][1] in the wave that starts the pair)
+					uint32_t *mine = wa.slab + ((uint64_t)(first_w + rep)*2 + (rep == 0 ? 1 : 0))*(PLANES*4*WAVE) + lane;
 #pragma unroll
-				for(int p = 0; p < PLANES; ++p){
+					for(int p = 0; p < PLANES; ++p){
 #pragma unroll
-					for(int d = 0; d < 4; ++d){ __hip_atomic_store(mine + (p*4 + d)*WAVE, plane[p][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-				}
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores are performed before the count says so
-				uint32_t old = 0;
-				if(lane == 0){ old = __hip_atomic_fetch_add(wa.done + first_w, jv1 - j0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-				old = __builtin_amdgcn_readfirstlane(old);
-				emit = false;
-				if(old + (jv1 - j0) == n){                            // this part completes the pair: add the others
-					const uint32_t last_w = (uint32_t)((pair_start + n - 1) / wa.per_wave);
-					for(uint32_t w = first_w; w <= last_w; ++w){
-						if(w == gw){ continue; }
-						const uint32_t *theirs = wa.slab + ((uint64_t)w*2 + (w == first_w ? 1 : 0))*(PLANES*4*WAVE) + lane;
-						planes_accumulate<PLANES>(plane, PLANES, [&](int p) -> u32x4 {
-							u32x4 v;
-#pragma unroll
-							for(int d = 0; d < 4; ++d){ v[d] = __hip_atomic_load(theirs + (p*4 + d)*WAVE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-							return v;
-						});
+						for(int d = 0; d < 4; ++d){ __hip_atomic_store(mine + (p*4 + d)*WAVE, plane[p][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 					}
-					if(lane == 0){ __hip_atomic_store(wa.done + first_w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-					emit = true;
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores are performed before the arrival says so
+					uint32_t *node = wa.arrived + (uint64_t)(first_w + parent)*CWALK_LEVELS + level;
+					uint32_t old = 0;
+					if(lane == 0){ old = __hip_atomic_fetch_add(node, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+					old = __builtin_amdgcn_readfirstlane(old);
+					if(old == 0){ emit = false; break; }                   // the sibling is still at work: it will take this sum along
+					const uint32_t sib = (rep == parent) ? rep + stride : parent;
+					const uint32_t *theirs = wa.slab + ((uint64_t)(first_w + sib)*2 + (sib == 0 ? 1 : 0))*(PLANES*4*WAVE) + lane;
+					planes_accumulate<PLANES>(plane, PLANES, [&](int p) -> u32x4 {
+						u32x4 v;
+#pragma unroll
+						for(int d = 0; d < 4; ++d){ v[d] = __hip_atomic_load(theirs + (p*4 + d)*WAVE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+						return v;
+					});
+					if(lane == 0){ __hip_atomic_store(node, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+					rep = parent;
 				}
 			}
 			if(emit){ emit_count_hits<PLANES>(a, q, unit, plane, qthr[q], live); }
@@ -1015,10 +1067,11 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_narrow_kernel(SearchArgs
 #pragma unroll
 	for(int p = 0; p < PLANES; ++p){ plane[p] = (u32x4)(0u); }
 
-	// eight k-mers per step: a narrow launch has few waves (10 k queries of 1 kb against one 2048-column file: 2500, ten per
-	// CU), so the bytes in flight come from the loads per wave (4 per step measured 4.2 TB/s where the AND form's 8 reach 5.7)
-	for(uint32_t i = 0; active && __any(i < nk); i += KPS){
-		u32x4 m[KPS];
+	// Eight k-mers per step, and the NEXT step's rows requested before the current step's matches are added up: a narrow
+	// launch has few waves (10 k queries of 1 kb against one 2048-column file: 2500, ten per CU), so the bytes in flight
+	// come from the loads per wave and nothing else covers the adders' time (4 per step, not pipelined: 4.2 TB/s where the
+	// AND form's 8 reach 5.6-5.7; 8 per step: 4.7).
+	auto fetch = [&](uint32_t i, u32x4 (&m)[KPS]) {
 #pragma unroll
 		for(int u = 0; u < KPS; ++u){
 			const bool real = (i + u < nk);
@@ -1030,8 +1083,19 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_narrow_kernel(SearchArgs
 			}
 			m[u] = real ? x : (u32x4)(0u);
 		}
-		if(KPS == 8){ planes_add8<PLANES>(plane, reinterpret_cast<const u32x4 (&)[8]>(m)); }
-		else{ planes_add4<PLANES>(plane, m[0], m[1], m[2], m[3]); }
+	};
+	if(active){
+		u32x4 cur[KPS], nxt[KPS];
+		fetch(0, cur);
+		for(uint32_t i = KPS; __any(i < nk); i += KPS){
+			fetch(i, nxt);
+			if(KPS == 8){ planes_add8<PLANES>(plane, reinterpret_cast<const u32x4 (&)[8]>(cur)); }
+			else{ planes_add4<PLANES>(plane, cur[0], cur[1], cur[2], cur[3]); }
+#pragma unroll
+			for(int u = 0; u < KPS; ++u){ cur[u] = nxt[u]; }
+		}
+		if(KPS == 8){ planes_add8<PLANES>(plane, reinterpret_cast<const u32x4 (&)[8]>(cur)); }
+		else{ planes_add4<PLANES>(plane, cur[0], cur[1], cur[2], cur[3]); }
 	}
 	__shared__ WgHitScratch wg_scratch;
 	emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q], active, &wg_scratch);      // every wave of the workgroup gets here, exactly once

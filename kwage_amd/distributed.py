@@ -328,3 +328,234 @@ class PipelinedDeviceSearcher:
     def collect(self, ticket):
         buf, n = self.collect_counted(ticket)
         return buf[1:1 + n]
+
+
+# ------------------------------------------------------------------------------------------------------
+# Steps over several groups, one list per step, an exchange proportional to the hits
+# ------------------------------------------------------------------------------------------------------
+_MIX1, _MIX2 = np.uint64(0x9E3779B97F4A7C15), np.uint64(0xBF58476D1CE4E5B9)
+
+
+def hits_checksum(records) -> int:
+    """Order-independent 64-bit checksum of (query, column, num_match) records: the sum (mod 2^64) of a mixed
+    word per record.  A rank computes it over its own list, rank 0 over the merged one; the sums agree iff the
+    exchange lost, duplicated or altered nothing (bench.py's exchange_check)."""
+    r = np.asarray(records).reshape(-1, 3)
+    if r.dtype == np.int32:               # device buffers hold the u32 fields in int32 tensors
+        r = r.view(np.uint32)
+    r = r.astype(np.uint64)
+    if not len(r):
+        return 0
+    with np.errstate(over="ignore"):
+        h = (r[:, 0] * _MIX1 + r[:, 1]) * _MIX2
+        h ^= h >> np.uint64(29)
+        h = (h + r[:, 2]) * _MIX1
+        return int(h.sum(dtype=np.uint64))
+
+
+def global_column_bases(dist, rank: int, world: int, local_spans: Sequence[int], device: str = "cpu"):
+    """Global column numbers for a database of several groups sharded by columns: group after group, inside a group
+    rank after rank.  local_spans[g] = column span of this rank's block of group g.
+    -> (this rank's base per group, spans[rank][group], total columns).  One all_gather at set-up."""
+    import torch
+    mine = torch.tensor([int(x) for x in local_spans], dtype=torch.int64, device=device)
+    if dist is None or world == 1:
+        spans = [[int(x) for x in local_spans]]
+    else:
+        outs = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(outs, mine)
+        spans = [[int(x) for x in o.tolist()] for o in outs]
+    bases, at = [], 0
+    for g in range(len(local_spans)):
+        bases.append(at + sum(spans[r][g] for r in range(rank)))
+        at += sum(spans[r][g] for r in range(world))
+    if at > 1 << 32:
+        raise OverflowError("global_column_bases: %d columns do not fit the 32-bit column field of a hit record" % at)
+    return bases, spans, at
+
+
+class StepPipeline:
+    """One rank's software pipeline over STEPS.  A step = one query batch searched against every group this rank holds
+    (one group for C2-C4, the eight filter sizes of C5), all of its hits appended to ONE device list through
+    kwage_search_device_append_submit: the engine counts into row 0 of the step's buffer (a u64), writes the records
+    behind it and adds the group's global column base, so the buffer is ready for the exchange as it stands -- what
+    the reference does when every file's matches go to one list per query (kwage.cpp:154-177).
+
+    A context runs two searches at a time (two slots): begin() queues a step's searches, finish() completes the
+    oldest step, feeding the slots as they come free -- so the next step's first gather kernels are already running
+    while the caller exchanges the finished step's hits.  Two buffers alternate; at most two steps may be open."""
+
+    def __init__(self, groups, column_bases, flags: int = 0, device: str = "cuda", initial_capacity: int = 1 << 18):
+        import torch
+        assert len(groups) == len(column_bases) and len(groups) >= 1
+        self.groups, self.bases, self.flags, self.device = list(groups), [int(b) for b in column_bases], flags, device
+        # torch.empty, not zeros: a fill kernel would run on torch's stream, unordered with the engine's streams
+        self.bufs = [torch.empty((1 + initial_capacity, 3), dtype=torch.int32, device=device) for _ in range(2)]
+        self.steps = []            # open steps, oldest first: dicts
+        self.todo = []             # (step, group index) not yet submitted, in order
+        self.inflight = []         # (handle, step, group index), oldest first
+        self.next_id = 0
+        self.last_kernel_ms = 0.0
+        self.searches_submitted = 0
+
+    def _submit(self, step, gi):
+        import ctypes as C
+        from .native import check, lib
+        buf = self.bufs[step["buf"]]
+        h = C.c_void_p()
+        check(lib().kwage_search_device_append_submit(self.groups[gi]._h, step["batch"]._h, C.c_float(step["threshold"]), self.flags,
+                                                      buf.data_ptr() + 12, buf.shape[0] - 1, buf.data_ptr(), self.bases[gi],
+                                                      1 if gi == 0 else 0, C.byref(h)))
+        self.searches_submitted += 1
+        return h
+
+    def _collect(self, h):
+        import ctypes as C
+        from .native import check, lib
+        n, ms = C.c_uint64(), C.c_float()
+        check(lib().kwage_search_device_collect(h, C.byref(n), None, C.byref(ms)))
+        return int(n.value), float(ms.value)
+
+    def _pump(self):
+        while self.todo and len(self.inflight) < 2:
+            step, gi = self.todo.pop(0)
+            self.inflight.append((self._submit(step, gi), step, gi))
+
+    def begin(self, batch, threshold: float):
+        if len(self.steps) >= 2:
+            raise RuntimeError("StepPipeline: two steps are open already; finish() one first")
+        step = {"id": self.next_id, "buf": self.next_id & 1, "batch": batch, "threshold": threshold, "done": 0, "n": 0, "ms": 0.0}
+        self.next_id += 1
+        self.steps.append(step)
+        self.todo += [(step, gi) for gi in range(len(self.groups))]
+        self._pump()
+
+    def finish(self):
+        """Complete the oldest open step -> (its buffer [1 + capacity, 3] with the count in row 0, n_hits)."""
+        import torch
+        if not self.steps:
+            raise RuntimeError("StepPipeline: no open step")
+        step = self.steps[0]
+        while step["done"] < len(self.groups):
+            h, st, gi = self.inflight.pop(0)
+            n, ms = self._collect(h)
+            st["done"] += 1
+            st["n"] = n                # the running total: the last search of a step leaves the step's total
+            st["ms"] += ms
+            self._pump()
+        self.steps.pop(0)
+        if step["n"] > self.bufs[step["buf"]].shape[0] - 1:
+            # The list outgrew the buffer (first steps only): let what is in flight for the next step finish (it
+            # writes the OTHER buffer), grow this one and redo the step, search by search.
+            while self.inflight:
+                h, st, gi = self.inflight.pop(0)
+                n, ms = self._collect(h)
+                st["done"] += 1; st["n"] = n; st["ms"] += ms
+            while step["n"] > self.bufs[step["buf"]].shape[0] - 1:
+                self.bufs[step["buf"]] = torch.empty((int(step["n"] * 1.25) + 2, 3), dtype=torch.int32, device=self.device)
+                step["ms"] = 0.0
+                for gi in range(len(self.groups)):
+                    n, ms = self._collect(self._submit(step, gi))
+                    step["n"] = n; step["ms"] += ms
+            self._pump()
+        self.last_kernel_ms = step["ms"]
+        return self.bufs[step["buf"]], step["n"]
+
+    def drain(self):
+        """Finish every open step, discarding the results (error paths)."""
+        while self.steps:
+            self.finish()
+
+
+class HitExchange:
+    """The one exchange of the sharded search: every rank's hit list (records that already carry GLOBAL column numbers,
+    StepPipeline) to rank 0, in bytes proportional to the hits.
+
+      small lists  ONE collective: all_gather of [count | first `spec` records] (48 KB per rank); when every count fits,
+                   that is all -- one copy-back to pinned memory, merge on rank 0.
+      large lists  what does not fit goes to rank 0 ONLY, in exact sizes, by one grouped send/recv (RCCL has no gatherv);
+                   after a step with a large list the first collective carries the counts alone (one 12-byte row per
+                   rank) until the lists are small again, so ranks other than 0 receive nothing but counts.
+
+    Every rank takes the same decisions (all of them see all counts).  Nothing here needs device work besides the
+    collectives and copy-backs, so it overlaps with the next step's gather kernel.  Works on host tensors with gloo."""
+
+    def __init__(self, dist, rank: int, world: int, spec: int = 4096):
+        self.dist, self.rank, self.world, self.spec = dist, rank, world, int(spec)
+        self.counts_only = False          # mode of the NEXT step's first collective
+        self._recv = self._host = self._pad = None
+        self.last_counts = None
+        self.stats = {"collectives": 0, "p2p_batches": 0, "bytes_received": 0}
+
+    def _pinned(self, rows, like):
+        import torch
+        if self._host is None or self._host.shape[0] < rows:
+            self._host = torch.empty((max(rows, 1), 3), dtype=torch.int32, pin_memory=like.is_cuda)
+        return self._host[:rows]
+
+    def exchange_step(self, buf, n: int):
+        """buf: int32 [>= 1 + n, 3], row 0 = u64 record count (as StepPipeline leaves it), rows 1.. the records.
+        -> on rank 0 the merged list sorted by (query, column) (int64 [N, 3]); None elsewhere."""
+        import torch
+        if n > int(buf.shape[0]) - 1:
+            raise ValueError("exchange_step: the buffer holds fewer records than its count says")
+        W, spec = self.world, (0 if self.counts_only else self.spec)
+        rows = 1 + spec
+        if int(buf.shape[0]) >= rows:
+            send = buf[:rows]
+        else:                             # a buffer smaller than the speculative part: pad (rare, tiny buffers)
+            if self._pad is None or self._pad.shape[0] != rows or self._pad.device != buf.device:
+                self._pad = torch.zeros((rows, 3), dtype=torch.int32, device=buf.device)
+            self._pad[:buf.shape[0]] = buf
+            send = self._pad
+        if self._recv is None or self._recv.shape[0] != W * rows or self._recv.device != buf.device:
+            self._recv = torch.empty((W * rows, 3), dtype=torch.int32, device=buf.device)
+        if self.dist is not None:
+            self.dist.all_gather_into_tensor(self._recv, send)
+            self.stats["bytes_received"] += (W - 1) * rows * 12
+            self.stats["collectives"] += 1
+            gathered = self._recv
+        else:
+            gathered = send               # no process group at all (one rank): nothing to gather
+        if buf.is_cuda:
+            host = self._pinned(W * rows, buf)
+            host.copy_(gathered, non_blocking=True)
+            torch.cuda.current_stream(buf.device).synchronize()
+            head = host.numpy().reshape(W, rows, 3)
+        else:
+            head = gathered.numpy().reshape(W, rows, 3)
+        c64 = head[:, 0, :2].astype(np.int64) & 0xFFFFFFFF
+        counts = [int(c64[r, 0] | (c64[r, 1] << 32)) for r in range(W)]
+        self.last_counts = counts
+        rest = [max(0, c - spec) for c in counts]
+        parts = [head[r, 1:1 + min(counts[r], spec)].copy() if self.rank == 0 else None for r in range(W)]
+        if any(rest):
+            tails = {}
+            ops = []
+            if self.rank == 0:
+                for r in range(1, W):
+                    if rest[r]:
+                        tails[r] = torch.empty((rest[r], 3), dtype=torch.int32, device=buf.device)
+                        ops.append(self.dist.P2POp(self.dist.irecv, tails[r], r))
+                        self.stats["bytes_received"] += rest[r] * 12
+            elif rest[self.rank]:
+                ops.append(self.dist.P2POp(self.dist.isend, buf[1 + spec:1 + counts[self.rank]].contiguous(), 0))
+            if ops:
+                for req in self.dist.batch_isend_irecv(ops):        # ONE grouped ncclSend/ncclRecv launch on RCCL
+                    req.wait()
+                self.stats["p2p_batches"] += 1
+            if self.rank == 0:
+                if rest[0]:
+                    tails[0] = buf[1 + spec:1 + counts[0]]
+                for r, t in tails.items():
+                    if t.is_cuda:
+                        hp = torch.empty((t.shape[0], 3), dtype=torch.int32, pin_memory=True)
+                        hp.copy_(t, non_blocking=True)
+                        torch.cuda.current_stream(t.device).synchronize()
+                        t = hp
+                    parts[r] = np.concatenate([parts[r], t.numpy()]) if len(parts[r]) else t.numpy()
+        # the NEXT step's first collective: counts alone after a large list, counts + records after small ones
+        self.counts_only = max(counts) > self.spec
+        if self.rank != 0:
+            return None
+        return merge_hits(parts, [0] * W)

@@ -389,7 +389,7 @@ def test_long_queries_are_segmented(ka, ctx, oracle, num_hash, monkeypatch):
     # (0 = the natural choice: few tiles -> segments; "cw" = the persistent count kernel with a pair spread over
     # up to 40 waves instead of the segment slab)
     for force in (0, 1, 7, 64, "cw"):
-        knobs = dict(force_segs=0, count_walk_min_rows=1, count_walk_waves=1500, count_walk_max_parts=64) if force == "cw" else dict(force_segs=force)
+        knobs = dict(force_segs=0, count_walk_min_rows=1, count_walk_waves=1500) if force == "cw" else dict(force_segs=force)
         with ctx.tuning(**knobs):
             for threshold in (1.0, 0.97, 0.5):
                 thr32 = float(np.float32(threshold))
@@ -732,7 +732,7 @@ def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, request):
         thr32 = float(np.float32(thr))
         assert ref.per_query() == [oracle.search_image(image, image.shape[1], k, nh, L, n_cols, oracle.unique_kmers(s, k), thr32)[0] for s in seqs]
         for waves in (0, 7, 3001, 30000):
-            with ctx.tuning(count_walk_waves=waves, count_walk_min_rows=1, count_walk_max_parts=1 << 20):
+            with ctx.tuning(count_walk_waves=waves, count_walk_min_rows=1):
                 for rep in range(2):
                     r = g.search(b, thr, 0)
                     assert r.search_kernel.startswith("count_walk_kernel<"), r.search_kernel

@@ -20,7 +20,7 @@ for name, w in (("1 x 100 kb vs 100k samples", synth.Workload("long1", 100_000, 
             if force == "cw" and thr == 1.0:
                 continue
             ctx.set_tuning("force_segs", int(force) if force == "1" else 0)
-            ctx.set_tuning("count_walk_max_parts", 1 << 20 if force == "cw" else 8)
+            ctx.set_tuning("count_walk", 1 if force == "cw" else 0)
             best = None
             for _ in range(3):
                 r = s.group.search(s.batch, thr, ka.SEARCH_TIMING | ka.SEARCH_TIMING_KMER)

@@ -17,7 +17,8 @@ sizes = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else []
 ctx = ka.Context(0)
 s = synth.build(ctx, synth.WORKLOADS[wl])
 thr = s.workload.threshold
-variants = [("tiled", dict(count_walk=0))] + [("walk %d waves/CU" % w, dict(count_walk=1, count_walk_wpc=w, count_walk_min_rows=1)) for w in (8, 12, 16, 20)]
+variants = [("tiled", dict(count_walk=0))] + [("walk %d waves/CU%s" % (w, " pf" if pf else ""), dict(count_walk=1, count_walk_wpc=w, count_walk_min_rows=1, count_walk_prefetch=pf))
+                                               for w, pf in ((6, 0), (8, 0), (8, 1), (12, 0), (12, 1))]
 
 
 def run(batch, label):
@@ -37,7 +38,7 @@ def run(batch, label):
     print("%s: algorithmic bytes/launch %.3f GB, %d rounds" % (label, ab / 1e9, rounds))
     for n, _ in variants:
         m = np.array(ms[n][1:])
-        print("  %-18s %-26s median %.4f ms  min %.4f  max %.4f -> %.0f GB/s (median)" % (n, names[n], np.median(m), m.min(), m.max(), ab / np.median(m) / 1e6), flush=True)
+        print("  %-20s %-30s median %.4f ms  min %.4f  max %.4f -> %.0f GB/s (median)" % (n, names[n], np.median(m), m.min(), m.max(), ab / np.median(m) / 1e6), flush=True)
 
 
 run(s.batch, "workload %s" % wl)
