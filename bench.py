@@ -177,25 +177,41 @@ def cpu_baseline(w, queries, n_files):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def kernel_code_hash():
+    """Identity of the device code and the launch logic a PMC pass was taken on: SHA-256 (first 16 hex digits) over the
+    kernel sources and the engine.  profiles/pmc_traffic.json carries it per entry (tools/pmc_refresh.py writes it)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("kernels.hpp", "kmer_device.hpp", "engine.hip"):
+        with open(os.path.join(ROOT, "kwage_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(workload, kernel, early_exit):
     """HBM bytes per launch from the PMC counters: they come from a SEPARATE rocprofv3 --pmc pass of this same
-    command (counters cannot be collected from inside the run), kept in profiles/pmc_traffic.json with the
-    kernel (name + template shape) and commit they were taken on.  The number is reported only when that
-    kernel is the one this run used; otherwise null, with the reason in traffic_source."""
+    command (counters cannot be collected from inside the run), kept in profiles/pmc_traffic.json with the kernel
+    (name + template shape) and the HASH OF THE CODE they were taken on.  The number is reported only when this run
+    used that kernel AND the kernel sources + engine are byte for byte what the pass profiled; otherwise null, with
+    the reason in traffic_source.  tools/pmc_refresh.py regenerates every entry in one GPU session."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(workload)
     except Exception as exc:
         return None, {"file": "profiles/pmc_traffic.json", "status": "unreadable: %r" % (exc,)}
     if not t:
         return None, {"file": "profiles/pmc_traffic.json", "status": "no PMC pass recorded for workload %r" % workload}
-    src = {"file": "profiles/pmc_traffic.json", "pmc_pass": t.get("source"), "kernel": t.get("kernel"), "commit": t.get("commit")}
+    src = {"file": "profiles/pmc_traffic.json", "pmc_pass": t.get("source"), "kernel": t.get("kernel"), "code_hash": t.get("code_hash")}
     if early_exit:
         src["status"] = "not applicable with --early-exit"
         return None, src
     if t.get("kernel") != kernel:
         src["status"] = "stale: the PMC pass profiled %s, this run used %s" % (t.get("kernel"), kernel)
         return None, src
-    src["status"] = "kernel matches"
+    now = kernel_code_hash()
+    if t.get("code_hash") != now:
+        src["status"] = "stale: the kernel sources / engine changed since the PMC pass (pass %s, now %s)" % (t.get("code_hash"), now)
+        return None, src
+    src["status"] = "kernel and code hash match"
     return t["hbm_read_bytes_per_launch"], src
 
 

@@ -13,6 +13,7 @@
 #include <chrono>
 #include <deque>
 #include <memory>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -82,6 +83,57 @@ struct PinBuf {
 	}
 };
 
+// Pinned host blocks for LONG hit lists, recycled between searches: a list of 100 M records (1.2 GB) crosses PCIe in
+// 22 ms, but landing it in fresh pageable memory cost 0.2 s (a page fault per 4 KiB, one thread's memcpy) -- so the
+// result array of a long list IS a pinned block, the D2H copy's destination, and kwage_result_free hands it back for
+// the next search.  Results may outlive their context: the pool is shared, kwage_shutdown closes it.
+struct PinnedPool {
+	static const size_t MAX_CACHED_BLOCKS = 2;
+	static const uint64_t MAX_CACHED_BYTES = 8ull << 30;
+	std::mutex mu;
+	bool open = true;
+	std::vector<PinBuf> cached;
+	int acquire(uint64_t bytes, PinBuf *out)
+	{
+		{
+			std::lock_guard<std::mutex> lock(mu);
+			size_t best = cached.size();
+			for(size_t i = 0; i < cached.size(); ++i){
+				if(cached[i].cap >= bytes && (best == cached.size() || cached[i].cap < cached[best].cap)){ best = i; }
+			}
+			if(best != cached.size()){
+				*out = cached[best];
+				cached.erase(cached.begin() + (long)best);
+				return KWAGE_OK;
+			}
+		}
+		out->p = nullptr; out->cap = 0;
+		return out->reserve(bytes);
+	}
+	void release(PinBuf &b)
+	{
+		if(!b.p){ return; }
+		{
+			std::lock_guard<std::mutex> lock(mu);
+			uint64_t held = 0;
+			for(const PinBuf &c : cached){ held += c.cap; }
+			if(open && cached.size() < MAX_CACHED_BLOCKS && held + b.cap <= MAX_CACHED_BYTES){
+				cached.push_back(b);
+				b.p = nullptr; b.cap = 0;
+				return;
+			}
+		}
+		b.release();
+	}
+	void close()
+	{
+		std::lock_guard<std::mutex> lock(mu);
+		open = false;
+		for(PinBuf &c : cached){ c.release(); }
+		cached.clear();
+	}
+};
+
 }  // namespace
 
 // Everything one in-flight search owns.  A context has two slots so that a second search can be
@@ -143,8 +195,9 @@ struct Tuning {
 	int64_t count_walk = 1;         // KWAGE_COUNT_WALK: the persistent count kernel where it applies
 	int64_t count_walk_wpc = 8;     // KWAGE_COUNT_WALK_WPC: its waves per CU (8: 6335 GB/s at C2's shape, 12: 6271, 16: 6250, 20: 5876)
 	int64_t count_walk_waves = 0;   // KWAGE_COUNT_WALK_WAVES: exactly this many waves (tests)
-	int64_t count_walk_min_rows = -1;   // KWAGE_COUNT_WALK_MIN_ROWS: smaller batches use the tiled kernel (-1: 64 rows for one wave per CU)
-	int64_t count_walk_prefetch = 0;    // KWAGE_COUNT_WALK_PREFETCH: request the next four k-mers' rows before adding the current four
+	int64_t count_walk_min_rows = -1;   // KWAGE_COUNT_WALK_MIN_ROWS: smaller batches use the tiled kernel (-1: 64 rows for each of its waves)
+	int64_t count_walk_one_round = 1;   // KWAGE_COUNT_WALK_ONE_ROUND: 1 = batches whose tiles fit the chip in one round stay with the tiled kernel
+	int64_t count_walk_prefetch = 1;    // KWAGE_COUNT_WALK_PREFETCH: request the next four k-mers' rows before adding the current four (+1.3 % at C2's shape)
 	int64_t count_narrow_kps = 8;   // KWAGE_COUNT_NARROW_KPS: k-mers per step of the narrow count kernel (8 or 4)
 	int64_t hit_sort_host = 0;      // KWAGE_HIT_SORT=host: order long hit lists on the host (A/B runs, the fallback)
 	int64_t hit_copy_piece_kb = 0;  // KWAGE_HIT_COPY_PIECE_KB: piece size of the copy-back of a long hit list (0 = default)
@@ -159,6 +212,7 @@ static const TuningName TUNING_NAMES[] = {
 	{"and_block_waves", &Tuning::and_block_waves}, {"narrow", &Tuning::narrow}, {"force_segs", &Tuning::force_segs},
 	{"count_walk", &Tuning::count_walk}, {"count_walk_wpc", &Tuning::count_walk_wpc}, {"count_walk_waves", &Tuning::count_walk_waves},
 	{"count_walk_min_rows", &Tuning::count_walk_min_rows}, {"count_walk_prefetch", &Tuning::count_walk_prefetch},
+	{"count_walk_one_round", &Tuning::count_walk_one_round},
 	{"count_narrow_kps", &Tuning::count_narrow_kps},
 	{"hit_sort_host", &Tuning::hit_sort_host}, {"hit_copy_piece_kb", &Tuning::hit_copy_piece_kb}, {"shared_table_log2", &Tuning::shared_table_log2},
 };
@@ -183,6 +237,7 @@ struct kwage_ctx {
 	std::deque<LockedWindow> locked;
 	std::vector<hipEvent_t> spare_events;
 	volatile uint64_t *load_progress = nullptr;      // kwage_set_load_progress
+	std::shared_ptr<PinnedPool> result_pool = std::make_shared<PinnedPool>();      // result arrays of long hit lists
 };
 
 namespace {
@@ -785,13 +840,18 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 		const uint32_t planes = planes_for(b->max_pos);
 		const bool narrow = tn.narrow && a.units_per_row <= 32 && a.units_per_row > 8 && a.n_queries >= 64 && planes <= 14;
 		// The persistent form (count_walk_kernel): equal shares of the batch's (query, KiB tile, position) list per wave,
-		// pairs cut by share boundaries added up as a tree through memory.  Taken whenever the batch gives a wave per CU
-		// its 64 rows and no early exit is asked for (a persistent wave has no tile of its own to give up): long queries
-		// need no segment slab and no combine pass then.  Early exit, tiny batches and forced segment counts go on below.
-		if(tn.count_walk && !a.early_exit && !narrow && tn.force_segs <= 0 && b->total_pos > 0){
+		// pairs cut by share boundaries added up as a tree through memory.  Taken when the batch gives every wave of the
+		// launch its 64 rows and no early exit is asked for (a persistent wave has no tile of its own to give up): long
+		// queries need no segment slab and no combine pass then (1 x 100 kb: 5076 vs 4694 GB/s, 4 x 1 Mb: 6159 vs 5735),
+		// and no batch size ends in a part-filled round of waves.  The tiled kernel keeps the batches whose tiles all fit
+		// the chip at once (2048 .. 16 per CU: 300 queries at C2's shape 0.582 vs 0.598 ms -- its neighbouring waves read
+		// neighbouring KiB of the same rows), early exit, tiny batches and forced segment counts.
+		const uint64_t tiles = (uint64_t)a.n_queries*a.chunks;
+		const bool one_round = tn.count_walk_one_round && tiles >= 2048 && tiles <= ncu*16;
+		if(tn.count_walk && !a.early_exit && !narrow && !one_round && tn.force_segs <= 0 && b->total_pos > 0){
 			const uint64_t slots = (uint64_t)a.chunks*b->total_pos;
-			const uint64_t min_rows = (tn.count_walk_min_rows >= 0) ? (uint64_t)tn.count_walk_min_rows : (uint64_t)WALK_MIN_ROWS_PER_WAVE*ncu;
 			const uint64_t chip_waves = ncu*(uint64_t)std::max<int64_t>(tn.count_walk_wpc, 1);
+			const uint64_t min_rows = (tn.count_walk_min_rows >= 0) ? (uint64_t)tn.count_walk_min_rows : (uint64_t)WALK_MIN_ROWS_PER_WAVE*chip_waves;
 			const uint64_t want_waves = (tn.count_walk_waves > 0) ? std::min<uint64_t>((uint64_t)tn.count_walk_waves, slots)
 				: std::max<uint64_t>(1, std::min<uint64_t>(chip_waves, slots*a.num_hash/WALK_MIN_ROWS_PER_WAVE));
 			const uint32_t wgs = (uint32_t)((want_waves + 3)/4);
@@ -871,7 +931,6 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 }
 
 static const uint64_t SPEC_HITS = 8192;     // hit records copied back together with the counters
-static const uint64_t RESULT_PIECE_HITS = 1u << 20;       // a longer list comes back in pieces of this many records (12 MiB)
 static const uint64_t SORT_SCRATCH_KEEP = 1ull << 30;     // device sort buffers above this size are freed after use
 
 struct SearchOutcome {
@@ -1128,6 +1187,7 @@ extern "C" void kwage_shutdown(kwage_ctx *ctx)
 		if(sl->stream){ (void)hipStreamDestroy(sl->stream); }
 	}
 	ctx->kmers.release();
+	ctx->result_pool->close();
 	for(int i = 0; i < 2; ++i){
 		ctx->load_pin[i].release(); ctx->load_dev[i].release();
 		if(ctx->load_done[i]){ (void)hipEventDestroy(ctx->load_done[i]); }
@@ -2032,9 +2092,12 @@ void sort_hits(kwage_hit *hits, size_t n)
 
 struct ResultStorage {
 	kwage_result pub;
-	std::unique_ptr<kwage_hit[]> hits;
+	std::unique_ptr<kwage_hit[]> hits;            // short lists
+	std::shared_ptr<PinnedPool> pool;             // long lists: a pinned block of the context's pool
+	PinBuf pinned;
 	std::vector<uint32_t> nkmer, qthr;
 	char kernel[64];
+	~ResultStorage() { if(pool){ pool->release(pinned); } }
 };
 
 // Build the host result of a collected search from the slot's staging buffer.
@@ -2042,8 +2105,6 @@ int build_result(Slot *sl, kwage_group *g, kwage_batch *b, const SearchOutcome &
 {
 	ResultStorage *rs = new (std::nothrow) ResultStorage();
 	if(!rs){ return fail(KWAGE_ERR_DEVICE, "out of host memory"); }
-	rs->hits.reset(new (std::nothrow) kwage_hit[std::max<uint64_t>(so.n_hits, 1)]);      // not zero-filled: every record is written below
-	if(!rs->hits){ delete rs; return fail(KWAGE_ERR_DEVICE, "out of host memory (%llu hits)", (unsigned long long)so.n_hits); }
 	rs->nkmer.resize(b->n);
 	rs->qthr.resize(b->n);
 	const uint64_t nq_bytes = (uint64_t)b->n*sizeof(uint32_t);
@@ -2053,16 +2114,24 @@ int build_result(Slot *sl, kwage_group *g, kwage_batch *b, const SearchOutcome &
 		memcpy(rs->qthr.data(), hs + 32 + nq_bytes, nq_bytes);
 	}
 	const uint64_t have = std::min(so.n_hits, so.staged_hits);
+	kwage_hit *hits = nullptr;
 	if(so.n_hits <= have){
-		if(have){ memcpy(rs->hits.get(), hs + sl->head_bytes, have*sizeof(kwage_hit)); }
+		rs->hits.reset(new (std::nothrow) kwage_hit[std::max<uint64_t>(so.n_hits, 1)]);      // not zero-filled: every record is written below
+		if(!rs->hits){ delete rs; return fail(KWAGE_ERR_DEVICE, "out of host memory (%llu hits)", (unsigned long long)so.n_hits); }
+		hits = rs->hits.get();
+		if(have){ memcpy(hits, hs + sl->head_bytes, have*sizeof(kwage_hit)); }
 		// deterministic order; the reference's own order among ties is unspecified (sort.h:22-27)
-		sort_hits(rs->hits.get(), so.n_hits);
+		sort_hits(hits, so.n_hits);
 	} else {
-		// A large hit list is sorted where it lies (hit_sort.hip) and then fetched whole, in pieces through the two
-		// halves of the pinned staging buffer: piece i+1 crosses PCIe while piece i is copied into the result.
+		// A long list is sorted where it lies (hit_sort.hip) and then crosses PCIe ONCE, straight into the result array --
+		// a pinned block of the context's pool (PinnedPool above): no staging hop, no host copy, no page faults.
+		rs->pool = g->ctx->result_pool;
+		int rc2 = rs->pool->acquire(so.n_hits*sizeof(kwage_hit), &rs->pinned);
+		if(rc2){ delete rs; return rc2; }
+		hits = (kwage_hit*)rs->pinned.p;
 		uint64_t scratch = 0;
 		const bool host_sort = g->ctx->tune.hit_sort_host != 0;      // the sort of round 1, kept for A/B runs and as the fallback
-		const uint64_t column_span = g->stride*8;      // no hit carries a column beyond the row (files are padded apart: more than num_columns)
+		const uint64_t column_span = std::min<uint64_t>((uint64_t)sl->col_base + g->stride*8, 1ull << 32);      // no hit carries a column beyond the row (files are padded apart: more than num_columns)
 		bool on_device = !host_sort
 		                 && hit_sort_scratch_bytes(so.n_hits, b->n, column_span, &scratch) == KWAGE_OK
 		                 && sl->sort_scratch.reserve(scratch) == KWAGE_OK
@@ -2074,40 +2143,27 @@ int build_result(Slot *sl, kwage_group *g, kwage_batch *b, const SearchOutcome &
 				        (unsigned long long)scratch, (unsigned long long)so.n_hits);
 			}
 		}
-		const uint64_t first = on_device ? 0 : have;
-		if(first){ memcpy(rs->hits.get(), hs + sl->head_bytes, first*sizeof(kwage_hit)); }
-		const uint64_t piece = std::min<uint64_t>(so.n_hits - first, RESULT_PIECE_HITS), piece_bytes = piece*sizeof(kwage_hit);
-		int rc2 = sl->h_stage.reserve(2*piece_bytes);      // the staged head has been consumed above
-		if(rc2){ delete rs; return rc2; }
+		// (pieces only so that a knob can shrink them in tests: one copy is what the link likes)
+		const uint64_t piece_kb = (uint64_t)std::max<int64_t>(g->ctx->tune.hit_copy_piece_kb, 0);
+		const uint64_t piece = piece_kb ? std::max<uint64_t>(1, (piece_kb << 10)/sizeof(kwage_hit)) : so.n_hits;
 		hipError_t e = hipSuccess;
-		uint64_t queued = first, landed = first;
-		int qi = 0, li = 0;
-		while(landed < so.n_hits && e == hipSuccess){
-			while(queued < so.n_hits && qi - li < 2 && e == hipSuccess){
-				const uint64_t m = std::min(piece, so.n_hits - queued);
-				e = hipMemcpyAsync((char*)sl->h_stage.p + (qi & 1)*piece_bytes, sl->d_hits + queued, m*sizeof(kwage_hit), hipMemcpyDeviceToHost, sl->stream);
-				if(e == hipSuccess){ e = hipEventRecord(sl->ev[qi & 1], sl->stream); }
-				queued += m; ++qi;
-			}
-			if(e == hipSuccess){ e = hipEventSynchronize(sl->ev[li & 1]); }
-			if(e == hipSuccess){
-				const uint64_t m = std::min(piece, so.n_hits - landed);
-				memcpy(rs->hits.get() + landed, (const char*)sl->h_stage.p + (li & 1)*piece_bytes, m*sizeof(kwage_hit));
-				landed += m; ++li;
-			}
+		for(uint64_t at = 0; at < so.n_hits && e == hipSuccess; at += piece){
+			const uint64_t m = std::min(piece, so.n_hits - at);
+			e = hipMemcpyAsync(hits + at, sl->d_hits + at, m*sizeof(kwage_hit), hipMemcpyDeviceToHost, sl->stream);
 		}
+		if(e == hipSuccess){ e = hipStreamSynchronize(sl->stream); }
 		if(e != hipSuccess){
 			(void)hipStreamSynchronize(sl->stream);
 			delete rs;
 			return fail(KWAGE_ERR_DEVICE, "kwage_search: copying results failed: %s", hipGetErrorString(e));
 		}
-		if(!on_device){ sort_hits(rs->hits.get(), so.n_hits); }
+		if(!on_device){ sort_hits(hits, so.n_hits); }
 		if(sl->sort_scratch.cap > SORT_SCRATCH_KEEP){ sl->sort_scratch.release(); }      // a rare giant list: give the memory back
 	}
 
 	kwage_result &r = rs->pub;
 	r.n_hits = so.n_hits;
-	r.hits = rs->hits.get();
+	r.hits = hits;
 	r.n_queries = b->n;
 	r.num_query_kmer = rs->nkmer.data();
 	r.query_threshold = rs->qthr.data();

@@ -63,17 +63,28 @@ def test_multi_gpu_request_without_a_launcher_starts_ranks_instead_of_exiting(mo
     assert seen == {"rank": 1}
 
 
-def test_traffic_is_reported_only_for_the_kernel_that_was_profiled():
+def test_traffic_is_reported_only_for_the_kernel_and_code_that_were_profiled(monkeypatch):
+    """roofline.traffic comes from a separate PMC pass; it is bound to the kernel's name + template shape AND to the hash
+    of the kernel sources + engine the pass ran on: a changed kernel body under the same name reports null."""
     import bench
     rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert len(bench.kernel_code_hash()) == 16 and bench.kernel_code_hash() == bench.kernel_code_hash()
+    n = 0
     for name, entry in rec.items():
         if name.startswith("_"):
             continue
+        n += 1
+        assert isinstance(entry.get("code_hash"), str) and len(entry["code_hash"]) == 16, name
+        monkeypatch.setattr(bench, "kernel_code_hash", lambda e=entry: e["code_hash"])
         t, src = bench.measured_traffic(name, entry["kernel"], False)
-        assert t == entry["hbm_read_bytes_per_launch"] and src["status"] == "kernel matches" and src["kernel"] == entry["kernel"]
+        assert t == entry["hbm_read_bytes_per_launch"] and src["status"] == "kernel and code hash match" and src["kernel"] == entry["kernel"]
         t, src = bench.measured_traffic(name, "some_other_kernel<1,2>", False)
-        assert t is None and src["status"].startswith("stale")
+        assert t is None and src["status"].startswith("stale: the PMC pass profiled")
         assert bench.measured_traffic(name, entry["kernel"], True)[0] is None
+        monkeypatch.setattr(bench, "kernel_code_hash", lambda: "0123456789abcdef")
+        t, src = bench.measured_traffic(name, entry["kernel"], False)
+        assert t is None and src["status"].startswith("stale: the kernel sources / engine changed")
+    assert n >= 4
     assert bench.measured_traffic("no-such-workload", "k", False)[0] is None
 
 
@@ -95,13 +106,19 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     assert line["rccl"]["world"] == 2 and line["rccl"]["backend"] == "gloo"
     assert line["sustained"]["steps"] >= 4 and len(line["sustained"]["kernel_ms_mean_per_rank"]) == 2
     assert line["config"]["step_pipeline"] == "on"
+    # the run verified its own exchange: every rank's hit count + checksum against the merged list on rank 0
+    ec = line["exchange_check"]
+    assert ec["ok"] and ec["ranks"] == 2 and ec["hits"] == sum(ec["hits_per_rank"]) and ec["checksum"] == ec["sum_of_rank_checksums"]
+    assert ec["sorted_unique"] and ec["columns_in_range"] and line["config"]["hits_per_step"] == ec["hits"]
+    assert line["rccl"]["searches_per_step"] == 1
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--workload", "tiny", "--no-cpu-baseline", "--no-sustained"],
                          capture_output=True, text=True, env=env, timeout=900)
     assert one.returncode == 0, one.stderr[-3000:]
     single = json.loads(one.stdout.strip().splitlines()[-1])
     assert single["n_gpus"] == 1 and "sustained" not in single
     assert line["roofline"]["algorithmic_bytes_per_launch"] == single["roofline"]["algorithmic_bytes_per_launch"]    # weak scaling: same share per GPU
-    # the C5 code path (several filter-size groups per rank, one exchange per group and step) on toy groups, two ranks
+    # the C5 code path (several filter-size groups per rank: ONE list and ONE exchange per step for all of them, the
+    # searches pipelined through the context's two slots) on toy groups, two ranks
     r5 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "c5tiny", "--no-sustained"],
                         capture_output=True, text=True, env=env, timeout=900)
     assert r5.returncode == 0, r5.stderr[-3000:]
@@ -109,3 +126,8 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     assert l5["n_gpus"] == 2 and len(l5["config"]["groups"]) == 4 and l5["config"]["threshold"] == 0.8
     assert len(l5["aggregate"]["kernel_ms_per_rank"]) == 2 and all(x > 0 for x in l5["aggregate"]["kernel_ms_per_rank"])
     assert l5["roofline"]["kernel"].startswith("count_")
+    assert l5["config"]["step_pipeline"] == "on" and l5["rccl"]["searches_per_step"] == 4
+    # one collective per step: 2 warm-up steps + 3 timed ones (small lists ride in the first collective whole)
+    assert l5["rccl"]["collectives"] == 5 and l5["rccl"]["p2p_batches"] == 0
+    e5 = l5["exchange_check"]
+    assert e5["ok"] and e5["hits"] == sum(e5["hits_per_rank"]) == l5["config"]["hits_per_step"] and e5["hits"] > 0

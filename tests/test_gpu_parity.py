@@ -173,7 +173,8 @@ def test_multiple_files_in_one_group(ka, ctx, oracle):
 def test_hit_buffer_growth(ka, ctx, oracle, n_queries, monkeypatch):
     """threshold truncating to 0 makes EVERY column match (kwage.cpp:388,497): more hits than the
     initial device buffer holds -> the engine must grow it and still return all of them.  Lists this long are
-    sorted on the device and come back in pieces (2 and 4 of them here, the last one ragged)."""
+    sorted on the device and land in a pinned block of the context's pool, in one copy or (knob) in ragged pieces;
+    the block goes back to the pool with the result and serves the next long list."""
     n_cols, L, k = 40000, 6, 31
     g = ka.Group(ctx, k, 1, L, n_cols)
     g.add_random_columns(n_cols, 7, 64)
@@ -184,6 +185,11 @@ def test_hit_buffer_growth(ka, ctx, oracle, n_queries, monkeypatch):
     r = g.search(b, 0.001)
     with ctx.tuning(hit_sort_host=1):
         assert np.array_equal(g.search(b, 0.001).hits, r.hits)      # the host's sort of the same list
+    with ctx.tuning(hit_copy_piece_kb=5000):
+        assert np.array_equal(g.search(b, 0.001).hits, r.hits)      # 4 resp. 9 pieces, the last one ragged
+    p1, p2 = g.submit(b, 0.001), g.submit(b, 0.001)                 # two long lists alive at once: two pool blocks
+    r1, r2 = p1.collect(), p2.collect()
+    assert np.array_equal(r1.hits, r.hits) and np.array_equal(r2.hits, r.hits)
     assert len(r.hits) == n_cols * len(seqs) and r.search_kernel_launches == 2
     assert np.array_equal(r.hits["query"], np.repeat(np.arange(len(seqs), dtype=np.uint32), n_cols))
     assert np.array_equal(r.hits["column"][:n_cols], np.arange(n_cols, dtype=np.uint32))
@@ -389,7 +395,7 @@ def test_long_queries_are_segmented(ka, ctx, oracle, num_hash, monkeypatch):
     # (0 = the natural choice: few tiles -> segments; "cw" = the persistent count kernel with a pair spread over
     # up to 40 waves instead of the segment slab)
     for force in (0, 1, 7, 64, "cw"):
-        knobs = dict(force_segs=0, count_walk_min_rows=1, count_walk_waves=1500) if force == "cw" else dict(force_segs=force)
+        knobs = dict(force_segs=0, count_walk_min_rows=1, count_walk_one_round=0, count_walk_waves=1500) if force == "cw" else dict(force_segs=force)
         with ctx.tuning(**knobs):
             for threshold in (1.0, 0.97, 0.5):
                 thr32 = float(np.float32(threshold))
@@ -731,8 +737,8 @@ def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, request):
         assert ref.search_kernel.startswith("count_kernel<"), ref.search_kernel
         thr32 = float(np.float32(thr))
         assert ref.per_query() == [oracle.search_image(image, image.shape[1], k, nh, L, n_cols, oracle.unique_kmers(s, k), thr32)[0] for s in seqs]
-        for waves in (0, 7, 3001, 30000):
-            with ctx.tuning(count_walk_waves=waves, count_walk_min_rows=1):
+        for waves, pf in ((0, 1), (7, 0), (3001, 1), (30000, 0)):
+            with ctx.tuning(count_walk_waves=waves, count_walk_min_rows=1, count_walk_one_round=0, count_walk_prefetch=pf):
                 for rep in range(2):
                     r = g.search(b, thr, 0)
                     assert r.search_kernel.startswith("count_walk_kernel<"), r.search_kernel

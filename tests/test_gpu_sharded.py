@@ -39,6 +39,6 @@ def test_sharded_hip_search_equals_unsharded_and_oracle(world, tmp_path):
             out += "\n[killed: timeout]"
         failed = failed or p.returncode != 0
         outs.append(out)
-    for rank, (p, out) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, "rank %d failed:\n%s" % (rank, out[-4000:])
-        assert os.path.exists(tmp_path / ("ok%d" % rank))
+    report = "\n".join("---- rank %d (exit %s) ----\n%s" % (rank, p.returncode, out[-3000:]) for rank, (p, out) in enumerate(zip(procs, outs)))
+    assert all(p.returncode == 0 for p in procs), report
+    assert all(os.path.exists(tmp_path / ("ok%d" % rank)) for rank in range(world)), report
