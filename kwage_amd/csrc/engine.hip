@@ -23,6 +23,7 @@
 
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -191,6 +192,7 @@ struct Tuning {
 	int64_t and_lds_kb = 0;         //   dynamic LDS per workgroup caps the waves per CU (tuning only)
 	int64_t and_block_waves = SEARCH_THREADS/WAVE;
 	int64_t narrow = 1;             // KWAGE_NARROW: several queries per wave for rows <= 512 B
+	int64_t narrow_unroll = 0;      // KWAGE_NARROW_UNROLL: rows in flight per wave of the narrow AND kernel (0 = by the number of waves; 8, 16)
 	int64_t force_segs = 0;         // KWAGE_FORCE_SEGS: cut every query's k-mer list into this many segments (tests)
 	int64_t count_walk = 1;         // KWAGE_COUNT_WALK: the persistent count kernel where it applies
 	int64_t count_walk_wpc = 8;     // KWAGE_COUNT_WALK_WPC: its waves per CU (8: 6335 GB/s at C2's shape, 12: 6271, 16: 6250, 20: 5876)
@@ -209,7 +211,7 @@ static const TuningName TUNING_NAMES[] = {
 	{"walk", &Tuning::walk}, {"walk_min_rows", &Tuning::walk_min_rows}, {"walk_max_kib", &Tuning::walk_max_kib},
 	{"walk_early_exit", &Tuning::walk_early_exit}, {"walk_waves", &Tuning::walk_waves}, {"walk_fences", &Tuning::walk_fences},
 	{"and_vec", &Tuning::and_vec}, {"and_unroll", &Tuning::and_unroll}, {"and_nt", &Tuning::and_nt}, {"and_lds_kb", &Tuning::and_lds_kb},
-	{"and_block_waves", &Tuning::and_block_waves}, {"narrow", &Tuning::narrow}, {"force_segs", &Tuning::force_segs},
+	{"and_block_waves", &Tuning::and_block_waves}, {"narrow", &Tuning::narrow}, {"narrow_unroll", &Tuning::narrow_unroll}, {"force_segs", &Tuning::force_segs},
 	{"count_walk", &Tuning::count_walk}, {"count_walk_wpc", &Tuning::count_walk_wpc}, {"count_walk_waves", &Tuning::count_walk_waves},
 	{"count_walk_min_rows", &Tuning::count_walk_min_rows}, {"count_walk_prefetch", &Tuning::count_walk_prefetch},
 	{"count_walk_one_round", &Tuning::count_walk_one_round},
@@ -238,6 +240,10 @@ struct kwage_ctx {
 	std::vector<hipEvent_t> spare_events;
 	volatile uint64_t *load_progress = nullptr;      // kwage_set_load_progress
 	std::shared_ptr<PinnedPool> result_pool = std::make_shared<PinnedPool>();      // result arrays of long hit lists
+	// CPUs of the NUMA node the device hangs on (empty: unknown, or the process may not run there): database loading
+	// runs on them (the page-cache pages it pins and the staging traffic then stay on the GPU's side of the host)
+	std::vector<int> numa_cpus;
+	int numa_node = -1;
 };
 
 namespace {
@@ -761,13 +767,17 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 			const uint32_t G = (a.units_per_row <= 4) ? 16 : (a.units_per_row <= 8) ? 8 : (a.units_per_row <= 16) ? 4 : 2;
 			const uint64_t waves = ((uint64_t)a.n_queries + G - 1)/G;
 			const dim3 grid((uint32_t)((waves + 3)/4)), block(SEARCH_THREADS);
-			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_narrow_kernel<%u,8>", G);
+			// few waves (10 k queries of 1 kb: ten per CU): sixteen rows in flight per wave instead of eight
+			const int unroll = (tn.narrow_unroll == 8 || tn.narrow_unroll == 16) ? (int)tn.narrow_unroll : ((waves < ncu*16) ? 16 : 8);
+			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_narrow_kernel<%u,%d>", G, unroll);
+#define KWAGE_NARROW_CASE(GG) case GG: \
+				if(unroll == 16){ hipLaunchKernelGGL((and_narrow_kernel<GG, 16>), grid, block, 0, sl->stream, a); } \
+				else{ hipLaunchKernelGGL((and_narrow_kernel<GG, 8>), grid, block, 0, sl->stream, a); } break;
 			switch(G){
-				case 16: hipLaunchKernelGGL((and_narrow_kernel<16, 8>), grid, block, 0, sl->stream, a); break;
-				case 8: hipLaunchKernelGGL((and_narrow_kernel<8, 8>), grid, block, 0, sl->stream, a); break;
-				case 4: hipLaunchKernelGGL((and_narrow_kernel<4, 8>), grid, block, 0, sl->stream, a); break;
-				default: hipLaunchKernelGGL((and_narrow_kernel<2, 8>), grid, block, 0, sl->stream, a); break;
+				KWAGE_NARROW_CASE(16) KWAGE_NARROW_CASE(8) KWAGE_NARROW_CASE(4)
+				default: KWAGE_NARROW_CASE(2)
 			}
+#undef KWAGE_NARROW_CASE
 			HIP_TRY(hipGetLastError());
 			return KWAGE_OK;
 		}
@@ -1075,6 +1085,62 @@ Slot *free_slot(kwage_ctx *ctx)
 
 namespace {
 
+// The NUMA node of a HIP device and the CPUs of that node this process is allowed to run on (sysfs; empty when the
+// platform does not say, e.g. a single-node guest).
+void find_numa_cpus(int device, int *node, std::vector<int> *cpus)
+{
+	*node = -1;
+	cpus->clear();
+	char bus[64] = "";
+	if(hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess){ (void)hipGetLastError(); return; }
+	for(char *c = bus; *c; ++c){ *c = (char)tolower((unsigned char)*c); }
+	char path[256];
+	snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+	FILE *f = fopen(path, "r");
+	if(!f){ return; }
+	int n = -1;
+	const int got = fscanf(f, "%d", &n);
+	fclose(f);
+	if(got != 1 || n < 0){ return; }
+	snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", n);
+	f = fopen(path, "r");
+	if(!f){ return; }
+	char list[4096] = "";
+	const bool ok = fgets(list, sizeof(list), f) != nullptr;
+	fclose(f);
+	if(!ok){ return; }
+	cpu_set_t allowed;
+	CPU_ZERO(&allowed);
+	if(sched_getaffinity(0, sizeof(allowed), &allowed) != 0){ return; }
+	for(char *tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")){      // "0-47,96-143"
+		int lo = 0, hi = 0;
+		const int k = sscanf(tok, "%d-%d", &lo, &hi);
+		if(k == 1){ hi = lo; }
+		if(k < 1){ continue; }
+		for(int c = lo; c <= hi && c < CPU_SETSIZE; ++c){ if(CPU_ISSET(c, &allowed)){ cpus->push_back(c); } }
+	}
+	*node = n;
+}
+
+// Run the calling thread (and the threads it starts meanwhile) on the device's NUMA node for the lifetime of the object.
+struct NumaScope {
+	cpu_set_t before;
+	bool active = false;
+	explicit NumaScope(const kwage_ctx *ctx)
+	{
+		static const bool wanted = []() { const char *e = getenv("KWAGE_LOAD_NUMA"); return !(e && atoi(e) == 0); }();
+		if(!wanted || ctx->numa_cpus.empty()){ return; }
+		CPU_ZERO(&before);
+		if(sched_getaffinity(0, sizeof(before), &before) != 0){ return; }
+		cpu_set_t want;
+		CPU_ZERO(&want);
+		for(int c : ctx->numa_cpus){ CPU_SET(c, &want); }
+		if(CPU_EQUAL(&want, &before)){ return; }
+		active = sched_setaffinity(0, sizeof(want), &want) == 0;
+	}
+	~NumaScope() { if(active){ (void)sched_setaffinity(0, sizeof(before), &before); } }
+};
+
 // The knobs' values at context creation: KWAGE_<NAME> for every name of TUNING_NAMES, plus the two historic spellings
 // KWAGE_AND_CFG="vec,unroll,nt[,ldsKB[,block waves]]" and KWAGE_HIT_SORT=host.
 void tuning_from_environment(Tuning *t)
@@ -1156,6 +1222,7 @@ extern "C" int kwage_init(int device, kwage_ctx **out)
 	ctx->device = device;
 	ctx->ncu = prop.multiProcessorCount;
 	tuning_from_environment(&ctx->tune);
+	find_numa_cpus(device, &ctx->numa_node, &ctx->numa_cpus);
 	for(int k = 0; k < 2; ++k){
 		Slot *sl = &ctx->slot[k];
 		// (a lowest-priority stream was tried so that a caller's small kernels get in between the gather
@@ -1825,6 +1892,7 @@ extern "C" int kwage_group_add_db_files(kwage_group *g, const char *const *paths
 	for(uint32_t i = 0; i < n; ++i){ if(!paths[i]){ return fail(KWAGE_ERR_ARG, "kwage_group_add_db_files: path %u is NULL", i); } }
 	int rc = set_device(g->ctx);
 	if(rc){ return rc; }
+	const NumaScope on_the_gpus_node(g->ctx);      // this thread and the reader threads it starts, until the call returns
 	// Files are taken in the order given (that is the column order).  Raw files go through the copy-engine pipeline
 	// (SdmaPipe; KWAGE_LOAD_SDMA=0 disables it), or -- opt-in -- LOAD_GANG at a time through the direct copy kernel;
 	// compressed files, sparse groups and whatever those paths cannot take go through the staged paths file by file.
