@@ -159,6 +159,7 @@ struct Slot {
 	bool busy = false;
 	kwage_group *g = nullptr;
 	kwage_batch *b = nullptr;
+	const struct KmerLayout *lay = nullptr;     // the batch's layout for the group's k-mer length
 	float threshold = 1.0f;
 	uint32_t flags = 0;
 	uint32_t launches = 0;
@@ -351,6 +352,31 @@ struct kwage_group {
 	uint32_t *d_row_map = nullptr;
 };
 
+// Where the k-mer positions of a batch's queries lie for ONE k-mer length: what the k-mer stage and the gather kernels
+// index their row lists with.
+struct KmerLayout {
+	uint32_t k = 0;
+	uint64_t total_pos = 0;        // sum over the queries of max(len - k + 1, 0)
+	uint64_t max_pos = 0;
+	uint64_t table_slots = 0;      // global hash-set slots needed by long queries
+	uint64_t *d_pos_off = nullptr; // n+1: position prefix
+	uint64_t *d_tab_off = nullptr; // n: slot offset of a long query's global distinct set
+	// k-mer stage work list: one workgroup per chunk; a query above KM_LDS_SLOTS/2 positions is cut into chunks of
+	// KM_CHUNK positions that share its global distinct set, everything shorter is one chunk
+	uint32_t *d_chunk_q = nullptr;     // n_chunks: query of the chunk
+	uint64_t *d_chunk_t0 = nullptr;    // n_chunks: its first position within the query
+	uint64_t n_chunks = 0;
+	bool multi_chunk = false;          // some query has more than one chunk
+	std::vector<uint64_t> h_pos_off;
+	~KmerLayout()
+	{
+		if(d_pos_off){ (void)hipFree(d_pos_off); }
+		if(d_tab_off){ (void)hipFree(d_tab_off); }
+		if(d_chunk_q){ (void)hipFree(d_chunk_q); }
+		if(d_chunk_t0){ (void)hipFree(d_chunk_t0); }
+	}
+};
+
 struct kwage_batch {
 	kwage_ctx *ctx = nullptr;
 	uint32_t n = 0;
@@ -358,20 +384,10 @@ struct kwage_batch {
 	char *d_seqs = nullptr;
 	uint64_t *d_seq_off = nullptr;
 	std::vector<uint64_t> h_seq_off;
-	// per-k layout, cached between searches with the same k-mer length
-	uint32_t cached_k = 0;
-	uint64_t total_pos = 0;
-	uint64_t max_pos = 0;
-	uint64_t table_slots = 0;      // global hash-set slots needed by long queries
-	uint64_t *d_pos_off = nullptr; // n+1
-	uint64_t *d_tab_off = nullptr; // n
-	// k-mer stage work list: one workgroup per chunk; a query above KM_LDS_SLOTS/2 positions is cut into chunks of
-	// KM_CHUNK positions that share its global distinct set, everything shorter is one chunk
-	uint32_t *d_chunk_q = nullptr;     // n_chunks: query of the chunk
-	uint64_t *d_chunk_t0 = nullptr;    // n_chunks: its first position within the query
-	uint64_t n_chunks = 0, chunk_cap = 0;
-	bool multi_chunk = false;          // some query has more than one chunk
-	std::vector<uint64_t> h_pos_off;
+	// One layout per k-mer length the batch has been searched with (a database directory may hold files of several
+	// k: two or three in practice).  A layout never changes once built, so searches with different k-mer lengths can
+	// be in flight on the same batch side by side.
+	std::vector<std::unique_ptr<KmerLayout>> layouts;
 };
 
 namespace {
@@ -430,18 +446,22 @@ uint32_t host_table_log2(uint64_t npos)
 	return lg;
 }
 
-// (Re)build the per-k layout of a batch: position prefix and global hash-set offsets.
-int batch_prepare(kwage_batch *b, uint32_t k)
+// The batch's layout for k-mer length k: position prefix, global hash-set offsets and the k-mer stage's work list.
+// Built on first use (one synchronous upload), kept for the life of the batch.
+int batch_prepare(kwage_batch *b, uint32_t k, const KmerLayout **out)
 {
-	if(b->cached_k == k){ return KWAGE_OK; }
+	for(const auto &have : b->layouts){ if(have->k == k){ *out = have.get(); return KWAGE_OK; } }
+	std::unique_ptr<KmerLayout> L(new (std::nothrow) KmerLayout());
+	if(!L){ return fail(KWAGE_ERR_DEVICE, "out of host memory"); }
+	L->k = k;
 	const uint32_t n = b->n;
-	b->h_pos_off.assign((size_t)n + 1, 0);
+	L->h_pos_off.assign((size_t)n + 1, 0);
 	std::vector<uint64_t> tab_off(n, 0);
 	uint64_t slots = 0, maxp = 0;
 	for(uint32_t i = 0; i < n; ++i){
 		const uint64_t len = b->h_seq_off[i + 1] - b->h_seq_off[i];
 		const uint64_t npos = (len >= k) ? (len - k + 1) : 0;
-		b->h_pos_off[i + 1] = b->h_pos_off[i] + npos;
+		L->h_pos_off[i + 1] = L->h_pos_off[i] + npos;
 		maxp = std::max(maxp, npos);
 		if(npos){
 			const uint32_t lg = host_table_log2(npos);
@@ -455,53 +475,43 @@ int batch_prepare(kwage_batch *b, uint32_t k)
 	std::vector<uint64_t> chunk_t0;
 	chunk_q.reserve(n);
 	chunk_t0.reserve(n);
-	b->multi_chunk = false;
 	for(uint32_t i = 0; i < n; ++i){
-		const uint64_t npos = b->h_pos_off[i + 1] - b->h_pos_off[i];
+		const uint64_t npos = L->h_pos_off[i + 1] - L->h_pos_off[i];
 		const bool is_long = npos && (1ull << host_table_log2(npos)) > KM_LDS_SLOTS;      // the same rule as the table choice above
 		if(!is_long || npos <= KM_CHUNK){ chunk_q.push_back(i); chunk_t0.push_back(0); continue; }
-		b->multi_chunk = true;
+		L->multi_chunk = true;
 		for(uint64_t t0 = 0; t0 < npos; t0 += KM_CHUNK){ chunk_q.push_back(i); chunk_t0.push_back(t0); }
 	}
 	if(chunk_q.size() > 0x7FFFFFFFull){ return fail(KWAGE_ERR_ARG, "batch too large for one k-mer launch"); }
-	if(chunk_q.size() > b->chunk_cap){
-		if(b->d_chunk_q){ (void)hipFree(b->d_chunk_q); b->d_chunk_q = nullptr; }
-		if(b->d_chunk_t0){ (void)hipFree(b->d_chunk_t0); b->d_chunk_t0 = nullptr; }
-		b->chunk_cap = chunk_q.size();
-		HIP_TRY(hipMalloc(&b->d_chunk_q, std::max<size_t>(b->chunk_cap, 1)*sizeof(uint32_t)));
-		HIP_TRY(hipMalloc(&b->d_chunk_t0, std::max<size_t>(b->chunk_cap, 1)*sizeof(uint64_t)));
+	L->n_chunks = chunk_q.size();
+	HIP_TRY(hipMalloc(&L->d_chunk_q, std::max<size_t>(chunk_q.size(), 1)*sizeof(uint32_t)));
+	HIP_TRY(hipMalloc(&L->d_chunk_t0, std::max<size_t>(chunk_q.size(), 1)*sizeof(uint64_t)));
+	HIP_TRY(hipMalloc(&L->d_pos_off, ((size_t)n + 1)*sizeof(uint64_t)));
+	HIP_TRY(hipMalloc(&L->d_tab_off, std::max<size_t>(n, 1)*sizeof(uint64_t)));
+	// (synchronous copies: the sources are locals, and the layout may be used on either search stream right away)
+	if(L->n_chunks){
+		HIP_TRY(hipMemcpy(L->d_chunk_q, chunk_q.data(), chunk_q.size()*sizeof(uint32_t), hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(L->d_chunk_t0, chunk_t0.data(), chunk_t0.size()*sizeof(uint64_t), hipMemcpyHostToDevice));
 	}
-	b->n_chunks = chunk_q.size();
-	if(b->n_chunks){
-		HIP_TRY(hipMemcpyAsync(b->d_chunk_q, chunk_q.data(), chunk_q.size()*sizeof(uint32_t), hipMemcpyHostToDevice, b->ctx->stream));
-		HIP_TRY(hipMemcpyAsync(b->d_chunk_t0, chunk_t0.data(), chunk_t0.size()*sizeof(uint64_t), hipMemcpyHostToDevice, b->ctx->stream));
-	}
-	if(!b->d_pos_off){ HIP_TRY(hipMalloc(&b->d_pos_off, ((size_t)n + 1)*sizeof(uint64_t))); }
-	if(!b->d_tab_off){ HIP_TRY(hipMalloc(&b->d_tab_off, std::max<size_t>(n, 1)*sizeof(uint64_t))); }
-	HIP_TRY(hipMemcpyAsync(b->d_pos_off, b->h_pos_off.data(), ((size_t)n + 1)*sizeof(uint64_t),
-	                       hipMemcpyHostToDevice, b->ctx->stream));
-	if(n){
-		HIP_TRY(hipMemcpyAsync(b->d_tab_off, tab_off.data(), (size_t)n*sizeof(uint64_t),
-		                       hipMemcpyHostToDevice, b->ctx->stream));
-	}
-	HIP_TRY(hipStreamSynchronize(b->ctx->stream));   // tab_off and the chunk lists are locals
-	b->total_pos = b->h_pos_off[n];
-	b->max_pos = maxp;
-	b->table_slots = slots;
-	b->cached_k = k;
+	HIP_TRY(hipMemcpy(L->d_pos_off, L->h_pos_off.data(), ((size_t)n + 1)*sizeof(uint64_t), hipMemcpyHostToDevice));
+	if(n){ HIP_TRY(hipMemcpy(L->d_tab_off, tab_off.data(), (size_t)n*sizeof(uint64_t), hipMemcpyHostToDevice)); }
+	L->total_pos = L->h_pos_off[n];
+	L->max_pos = maxp;
+	L->table_slots = slots;
+	*out = L.get();
+	b->layouts.push_back(std::move(L));
 	return KWAGE_OK;
 }
 
 // Launch the k-mer stage on the ctx stream. rows/kmers_out may be null.
-int launch_kmer_stage(Slot *sl, const kwage_params &p, kwage_batch *b, float threshold,
+int launch_kmer_stage(Slot *sl, const kwage_params &p, kwage_batch *b, const KmerLayout *L, float threshold,
                       uint32_t *d_rows, uint64_t *d_kmers)
 {
-	int rc = batch_prepare(b, p.kmer_len);
+	int rc = layout_result(sl, b->n, 0, false);
 	if(rc){ return rc; }
-	if((rc = layout_result(sl, b->n, 0, false))){ return rc; }
-	if(b->table_slots){
-		if((rc = sl->tables.reserve(b->table_slots*sizeof(uint64_t)))){ return rc; }
-		HIP_TRY(hipMemsetAsync(sl->tables.p, 0xFF, b->table_slots*sizeof(uint64_t), sl->stream));
+	if(L->table_slots){
+		if((rc = sl->tables.reserve(L->table_slots*sizeof(uint64_t)))){ return rc; }
+		HIP_TRY(hipMemsetAsync(sl->tables.p, 0xFF, L->table_slots*sizeof(uint64_t), sl->stream));
 	}
 	HIP_TRY(hipMemsetAsync(sl->d_counters, 0, 4*sizeof(uint64_t), sl->stream));
 	if(b->n == 0){ return KWAGE_OK; }
@@ -509,8 +519,8 @@ int launch_kmer_stage(Slot *sl, const kwage_params &p, kwage_batch *b, float thr
 	KmerArgs a;
 	a.seqs = b->d_seqs;
 	a.seq_off = b->d_seq_off;
-	a.pos_off = b->d_pos_off;
-	a.tab_off = b->d_tab_off;
+	a.pos_off = L->d_pos_off;
+	a.tab_off = L->d_tab_off;
 	a.g_tables = (unsigned long long*)sl->tables.p;
 	a.k = p.kmer_len;
 	a.num_hash = p.num_hash;
@@ -524,20 +534,20 @@ int launch_kmer_stage(Slot *sl, const kwage_params &p, kwage_batch *b, float thr
 	a.total_kmers = nullptr;           // summed on the host from nkmer[] (a per-workgroup atomic serialises)
 	a.shared_lg = 0;
 	a.bloom_bits = nullptr;
-	a.chunk_q = b->d_chunk_q;
-	a.chunk_t0 = b->d_chunk_t0;
-	if(b->multi_chunk){      // the chunks of a long query add their new k-mers into nkmer[q]
+	a.chunk_q = L->d_chunk_q;
+	a.chunk_t0 = L->d_chunk_t0;
+	if(L->multi_chunk){      // the chunks of a long query add their new k-mers into nkmer[q]
 		HIP_TRY(hipMemsetAsync(sl->d_nkmer, 0, (size_t)b->n*sizeof(uint32_t), sl->stream));
 	}
 	// workgroup and LDS table sized for the longest query of the batch: queries whose table would not fit
 	// KM_LDS_SLOTS use the global tables laid out by batch_prepare (same rule there)
 	uint32_t slots = 64;
-	while(slots < KM_LDS_SLOTS && slots < 2*b->max_pos){ slots *= 2; }
+	while(slots < KM_LDS_SLOTS && slots < 2*L->max_pos){ slots *= 2; }
 	a.lds_slots = slots;
-	const uint32_t threads = (b->max_pos <= 192) ? 64 : (b->max_pos <= 768) ? 128 : KM_THREADS;
-	hipLaunchKernelGGL(kmer_kernel, dim3((uint32_t)b->n_chunks), dim3(threads), (size_t)slots*sizeof(uint64_t), sl->stream, a);
+	const uint32_t threads = (L->max_pos <= 192) ? 64 : (L->max_pos <= 768) ? 128 : KM_THREADS;
+	hipLaunchKernelGGL(kmer_kernel, dim3((uint32_t)L->n_chunks), dim3(threads), (size_t)slots*sizeof(uint64_t), sl->stream, a);
 	HIP_TRY(hipGetLastError());
-	if(b->multi_chunk){      // thresholds of the queries whose k-mers were counted by several workgroups
+	if(L->multi_chunk){      // thresholds of the queries whose k-mers were counted by several workgroups
 		hipLaunchKernelGGL(kmer_finish_kernel, dim3((b->n + 255)/256), dim3(256), 0, sl->stream, a, b->n);
 		HIP_TRY(hipGetLastError());
 	}
@@ -733,7 +743,7 @@ int reserve_zeroed(DevBuf &buf, uint64_t bytes, hipStream_t s)
 }
 
 // Launch the gather+reduce kernel(s) for the current batch.
-int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshold, uint32_t flags,
+int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayout *L, float threshold, uint32_t flags,
                         kwage_hit *d_hits, uint64_t cap, unsigned long long *hit_count)
 {
 	const Tuning &tn = g->ctx->tune;
@@ -744,7 +754,7 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 	a.units_per_row = (uint32_t)(g->stride/16);
 	a.valid = g->d_valid;
 	a.rows = (const uint32_t*)sl->rows.p;
-	a.pos_off = b->d_pos_off;
+	a.pos_off = L->d_pos_off;
 	a.nkmer = sl->d_nkmer;
 	a.qthr = sl->d_qthr;
 	a.num_hash = g->params.num_hash;
@@ -760,7 +770,7 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 	if(threshold == 1.0f){
 		const AndCfg cfg = and_config(tn, a.units_per_row);
 		a.chunks = (a.units_per_row + WAVE*cfg.vec - 1)/(WAVE*cfg.vec);
-		choose_segments(a, b->max_pos, 4096, tn.force_segs);
+		choose_segments(a, L->max_pos, 4096, tn.force_segs);
 		if((uint64_t)a.n_queries*a.segs*a.chunks/4 + 1 > 0x7FFFFFFFull){ return fail(KWAGE_ERR_ARG, "batch too large for one launch"); }
 		// narrow rows: several queries per wave (tools/bench_narrow.py)
 		if(tn.narrow && a.segs == 1 && a.units_per_row <= 32 && a.n_queries >= 64){
@@ -795,7 +805,7 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 		// when another tile of the same query holds a hit, whereas a walking wave covers the hit column's whole row
 		// width and never stops (C2 with early exit: 0.64 ms tiled, 1.29 ms walk).
 		const bool walk_ee_ok = !a.early_exit || tn.walk_early_exit;
-		const uint64_t walk_slots = (uint64_t)coltiles*b->total_pos;
+		const uint64_t walk_slots = (uint64_t)coltiles*L->total_pos;
 		if(walk_unroll && walk_ee_ok && kib >= 3 && kib <= walk_max_kib && walk_slots*a.num_hash >= walk_min_rows && walk_slots > 0){
 			// WALK_WAVES_PER_CU waves per CU, all resident at once (__launch_bounds__(256, 4) allows twice as many),
 			// fewer when the batch is small: a wave should have WALK_MIN_ROWS_PER_WAVE rows to walk
@@ -847,7 +857,7 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 	else{
 		a.chunks = (a.units_per_row + WAVE - 1)/WAVE;
 		// counter planes: enough bits for the largest possible num_query_kmer of the batch
-		const uint32_t planes = planes_for(b->max_pos);
+		const uint32_t planes = planes_for(L->max_pos);
 		const bool narrow = tn.narrow && a.units_per_row <= 32 && a.units_per_row > 8 && a.n_queries >= 64 && planes <= 14;
 		// The persistent form (count_walk_kernel): equal shares of the batch's (query, KiB tile, position) list per wave,
 		// pairs cut by share boundaries added up as a tree through memory.  Taken when the batch gives every wave of the
@@ -858,8 +868,8 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 		// neighbouring KiB of the same rows), early exit, tiny batches and forced segment counts.
 		const uint64_t tiles = (uint64_t)a.n_queries*a.chunks;
 		const bool one_round = tn.count_walk_one_round && tiles >= 2048 && tiles <= ncu*16;
-		if(tn.count_walk && !a.early_exit && !narrow && !one_round && tn.force_segs <= 0 && b->total_pos > 0){
-			const uint64_t slots = (uint64_t)a.chunks*b->total_pos;
+		if(tn.count_walk && !a.early_exit && !narrow && !one_round && tn.force_segs <= 0 && L->total_pos > 0){
+			const uint64_t slots = (uint64_t)a.chunks*L->total_pos;
 			const uint64_t chip_waves = ncu*(uint64_t)std::max<int64_t>(tn.count_walk_wpc, 1);
 			const uint64_t min_rows = (tn.count_walk_min_rows >= 0) ? (uint64_t)tn.count_walk_min_rows : (uint64_t)WALK_MIN_ROWS_PER_WAVE*chip_waves;
 			const uint64_t want_waves = (tn.count_walk_waves > 0) ? std::min<uint64_t>((uint64_t)tn.count_walk_waves, slots)
@@ -886,13 +896,13 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, float threshol
 		// Long queries: segments of the k-mer list are counted by different waves into a slab of partial counters
 		// and added by count_combine_kernel (a tree per (query, 64 units)); a segment's counters need only the
 		// planes its own k-mer count can reach.
-		choose_segments(a, b->max_pos, 1024, tn.force_segs);
+		choose_segments(a, L->max_pos, 1024, tn.force_segs);
 		uint32_t seg_planes = (a.segs > 1) ? planes_for(a.seg_kmers) : planes;
 		// keep the slab of partial counters bounded (1 GiB)
 		while(a.segs > 1 && (uint64_t)a.n_queries*a.segs*seg_planes*g->stride > (1ull << 30)){
 			const uint64_t want = a.segs/2;
-			a.seg_kmers = (uint32_t)((b->max_pos + want - 1)/std::max<uint64_t>(want, 1));
-			a.segs = (uint32_t)((b->max_pos + a.seg_kmers - 1)/a.seg_kmers);
+			a.seg_kmers = (uint32_t)((L->max_pos + want - 1)/std::max<uint64_t>(want, 1));
+			a.segs = (uint32_t)((L->max_pos + a.seg_kmers - 1)/a.seg_kmers);
 			seg_planes = (a.segs > 1) ? planes_for(a.seg_kmers) : planes;
 		}
 		if((uint64_t)a.n_queries*a.segs*a.chunks/4 + 1 > 0x7FFFFFFFull){ return fail(KWAGE_ERR_ARG, "batch too large for one launch"); }
@@ -972,7 +982,7 @@ int enqueue_search_and_copy(Slot *sl)
 		if(sl->append && sl->append_reset){ HIP_TRY(hipMemsetAsync(sl->ext_count, 0, sizeof(uint64_t), sl->stream)); }      // a new list starts here
 		if(timing){ HIP_TRY(hipEventRecord(sl->ev[2], sl->stream)); }
 		unsigned long long *hit_count = sl->append ? (unsigned long long*)sl->ext_count : (unsigned long long*)sl->d_counters;
-		if((rc = launch_search_stage(sl, g, b, sl->threshold, sl->flags, d_hits, cap, hit_count))){ return rc; }
+		if((rc = launch_search_stage(sl, g, b, sl->lay, sl->threshold, sl->flags, d_hits, cap, hit_count))){ return rc; }
 		if(timing){ HIP_TRY(hipEventRecord(sl->ev[3], sl->stream)); }
 		HIP_TRY(hipEventRecord(sl->search_done, sl->stream));
 		sl->search_done_valid = true;
@@ -1006,28 +1016,25 @@ int submit_search(Slot *sl, kwage_group *g, kwage_batch *b, float threshold, uin
 		return fail(KWAGE_ERR_ARG, "search threshold must satisfy 0 < t <= 1");
 	}
 	if((rc = set_device(ctx))){ return rc; }
-	if(b->cached_k != g->params.kmer_len){
-		// the batch's per-k layout is shared by every slot: re-laying it out needs the other slot idle
-		for(int i = 0; i < 2; ++i){ if(ctx->slot[i].busy && ctx->slot[i].b == b){ return fail(KWAGE_ERR_STATE, "batch is in use by a pending search with another k-mer length"); } }
+	const KmerLayout *L = nullptr;
+	if((rc = batch_prepare(b, g->params.kmer_len, &L))){ return rc; }
+	if(L->max_pos*g->params.num_hash > 0xFFFFFFFFull){      // the kernels index a query's row list with 32 bits
+		return fail(KWAGE_ERR_ARG, "a query of %llu k-mer positions x %u hash functions exceeds 2^32 rows", (unsigned long long)L->max_pos, g->params.num_hash);
 	}
-	if((rc = batch_prepare(b, g->params.kmer_len))){ return rc; }
-	if(b->max_pos*g->params.num_hash > 0xFFFFFFFFull){      // the kernels index a query's row list with 32 bits
-		return fail(KWAGE_ERR_ARG, "a query of %llu k-mer positions x %u hash functions exceeds 2^32 rows", (unsigned long long)b->max_pos, g->params.num_hash);
-	}
-	if((rc = sl->rows.reserve(std::max<uint64_t>(b->total_pos*g->params.num_hash, 1)*sizeof(uint32_t)))){ return rc; }
-	sl->g = g; sl->b = b; sl->threshold = threshold; sl->flags = flags;
+	if((rc = sl->rows.reserve(std::max<uint64_t>(L->total_pos*g->params.num_hash, 1)*sizeof(uint32_t)))){ return rc; }
+	sl->g = g; sl->b = b; sl->lay = L; sl->threshold = threshold; sl->flags = flags;
 	sl->ext_hits = ext_hits; sl->ext_cap = ext_cap; sl->ext_count = ext_count;
 	sl->append = append; sl->append_reset = append_reset; sl->col_base = col_base;
 	sl->launches = 0;
 
 	const bool timing_kmer = (flags & KWAGE_SEARCH_TIMING) && (flags & KWAGE_SEARCH_TIMING_KMER);
 	if(timing_kmer){ HIP_TRY(hipEventRecord(sl->ev[0], sl->stream)); }
-	if((rc = launch_kmer_stage(sl, g->params, b, threshold, (uint32_t*)sl->rows.p, nullptr))){ return rc; }
+	if((rc = launch_kmer_stage(sl, g->params, b, L, threshold, (uint32_t*)sl->rows.p, nullptr))){ return rc; }
 	if(g->d_row_map && b->n){      // sparse group: row index -> position in the group's row list (counter 2 = indices not listed)
 		// (a workgroup per 4096 row indices of the longest query, so that a genome-length query is not one workgroup's job)
-		const uint64_t per_q = std::max<uint64_t>(1, (b->max_pos*g->params.num_hash + 4095)/4096);
+		const uint64_t per_q = std::max<uint64_t>(1, (L->max_pos*g->params.num_hash + 4095)/4096);
 		const uint64_t wgs_per_q = std::min<uint64_t>(per_q, std::max<uint64_t>(1, 0x7FFFFFFFull/b->n));
-		hipLaunchKernelGGL(remap_rows_kernel, dim3((uint32_t)(b->n*wgs_per_q)), dim3(256), 0, sl->stream, (uint32_t*)sl->rows.p, b->d_pos_off, sl->d_nkmer,
+		hipLaunchKernelGGL(remap_rows_kernel, dim3((uint32_t)(b->n*wgs_per_q)), dim3(256), 0, sl->stream, (uint32_t*)sl->rows.p, L->d_pos_off, sl->d_nkmer,
 		                   g->params.num_hash, g->d_row_map, (uint32_t)g->h_row_map.size(), (unsigned long long*)sl->d_counters + 2, (uint32_t)wgs_per_q);
 		HIP_TRY(hipGetLastError());
 	}
@@ -2106,11 +2113,7 @@ extern "C" void kwage_batch_destroy(kwage_batch *b)
 	(void)hipStreamSynchronize(b->ctx->slot[1].stream);
 	if(b->d_seqs){ (void)hipFree(b->d_seqs); }
 	if(b->d_seq_off){ (void)hipFree(b->d_seq_off); }
-	if(b->d_pos_off){ (void)hipFree(b->d_pos_off); }
-	if(b->d_tab_off){ (void)hipFree(b->d_tab_off); }
-	if(b->d_chunk_q){ (void)hipFree(b->d_chunk_q); }
-	if(b->d_chunk_t0){ (void)hipFree(b->d_chunk_t0); }
-	delete b;
+	delete b;      // (its layouts free their device arrays)
 }
 
 extern "C" uint32_t kwage_batch_num_queries(const kwage_batch *b) { return b ? b->n : 0; }
@@ -2407,15 +2410,16 @@ extern "C" int kwage_hash_batch(kwage_ctx *ctx, const kwage_params *params, kwag
 	if((rc = set_device(ctx))){ return rc; }
 	Slot *sl = &ctx->slot[0];
 	if(sl->busy){ return fail(KWAGE_ERR_STATE, "kwage_hash_batch: a search is pending on this context"); }
-	if((rc = batch_prepare(b, params->kmer_len))){ return rc; }
-	const uint64_t np = std::max<uint64_t>(b->total_pos, 1);
+	const KmerLayout *L = nullptr;
+	if((rc = batch_prepare(b, params->kmer_len, &L))){ return rc; }
+	const uint64_t np = std::max<uint64_t>(L->total_pos, 1);
 	if((rc = sl->rows.reserve(np*params->num_hash*sizeof(uint32_t)))){ return rc; }
 	if((rc = ctx->kmers.reserve(np*sizeof(uint64_t)))){ return rc; }
-	if((rc = launch_kmer_stage(sl, *params, b, 1.0f, (uint32_t*)sl->rows.p, (uint64_t*)ctx->kmers.p))){ return rc; }
-	memcpy(kmer_offsets, b->h_pos_off.data(), ((size_t)b->n + 1)*sizeof(uint64_t));
+	if((rc = launch_kmer_stage(sl, *params, b, L, 1.0f, (uint32_t*)sl->rows.p, (uint64_t*)ctx->kmers.p))){ return rc; }
+	memcpy(kmer_offsets, L->h_pos_off.data(), ((size_t)b->n + 1)*sizeof(uint64_t));
 	if(b->n){ HIP_TRY(hipMemcpyAsync(num_query_kmer, sl->d_nkmer, (size_t)b->n*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
-	if(kmers && b->total_pos){ HIP_TRY(hipMemcpyAsync(kmers, ctx->kmers.p, b->total_pos*sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream)); }
-	if(rows && b->total_pos){ HIP_TRY(hipMemcpyAsync(rows, sl->rows.p, b->total_pos*params->num_hash*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
+	if(kmers && L->total_pos){ HIP_TRY(hipMemcpyAsync(kmers, ctx->kmers.p, L->total_pos*sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream)); }
+	if(rows && L->total_pos){ HIP_TRY(hipMemcpyAsync(rows, sl->rows.p, L->total_pos*params->num_hash*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	return KWAGE_OK;
 }
@@ -2430,11 +2434,12 @@ int run_shared_kmer_pass(kwage_ctx *ctx, const kwage_params &p, kwage_batch *b, 
 {
 	Slot *sl = &ctx->slot[0];
 	if(sl->busy){ return fail(KWAGE_ERR_STATE, "a search is pending on this context"); }
-	int rc = batch_prepare(b, p.kmer_len);
+	const KmerLayout *L = nullptr;
+	int rc = batch_prepare(b, p.kmer_len, &L);
 	if(rc){ return rc; }
 	if((rc = layout_result(sl, b->n, 0, false))){ return rc; }
 	uint32_t lg = 10;
-	while((1ull << lg) < 2*std::max<uint64_t>(b->total_pos, 1)){ ++lg; }
+	while((1ull << lg) < 2*std::max<uint64_t>(L->total_pos, 1)){ ++lg; }
 	// (the shared_table_log2 knob raises the table size: tests exercise the >= 2^32-slot arithmetic on small inputs)
 	if(ctx->tune.shared_table_log2 > 0){ lg = std::max<uint32_t>(lg, (uint32_t)ctx->tune.shared_table_log2); }
 	if(lg > 36){ return fail(KWAGE_ERR_ARG, "too many k-mer positions for one sample"); }
@@ -2443,7 +2448,7 @@ int run_shared_kmer_pass(kwage_ctx *ctx, const kwage_params &p, kwage_batch *b, 
 	HIP_TRY(hipMemsetAsync(sl->d_counters, 0, 4*sizeof(uint64_t), ctx->stream));
 	if(b->n){
 		KmerArgs a;
-		a.seqs = b->d_seqs; a.seq_off = b->d_seq_off; a.pos_off = b->d_pos_off; a.tab_off = b->d_tab_off;
+		a.seqs = b->d_seqs; a.seq_off = b->d_seq_off; a.pos_off = L->d_pos_off; a.tab_off = L->d_tab_off;
 		a.g_tables = (unsigned long long*)sl->tables.p;
 		a.k = p.kmer_len; a.num_hash = p.num_hash;
 		a.row_mask = (p.log_2_filter_len >= 32) ? 0xFFFFFFFFu : ((1u << p.log_2_filter_len) - 1u);

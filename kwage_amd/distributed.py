@@ -418,13 +418,7 @@ class StepPipeline:
 
     def _pump(self):
         while self.todo and len(self.inflight) < 2:
-            step, gi = self.todo[0]
-            # a batch carries ONE k-mer layout at a time: a search with another k-mer length waits until the searches
-            # in flight on the same batch have been collected (databases with mixed k-mer lengths are rare)
-            k = self.groups[gi].params.kmer_len
-            if any(st["batch"] is step["batch"] and self.groups[g2].params.kmer_len != k for _, st, g2 in self.inflight):
-                break
-            self.todo.pop(0)
+            step, gi = self.todo.pop(0)
             self.inflight.append((self._submit(step, gi), step, gi))
 
     def begin(self, batch, threshold: float):

@@ -54,6 +54,9 @@ WORKLOADS: Dict[str, Workload] = {
                    1000, 1000, 0.8, density_q8=194, num_genomes=32, genome_len=50_000),
     # the C5 code path (several groups searched back to back) on toy groups: C5_TEST_GROUPS (tests of bench.py)
     "c5tiny": Workload("C5 code path on toy groups 2^10-2^13", 0, 0, 31, 5, 64, 300, 0.8, density_q8=194, num_genomes=4, genome_len=1000),
+    # one reference file (2048 columns, 256-byte rows): the several-queries-per-wave kernels (tools/tune_knob.py)
+    "narrow": Workload("one 2048-column file x 2^25 rows, 10k x 1 kb queries", 2048, 25, 31, 1, 10_000, 1000, 1.0, num_genomes=16, genome_len=200_000),
+    "narrowt": Workload("one 2048-column file x 2^25 rows, 10k x 1 kb queries, t=0.8", 2048, 25, 31, 1, 10_000, 1000, 0.8, num_genomes=16, genome_len=200_000),
     # small shapes for tests
     "tiny": Workload("tiny", 5000, 14, 31, 2, 64, 300, 1.0, density_q8=128, num_genomes=4, genome_len=1000),
 }
