@@ -25,6 +25,11 @@ def as_tuples(a):
 
 
 def main():
+    import time
+    t_start = time.perf_counter()
+
+    def lap(what):
+        print("[rank %s] %6.1f s  %s" % (os.environ["RANK"], time.perf_counter() - t_start, what), flush=True)
     out_dir = sys.argv[1]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     import torch
@@ -34,6 +39,7 @@ def main():
     from kwage_amd.distributed import (HitExchange, PipelinedDeviceSearcher, ShardedSearch, StepPipeline, device_search_fn,
                                        device_tensor_search_fn, global_column_bases, partition_columns, partition_files)
     oracle.build()
+    lap("imports done")
     ctx = ka.Context(0)                       # before the process group: hardware queues are first come, first served
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -79,6 +85,7 @@ def main():
             assert len(expect[0.0001]) == n_cols * sum(1 for q in seqs if len(q) >= k and "N" not in q[:k] or len(oracle.unique_kmers(q, k)))
 
         span = int(g.column_span) if e > s else 0
+        lap("A: matrices resident, oracle expectations ready")
         # (1) synchronous forms: host lists (device_search_fn) and device-resident lists (device_tensor_search_fn), both exchanges
         for exchange in ("padded", "p2p"):
             for fn_name in ("host", "device"):
@@ -92,6 +99,7 @@ def main():
                         assert as_tuples(merged) == expect[t], (exchange, fn_name, t, len(merged), len(expect[t]))
                     else:
                         assert merged is None
+        lap("A1: synchronous exchanges done")
         # (2) the pipelined single-group searcher + exchange_counted (round 2's bench path)
         pipe = PipelinedDeviceSearcher(g, 0, "cuda:0", initial_capacity=8)
         ss = ShardedSearch(dist, rank, world, span, None, device="cpu", capacity=8)
@@ -103,6 +111,7 @@ def main():
             if rank == 0:
                 assert as_tuples(merged) == expect[t], ("exchange_counted", t)
             tk = nxt
+        lap("A2: exchange_counted done")
         # (3) the step pipeline (append mode, global columns from the engine) + the hit-proportional exchange; a buffer of
         # 16 records overflows on the rank(s) that hold the planted columns only at t = 0.7, on every rank at t -> 0
         bases, spans, total = global_column_bases(dist, rank, world, [span])
@@ -123,6 +132,7 @@ def main():
             if rank == 0:
                 assert as_tuples(merged) == expect[t], ("step pipeline", i, t, len(merged), len(expect[t]))
         g.close()
+        lap("A3: step pipeline done")
 
         # ------------------------------------------------------------------------------------------------------
         # B. the golden multi/ database: three parameter groups, whole files dealt to the ranks (partition_files)
@@ -199,6 +209,7 @@ def main():
                         exp_all |= {(qi, fi, c, m) for c, m in hits}
                 assert len(merged) == len(exp_all), ("multi: merged != oracle over all files", t, len(merged), len(exp_all))
                 assert sorted(m for _, _, m in as_tuples(merged)) == sorted(m for _, _, _, m in exp_all)
+        lap("B: multi/ done")
         for grp in mine:
             grp.close()
         qb.close()

@@ -736,7 +736,9 @@ def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, request):
             ref = g.search(b, thr, 0)
         assert ref.search_kernel.startswith("count_kernel<"), ref.search_kernel
         thr32 = float(np.float32(thr))
-        assert ref.per_query() == [oracle.search_image(image, image.shape[1], k, nh, L, n_cols, oracle.unique_kmers(s, k), thr32)[0] for s in seqs]
+        got = ref.per_query()           # (the oracle's per-bit counting loop over 300 k columns is slow: every 16th query)
+        for i in range(0, len(seqs), 16):
+            assert got[i] == oracle.search_image(image, image.shape[1], k, nh, L, n_cols, oracle.unique_kmers(seqs[i], k), thr32)[0], (n_cols, thr, i)
         for waves, pf in ((0, 1), (7, 0), (3001, 1), (30000, 0)):
             with ctx.tuning(count_walk_waves=waves, count_walk_min_rows=1, count_walk_one_round=0, count_walk_prefetch=pf):
                 for rep in range(2):

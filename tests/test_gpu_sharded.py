@@ -42,3 +42,4 @@ def test_sharded_hip_search_equals_unsharded_and_oracle(world, tmp_path):
     report = "\n".join("---- rank %d (exit %s) ----\n%s" % (rank, p.returncode, out[-3000:]) for rank, (p, out) in enumerate(zip(procs, outs)))
     assert all(p.returncode == 0 for p in procs), report
     assert all(os.path.exists(tmp_path / ("ok%d" % rank)) for rank in range(world)), report
+    print(report)          # (shown with -s / on failure: every rank's timing laps)
