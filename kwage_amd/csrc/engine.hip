@@ -199,7 +199,6 @@ struct Tuning {
 	int64_t count_walk_wpc = 8;     // KWAGE_COUNT_WALK_WPC: its waves per CU (8: 6335 GB/s at C2's shape, 12: 6271, 16: 6250, 20: 5876)
 	int64_t count_walk_waves = 0;   // KWAGE_COUNT_WALK_WAVES: exactly this many waves (tests)
 	int64_t count_walk_min_rows = -1;   // KWAGE_COUNT_WALK_MIN_ROWS: smaller batches use the tiled kernel (-1: 64 rows for each of its waves)
-	int64_t count_walk_one_round = 1;   // KWAGE_COUNT_WALK_ONE_ROUND: 1 = batches whose tiles fit the chip in one round stay with the tiled kernel
 	int64_t count_walk_prefetch = 1;    // KWAGE_COUNT_WALK_PREFETCH: request the next four k-mers' rows before adding the current four (+1.3 % at C2's shape)
 	int64_t count_narrow_kps = 8;   // KWAGE_COUNT_NARROW_KPS: k-mers per step of the narrow count kernel (8 or 4)
 	int64_t hit_sort_host = 0;      // KWAGE_HIT_SORT=host: order long hit lists on the host (A/B runs, the fallback)
@@ -215,7 +214,6 @@ static const TuningName TUNING_NAMES[] = {
 	{"and_block_waves", &Tuning::and_block_waves}, {"narrow", &Tuning::narrow}, {"narrow_unroll", &Tuning::narrow_unroll}, {"force_segs", &Tuning::force_segs},
 	{"count_walk", &Tuning::count_walk}, {"count_walk_wpc", &Tuning::count_walk_wpc}, {"count_walk_waves", &Tuning::count_walk_waves},
 	{"count_walk_min_rows", &Tuning::count_walk_min_rows}, {"count_walk_prefetch", &Tuning::count_walk_prefetch},
-	{"count_walk_one_round", &Tuning::count_walk_one_round},
 	{"count_narrow_kps", &Tuning::count_narrow_kps},
 	{"hit_sort_host", &Tuning::hit_sort_host}, {"hit_copy_piece_kb", &Tuning::hit_copy_piece_kb}, {"shared_table_log2", &Tuning::shared_table_log2},
 };
@@ -862,13 +860,13 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 		// The persistent form (count_walk_kernel): equal shares of the batch's (query, KiB tile, position) list per wave,
 		// pairs cut by share boundaries added up as a tree through memory.  Taken when the batch gives every wave of the
 		// launch its 64 rows and no early exit is asked for (a persistent wave has no tile of its own to give up): long
-		// queries need no segment slab and no combine pass then (1 x 100 kb: 5076 vs 4694 GB/s, 4 x 1 Mb: 6159 vs 5735),
-		// and no batch size ends in a part-filled round of waves.  The tiled kernel keeps the batches whose tiles all fit
-		// the chip at once (2048 .. 16 per CU: 300 queries at C2's shape 0.582 vs 0.598 ms -- its neighbouring waves read
-		// neighbouring KiB of the same rows), early exit, tiny batches and forced segment counts.
-		const uint64_t tiles = (uint64_t)a.n_queries*a.chunks;
-		const bool one_round = tn.count_walk_one_round && tiles >= 2048 && tiles <= ncu*16;
-		if(tn.count_walk && !a.early_exit && !narrow && !one_round && tn.force_segs <= 0 && L->total_pos > 0){
+		// queries need no segment slab and no combine pass then (1 x 100 kb: 5410 vs 4813 GB/s, 4 x 1 Mb: 6431 vs 5705),
+		// no batch size ends in a part-filled round of waves, and in a host's software pipeline its resident waves do not
+		// share the CUs with the next batch's k-mer stage the way the tiled kernel's 13 000 workgroups do (C2 at t = 0.8
+		// inside bench.py: 1.988 vs 2.077 ms, profiles/r03_c2t_bench_ab.txt).  (Alone on the chip, batches whose tiles
+		// all fit in one round are 2-3 % faster through the tiled kernel -- 300 queries 0.582 vs 0.598 ms --: not worth
+		// a rule of their own.)  Early exit, tiny batches and forced segment counts go on below.
+		if(tn.count_walk && !a.early_exit && !narrow && tn.force_segs <= 0 && L->total_pos > 0){
 			const uint64_t slots = (uint64_t)a.chunks*L->total_pos;
 			const uint64_t chip_waves = ncu*(uint64_t)std::max<int64_t>(tn.count_walk_wpc, 1);
 			const uint64_t min_rows = (tn.count_walk_min_rows >= 0) ? (uint64_t)tn.count_walk_min_rows : (uint64_t)WALK_MIN_ROWS_PER_WAVE*chip_waves;

@@ -149,7 +149,7 @@ def test_cli_equals_reference_binary(oracle, tmp_path, seed):
                 # from the environment, when the context is created) send even these tiny batches: and_walk_kernel /
                 # count_walk_kernel with a handful of waves, pairs cut by share boundaries added up through memory
                 walk = {"KWAGE_EARLY_EXIT": "0", "KWAGE_SPARSE": "0", "KWAGE_NARROW": "0", "KWAGE_WALK_MIN_ROWS": "1", "KWAGE_COUNT_WALK_MIN_ROWS": "1",
-                        "KWAGE_COUNT_WALK_ONE_ROUND": "0", "KWAGE_COUNT_WALK_WAVES": "37", "KWAGE_WALK_WAVES": "37"}
+                        "KWAGE_COUNT_WALK_WAVES": "37", "KWAGE_WALK_WAVES": "37"}
                 assert _run(native.KWAGE_BIN, db, fasta, cmd, thr, fmt, walk) == got, (seed, thr, fmt)
             if seed % 4 == 1:
                 # streamed in small batches against several resident units per pass, and against passes so small that

@@ -75,7 +75,7 @@ def test_random_configuration(oracle, seed, monkeypatch):
                 # rows): shares of a few positions / hundreds / more waves than the chip holds, long queries spread over
                 # dozens of waves each; twice per case (the kernel must leave its pair counters zero)
                 for waves in (0, int(rng.choice([3, 11, 64])), int(rng.choice([700, 2048, 9000]))):
-                    with ctx.tuning(count_walk_min_rows=1, count_walk_one_round=0, count_walk_waves=waves, narrow=0, count_walk_prefetch=int(waves % 2)):
+                    with ctx.tuning(count_walk_min_rows=1, count_walk_waves=waves, narrow=0, count_walk_prefetch=int(waves % 2)):
                         for _ in range(2):
                             r = g.search(b, thr, 0)
                             assert r.search_kernel.startswith("count_walk_kernel<"), r.search_kernel
