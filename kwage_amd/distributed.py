@@ -543,6 +543,10 @@ class HitExchange:
             if ops:
                 for req in self.dist.batch_isend_irecv(ops):        # ONE grouped ncclSend/ncclRecv launch on RCCL
                     req.wait()
+                if buf.is_cuda:
+                    # the engine's own streams (not ordered with torch's) refill this buffer two steps on: the send must
+                    # have left it before the call returns
+                    torch.cuda.current_stream(buf.device).synchronize()
                 self.stats["p2p_batches"] += 1
             if self.rank == 0:
                 if rest[0]:

@@ -414,6 +414,62 @@ def test_long_queries_are_segmented(ka, ctx, oracle, num_hash, monkeypatch):
     g.close()
 
 
+def test_queries_above_2_pow_20_positions_use_32_plane_counters(ka, ctx, oracle):
+    """A query with more than 2^20 k-mer positions (a bacterial chromosome) needs counters wider than 20 bits: the
+    32-plane instantiations of the count kernels -- tiled with segments + tree combine, and the persistent form whose
+    cut pairs carry 32 KiB of partial counters through the slab -- against the oracle and each other; plus the append-mode
+    search (kwage_search_device_append_submit): two searches filling ONE list with a column base each."""
+    import ctypes as C
+    from kwage_amd.native import check, lib
+    rng = np.random.default_rng(2 ** 20)
+    k, nh, L, n_cols = 31, 1, 10, 200
+    image = _make_random_db(rng, L, n_cols, 0.5)         # random columns count about n/2: below the threshold
+    genome = rand_seq(rng, 1_150_000)
+    for col in (5, 199):
+        for r in oracle.row_indices(oracle.unique_kmers(genome, k), k, nh, L).reshape(-1):
+            image[r, col // 8] |= np.uint8(1 << (col % 8))
+    seqs = [genome, rand_seq(rng, 400), genome[1000:1500]]
+    g = ka.Group(ctx, k, nh, L, n_cols)
+    g.add_columns(image, n_cols)
+    g.finalize()
+    b = ka.Batch(ctx, seqs)
+    thr = 0.9
+    exp = [oracle.search_image(image, image.shape[1], k, nh, L, n_cols, oracle.unique_kmers(s, k), float(np.float32(thr)))[0] for s in seqs]
+    assert {5, 199} <= {c for c, _ in exp[0]} and max(m for _, m in exp[0]) > 1 << 20
+    seen = set()
+    for knobs, flags in ((dict(count_walk=0), 0), (dict(count_walk=0), ka.SEARCH_EARLY_EXIT), (dict(count_walk=1, count_walk_min_rows=1), 0),
+                         (dict(count_walk=1, count_walk_min_rows=1, count_walk_waves=333, count_walk_prefetch=0), 0)):
+        with ctx.tuning(narrow=0, **knobs):
+            r = g.search(b, thr, flags)
+        seen.add(r.search_kernel)
+        assert r.per_query() == exp, (knobs, flags, r.search_kernel)
+    assert any(n.startswith("count_walk_kernel<32,1") for n in seen) and any("->32" in n for n in seen), seen
+
+    # append mode: the same batch searched twice into one caller-owned list -- first with a fresh counter and column base
+    # 1000, then appended behind it with base 5000; a list that does not fit is counted, not overrun
+    import torch
+    buf = torch.empty((1 + 4096, 3), dtype=torch.int32, device="cuda:0")
+    n, ms, h = C.c_uint64(), C.c_float(), C.c_void_p()
+    for base, reset in ((1000, 1), (5000, 0)):
+        check(lib().kwage_search_device_append_submit(g._h, b._h, C.c_float(thr), 0, buf.data_ptr() + 12, buf.shape[0] - 1, buf.data_ptr(), base, reset, C.byref(h)))
+        check(lib().kwage_search_device_collect(h, C.byref(n), None, C.byref(ms)))
+    flat = sorted((q, c, m) for q, e in enumerate(exp) for c, m in e)
+    assert n.value == 2 * len(flat)
+    host = buf.cpu().numpy().view(np.uint32)
+    assert int(host[0, 0]) == n.value
+    got = sorted(map(tuple, host[1:1 + n.value].tolist()))
+    assert got == sorted([(q, c + 1000, m) for q, c, m in flat] + [(q, c + 5000, m) for q, c, m in flat])
+    check(lib().kwage_search_device_append_submit(g._h, b._h, C.c_float(thr), 0, buf.data_ptr() + 12, 3, buf.data_ptr(), 0, 1, C.byref(h)))
+    check(lib().kwage_search_device_collect(h, C.byref(n), None, None))
+    assert n.value == len(flat) > 3                      # counted in full, three stored
+    with pytest.raises(ka.KwageError):                  # a column base that would leave the 32-bit column field
+        check(lib().kwage_search_device_append_submit(g._h, b._h, C.c_float(thr), 0, buf.data_ptr() + 12, 3, buf.data_ptr(), 0xFFFFFF00, 1, C.byref(h)))
+    with pytest.raises(ka.KwageError):                  # append mode needs the counter word
+        check(lib().kwage_search_device_append_submit(g._h, b._h, C.c_float(thr), 0, buf.data_ptr() + 12, 3, None, 0, 1, C.byref(h)))
+    b.close()
+    g.close()
+
+
 def test_cli_sharded_over_two_contexts(ka, oracle):
     """KWAGE_DEVICES shards whole files over devices, one host thread + ctx each.  With one GPU on
     the box both contexts sit on device 0, which still exercises the sharding, threading and merge."""
