@@ -187,6 +187,7 @@ struct Tuning {
 	int64_t walk_early_exit = 0;    // KWAGE_WALK_EARLY_EXIT: use the walk form with early exit too (the tiled kernel stops sooner)
 	int64_t walk_waves = 0;         // KWAGE_WALK_WAVES: exactly this many waves (tests: shares of every size); 0 = from the CU count
 	int64_t walk_fences = 0;        // KWAGE_WALK_FENCES: agent-scope fences around the cut-pair count (measurement only)
+	int64_t walk_one_wg_per_cu = 1; // KWAGE_WALK_ONE_WG_PER_CU: chip-filling launches of the persistent kernels use one workgroup of 8 waves per CU (0: workgroups of 4 waves, placed by the dispatcher)
 	int64_t and_vec = 0;            // KWAGE_AND_CFG="vec,unroll,nt[,ldsKB[,block waves]]": shape of the tiled AND kernel (0 = by row width)
 	int64_t and_unroll = 8;
 	int64_t and_nt = 1;
@@ -209,7 +210,7 @@ struct Tuning {
 struct TuningName { const char *name; int64_t Tuning::*field; };
 static const TuningName TUNING_NAMES[] = {
 	{"walk", &Tuning::walk}, {"walk_min_rows", &Tuning::walk_min_rows}, {"walk_max_kib", &Tuning::walk_max_kib},
-	{"walk_early_exit", &Tuning::walk_early_exit}, {"walk_waves", &Tuning::walk_waves}, {"walk_fences", &Tuning::walk_fences},
+	{"walk_early_exit", &Tuning::walk_early_exit}, {"walk_waves", &Tuning::walk_waves}, {"walk_fences", &Tuning::walk_fences}, {"walk_one_wg_per_cu", &Tuning::walk_one_wg_per_cu},
 	{"and_vec", &Tuning::and_vec}, {"and_unroll", &Tuning::and_unroll}, {"and_nt", &Tuning::and_nt}, {"and_lds_kb", &Tuning::and_lds_kb},
 	{"and_block_waves", &Tuning::and_block_waves}, {"narrow", &Tuning::narrow}, {"narrow_unroll", &Tuning::narrow_unroll}, {"force_segs", &Tuning::force_segs},
 	{"count_walk", &Tuning::count_walk}, {"count_walk_wpc", &Tuning::count_walk_wpc}, {"count_walk_waves", &Tuning::count_walk_waves},
@@ -561,6 +562,22 @@ uint32_t search_blocks(const SearchArgs &a)
 	return (uint32_t)((tiles + 3)/4);
 }
 
+// Launch shape of a persistent kernel that wants `want_waves` waves.  A chip-filling launch (8 waves per CU) uses ONE
+// workgroup of 8 waves per CU -- a dynamic-LDS pad of more than half a CU's LDS keeps a second workgroup off --, so
+// that every CU runs exactly 8 waves; smaller launches use workgroups of four waves wherever the dispatcher puts them.
+struct WalkShape { uint32_t wgs, wg_waves; size_t lds; };
+static const size_t WALK_PAD_LDS = 100*1024;
+
+WalkShape walk_shape(const Tuning &tn, uint64_t want_waves, uint64_t ncu)
+{
+	WalkShape w;
+	const bool pinned = tn.walk_one_wg_per_cu && want_waves == ncu*WALK_WG_WAVES;
+	w.wg_waves = pinned ? (uint32_t)WALK_WG_WAVES : 4u;
+	w.wgs = (uint32_t)((want_waves + w.wg_waves - 1)/w.wg_waves);
+	w.lds = pinned ? WALK_PAD_LDS : 0;
+	return w;
+}
+
 // Shape of the tiled AND kernel: VEC 16-byte vectors per lane, UNROLL rows in flight, nontemporal loads, and (tuning
 // only) dynamic LDS per workgroup and waves per workgroup.  Defaults come from measurements on MI355X.
 struct AndCfg { int vec, unroll, nt, lds_bytes, block_waves; };
@@ -671,28 +688,34 @@ void launch_count_planes(uint32_t planes, const SearchArgs &a, hipStream_t s)
 	}
 }
 
-template <int PLANES, bool PF>
-void launch_count_walk_nh(const SearchArgs &a, const CountWalkArgs &wa, uint32_t wgs, hipStream_t s)
+template <int PLANES, int NH, bool PF>
+void launch_count_walk(const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s)
 {
-	const dim3 grid(wgs), block(SEARCH_THREADS);
+	if(w.lds > 48*1024){ (void)hipFuncSetAttribute((const void*)count_walk_kernel<PLANES, NH, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds); }
+	hipLaunchKernelGGL((count_walk_kernel<PLANES, NH, PF>), dim3(w.wgs), dim3(w.wg_waves*WAVE), w.lds, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr);
+}
+
+template <int PLANES, bool PF>
+void launch_count_walk_nh(const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s)
+{
 	switch(a.num_hash){
-		case 1: hipLaunchKernelGGL((count_walk_kernel<PLANES, 1, PF>), grid, block, 0, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr); break;
-		case 2: hipLaunchKernelGGL((count_walk_kernel<PLANES, 2, PF>), grid, block, 0, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr); break;
-		case 3: hipLaunchKernelGGL((count_walk_kernel<PLANES, 3, PF>), grid, block, 0, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr); break;
-		case 4: hipLaunchKernelGGL((count_walk_kernel<PLANES, 4, PF>), grid, block, 0, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr); break;
-		default: hipLaunchKernelGGL((count_walk_kernel<PLANES, 5, PF>), grid, block, 0, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr); break;
+		case 1: launch_count_walk<PLANES, 1, PF>(a, wa, w, s); break;
+		case 2: launch_count_walk<PLANES, 2, PF>(a, wa, w, s); break;
+		case 3: launch_count_walk<PLANES, 3, PF>(a, wa, w, s); break;
+		case 4: launch_count_walk<PLANES, 4, PF>(a, wa, w, s); break;
+		default: launch_count_walk<PLANES, 5, PF>(a, wa, w, s); break;
 	}
 }
 
 template <bool PF>
-void launch_count_walk_planes(uint32_t planes, const SearchArgs &a, const CountWalkArgs &wa, uint32_t wgs, hipStream_t s)
+void launch_count_walk_planes(uint32_t planes, const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s)
 {
 	switch(planes){
-		case 7: launch_count_walk_nh<7, PF>(a, wa, wgs, s); break;
-		case 10: launch_count_walk_nh<10, PF>(a, wa, wgs, s); break;
-		case 14: launch_count_walk_nh<14, PF>(a, wa, wgs, s); break;
-		case 20: launch_count_walk_nh<20, PF>(a, wa, wgs, s); break;
-		default: launch_count_walk_nh<32, PF>(a, wa, wgs, s); break;
+		case 7: launch_count_walk_nh<7, PF>(a, wa, w, s); break;
+		case 10: launch_count_walk_nh<10, PF>(a, wa, w, s); break;
+		case 14: launch_count_walk_nh<14, PF>(a, wa, w, s); break;
+		case 20: launch_count_walk_nh<20, PF>(a, wa, w, s); break;
+		default: launch_count_walk_nh<32, PF>(a, wa, w, s); break;
 	}
 }
 
@@ -810,8 +833,9 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 			const uint64_t chip_waves = ncu*WALK_WAVES_PER_CU;
 			const uint64_t want_waves = (tn.walk_waves > 0) ? std::min<uint64_t>((uint64_t)tn.walk_waves, walk_slots)
 				: std::max<uint64_t>(1, std::min<uint64_t>(chip_waves, walk_slots*a.num_hash/WALK_MIN_ROWS_PER_WAVE));
-			const uint32_t wgs = (uint32_t)((want_waves + 3)/4);
-			const uint64_t waves = (uint64_t)wgs*4;
+			const WalkShape shape = walk_shape(tn, want_waves, ncu);
+			const uint32_t wgs = shape.wgs;
+			const uint64_t waves = (uint64_t)wgs*shape.wg_waves;
 			WalkArgs wa;
 			wa.total_slots = walk_slots;
 			wa.per_wave = (walk_slots + waves - 1)/waves;
@@ -825,10 +849,12 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 			a.segs = 1;
 			a.chunks = coltiles;
 			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_walk_kernel<%u,%d>", walk_ch, walk_unroll == 2 ? 2 : 4);
-			const dim3 grid(wgs), block(SEARCH_THREADS);
+			const dim3 grid(wgs), block(shape.wg_waves*WAVE);
+#define KWAGE_WALK_LAUNCH(...) do { \
+				if(shape.lds > 48*1024){ (void)hipFuncSetAttribute((const void*)and_walk_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shape.lds); } \
+				hipLaunchKernelGGL((and_walk_kernel<__VA_ARGS__>), grid, block, shape.lds, sl->stream, a, wa, a.rows, a.pos_off, a.nkmer); } while(0)
 #define KWAGE_WALK_CASE(CH) case CH: \
-				if(walk_unroll == 2){ hipLaunchKernelGGL((and_walk_kernel<CH, 2>), grid, block, 0, sl->stream, a, wa, a.rows, a.pos_off, a.nkmer); } \
-				else{ hipLaunchKernelGGL((and_walk_kernel<CH, 4>), grid, block, 0, sl->stream, a, wa, a.rows, a.pos_off, a.nkmer); } break;
+				if(walk_unroll == 2){ KWAGE_WALK_LAUNCH(CH, 2); } else{ KWAGE_WALK_LAUNCH(CH, 4); } break;
 			switch(walk_ch){
 				KWAGE_WALK_CASE(3) KWAGE_WALK_CASE(4) KWAGE_WALK_CASE(5) KWAGE_WALK_CASE(6) KWAGE_WALK_CASE(7)
 				KWAGE_WALK_CASE(8) KWAGE_WALK_CASE(9) KWAGE_WALK_CASE(10) KWAGE_WALK_CASE(11) KWAGE_WALK_CASE(12)
@@ -836,6 +862,7 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 				default: KWAGE_WALK_CASE(16)
 			}
 #undef KWAGE_WALK_CASE
+#undef KWAGE_WALK_LAUNCH
 			HIP_TRY(hipGetLastError());
 			return KWAGE_OK;
 		}
@@ -872,8 +899,8 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 			const uint64_t min_rows = (tn.count_walk_min_rows >= 0) ? (uint64_t)tn.count_walk_min_rows : (uint64_t)WALK_MIN_ROWS_PER_WAVE*chip_waves;
 			const uint64_t want_waves = (tn.count_walk_waves > 0) ? std::min<uint64_t>((uint64_t)tn.count_walk_waves, slots)
 				: std::max<uint64_t>(1, std::min<uint64_t>(chip_waves, slots*a.num_hash/WALK_MIN_ROWS_PER_WAVE));
-			const uint32_t wgs = (uint32_t)((want_waves + 3)/4);
-			const uint64_t waves = (uint64_t)wgs*4;
+			const WalkShape shape = walk_shape(tn, want_waves, ncu);
+			const uint64_t waves = (uint64_t)shape.wgs*shape.wg_waves;
 			if(slots*a.num_hash >= min_rows){
 				CountWalkArgs wa;
 				wa.total_slots = slots;
@@ -885,8 +912,8 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 				wa.arrived = (uint32_t*)sl->cwalk_arrived.p;
 				a.segs = 1;
 				snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_walk_kernel<%u,%u%s>", planes, std::min(a.num_hash, 5u), tn.count_walk_prefetch ? ",pf" : "");
-				if(tn.count_walk_prefetch){ launch_count_walk_planes<true>(planes, a, wa, wgs, sl->stream); }
-				else{ launch_count_walk_planes<false>(planes, a, wa, wgs, sl->stream); }
+				if(tn.count_walk_prefetch){ launch_count_walk_planes<true>(planes, a, wa, shape, sl->stream); }
+				else{ launch_count_walk_planes<false>(planes, a, wa, shape, sl->stream); }
 				HIP_TRY(hipGetLastError());
 				return KWAGE_OK;
 			}
@@ -2517,10 +2544,16 @@ extern "C" int kwage_stream_read_gbps(kwage_group *g, uint64_t bytes, uint32_t i
 	if((rc = layout_result(sl, 0, 0, false))){ return rc; }
 	uint32_t *sink = (uint32_t*)(sl->d_counters + 3);
 	const uint64_t n16 = bytes/16;
-	hipLaunchKernelGGL(stream_read_kernel, dim3(256*8), dim3(256), 0, ctx->stream, (const u32x4*)g->d_bits, n16, sink);   // warm-up
+	// every wave walks a contiguous region of whole 8 KiB steps: up to 8192 waves, fewer for a small matrix
+	const uint64_t step16 = (uint64_t)WAVE*8;
+	if(n16 < step16){ return fail(KWAGE_ERR_ARG, "kwage_stream_read_gbps: the matrix is smaller than one 8 KiB step"); }
+	const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(256*8, n16/step16/4));
+	const uint64_t nwaves = (uint64_t)blocks*4;
+	bytes = nwaves*((n16/nwaves)/step16*step16)*16;          // what the kernel reads (a remainder below one step per wave is left out)
+	hipLaunchKernelGGL(stream_read_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const u32x4*)g->d_bits, n16, sink);   // warm-up
 	HIP_TRY(hipEventRecord(sl->ev[0], ctx->stream));
 	for(uint32_t i = 0; i < iters; ++i){
-		hipLaunchKernelGGL(stream_read_kernel, dim3(256*8), dim3(256), 0, ctx->stream, (const u32x4*)g->d_bits, n16, sink);
+		hipLaunchKernelGGL(stream_read_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const u32x4*)g->d_bits, n16, sink);
 	}
 	HIP_TRY(hipEventRecord(sl->ev[1], ctx->stream));
 	HIP_TRY(hipGetLastError());

@@ -468,6 +468,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void and_kernel(SearchArgs a)
 //     `orbuf` -- and adds its k-mer count to the slot's counter; the wave whose add completes the pair's nkmer
 //     reads the result back, emits, and leaves slot, flags and counter ZERO again: the buffers are cleared
 //     once when they are allocated, never per search.
+static constexpr int WALK_WG_WAVES = 8;        // waves per workgroup (= per CU) of a chip-filling launch of the persistent kernels
 static constexpr uint32_t WALK_DEAD = 1u;      // some part of the pair has an all-zero mask: nothing to report
 static constexpr uint32_t WALK_DIRTY = 2u;     // some part ORed its mask into the slot: clear it when the pair is done
 
@@ -483,12 +484,16 @@ struct WalkArgs {
 // (rows, pos_off and nkmer are passed as __restrict__ parameters of their own besides SearchArgs: the kernel stores
 // hits and updates the cut-pair slots inside its work loop, and only with the no-alias promise does the compiler
 // keep the row-index loads on the scalar path -- otherwise every row descriptor goes through a waterfall loop)
+// (launched with workgroups of WALK_WG_WAVES waves and a dynamic-LDS pad of more than half a CU's LDS when the launch
+// fills the chip: ONE workgroup per CU, so every CU runs exactly the same number of waves -- with workgroups of four
+// waves the dispatcher's placement left some CUs with three workgroups and others with one: +0.8-0.9 % at C2's shape,
+// profiles/r03_walk_cu_shapes.txt)
 template <int CH, int UNROLL>
-__global__ __launch_bounds__(SEARCH_THREADS, 4) void and_walk_kernel(SearchArgs a, WalkArgs wa, const uint32_t *__restrict__ rows,
-                                                                     const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ nkmer)
+__global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void and_walk_kernel(SearchArgs a, WalkArgs wa, const uint32_t *__restrict__ rows,
+                                                                      const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ nkmer)
 {
 	const uint32_t lane = threadIdx.x & (WAVE - 1);
-	const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x*(SEARCH_THREADS/WAVE) + (threadIdx.x >> 6));
+	const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x*(blockDim.x/WAVE) + (threadIdx.x >> 6));
 	uint64_t s = (uint64_t)gw*wa.per_wave;
 	const uint64_t s1 = min(wa.total_slots, s + wa.per_wave);
 	if(s >= s1){ return; }
@@ -716,7 +721,7 @@ __device__ __forceinline__ u32x4 planes_ge(const u32x4 (&plane)[PLANES], uint32_
 		eq &= ~(plane[p] ^ t4);
 	}
 	u32x4 ge = gt | eq;
-	if(PLANES < 32 && (thr >> PLANES) != 0){ ge = (u32x4)(0u); }   // a counter of PLANES bits cannot reach thr
+	if(PLANES < 32 && (thr >> (PLANES & 31)) != 0){ ge = (u32x4)(0u); }   // a counter of PLANES bits cannot reach thr
 	return ge;
 }
 
@@ -962,12 +967,12 @@ struct CountWalkArgs {
 };
 
 template <int PLANES, int NH, bool PF>
-__global__ __launch_bounds__(SEARCH_THREADS) void count_walk_kernel(SearchArgs a, CountWalkArgs wa, const uint32_t *__restrict__ rows,
+__global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void count_walk_kernel(SearchArgs a, CountWalkArgs wa, const uint32_t *__restrict__ rows,
                                                                     const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ nkmer,
                                                                     const uint32_t *__restrict__ qthr)
 {
 	const uint32_t lane = threadIdx.x & (WAVE - 1);
-	const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x*(SEARCH_THREADS/WAVE) + (threadIdx.x >> 6));
+	const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x*(blockDim.x/WAVE) + (threadIdx.x >> 6));
 	uint64_t s = (uint64_t)gw*wa.per_wave;
 	const uint64_t s1 = min(wa.total_slots, s + wa.per_wave);
 	if(s >= s1){ return; }
@@ -1280,21 +1285,24 @@ __global__ void gather_rows_kernel(const uint8_t *db, uint64_t stride, const uin
 	}
 }
 
-// Streaming read of the matrix (measures the achievable HBM read rate on this box): every wave
-// keeps eight 1-KiB loads in flight, blocks walk the buffer grid-stride.
+// Streaming read of the matrix: the box's achievable HBM read rate, reported beside every roofline number.  Every wave
+// walks a contiguous region of its own, eight 1-KiB loads in flight (tools/micro/power_probe.hip: this pattern streams
+// 6.9 TB/s where a grid-stride walk -- round 1/2's probe -- measured 6.4 on the same box; a random-row gather reaches
+// 6.7 TB/s of touched bytes).
 __global__ __launch_bounds__(256) void stream_read_kernel(const u32x4 *src, uint64_t n16, uint32_t *sink)
 {
 	u32x4 acc = (u32x4)(0u);
-	const uint64_t step = (uint64_t)gridDim.x*blockDim.x;
-	uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x;
-	for(; i + 7*step < n16; i += 8*step){
+	const uint64_t nwaves = (uint64_t)gridDim.x*(blockDim.x/WAVE);
+	const uint64_t wave = (uint64_t)blockIdx.x*(blockDim.x/WAVE) + (threadIdx.x >> 6);
+	const uint64_t per = (n16/nwaves)/(WAVE*8)*(WAVE*8);                 // whole 8 KiB steps; the remainder is left unread
+	const u32x4 *p = src + wave*per + (threadIdx.x & (WAVE - 1));
+	for(uint64_t i = 0; i < per; i += WAVE*8){
 		u32x4 a[8];
 #pragma unroll
-		for(int u = 0; u < 8; ++u){ a[u] = __builtin_nontemporal_load(src + i + u*step); }
+		for(int u = 0; u < 8; ++u){ a[u] = __builtin_nontemporal_load(p + i + u*WAVE); }
 #pragma unroll
 		for(int u = 0; u < 8; ++u){ acc ^= a[u]; }
 	}
-	for(; i < n16; i += step){ acc ^= src[i]; }
 	if((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u){ *sink = 1; }   // keep the loads alive
 }
 

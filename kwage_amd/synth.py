@@ -37,6 +37,9 @@ WORKLOADS: Dict[str, Workload] = {
     # BASELINE.json configs[1]: the configuration the metric is quoted on
     "c2": Workload("C2: 100k samples x 2^23-bit filters, 1k x 1 kb queries, 1 hash, t=1.0", 100_000, 23, 31, 1,
                    1000, 1000, 1.0, num_genomes=32, genome_len=50_000),
+    # C2 with rows of exactly 12 KiB (98 304 samples): no ragged last KiB-step in the walk kernels (tools: what does the 212-byte tail of C2's 12 500-byte rows cost?)
+    "c2e": Workload("C2 with 98 304 samples (12 KiB rows)", 98_304, 23, 31, 1, 1000, 1000, 1.0, num_genomes=32, genome_len=50_000),
+    "c2et": Workload("C2 with 98 304 samples (12 KiB rows), t=0.8", 98_304, 23, 31, 1, 1000, 1000, 0.8, num_genomes=32, genome_len=50_000),
     # C2 through the count path (threshold < 1, one hash): fewest loads in flight per wave
     "c2t": Workload("C2 at t=0.8 (count path, 1 hash): 100k samples x 2^23-bit filters, 1k x 1 kb queries", 100_000, 23, 31, 1,
                     1000, 1000, 0.8, num_genomes=32, genome_len=50_000),

@@ -32,6 +32,64 @@ __global__ __launch_bounds__(1024) void walk(const u32x4 *src, uint64_t n16, uin
 	if((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u){ *sink = pad[0]; }
 }
 
+// and_walk_kernel's access pattern: a wave takes R random rows of `row_kib` KiB at a time and walks them KiB-step after
+// KiB-step (R loads of 1 KiB in flight per wave)
+template <int R>
+__global__ __launch_bounds__(1024) void gather(const u32x4 *src, uint64_t nrows, uint32_t row_kib, uint64_t stride16, uint64_t rows_per_wave, uint32_t *sink)
+{
+	extern __shared__ uint32_t pad[];
+	u32x4 acc = (u32x4)(0u);
+	const uint64_t wave = (uint64_t)blockIdx.x*(blockDim.x/64) + (threadIdx.x >> 6);
+	const uint32_t lane = threadIdx.x & 63;
+	uint64_t x = wave*0x9E3779B97F4A7C15ull + 12345;
+	for(uint64_t r = 0; r < rows_per_wave; r += R){
+		const u32x4 *p[R];
+#pragma unroll
+		for(int u = 0; u < R; ++u){
+			x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+			const uint64_t row = __builtin_amdgcn_readfirstlane((uint32_t)((x*0x2545F4914F6CDD1Dull) >> 33)) % nrows;
+			p[u] = src + row*stride16 + lane;
+		}
+		for(uint32_t j = 0; j < row_kib; ++j){
+			u32x4 a[R];
+#pragma unroll
+			for(int u = 0; u < R; ++u){ a[u] = __builtin_nontemporal_load(p[u] + j*64); }
+#pragma unroll
+			for(int u = 0; u < R; ++u){ acc ^= a[u]; }
+		}
+	}
+	if((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u){ *sink = pad[0]; }
+}
+
+template <int R>
+int run_gather(const char *name, int wgs, int threads, size_t lds, const u32x4 *buf, uint64_t bytes, uint32_t *sink, double seconds)
+{
+	CK(hipFuncSetAttribute((const void*)gather<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	const uint32_t row_kib = 13;                       // C2: 12 500-byte rows, 12 544-byte stride
+	const uint64_t stride16 = 12544/16, nrows = bytes/12544;
+	const uint64_t total_rows = 970000;                 // one C2 step
+	const uint64_t waves = (uint64_t)wgs*(threads/64);
+	const uint64_t rpw = (total_rows + waves - 1)/waves/R*R + R;
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+	printf("%-44s", name);
+	const auto t0 = std::chrono::steady_clock::now();
+	double last_report = 0;
+	while(true){
+		CK(hipEventRecord(e0, 0));
+		for(int r = 0; r < 8; ++r){ hipLaunchKernelGGL(gather<R>, dim3(wgs), dim3(threads), lds, 0, buf, nrows, row_kib, stride16, rpw, sink); }
+		CK(hipEventRecord(e1, 0));
+		CK(hipEventSynchronize(e1));
+		float ms = 0;
+		CK(hipEventElapsedTime(&ms, e0, e1));
+		const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		if(el - last_report >= 1.0){ printf(" %5.0f", 8.0*waves*rpw*row_kib*1024/ms/1e6); fflush(stdout); last_report = el; }
+		if(el >= seconds){ break; }
+	}
+	printf("  GB/s per second (bytes touched, 13 KiB per row)\n");
+	return 0;
+}
+
 template <int U>
 int run(const char *name, int wgs, int threads, size_t lds, const u32x4 *buf, uint64_t n16, uint32_t *sink, double seconds)
 {
@@ -59,19 +117,31 @@ int run(const char *name, int wgs, int threads, size_t lds, const u32x4 *buf, ui
 int main(int argc, char **argv)
 {
 	const double seconds = argc > 1 ? atof(argv[1]) : 6.0;
-	const uint64_t bytes = 32ull << 30;
+	const uint64_t bytes = 96ull << 30;
 	u32x4 *buf; uint32_t *sink;
 	CK(hipMalloc(&buf, bytes)); CK(hipMalloc(&sink, 4));
 	CK(hipMemset(buf, 1, bytes));
-	const uint64_t n16 = bytes/16;
+	const uint64_t n16 = (32ull << 30)/16;
 	const size_t big = 100*1024;     // more than half a CU's LDS: one workgroup per CU
-	if(run<4>("2048 WGs x 256 thr, 4 KiB/wave (all CUs, 32 waves)", 2048, 256, 0, buf, n16, sink, seconds)) return 1;
-	if(run<4>("256 WGs x 1024 thr, 1/CU, 4 KiB/wave", 256, 1024, big, buf, n16, sink, seconds)) return 1;
-	if(run<8>("192 WGs x 1024 thr, 1/CU, 8 KiB/wave", 192, 1024, big, buf, n16, sink, seconds)) return 1;
-	if(run<8>("128 WGs x 1024 thr, 1/CU, 8 KiB/wave", 128, 1024, big, buf, n16, sink, seconds)) return 1;
-	if(run<16>("128 WGs x 1024 thr, 1/CU, 16 KiB/wave", 128, 1024, big, buf, n16, sink, seconds)) return 1;
-	if(run<16>("64 WGs x 1024 thr, 1/CU, 16 KiB/wave", 64, 1024, big, buf, n16, sink, seconds)) return 1;
-	if(run<8>("256 WGs x 512 thr, 1/CU, 8 KiB/wave (8 waves/CU)", 256, 512, big, buf, n16, sink, seconds)) return 1;
-	if(run<4>("2048 WGs x 256 thr again", 2048, 256, 0, buf, n16, sink, seconds)) return 1;
+	char name[128];
+	if(run<4>("stream: 2048 WGs x 256 thr, 4 KiB/wave", 2048, 256, 0, buf, n16, sink, seconds)) return 1;
+	for(int wpc : {8, 16}){
+		for(int cus : {160, 192, 208, 224, 240, 256}){
+			snprintf(name, sizeof(name), "stream: %d CUs x %d waves, 8 KiB/wave", cus, wpc);
+			if(run<8>(name, cus, wpc*64, big, buf, n16, sink, seconds)) return 1;
+		}
+	}
+	if(run_gather<4>("gather: 512 WGs x 256 thr (8 waves/CU), R=4", 512, 256, 0, buf, bytes, sink, seconds)) return 1;
+	for(int wpc : {8, 16}){
+		for(int cus : {160, 192, 224, 256}){
+			snprintf(name, sizeof(name), "gather: %d CUs x %d waves, R=4", cus, wpc);
+			if(run_gather<4>(name, cus, wpc*64, big, buf, bytes, sink, seconds)) return 1;
+		}
+	}
+	for(int cus : {192, 256}){
+		snprintf(name, sizeof(name), "gather: %d CUs x 8 waves, R=8", cus);
+		if(run_gather<8>(name, cus, 8*64, big, buf, bytes, sink, seconds)) return 1;
+	}
+	if(run<4>("stream: 2048 WGs x 256 thr again", 2048, 256, 0, buf, n16, sink, seconds)) return 1;
 	return 0;
 }

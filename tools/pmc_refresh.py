@@ -64,7 +64,9 @@ def main():
                 agg[row["Kernel_Name"]].append(float(row["Counter_Value"]))
         # calibration: stream_read_kernel reads min(matrix, 8 GiB) per dispatch (kwage_stream_read_gbps)
         cal = [v for k, vs in agg.items() if "stream_read_kernel" in k for v in vs]
-        known = min(int(line["config"]["db_bytes_per_gpu"]), 8 << 30) // 16 * 16
+        n16 = min(int(line["config"]["db_bytes_per_gpu"]), 8 << 30) // 16          # (kwage_stream_read_gbps: whole 8 KiB steps per wave)
+        nwaves = 4 * max(1, min(2048, n16 // 512 // 4))
+        known = nwaves * ((n16 // nwaves) // 512 * 512) * 16
         factor = (known / (sum(cal) / len(cal) * 1024.0)) if cal else 2.0
         gather = {k: vs for k, vs in agg.items() if any(("kwage::" + g + "<") in k for g in GATHER)}
         if not gather:
