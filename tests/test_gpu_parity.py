@@ -483,6 +483,10 @@ def test_cli_sharded_over_two_contexts(ka, oracle):
             three = subprocess.run(args, cwd=cdir, capture_output=True, env=dict(os.environ, KWAGE_DEVICES="0,0,0"))
             assert one.returncode == 0 and two.returncode == 0 and three.returncode == 0, two.stderr.decode()
             assert one.stdout == two.stdout == three.stdout      # deterministic, independent of the sharding
+            # "all": the devices are counted by a short-lived child process, so that the page-cache readers are still
+            # forked from a process in which HIP is not up (KWAGE_VERBOSE names the devices on stderr)
+            every = subprocess.run(args, cwd=cdir, capture_output=True, env=dict(os.environ, KWAGE_DEVICES="all", KWAGE_CACHE_READER="2"))
+            assert every.returncode == 0 and every.stdout == one.stdout, every.stderr.decode()
             # a database larger than HBM is searched in several passes over whole files: force one file per pass
             passes = subprocess.run(args, cwd=cdir, capture_output=True, env=dict(os.environ, KWAGE_MAX_GROUP_BYTES="1"))
             assert passes.returncode == 0 and passes.stdout == one.stdout

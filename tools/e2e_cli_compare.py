@@ -78,11 +78,11 @@ try:
                        env=dict(os.environ, KWAGE_VERBOSE="1", KWAGE_LOAD_DIRECT="1", KWAGE_LOAD_GANG="1"))
     print("with KWAGE_LOAD_DIRECT=1 KWAGE_LOAD_GANG=1 (copy kernel reading HSA-locked file windows, one file per launch):\n" + r.stderr.decode().strip())
     assert open(os.path.join(tmp, "o.csv")).read() == open(os.path.join(tmp, "o2.csv")).read()
-    for rep in range(2):
-        for extra in ({}, {"KWAGE_LOAD_SDMA": "0"}, {"KWAGE_LOAD_DIRECT": "1", "KWAGE_LOAD_GANG": "1"}, {"KWAGE_LOAD_MMAP": "0"}):
+    for rep in range(3):
+        for extra in ({}, {"KWAGE_LOAD_NUMA": "0"}, {"KWAGE_LOAD_SDMA": "0"}, {"KWAGE_LOAD_DIRECT": "1", "KWAGE_LOAD_GANG": "1"}, {"KWAGE_LOAD_MMAP": "0"}):
             r = subprocess.run([native.KWAGE_BIN, "-d", os.path.join(tmp, "db"), "-i", q, "--o.csv", "-o", os.path.join(tmp, "o3.csv")], capture_output=True,
                                env=dict(os.environ, KWAGE_VERBOSE="1", **extra))
-            print("%s: %s" % (extra or "default (copy-engine pipeline)", [l for l in r.stderr.decode().splitlines() if "loaded" in l and "GB/s" in l][0]))
+            print("%s: %s" % (extra or "default (copy-engine pipeline, loading thread on the GPU's NUMA node)", [l for l in r.stderr.decode().splitlines() if "loaded" in l and "GB/s" in l][0]))
     bit_tests = sum(len(oracle.unique_kmers(s, k)) for s in queries) * nh * ncol * n_files
     print("this repo's kwage (1 GPU): wall %.2f s  -> %.1f G bit-tests/s end to end (file read + H2D + search + report)" % (t_gpu, bit_tests / t_gpu / 1e9))
     if os.access(oracle.REF_KWAGE, os.X_OK):
