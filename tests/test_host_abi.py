@@ -146,9 +146,10 @@ def test_query_threshold(L, oracle):
 
 def test_sort_hits_orders_by_query_then_column(L):
     """kwage_sort_hits (host, no device): every size around the switch from std::sort to the radix sort, keys that
-    differ in one digit only, values at both ends of 32 bits; against numpy's lexsort, the payload carried along."""
+    differ in one digit only, values at both ends of 32 bits, and sizes on both sides of the switch to the multi-threaded
+    passes (2^20 records); against numpy's lexsort, the payload carried along."""
     rng = np.random.default_rng(12)
-    for n in (0, 1, 2, 255, 256, 257, 5000, 300_000):
+    for n in (0, 1, 2, 255, 256, 257, 5000, 300_000, (1 << 20) - 1, (1 << 20) + 12345):
         for spread in ("wide", "narrow", "extreme"):
             if spread == "wide":
                 q, c = rng.integers(0, 1 << 20, n), rng.integers(0, 1 << 17, n)
@@ -162,7 +163,10 @@ def test_sort_hits_orders_by_query_then_column(L):
             L.kwage_sort_hits(got.ctypes.data, n)
             assert np.array_equal(got[:, :2], want[:, :2]), (n, spread)
             # equal keys may come in any order: compare the payloads as multisets per key
-            assert sorted(map(tuple, got.tolist())) == sorted(map(tuple, want.tolist())), (n, spread)
+            if n <= 300_000:
+                assert sorted(map(tuple, got.tolist())) == sorted(map(tuple, want.tolist())), (n, spread)
+            else:         # (a million Python tuples are slow) the radix sort is stable: payloads keep their order within a key
+                assert np.array_equal(got, want), (n, spread)
     L.kwage_sort_hits(None, 0)
 
 
