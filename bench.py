@@ -304,8 +304,9 @@ def rank_main(args):
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    if not sharded:
+        for _ in range(args.warmup):
+            step()
     pipe = None
     pipeline_note = "on"
     kernel_ms = []
@@ -325,11 +326,16 @@ def rank_main(args):
         return buf, n
 
     if not sharded:
-        # untimed: let the second search slot allocate its scratch too (the timed loop uses both)
-        p1 = members[0].group.submit(s.batch, threshold, flags)
-        p2 = members[-1].group.submit(s.batch, threshold, flags)
-        p1.collect()
-        p2.collect()
+        # untimed: let the second search slot allocate its scratch too (the timed loop uses both).  Whole steps only
+        # (every group once per step), so that a profiler's per-kernel totals divide by the number of steps.
+        for m0 in range(0, n_groups, 2):
+            pair = [m.group.submit(s.batch, threshold, flags) for m in members[m0:m0 + 2]]
+            for p_ in pair:
+                p_.collect()
+        if n_groups == 1:
+            p1, p2 = s.group.submit(s.batch, threshold, flags), s.group.submit(s.batch, threshold, flags)
+            p1.collect()
+            p2.collect()
     else:
         # untimed warm-up of both buffers of the step pipeline.  Rank-LOCAL work first (submit + collect, may fail on
         # one rank only, e.g. out of memory), then every rank learns whether all succeeded, and only then the first
@@ -421,6 +427,13 @@ def rank_main(args):
                 kernel_ms.append(ms)
         return nhits
 
+    if sharded:
+        # warm-up through the code that is timed (the step pipeline + its exchange); the synchronous form only if that failed
+        if pipe is not None:
+            timed_steps(max(args.warmup, 1))
+        else:
+            for _ in range(args.warmup):
+                step()
     sync_all()
     t0 = time.perf_counter()
     kernel_ms.clear()

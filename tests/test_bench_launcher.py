@@ -127,7 +127,8 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     assert len(l5["aggregate"]["kernel_ms_per_rank"]) == 2 and all(x > 0 for x in l5["aggregate"]["kernel_ms_per_rank"])
     assert l5["roofline"]["kernel"].startswith("count_")
     assert l5["config"]["step_pipeline"] == "on" and l5["rccl"]["searches_per_step"] == 4
-    # one collective per step: 2 warm-up steps + 3 timed ones (small lists ride in the first collective whole)
-    assert l5["rccl"]["collectives"] == 5 and l5["rccl"]["p2p_batches"] == 0
+    # one collective per step: 2 steps that warm the pipeline's two buffers + 1 warm-up step + 3 timed ones (small lists
+    # ride in the first collective whole)
+    assert l5["rccl"]["collectives"] == 6 and l5["rccl"]["p2p_batches"] == 0
     e5 = l5["exchange_check"]
     assert e5["ok"] and e5["hits"] == sum(e5["hits_per_rank"]) == l5["config"]["hits_per_step"] and e5["hits"] > 0
