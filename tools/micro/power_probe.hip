@@ -34,8 +34,11 @@ __global__ __launch_bounds__(1024) void walk(const u32x4 *src, uint64_t n16, uin
 
 // and_walk_kernel's access pattern: a wave takes R random rows of `row_kib` KiB at a time and walks them KiB-step after
 // KiB-step (R loads of 1 KiB in flight per wave)
+// (gap != 0: instead of uniformly random rows, every wave takes ASCENDING rows of a region of its own, one row in `gap`
+// with a jitter -- what a batch's row list sorted by address would look like: same bytes, translations and DRAM pages
+// visited in order)
 template <int R>
-__global__ __launch_bounds__(1024) void gather(const u32x4 *src, uint64_t nrows, uint32_t row_kib, uint64_t stride16, uint64_t rows_per_wave, uint32_t *sink)
+__global__ __launch_bounds__(1024) void gather(const u32x4 *src, uint64_t nrows, uint32_t row_kib, uint64_t stride16, uint64_t rows_per_wave, uint32_t *sink, uint32_t gap = 0)
 {
 	extern __shared__ uint32_t pad[];
 	u32x4 acc = (u32x4)(0u);
@@ -47,7 +50,8 @@ __global__ __launch_bounds__(1024) void gather(const u32x4 *src, uint64_t nrows,
 #pragma unroll
 		for(int u = 0; u < R; ++u){
 			x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
-			const uint64_t row = __builtin_amdgcn_readfirstlane((uint32_t)((x*0x2545F4914F6CDD1Dull) >> 33)) % nrows;
+			uint64_t row = __builtin_amdgcn_readfirstlane((uint32_t)((x*0x2545F4914F6CDD1Dull) >> 33));
+			row = gap ? ((wave*rows_per_wave + r + u)*gap + row % gap) % nrows : row % nrows;
 			p[u] = src + row*stride16 + lane;
 		}
 		for(uint32_t j = 0; j < row_kib; ++j){
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(1024) void gather(const u32x4 *src, uint64_t nrows,
 }
 
 template <int R>
-int run_gather(const char *name, int wgs, int threads, size_t lds, const u32x4 *buf, uint64_t bytes, uint32_t *sink, double seconds)
+int run_gather(const char *name, int wgs, int threads, size_t lds, const u32x4 *buf, uint64_t bytes, uint32_t *sink, double seconds, uint32_t gap = 0)
 {
 	CK(hipFuncSetAttribute((const void*)gather<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	const uint32_t row_kib = 13;                       // C2: 12 500-byte rows, 12 544-byte stride
@@ -77,7 +81,7 @@ int run_gather(const char *name, int wgs, int threads, size_t lds, const u32x4 *
 	double last_report = 0;
 	while(true){
 		CK(hipEventRecord(e0, 0));
-		for(int r = 0; r < 8; ++r){ hipLaunchKernelGGL(gather<R>, dim3(wgs), dim3(threads), lds, 0, buf, nrows, row_kib, stride16, rpw, sink); }
+		for(int r = 0; r < 8; ++r){ hipLaunchKernelGGL(gather<R>, dim3(wgs), dim3(threads), lds, 0, buf, nrows, row_kib, stride16, rpw, sink, gap); }
 		CK(hipEventRecord(e1, 0));
 		CK(hipEventSynchronize(e1));
 		float ms = 0;
@@ -117,6 +121,7 @@ int run(const char *name, int wgs, int threads, size_t lds, const u32x4 *buf, ui
 int main(int argc, char **argv)
 {
 	const double seconds = argc > 1 ? atof(argv[1]) : 6.0;
+	const bool full = argc > 2;
 	const uint64_t bytes = 96ull << 30;
 	u32x4 *buf; uint32_t *sink;
 	CK(hipMalloc(&buf, bytes)); CK(hipMalloc(&sink, 4));
@@ -125,23 +130,25 @@ int main(int argc, char **argv)
 	const size_t big = 100*1024;     // more than half a CU's LDS: one workgroup per CU
 	char name[128];
 	if(run<4>("stream: 2048 WGs x 256 thr, 4 KiB/wave", 2048, 256, 0, buf, n16, sink, seconds)) return 1;
-	for(int wpc : {8, 16}){
-		for(int cus : {160, 192, 208, 224, 240, 256}){
-			snprintf(name, sizeof(name), "stream: %d CUs x %d waves, 8 KiB/wave", cus, wpc);
-			if(run<8>(name, cus, wpc*64, big, buf, n16, sink, seconds)) return 1;
+	if(full){
+		for(int wpc : {8, 16}){
+			for(int cus : {160, 192, 208, 224, 240, 256}){
+				snprintf(name, sizeof(name), "stream: %d CUs x %d waves, 8 KiB/wave", cus, wpc);
+				if(run<8>(name, cus, wpc*64, big, buf, n16, sink, seconds)) return 1;
+			}
+		}
+		for(int wpc : {8, 16}){
+			for(int cus : {160, 192, 224, 256}){
+				snprintf(name, sizeof(name), "gather: %d CUs x %d waves, R=4", cus, wpc);
+				if(run_gather<4>(name, cus, wpc*64, big, buf, bytes, sink, seconds)) return 1;
+			}
 		}
 	}
-	if(run_gather<4>("gather: 512 WGs x 256 thr (8 waves/CU), R=4", 512, 256, 0, buf, bytes, sink, seconds)) return 1;
-	for(int wpc : {8, 16}){
-		for(int cus : {160, 192, 224, 256}){
-			snprintf(name, sizeof(name), "gather: %d CUs x %d waves, R=4", cus, wpc);
-			if(run_gather<4>(name, cus, wpc*64, big, buf, bytes, sink, seconds)) return 1;
-		}
-	}
-	for(int cus : {192, 256}){
-		snprintf(name, sizeof(name), "gather: %d CUs x 8 waves, R=8", cus);
-		if(run_gather<8>(name, cus, 8*64, big, buf, bytes, sink, seconds)) return 1;
-	}
-	if(run<4>("stream: 2048 WGs x 256 thr again", 2048, 256, 0, buf, n16, sink, seconds)) return 1;
+	if(run_gather<4>("gather: 256 CUs x 8 waves, R=4, random rows", 256, 512, big, buf, bytes, sink, seconds)) return 1;
+	// the same bytes with the rows in address order per wave (one row in 9 touched, as for one C2 batch over 2^23 rows)
+	if(run_gather<4>("gather: 256 CUs x 8 waves, R=4, ASCENDING rows (1 in 9)", 256, 512, big, buf, bytes, sink, seconds, 9)) return 1;
+	if(run_gather<4>("gather: 256 CUs x 8 waves, R=4, ascending, every row", 256, 512, big, buf, bytes, sink, seconds, 1)) return 1;
+	if(run_gather<8>("gather: 256 CUs x 8 waves, R=8, ASCENDING rows (1 in 9)", 256, 512, big, buf, bytes, sink, seconds, 9)) return 1;
+	if(run_gather<4>("gather: 256 CUs x 8 waves, R=4, random rows again", 256, 512, big, buf, bytes, sink, seconds)) return 1;
 	return 0;
 }
