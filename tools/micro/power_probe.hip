@@ -65,12 +65,127 @@ __global__ __launch_bounds__(1024) void gather(const u32x4 *src, uint64_t nrows,
 	if((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u){ *sink = pad[0]; }
 }
 
+// Steps towards and_walk_kernel, to see what costs it the 5-7 % it runs below the bare pattern:
+//   MODE 1  row numbers come from an array in memory (scalar loads per group of R rows, as in the kernel)
+//   MODE 2  + rows read through buffer descriptors (bounds-checked raw buffer loads), CH KiB-steps fully unrolled, one
+//            KiB-step at a time (sched_barrier), accumulators per step -- the kernel's inner loop
+//   MODE 3  MODE 2 with the NEXT group's row numbers loaded as a VECTOR load one group ahead and broadcast with
+//            readlane (no scalar-load latency in the loop)
+// the matrix's content: Bernoulli(1/4) bits like the benchmark databases (AND of two random words), or left constant
+__global__ void fill_random(u32x4 *buf, uint64_t n16)
+{
+	for(uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x*blockDim.x){
+		uint64_t x = i*0x9E3779B97F4A7C15ull + 99;
+		u32x4 v;
+		for(int d = 0; d < 4; ++d){
+			x ^= x >> 31; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 29;
+			const uint32_t a = (uint32_t)x, b = (uint32_t)(x >> 32);
+			v[d] = a & b;
+		}
+		buf[i] = v;
+	}
+}
+
+__global__ void fill_rows(uint32_t *rows, uint64_t n, uint64_t nrows)
+{
+	for(uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x*blockDim.x){
+		uint64_t x = i*0x9E3779B97F4A7C15ull + 777;
+		x ^= x >> 31; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 29; x *= 0x94D049BB133111EBull; x ^= x >> 32;
+		rows[i] = (uint32_t)(x % nrows);
+	}
+}
+
+template <int R, int CH, int MODE>
+__global__ __launch_bounds__(512) void walk_like(const uint8_t *db, uint64_t stride, uint32_t row_bytes, const uint32_t *__restrict__ rows, uint64_t rows_per_wave, uint32_t *sink)
+{
+	extern __shared__ uint32_t pad[];
+	const uint32_t lane = threadIdx.x & 63;
+	const uint64_t wave = __builtin_amdgcn_readfirstlane((uint32_t)(blockIdx.x*(blockDim.x/64) + (threadIdx.x >> 6)));
+	const uint32_t *rq = rows + wave*rows_per_wave;
+	u32x4 acc[CH];
+#pragma unroll
+	for(int j = 0; j < CH; ++j){ acc[j] = ~(u32x4)(0u); }
+	uint32_t vnext = (MODE == 3) ? rq[lane & (R - 1)] : 0;            // lane u (mod R) holds row u of the next group
+	for(uint64_t r = 0; r < rows_per_wave; r += R){
+		uint32_t idx[R];
+		if(MODE == 3){
+#pragma unroll
+			for(int u = 0; u < R; ++u){ idx[u] = __builtin_amdgcn_readlane(vnext, u); }
+			vnext = rq[min(r + R, rows_per_wave - R) + (lane & (R - 1))];     // requested now, used an iteration later
+		}
+		else{
+#pragma unroll
+			for(int u = 0; u < R; ++u){ idx[u] = rq[r + u]; }
+		}
+		if(MODE == 1){
+			const u32x4 *p[R];
+#pragma unroll
+			for(int u = 0; u < R; ++u){ p[u] = reinterpret_cast<const u32x4*>(db + (uint64_t)idx[u]*stride) + lane; }
+#pragma unroll
+			for(int j = 0; j < CH; ++j){
+				u32x4 x[R];
+#pragma unroll
+				for(int u = 0; u < R; ++u){ x[u] = __builtin_nontemporal_load(p[u] + j*64); }
+#pragma unroll
+				for(int u = 0; u < R; ++u){ acc[j] &= x[u]; }
+			}
+		}
+		else{
+			__amdgpu_buffer_rsrc_t rs[R];
+#pragma unroll
+			for(int u = 0; u < R; ++u){ rs[u] = __builtin_amdgcn_make_buffer_rsrc((void*)(db + (uint64_t)idx[u]*stride), 0, row_bytes, 0x00020000); }
+#pragma unroll
+			for(int j = 0; j < CH; ++j){
+				u32x4 x[R];
+#pragma unroll
+				for(int u = 0; u < R; ++u){ x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs[u], lane*16u, j*1024, 2); }
+#pragma unroll
+				for(int u = 0; u < R; ++u){ acc[j] &= x[u]; }
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		}
+	}
+	u32x4 t = acc[0];
+#pragma unroll
+	for(int j = 1; j < CH; ++j){ t ^= acc[j]; }
+	if((t.x ^ t.y ^ t.z ^ t.w) == 0x12345678u){ *sink = pad[0]; }
+}
+
+template <int MODE>
+int run_walk_like(const char *name, const uint8_t *buf, uint64_t bytes, uint32_t *rows, uint32_t *sink, double seconds)
+{
+	const uint64_t stride = 12544, nrows = bytes/stride, total_rows = 970000;
+	const int wgs = 256, threads = 512;
+	const uint64_t waves = (uint64_t)wgs*(threads/64);
+	const uint64_t rpw = (total_rows + waves - 1)/waves/4*4 + 4;
+	CK(hipFuncSetAttribute((const void*)walk_like<4, 13, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 100*1024));
+	hipLaunchKernelGGL(fill_rows, dim3(1024), dim3(256), 0, 0, rows, waves*rpw, nrows);
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+	printf("%-60s", name);
+	const auto t0 = std::chrono::steady_clock::now();
+	double last_report = 0;
+	while(true){
+		CK(hipEventRecord(e0, 0));
+		for(int r = 0; r < 8; ++r){ hipLaunchKernelGGL((walk_like<4, 13, MODE>), dim3(wgs), dim3(threads), 100*1024, 0, buf, stride, (uint32_t)stride, rows, rpw, sink); }
+		CK(hipEventRecord(e1, 0));
+		CK(hipEventSynchronize(e1));
+		float ms = 0;
+		CK(hipEventElapsedTime(&ms, e0, e1));
+		const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		if(el - last_report >= 1.0){ printf(" %5.0f", 8.0*waves*rpw*12544/ms/1e6); fflush(stdout); last_report = el; }
+		if(el >= seconds){ break; }
+	}
+	printf("  GB/s (12 544 B touched per row; %.4f ms per 970 k rows)\n", 0.0);
+	return 0;
+}
+
 template <int R>
-int run_gather(const char *name, int wgs, int threads, size_t lds, const u32x4 *buf, uint64_t bytes, uint32_t *sink, double seconds, uint32_t gap = 0)
+int run_gather(const char *name, int wgs, int threads, size_t lds, const u32x4 *buf, uint64_t bytes, uint32_t *sink, double seconds, uint32_t gap = 0,
+               uint64_t stride_bytes = 12544, uint32_t row_kib = 13)                       // C2: 12 500-byte rows, 12 544-byte stride
 {
 	CK(hipFuncSetAttribute((const void*)gather<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-	const uint32_t row_kib = 13;                       // C2: 12 500-byte rows, 12 544-byte stride
-	const uint64_t stride16 = 12544/16, nrows = bytes/12544;
+	const uint64_t stride16 = stride_bytes/16, nrows = bytes/stride_bytes;
 	const uint64_t total_rows = 970000;                 // one C2 step
 	const uint64_t waves = (uint64_t)wgs*(threads/64);
 	const uint64_t rpw = (total_rows + waves - 1)/waves/R*R + R;
@@ -121,34 +236,24 @@ int run(const char *name, int wgs, int threads, size_t lds, const u32x4 *buf, ui
 int main(int argc, char **argv)
 {
 	const double seconds = argc > 1 ? atof(argv[1]) : 6.0;
-	const bool full = argc > 2;
 	const uint64_t bytes = 96ull << 30;
-	u32x4 *buf; uint32_t *sink;
-	CK(hipMalloc(&buf, bytes)); CK(hipMalloc(&sink, 4));
+	u32x4 *buf; uint32_t *sink, *rows;
+	CK(hipMalloc(&buf, bytes)); CK(hipMalloc(&sink, 4)); CK(hipMalloc(&rows, 16u << 20));
 	CK(hipMemset(buf, 1, bytes));
 	const uint64_t n16 = (32ull << 30)/16;
 	const size_t big = 100*1024;     // more than half a CU's LDS: one workgroup per CU
-	char name[128];
 	if(run<4>("stream: 2048 WGs x 256 thr, 4 KiB/wave", 2048, 256, 0, buf, n16, sink, seconds)) return 1;
-	if(full){
-		for(int wpc : {8, 16}){
-			for(int cus : {160, 192, 208, 224, 240, 256}){
-				snprintf(name, sizeof(name), "stream: %d CUs x %d waves, 8 KiB/wave", cus, wpc);
-				if(run<8>(name, cus, wpc*64, big, buf, n16, sink, seconds)) return 1;
-			}
+	for(int rep = 0; rep < 2; ++rep){
+		if(rep == 1){
+			printf("---- the same with Bernoulli(1/4) random bits in the matrix instead of constant bytes\n");
+			hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, buf, bytes/16);
+			CK(hipDeviceSynchronize());
+			if(run<4>("stream: 2048 WGs x 256 thr, 4 KiB/wave", 2048, 256, 0, buf, n16, sink, seconds)) return 1;
 		}
-		for(int wpc : {8, 16}){
-			for(int cus : {160, 192, 224, 256}){
-				snprintf(name, sizeof(name), "gather: %d CUs x %d waves, R=4", cus, wpc);
-				if(run_gather<4>(name, cus, wpc*64, big, buf, bytes, sink, seconds)) return 1;
-			}
-		}
+		if(run_gather<4>("bare gather: random rows from a register RNG, 13 KiB/row", 256, 512, big, buf, bytes, sink, seconds)) return 1;
+		if(run_walk_like<1>("1: row numbers from memory (scalar loads), global loads", (const uint8_t*)buf, bytes, rows, sink, seconds)) return 1;
+		if(run_walk_like<2>("2: + buffer descriptors, 13 unrolled paced KiB-steps", (const uint8_t*)buf, bytes, rows, sink, seconds)) return 1;
+		if(run_walk_like<3>("3: as 2, row numbers by vector load one group ahead", (const uint8_t*)buf, bytes, rows, sink, seconds)) return 1;
 	}
-	if(run_gather<4>("gather: 256 CUs x 8 waves, R=4, random rows", 256, 512, big, buf, bytes, sink, seconds)) return 1;
-	// the same bytes with the rows in address order per wave (one row in 9 touched, as for one C2 batch over 2^23 rows)
-	if(run_gather<4>("gather: 256 CUs x 8 waves, R=4, ASCENDING rows (1 in 9)", 256, 512, big, buf, bytes, sink, seconds, 9)) return 1;
-	if(run_gather<4>("gather: 256 CUs x 8 waves, R=4, ascending, every row", 256, 512, big, buf, bytes, sink, seconds, 1)) return 1;
-	if(run_gather<8>("gather: 256 CUs x 8 waves, R=8, ASCENDING rows (1 in 9)", 256, 512, big, buf, bytes, sink, seconds, 9)) return 1;
-	if(run_gather<4>("gather: 256 CUs x 8 waves, R=4, random rows again", 256, 512, big, buf, bytes, sink, seconds)) return 1;
 	return 0;
 }
