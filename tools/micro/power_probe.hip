@@ -151,6 +151,72 @@ __global__ __launch_bounds__(512) void walk_like(const uint8_t *db, uint64_t str
 	if((t.x ^ t.y ^ t.z ^ t.w) == 0x12345678u){ *sink = pad[0]; }
 }
 
+// Wide rows (C3: 125 000-byte rows).  PIECES: every wave reads random 8 KiB pieces (row, piece) on its own, R in flight --
+// what the tiled kernel and the column-tiled walk do to the memory: a row's pieces are fetched by different waves at
+// different times.  COOP: the 16 waves of a workgroup take the SAME row at the same time, wave w its w-th 8 KiB -- the row
+// arrives as one 122 KiB burst.
+template <int R, bool COOP>
+__global__ __launch_bounds__(1024) void wide_rows(const u32x4 *src, uint64_t nrows, uint64_t stride16, uint32_t row_units, uint64_t iters, uint32_t *sink)
+{
+	extern __shared__ uint32_t pad[];
+	u32x4 acc = (u32x4)(0u);
+	const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const uint64_t wave = (uint64_t)blockIdx.x*(blockDim.x/64) + w;
+	uint64_t x = (COOP ? (uint64_t)blockIdx.x : wave)*0x9E3779B97F4A7C15ull + 4242;
+	for(uint64_t it = 0; it < iters; it += R){
+		const u32x4 *p[R];
+		uint32_t units[R];
+#pragma unroll
+		for(int u = 0; u < R; ++u){
+			x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+			const uint64_t h = x*0x2545F4914F6CDD1Dull;
+			const uint64_t row = __builtin_amdgcn_readfirstlane((uint32_t)(h >> 33)) % nrows;
+			const uint32_t piece = COOP ? w : __builtin_amdgcn_readfirstlane((uint32_t)(h & 0xFFFF)) % 16u;
+			p[u] = src + row*stride16 + (uint64_t)piece*512 + lane;
+			units[u] = (piece*512 < row_units) ? min(512u, row_units - piece*512) : 0u;      // 16-byte units of this piece inside the row
+		}
+#pragma unroll
+		for(int j = 0; j < 8; ++j){
+			u32x4 a[R];
+#pragma unroll
+			for(int u = 0; u < R; ++u){ a[u] = __builtin_nontemporal_load(p[u] + min(j*64u, units[u] - 1u - min(lane, units[u] - 1u))); }      // past the row end: clamped onto its last units (as the tiled kernel does)
+#pragma unroll
+			for(int u = 0; u < R; ++u){ acc ^= a[u]; }
+		}
+	}
+	if((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u){ *sink = pad[0]; }
+}
+
+template <int R, bool COOP>
+int run_wide(const char *name, int wgs, int threads, size_t lds, const u32x4 *buf, uint64_t bytes, uint32_t *sink, double seconds)
+{
+	CK(hipFuncSetAttribute((const void*)wide_rows<R, COOP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	const uint64_t stride = 125056, nrows = bytes/stride;
+	const uint32_t row_units = 125000/16 + 1;
+	const uint64_t waves = (uint64_t)wgs*(threads/64);
+	const uint64_t iters = (1500000ull*16/waves)/R*R + R;             // ~1.5 M rows x 16 pieces per launch
+	// bytes touched per launch: every (row, piece) reads the part of its 8 KiB inside the row; on average a row's 16 pieces hold 125 008 bytes
+	const double bytes_per_launch = (double)waves*iters*(125008.0/16);
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+	printf("%-60s", name);
+	const auto t0 = std::chrono::steady_clock::now();
+	double last_report = 0;
+	while(true){
+		CK(hipEventRecord(e0, 0));
+		for(int r = 0; r < 2; ++r){ hipLaunchKernelGGL((wide_rows<R, COOP>), dim3(wgs), dim3(threads), lds, 0, buf, nrows, stride/16, row_units, iters, sink); }
+		CK(hipEventRecord(e1, 0));
+		CK(hipEventSynchronize(e1));
+		float ms = 0;
+		CK(hipEventElapsedTime(&ms, e0, e1));
+		const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		if(el - last_report >= 1.0){ printf(" %5.0f", 2.0*bytes_per_launch/ms/1e6); fflush(stdout); last_report = el; }
+		if(el >= seconds){ break; }
+	}
+	printf("  GB/s touched\n");
+	return 0;
+}
+
 template <int MODE>
 int run_walk_like(const char *name, const uint8_t *buf, uint64_t bytes, uint32_t *rows, uint32_t *sink, double seconds)
 {
@@ -243,6 +309,17 @@ int main(int argc, char **argv)
 	const uint64_t n16 = (32ull << 30)/16;
 	const size_t big = 100*1024;     // more than half a CU's LDS: one workgroup per CU
 	if(run<4>("stream: 2048 WGs x 256 thr, 4 KiB/wave", 2048, 256, 0, buf, n16, sink, seconds)) return 1;
+	if(argc > 2 && argv[2][0] == 'w'){
+		for(int rep = 0; rep < 2; ++rep){
+			if(run_wide<4, false>("wide rows: independent waves, random 8 KiB pieces, 4 in flight (8/CU)", 256, 512, big, buf, bytes, sink, seconds)) return 1;
+			if(run_wide<4, false>("wide rows: independent waves, 16 waves/CU", 256, 1024, big, buf, bytes, sink, seconds)) return 1;
+			if(run_wide<2, true>("wide rows: 16 waves of a WG share the row, 2 rows in flight", 256, 1024, big, buf, bytes, sink, seconds)) return 1;
+			if(run_wide<4, true>("wide rows: 16 waves of a WG share the row, 4 rows in flight", 256, 1024, big, buf, bytes, sink, seconds)) return 1;
+			if(run_wide<1, true>("wide rows: 16 waves of a WG share the row, 1 row in flight", 256, 1024, big, buf, bytes, sink, seconds)) return 1;
+			if(run_wide<2, true>("wide rows: shared row, 2 in flight, 192 CUs", 192, 1024, big, buf, bytes, sink, seconds)) return 1;
+		}
+		return 0;
+	}
 	for(int rep = 0; rep < 2; ++rep){
 		if(rep == 1){
 			printf("---- the same with Bernoulli(1/4) random bits in the matrix instead of constant bytes\n");
