@@ -1144,7 +1144,8 @@ void find_numa_cpus(int device, int *node, std::vector<int> *cpus)
 	cpu_set_t allowed;
 	CPU_ZERO(&allowed);
 	if(sched_getaffinity(0, sizeof(allowed), &allowed) != 0){ return; }
-	for(char *tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")){      // "0-47,96-143"
+	char *save = nullptr;                 // (strtok_r: contexts are created from several threads at once in the CLI's node mode)
+	for(char *tok = strtok_r(list, ",\n", &save); tok; tok = strtok_r(nullptr, ",\n", &save)){      // "0-47,96-143"
 		int lo = 0, hi = 0;
 		const int k = sscanf(tok, "%d-%d", &lo, &hi);
 		if(k == 1){ hi = lo; }

@@ -349,11 +349,16 @@ def test_sparse_group_gives_the_same_hits(ka, ctx, oracle, tmp_path):
     sp = ka.Group.sparse(ctx, k, nh, L, full_cols, need)
     assert sp.add_db_files(files) == firsts_full and sp.device_bytes < full.device_bytes
     sp.finalize()
-    for thr in (1.0, 0.8, 0.3):
-        for flags in (0, ka.SEARCH_EARLY_EXIT):
-            a, c = full.search(b, thr, flags), sp.search(b, thr, flags)
-            assert np.array_equal(a.hits, c.hits) and np.array_equal(a.num_query_kmer, c.num_query_kmer), (thr, flags)
-            assert len(a.hits) > 0
+    kernels = set()
+    for knobs in ({}, dict(walk_min_rows=1, count_walk_min_rows=1, walk_waves=23, count_walk_waves=23)):      # tiled kernels; the persistent ones on translated row lists
+        with ctx.tuning(**knobs):
+            for thr in (1.0, 0.8, 0.3):
+                for flags in (0, ka.SEARCH_EARLY_EXIT):
+                    a, c = full.search(b, thr, flags), sp.search(b, thr, flags)
+                    assert np.array_equal(a.hits, c.hits) and np.array_equal(a.num_query_kmer, c.num_query_kmer), (thr, flags, knobs)
+                    assert len(a.hits) > 0 and a.search_kernel == c.search_kernel
+                    kernels.add(c.search_kernel.split("<")[0])
+    assert {"and_kernel", "and_walk_kernel", "count_kernel", "count_walk_kernel"} <= kernels, kernels
     other = ka.Batch(ctx, [rand_seq(rng, 400)])
     with pytest.raises(ka.KwageError) as ei:
         sp.search(other, 1.0)
