@@ -22,7 +22,8 @@ def pytest_sessionstart(session):
     if not (os.path.exists(os.path.join(ROOT, "kwage_amd", "lib", "libkwage_amd.so"))
             and os.path.exists(os.path.join(ROOT, "kwage_amd", "bin", "kwage"))
             and os.path.exists(os.path.join(ROOT, "kwage_amd", "bin", "kwage_dbtool"))
-            and os.path.exists(os.path.join(ROOT, "kwage_amd", "bin", "sharded_search_rccl"))):
+            and os.path.exists(os.path.join(ROOT, "kwage_amd", "bin", "sharded_search_rccl"))
+            and os.path.exists(os.path.join(ROOT, "kwage_amd", "bin", "kwage_node"))):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "kwage_amd", "csrc"), "-j4", "all"], stdout=subprocess.DEVNULL)
     if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle_kwage.so")):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], stdout=subprocess.DEVNULL)

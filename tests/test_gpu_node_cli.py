@@ -1,0 +1,110 @@
+"""`kwage_node`: the kwage command line as one process per GPU, the per-GPU hit lists gathered on rank 0 over RCCL
+(kwage_amd/csrc/kwage_node.cpp).  It shares kwage's option parser, query readers and report writers (it includes
+kwage_main.cpp), so with any number of ranks its report must be kwage's, byte for byte -- and through kwage the
+reference's.  A one-GPU box can run ONE rank over RCCL (two ranks on one device are refused): that rank goes through the
+whole exchange (communicator, count all-gather, grouped send / recv with nothing to receive, merge, mapping of global
+columns back to files) on every golden case and on hostile option lines.  Several ranks are rehearsed with
+KWAGE_NODE_REHEARSE=1: all ranks on device 0, the records through a shared host segment where RCCL would carry them --
+the file sharding, the global column numbers, the gather order and the mapping back to (file, column) are the same code."""
+import json
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+KWAGE = os.path.join(ROOT, "kwage_amd", "bin", "kwage")
+NODE = os.path.join(ROOT, "kwage_amd", "bin", "kwage_node")
+
+
+def _env(**extra):
+    env = dict(os.environ, KWAGE_NODE_RANKS="1")
+    env.update(extra)
+    env.pop("NCCL_DEBUG", None)          # (RCCL's version banner would land on stderr -- never on stdout: NCCL_DEBUG_FILE -- and differ from kwage's)
+    return env
+
+
+def _cases():
+    return json.load(open(os.path.join(GOLDEN, "manifest.json")))["cases"]
+
+
+def _args(case):
+    args = []
+    for d in case["db"]:
+        args += ["-d", d]
+    for q in case["queries"]:
+        args += ["-i", q]
+    return args + ["-t", case["threshold"], "--o." + case["format"]] + case["cmdline"]
+
+
+def test_node_cli_option_handling_is_kwages_without_a_gpu():
+    """Everything that ends a run before the search happens in the parent process, which never touches a device."""
+    cdir = os.path.join(GOLDEN, "basic")
+    for argv in ([], ["-h"], ["-?"], ["-d", "db", "-t", "7", "ACGT"], ["-d", "no_such_dir", "ACGT"], ["-d", "db"], ["-d", "db", "-i", "reads.txt"],
+                 ["--o.cs", "-d", "db", "-t", "0", "ACGT"]):
+        a = subprocess.run([KWAGE] + argv, cwd=cdir, capture_output=True, timeout=60)
+        b = subprocess.run([NODE] + argv, cwd=cdir, capture_output=True, timeout=60, env=_env())
+        assert (b.returncode, b.stdout, b.stderr) == (a.returncode, a.stdout, a.stderr), argv
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: "%s-%s" % (c["name"], c["expected"]))
+def test_node_cli_report_is_kwages(case):
+    cdir = os.path.join(GOLDEN, case["name"])
+    one = subprocess.run([KWAGE] + _args(case), cwd=cdir, capture_output=True, timeout=300)
+    node = subprocess.run([NODE] + _args(case), cwd=cdir, capture_output=True, timeout=300, env=_env())
+    assert one.returncode == 0 and node.returncode == 0, (one.stderr.decode(), node.stderr.decode())
+    assert node.stdout == one.stdout
+    secs = lambda b: re.sub(rb"in \d+ sec", b"in N sec", b)
+    assert secs(node.stderr) == secs(one.stderr)
+    if len(case["db"]) == 1 and case["name"] != "multi":
+        assert node.stdout == open(os.path.join(cdir, case["expected"]), "rb").read()       # the reference's own bytes
+
+
+@pytest.mark.gpu
+def test_node_cli_streams_batches_and_writes_files(tmp_path):
+    """Small query batches (several exchanges per run), early exit off (the persistent kernels), -o."""
+    cdir = os.path.join(GOLDEN, "multi")
+    args = ["-d", "dbs", "-i", "reads.fastq", "-i", "contigs.fa.gz", "-t", "0.7", "--o.json", "TTACAGCCGATGTTAGCGCGCGCTGGAATTACAAAGCTCACTGCCAAGTTAAACCATGGGGCGCGGGTAT"]
+    want = subprocess.run([KWAGE] + args, cwd=cdir, capture_output=True, timeout=300)
+    assert want.returncode == 0
+    # with NCCL_DEBUG=VERSION the banner goes to stderr, the report stays clean
+    r = subprocess.run([NODE] + args, cwd=cdir, capture_output=True, timeout=300, env=dict(os.environ, KWAGE_NODE_RANKS="1", NCCL_DEBUG="VERSION"))
+    assert r.returncode == 0 and r.stdout == want.stdout
+    for env in ({"KWAGE_BATCH_BASES": "300"}, {"KWAGE_EARLY_EXIT": "0", "KWAGE_COUNT_WALK_MIN_ROWS": "1", "KWAGE_NARROW": "0"}):
+        out = tmp_path / "node.json"
+        r = subprocess.run([NODE] + args + ["-o", str(out)], cwd=cdir, capture_output=True, timeout=300, env=_env(**env))
+        assert r.returncode == 0 and r.stdout == b"", r.stderr.decode()
+        assert out.read_bytes() == want.stdout, env
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 3, 5])
+def test_node_cli_several_ranks_rehearsed(ranks, tmp_path):
+    """multi/ has files of two k-mer lengths and several filter sizes: with 2, 3 and 5 ranks the groups split unevenly
+    and some ranks own no file of a group (5 ranks: some own none at all)."""
+    for name, args in (("multi", ["-d", "dbs", "-i", "reads.fastq", "-i", "contigs.fa.gz", "-t", "0.7", "--o.json", "TTACAGCCGATGTTAGCGCGCGCTGGAATTACAAAGCTCACTGCCAAGTTAAACCATGGGGCGCGGGTAT"]),
+                       ("multi", ["-d", "dbs", "-i", "reads.fastq", "-t", "1", "--o.csv"])):
+        cdir = os.path.join(GOLDEN, name)
+        want = subprocess.run([KWAGE] + args, cwd=cdir, capture_output=True, timeout=300)
+        assert want.returncode == 0 and want.stdout
+        for env in ({}, {"KWAGE_BATCH_BASES": "300", "KWAGE_EARLY_EXIT": "0"}):
+            r = subprocess.run([NODE] + args, cwd=cdir, capture_output=True, timeout=300,
+                               env=_env(KWAGE_NODE_RANKS=str(ranks), KWAGE_NODE_REHEARSE="1", **env))
+            assert r.returncode == 0, r.stderr.decode()
+            assert r.stdout == want.stdout, (ranks, args, env)
+
+
+@pytest.mark.gpu
+def test_node_cli_a_failing_rank_ends_the_run(tmp_path):
+    """A rank that cannot continue (here: a rehearsal segment too small for the hit list) must not leave the others waiting."""
+    cdir = os.path.join(GOLDEN, "multi")
+    r = subprocess.run([NODE, "-d", "dbs", "-i", "reads.fastq", "-t", "0.5", "--o.csv"], cwd=cdir, capture_output=True, timeout=120,
+                       env=_env(KWAGE_NODE_RANKS="2", KWAGE_NODE_REHEARSE="1", KWAGE_NODE_REHEARSE_RECORDS="1"))
+    assert r.returncode != 0 and b"rehearsal segment is too small" in r.stderr
+    # rank 0 alone fails (it opens the output file); rank 1 is already on its way into the exchange
+    r = subprocess.run([NODE, "-d", "dbs", "-i", "reads.fastq", "-t", "0.5", "--o.csv", "-o", "/no_such_dir/out.csv"], cwd=cdir, capture_output=True,
+                       timeout=120, env=_env(KWAGE_NODE_RANKS="2", KWAGE_NODE_REHEARSE="1"))
+    assert r.returncode != 0 and b"Unable to open" in r.stderr
