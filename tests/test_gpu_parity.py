@@ -776,7 +776,7 @@ def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, request):
     b = ka.Batch(ctx, seqs)
     exp = [oracle.search_image(image, image.shape[1], k, nh, L, n_cols, oracle.unique_kmers(s, k), 1.0)[0] for s in seqs]
     first = None
-    for waves in (0, 5, 3001, 16384):
+    for waves in ((0, 5, 3001, 16384) if n_cols < 100000 or n_cols == 131073 else (0, 3001)):       # (wide matrices return millions of records per search)
         ctx.set_tuning("walk_waves", waves)
         for flags, ee in ((0, 0), (ka.SEARCH_EARLY_EXIT, 1), (ka.SEARCH_EARLY_EXIT, 0)):
             ctx.set_tuning("walk_early_exit", ee)      # with early exit the host prefers the tiled kernel unless told otherwise
