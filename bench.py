@@ -182,7 +182,7 @@ def kernel_code_hash():
     kernel sources and the engine.  profiles/pmc_traffic.json carries it per entry (tools/pmc_refresh.py writes it)."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("kernels.hpp", "kmer_device.hpp", "engine.hip"):
+    for name in ("kernels.hpp", "kmer_device.hpp", "engine_state.hpp", "engine.hip"):
         with open(os.path.join(ROOT, "kwage_amd", "csrc", name), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

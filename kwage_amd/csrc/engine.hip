@@ -1,19 +1,15 @@
-// kwage_amd/csrc/engine.hip -- device side of the C ABI declared in include/kwage_amd.h.
+// kwage_amd/csrc/engine.hip -- device side of the C ABI declared in include/kwage_amd.h: contexts, tuning knobs, query
+// batches and the search pipeline.  (Database groups and their loaders: loader.hip; shared state: engine_state.hpp.)
 //
-// One kwage_ctx = one GPU = one HIP stream.  A kwage_group owns the HBM-resident bit matrix of
-// all same-parameter columns; kwage_search() runs, on the context's stream,
-//     kmer_kernel  ->  and_kernel | count_kernel  ->  D2H of the hit list
+// One kwage_ctx = one GPU = two slots, each a HIP stream of its own.  A kwage_group owns the HBM-resident bit matrix of
+// all same-parameter columns; a search runs, on its slot's stream,
+//     kmer_kernel  ->  and_kernel | and_walk_kernel | count_kernel | count_walk_kernel | ...  ->  D2H of the hit list
 // which together replace the reference's search() (kwage.cpp:340-541) for a whole batch of
 // queries.  There is no CPU fallback anywhere in this file.
 #include <hip/hip_runtime.h>
-#include <hsa/hsa.h>                 // types only: every HSA function is looked up at run time (see HsaApi)
-#include <hsa/hsa_ext_amd.h>
 
 #include <algorithm>
 #include <chrono>
-#include <deque>
-#include <memory>
-#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -21,191 +17,15 @@
 #include <thread>
 #include <vector>
 
-#include <dlfcn.h>
-#include <fcntl.h>
-#include <sched.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
 #include <unistd.h>
 
 #include "host.hpp"
-#include "internal.h"
+#include "engine_state.hpp"
 #include "kernels.hpp"
 
 using namespace kwage;
 
-#define HIP_TRY(expr)                                                                          \
-	do {                                                                                       \
-		hipError_t _e = (expr);                                                                \
-		if(_e != hipSuccess){                                                                  \
-			return fail(KWAGE_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
-			            __FILE__, __LINE__);                                                   \
-		}                                                                                      \
-	} while(0)
-
-namespace {
-
-// A device buffer that only ever grows (scratch reused across searches).
-struct DevBuf {
-	void *p = nullptr;
-	uint64_t cap = 0;
-	int reserve(uint64_t bytes)
-	{
-		if(bytes <= cap){ return KWAGE_OK; }
-		if(p){ (void)hipFree(p); p = nullptr; cap = 0; }
-		const uint64_t want = std::max<uint64_t>(bytes + bytes/4, 4096);
-		HIP_TRY(hipMalloc(&p, want));
-		cap = want;
-		return KWAGE_OK;
-	}
-	void release()
-	{
-		if(p){ (void)hipFree(p); }
-		p = nullptr; cap = 0;
-	}
-};
-
-struct PinBuf {
-	void *p = nullptr;
-	uint64_t cap = 0;
-	int reserve(uint64_t bytes)
-	{
-		if(bytes <= cap){ return KWAGE_OK; }
-		if(p){ (void)hipHostFree(p); p = nullptr; cap = 0; }
-		const uint64_t want = std::max<uint64_t>(bytes + bytes/4, 4096);
-		HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
-		cap = want;
-		return KWAGE_OK;
-	}
-	void release()
-	{
-		if(p){ (void)hipHostFree(p); }
-		p = nullptr; cap = 0;
-	}
-};
-
-// Pinned host blocks for LONG hit lists, recycled between searches: a list of 100 M records (1.2 GB) crosses PCIe in
-// 22 ms, but landing it in fresh pageable memory cost 0.2 s (a page fault per 4 KiB, one thread's memcpy) -- so the
-// result array of a long list IS a pinned block, the D2H copy's destination, and kwage_result_free hands it back for
-// the next search.  Results may outlive their context: the pool is shared, kwage_shutdown closes it.
-struct PinnedPool {
-	static const size_t MAX_CACHED_BLOCKS = 2;
-	static const uint64_t MAX_CACHED_BYTES = 8ull << 30;
-	std::mutex mu;
-	bool open = true;
-	std::vector<PinBuf> cached;
-	int acquire(uint64_t bytes, PinBuf *out)
-	{
-		{
-			std::lock_guard<std::mutex> lock(mu);
-			size_t best = cached.size();
-			for(size_t i = 0; i < cached.size(); ++i){
-				if(cached[i].cap >= bytes && (best == cached.size() || cached[i].cap < cached[best].cap)){ best = i; }
-			}
-			if(best != cached.size()){
-				*out = cached[best];
-				cached.erase(cached.begin() + (long)best);
-				return KWAGE_OK;
-			}
-		}
-		out->p = nullptr; out->cap = 0;
-		return out->reserve(bytes);
-	}
-	void release(PinBuf &b)
-	{
-		if(!b.p){ return; }
-		{
-			std::lock_guard<std::mutex> lock(mu);
-			uint64_t held = 0;
-			for(const PinBuf &c : cached){ held += c.cap; }
-			if(open && cached.size() < MAX_CACHED_BLOCKS && held + b.cap <= MAX_CACHED_BYTES){
-				cached.push_back(b);
-				b.p = nullptr; b.cap = 0;
-				return;
-			}
-		}
-		b.release();
-	}
-	void close()
-	{
-		std::lock_guard<std::mutex> lock(mu);
-		open = false;
-		for(PinBuf &c : cached){ c.release(); }
-		cached.clear();
-	}
-};
-
-}  // namespace
-
-// Everything one in-flight search owns.  A context has two slots so that a second search can be
-// submitted (and its k-mer stage run) while the first one's results are still being collected.
-struct Slot {
-	hipStream_t stream = nullptr;
-	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-	hipEvent_t search_done = nullptr;   // recorded behind the slot's gather kernel(s)
-	bool search_done_valid = false;
-	// scratch, grown on demand and reused
-	DevBuf rows, tables, partial;
-	// One contiguous result block per search, so that a single D2H copy returns everything:
-	//   [counters: 4 x u64 (hits, -, -, sink)] [nkmer: n x u32] [qthr: n x u32] [pad to 16] [hits: cap x 12 B]
-	DevBuf result;
-	uint64_t *d_counters = nullptr;
-	uint32_t *d_nkmer = nullptr, *d_qthr = nullptr;
-	kwage_hit *d_hits = nullptr;
-	uint64_t hit_cap = 0, head_bytes = 0;
-	PinBuf h_stage;        // host image of the head of the result block + the first SPEC_HITS records
-	DevBuf sort_scratch;   // key / value buffers of the device hit sort (lists beyond SPEC_HITS only)
-	// the submission occupying the slot
-	bool busy = false;
-	kwage_group *g = nullptr;
-	kwage_batch *b = nullptr;
-	const struct KmerLayout *lay = nullptr;     // the batch's layout for the group's k-mer length
-	float threshold = 1.0f;
-	uint32_t flags = 0;
-	uint32_t launches = 0;
-	char kernel_name[64] = "";          // the gather kernel launch_search_stage picked, with its template shape
-	// and_walk_kernel's meeting place for (query, tile) pairs cut by a wave-share boundary: all zero between searches
-	DevBuf walk_or, walk_done;
-	// count_walk_kernel's: partial counters of cut pairs (overwritten before they are read) and the arrival counters of their trees (zero between searches)
-	DevBuf cwalk_slab, cwalk_arrived;
-	uint64_t staged_hits = 0;
-	kwage_hit *ext_hits = nullptr;      // caller-owned device buffer (kwage_search_device) or null
-	uint64_t ext_cap = 0;
-	uint64_t *ext_count = nullptr;      // optional device word that receives the hit count in stream order
-	// append mode (kwage_search_device_append_submit): *ext_count IS the hit counter -- not zeroed unless asked, so the
-	// searches of several groups fill one list -- and col_base is added to every reported column
-	bool append = false, append_reset = false;
-	uint32_t col_base = 0;
-};
-
-// Kernel-selection knobs.  They are parsed ONCE, from the environment, when a context is created, and changed afterwards
-// only through kwage_ctx_set_tuning (tests and tuning tools): nothing on the search path reads the environment.
-struct Tuning {
-	int64_t walk = 4;               // KWAGE_WALK: and_walk_kernel's rows in flight (4 or 2); 0 = always the tiled kernel
-	int64_t walk_min_rows = -1;     // KWAGE_WALK_MIN_ROWS: batches with fewer rows use the tiled kernel (-1: 64 rows per wave of the chip)
-	int64_t walk_max_kib = 16;      // KWAGE_WALK_MAX_KIB: widest row the walk form takes
-	int64_t walk_early_exit = 0;    // KWAGE_WALK_EARLY_EXIT: use the walk form with early exit too (the tiled kernel stops sooner)
-	int64_t walk_waves = 0;         // KWAGE_WALK_WAVES: exactly this many waves (tests: shares of every size); 0 = from the CU count
-	int64_t walk_fences = 0;        // KWAGE_WALK_FENCES: agent-scope fences around the cut-pair count (measurement only)
-	int64_t walk_one_wg_per_cu = 1; // KWAGE_WALK_ONE_WG_PER_CU: chip-filling launches of the persistent kernels use one workgroup of 8 waves per CU (0: workgroups of 4 waves, placed by the dispatcher)
-	int64_t and_vec = 0;            // KWAGE_AND_CFG="vec,unroll,nt[,ldsKB[,block waves]]": shape of the tiled AND kernel (0 = by row width)
-	int64_t and_unroll = 8;
-	int64_t and_nt = 1;
-	int64_t and_lds_kb = 0;         //   dynamic LDS per workgroup caps the waves per CU (tuning only)
-	int64_t and_block_waves = SEARCH_THREADS/WAVE;
-	int64_t narrow = 1;             // KWAGE_NARROW: several queries per wave for rows <= 512 B
-	int64_t narrow_unroll = 0;      // KWAGE_NARROW_UNROLL: rows in flight per wave of the narrow AND kernel (0 = by the number of waves; 8, 16)
-	int64_t force_segs = 0;         // KWAGE_FORCE_SEGS: cut every query's k-mer list into this many segments (tests)
-	int64_t count_walk = 1;         // KWAGE_COUNT_WALK: the persistent count kernel where it applies
-	int64_t count_walk_wpc = 8;     // KWAGE_COUNT_WALK_WPC: its waves per CU (8: 6335 GB/s at C2's shape, 12: 6271, 16: 6250, 20: 5876)
-	int64_t count_walk_waves = 0;   // KWAGE_COUNT_WALK_WAVES: exactly this many waves (tests)
-	int64_t count_walk_min_rows = -1;   // KWAGE_COUNT_WALK_MIN_ROWS: smaller batches use the tiled kernel (-1: 64 rows for each of its waves)
-	int64_t count_walk_prefetch = 1;    // KWAGE_COUNT_WALK_PREFETCH: request the next four k-mers' rows before adding the current four (+1.3 % at C2's shape)
-	int64_t count_narrow_kps = 8;   // KWAGE_COUNT_NARROW_KPS: k-mers per step of the narrow count kernel (8 or 4)
-	int64_t hit_sort_host = 0;      // KWAGE_HIT_SORT=host: order long hit lists on the host (A/B runs, the fallback)
-	int64_t hit_copy_piece_kb = 0;  // KWAGE_HIT_COPY_PIECE_KB: piece size of the copy-back of a long hit list (0 = default)
-	int64_t shared_table_log2 = 0;  // KWAGE_SHARED_TABLE_LOG2: at least this many slots in a sample's shared distinct set (tests)
-};
+static_assert(TUNING_DEFAULT_BLOCK_WAVES == SEARCH_THREADS/WAVE, "the tiled AND kernel's default workgroup");
 
 struct TuningName { const char *name; int64_t Tuning::*field; };
 static const TuningName TUNING_NAMES[] = {
@@ -219,183 +39,7 @@ static const TuningName TUNING_NAMES[] = {
 	{"hit_sort_host", &Tuning::hit_sort_host}, {"hit_copy_piece_kb", &Tuning::hit_copy_piece_kb}, {"shared_table_log2", &Tuning::shared_table_log2},
 };
 
-struct kwage_ctx {
-	int device = -1;
-	int ncu = 0;                        // compute units of the device (persistent grids are sized from it)
-	Tuning tune;
-	hipStream_t stream = nullptr;       // == slot[0].stream; loading, building and the synchronous calls use it
-	Slot slot[2];
-	DevBuf kmers;                       // kwage_hash_batch output
-	// database loading: two pinned + two device staging buffers, kept across files
-	PinBuf load_pin[2];
-	DevBuf load_dev[3];                 // [2] is used by the copy-engine pipeline only (three chunks in flight)
-	hipEvent_t load_done[3] = {nullptr, nullptr, nullptr};
-	// zero-copy loading: the file mapping whose H2D copies may still be in flight on `stream`
-	void *map_base = nullptr;
-	size_t map_len = 0;
-	hipEvent_t map_done = nullptr;      // recorded behind the last copy that reads the mapping
-	// direct loading: file windows locked through HSA whose copy kernels may still be running, oldest first
-	struct LockedWindow { void *base; size_t len; hipEvent_t done; bool owns_event; };     // the windows of one launch share its event; the last one owns it
-	std::deque<LockedWindow> locked;
-	std::vector<hipEvent_t> spare_events;
-	volatile uint64_t *load_progress = nullptr;      // kwage_set_load_progress
-	std::shared_ptr<PinnedPool> result_pool = std::make_shared<PinnedPool>();      // result arrays of long hit lists
-	// CPUs of the NUMA node the device hangs on (empty: unknown, or the process may not run there): database loading
-	// runs on them (the page-cache pages it pins and the staging traffic then stay on the GPU's side of the host)
-	std::vector<int> numa_cpus;
-	int numa_node = -1;
-};
-
 namespace {
-
-// hsa_amd_memory_lock / _unlock of the HSA runtime the HIP runtime of this process sits on, looked up at run time
-// (no link dependency: the Python binding runs on PyTorch's bundled ROCm, the CLI on the system's).  Unlike
-// hipHostRegister / hipHostUnregister they do not synchronise the device, so pinning the next file and
-// un-pinning the previous one overlap with the copy that is running.
-struct HsaLock {
-	typedef int (*lock_fn)(void *host_ptr, size_t size, void *agents, int num_agent, void **agent_ptr);
-	typedef int (*unlock_fn)(void *host_ptr);
-	lock_fn lock = nullptr;
-	unlock_fn unlock = nullptr;
-	HsaLock()
-	{
-		lock = (lock_fn)dlsym(RTLD_DEFAULT, "hsa_amd_memory_lock");
-		unlock = (unlock_fn)dlsym(RTLD_DEFAULT, "hsa_amd_memory_unlock");
-		if(!lock || !unlock){ lock = nullptr; unlock = nullptr; }
-	}
-};
-
-const HsaLock &hsa_lock()
-{
-	static const HsaLock h;
-	return h;
-}
-
-// The rest of the HSA runtime the loader's copy-engine pipeline needs (same run-time lookup).
-struct HsaApi {
-	decltype(&hsa_amd_memory_async_copy) async_copy = nullptr;
-	decltype(&hsa_signal_create) signal_create = nullptr;
-	decltype(&hsa_signal_destroy) signal_destroy = nullptr;
-	decltype(&hsa_signal_store_relaxed) signal_store = nullptr;
-	decltype(&hsa_signal_wait_scacquire) signal_wait = nullptr;
-	decltype(&hsa_iterate_agents) iterate_agents = nullptr;
-	decltype(&hsa_agent_get_info) agent_get_info = nullptr;
-	decltype(&hsa_amd_pointer_info) pointer_info = nullptr;
-	bool ok = false;
-	HsaApi()
-	{
-#define KWAGE_HSA_SYM(member, name) member = (decltype(member))dlsym(RTLD_DEFAULT, name)
-		KWAGE_HSA_SYM(async_copy, "hsa_amd_memory_async_copy");
-		KWAGE_HSA_SYM(signal_create, "hsa_signal_create");
-		KWAGE_HSA_SYM(signal_destroy, "hsa_signal_destroy");
-		KWAGE_HSA_SYM(signal_store, "hsa_signal_store_relaxed");
-		KWAGE_HSA_SYM(signal_wait, "hsa_signal_wait_scacquire");
-		KWAGE_HSA_SYM(iterate_agents, "hsa_iterate_agents");
-		KWAGE_HSA_SYM(agent_get_info, "hsa_agent_get_info");
-		KWAGE_HSA_SYM(pointer_info, "hsa_amd_pointer_info");
-#undef KWAGE_HSA_SYM
-		ok = async_copy && signal_create && signal_destroy && signal_store && signal_wait && iterate_agents && agent_get_info && pointer_info;
-	}
-};
-
-const HsaApi &hsa_api()
-{
-	static const HsaApi h;
-	return h;
-}
-
-// Release locked file windows, oldest first, until at most `keep` remain (each after its copy kernel has finished).
-void release_locked(kwage_ctx *ctx, size_t keep)
-{
-	while(ctx->locked.size() > keep){
-		kwage_ctx::LockedWindow w = ctx->locked.front();
-		ctx->locked.pop_front();
-		if(w.done){ (void)hipEventSynchronize(w.done); }
-		else{ (void)hipStreamSynchronize(ctx->stream); }
-		(void)hsa_lock().unlock(w.base);
-		(void)munmap(w.base, w.len);
-		if(w.done && w.owns_event){ ctx->spare_events.push_back(w.done); }
-	}
-}
-
-// Wait for the copies that read the pending file mapping, then unpin and unmap it.
-void release_mapping(kwage_ctx *ctx)
-{
-	release_locked(ctx, 0);
-	if(!ctx->map_base){ return; }
-	if(ctx->map_done){ (void)hipEventSynchronize(ctx->map_done); }
-	else{ (void)hipStreamSynchronize(ctx->stream); }
-	(void)hipHostUnregister(ctx->map_base);
-	(void)munmap(ctx->map_base, ctx->map_len);
-	ctx->map_base = nullptr;
-	ctx->map_len = 0;
-}
-
-}  // namespace
-
-struct kwage_group {
-	kwage_ctx *ctx = nullptr;
-	kwage_params params{};
-	uint64_t nrows = 0;
-	uint64_t stride = 0;           // bytes, multiple of 128
-	uint64_t next_byte = 0;        // next free byte column within a row
-	uint64_t num_columns = 0;      // valid columns
-	uint8_t *d_bits = nullptr;
-	uint8_t *d_valid = nullptr;
-	uint64_t alloc_bytes = 0;
-	std::vector<uint8_t> h_valid;
-	bool finalized = false;
-	// sparse group (kwage_group_create_sparse): the matrix holds only the listed rows of every file, in this order
-	// (sorted, distinct); row indices from the k-mer stage are translated to positions in the list before the gather
-	std::vector<uint32_t> h_row_map;
-	uint32_t *d_row_map = nullptr;
-};
-
-// Where the k-mer positions of a batch's queries lie for ONE k-mer length: what the k-mer stage and the gather kernels
-// index their row lists with.
-struct KmerLayout {
-	uint32_t k = 0;
-	uint64_t total_pos = 0;        // sum over the queries of max(len - k + 1, 0)
-	uint64_t max_pos = 0;
-	uint64_t table_slots = 0;      // global hash-set slots needed by long queries
-	uint64_t *d_pos_off = nullptr; // n+1: position prefix
-	uint64_t *d_tab_off = nullptr; // n: slot offset of a long query's global distinct set
-	// k-mer stage work list: one workgroup per chunk; a query above KM_LDS_SLOTS/2 positions is cut into chunks of
-	// KM_CHUNK positions that share its global distinct set, everything shorter is one chunk
-	uint32_t *d_chunk_q = nullptr;     // n_chunks: query of the chunk
-	uint64_t *d_chunk_t0 = nullptr;    // n_chunks: its first position within the query
-	uint64_t n_chunks = 0;
-	bool multi_chunk = false;          // some query has more than one chunk
-	std::vector<uint64_t> h_pos_off;
-	~KmerLayout()
-	{
-		if(d_pos_off){ (void)hipFree(d_pos_off); }
-		if(d_tab_off){ (void)hipFree(d_tab_off); }
-		if(d_chunk_q){ (void)hipFree(d_chunk_q); }
-		if(d_chunk_t0){ (void)hipFree(d_chunk_t0); }
-	}
-};
-
-struct kwage_batch {
-	kwage_ctx *ctx = nullptr;
-	uint32_t n = 0;
-	uint64_t total_len = 0;
-	char *d_seqs = nullptr;
-	uint64_t *d_seq_off = nullptr;
-	std::vector<uint64_t> h_seq_off;
-	// One layout per k-mer length the batch has been searched with (a database directory may hold files of several
-	// k: two or three in practice).  A layout never changes once built, so searches with different k-mer lengths can
-	// be in flight on the same batch side by side.
-	std::vector<std::unique_ptr<KmerLayout>> layouts;
-};
-
-namespace {
-
-int set_device(kwage_ctx *ctx)
-{
-	HIP_TRY(hipSetDevice(ctx->device));
-	return KWAGE_OK;
-}
 
 // Lay the result block out for n queries and at least min_cap hit records. Growing the block keeps
 // its head (counters + per-query arrays) when keep_head is set (hit-buffer growth mid-search).
@@ -430,12 +74,6 @@ int layout_result(Slot *sl, uint32_t n, uint64_t min_cap, bool keep_head)
 	sl->hit_cap = cap;
 	sl->head_bytes = head;
 	return KWAGE_OK;
-}
-
-uint32_t grid_for(uint64_t work_items, uint32_t block, uint32_t cap_blocks = 256*8)
-{
-	const uint64_t b = (work_items + block - 1)/block;
-	return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(b, cap_blocks));
 }
 
 uint32_t host_table_log2(uint64_t npos)
@@ -1117,63 +755,6 @@ Slot *free_slot(kwage_ctx *ctx)
 
 namespace {
 
-// The NUMA node of a HIP device and the CPUs of that node this process is allowed to run on (sysfs; empty when the
-// platform does not say, e.g. a single-node guest).
-void find_numa_cpus(int device, int *node, std::vector<int> *cpus)
-{
-	*node = -1;
-	cpus->clear();
-	char bus[64] = "";
-	if(hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess){ (void)hipGetLastError(); return; }
-	for(char *c = bus; *c; ++c){ *c = (char)tolower((unsigned char)*c); }
-	char path[256];
-	snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
-	FILE *f = fopen(path, "r");
-	if(!f){ return; }
-	int n = -1;
-	const int got = fscanf(f, "%d", &n);
-	fclose(f);
-	if(got != 1 || n < 0){ return; }
-	snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", n);
-	f = fopen(path, "r");
-	if(!f){ return; }
-	char list[4096] = "";
-	const bool ok = fgets(list, sizeof(list), f) != nullptr;
-	fclose(f);
-	if(!ok){ return; }
-	cpu_set_t allowed;
-	CPU_ZERO(&allowed);
-	if(sched_getaffinity(0, sizeof(allowed), &allowed) != 0){ return; }
-	char *save = nullptr;                 // (strtok_r: contexts are created from several threads at once in the CLI's node mode)
-	for(char *tok = strtok_r(list, ",\n", &save); tok; tok = strtok_r(nullptr, ",\n", &save)){      // "0-47,96-143"
-		int lo = 0, hi = 0;
-		const int k = sscanf(tok, "%d-%d", &lo, &hi);
-		if(k == 1){ hi = lo; }
-		if(k < 1){ continue; }
-		for(int c = lo; c <= hi && c < CPU_SETSIZE; ++c){ if(CPU_ISSET(c, &allowed)){ cpus->push_back(c); } }
-	}
-	*node = n;
-}
-
-// Run the calling thread (and the threads it starts meanwhile) on the device's NUMA node for the lifetime of the object.
-struct NumaScope {
-	cpu_set_t before;
-	bool active = false;
-	explicit NumaScope(const kwage_ctx *ctx)
-	{
-		static const bool wanted = []() { const char *e = getenv("KWAGE_LOAD_NUMA"); return !(e && atoi(e) == 0); }();
-		if(!wanted || ctx->numa_cpus.empty()){ return; }
-		CPU_ZERO(&before);
-		if(sched_getaffinity(0, sizeof(before), &before) != 0){ return; }
-		cpu_set_t want;
-		CPU_ZERO(&want);
-		for(int c : ctx->numa_cpus){ CPU_SET(c, &want); }
-		if(CPU_EQUAL(&want, &before)){ return; }
-		active = sched_setaffinity(0, sizeof(want), &want) == 0;
-	}
-	~NumaScope() { if(active){ (void)sched_setaffinity(0, sizeof(before), &before); } }
-};
-
 // The knobs' values at context creation: KWAGE_<NAME> for every name of TUNING_NAMES, plus the two historic spellings
 // KWAGE_AND_CFG="vec,unroll,nt[,ldsKB[,block waves]]" and KWAGE_HIT_SORT=host.
 void tuning_from_environment(Tuning *t)
@@ -1322,778 +903,6 @@ extern "C" int kwage_sync(kwage_ctx *ctx)
 	HIP_TRY(hipStreamSynchronize(ctx->slot[1].stream));
 	return KWAGE_OK;
 }
-
-// ------------------------------------------------------------------------------------------
-// database group
-// ------------------------------------------------------------------------------------------
-namespace {
-
-// Allocate and clear a group's matrix of `nrows` rows for `column_capacity` columns.
-int group_allocate(kwage_ctx *ctx, const kwage_params *params, uint64_t column_capacity, uint64_t nrows, kwage_group **out)
-{
-	*out = nullptr;
-	int rc = check_params(params);
-	if(rc){ return rc; }
-	if(column_capacity == 0){ return fail(KWAGE_ERR_ARG, "kwage_group_create: column_capacity is 0"); }
-	if((rc = set_device(ctx))){ return rc; }
-
-	kwage_group *g = new (std::nothrow) kwage_group();
-	if(!g){ return fail(KWAGE_ERR_DEVICE, "out of host memory"); }
-	g->ctx = ctx;
-	g->params = *params;
-	g->nrows = nrows;
-	const uint64_t row_bytes = (column_capacity + 7)/8;
-	g->stride = (row_bytes + 127)/128*128;
-	if(g->stride/16 > 0x7FFFFFFFull){ delete g; return fail(KWAGE_ERR_ARG, "kwage_group_create: row too wide"); }
-	g->alloc_bytes = g->stride*g->nrows;
-	hipError_t e = hipMalloc((void**)&g->d_bits, g->alloc_bytes);
-	if(e != hipSuccess){
-		const double gb = (double)g->alloc_bytes/1e9;
-		delete g;
-		return fail(KWAGE_ERR_DEVICE, "kwage_group_create: hipMalloc of %.3f GB for the bit matrix failed: %s",
-		            gb, hipGetErrorString(e));
-	}
-	e = hipMalloc((void**)&g->d_valid, g->stride);
-	if(e != hipSuccess){
-		(void)hipFree(g->d_bits);
-		delete g;
-		return fail(KWAGE_ERR_DEVICE, "kwage_group_create: hipMalloc(valid mask) failed: %s", hipGetErrorString(e));
-	}
-	e = hipMemsetAsync(g->d_bits, 0, g->alloc_bytes, ctx->stream);
-	if(e == hipSuccess){ e = hipMemsetAsync(g->d_valid, 0, g->stride, ctx->stream); }
-	if(e == hipSuccess){ e = hipStreamSynchronize(ctx->stream); }
-	if(e != hipSuccess){
-		(void)hipFree(g->d_bits); (void)hipFree(g->d_valid);
-		delete g;
-		return fail(KWAGE_ERR_DEVICE, "kwage_group_create: clearing the bit matrix failed: %s", hipGetErrorString(e));
-	}
-	g->h_valid.assign(g->stride, 0);
-	*out = g;
-	return KWAGE_OK;
-}
-
-}  // namespace
-
-extern "C" int kwage_group_create(kwage_ctx *ctx, const kwage_params *params, uint64_t column_capacity,
-                                  kwage_group **out)
-{
-	if(!ctx || !params || !out){ return fail(KWAGE_ERR_ARG, "kwage_group_create: NULL argument"); }
-	*out = nullptr;
-	int rc = check_params(params);
-	if(rc){ return rc; }
-	return group_allocate(ctx, params, column_capacity, 1ull << params->log_2_filter_len, out);
-}
-
-extern "C" int kwage_group_create_sparse(kwage_ctx *ctx, const kwage_params *params, uint64_t column_capacity,
-                                         const uint32_t *rows, uint64_t n_rows, kwage_group **out)
-{
-	if(!ctx || !params || !out || !rows){ return fail(KWAGE_ERR_ARG, "kwage_group_create_sparse: NULL argument"); }
-	*out = nullptr;
-	int rc = check_params(params);
-	if(rc){ return rc; }
-	if(n_rows == 0 || n_rows > 0xFFFFFFFFull){ return fail(KWAGE_ERR_ARG, "kwage_group_create_sparse: need 1 .. 2^32-1 rows"); }
-	const uint64_t filter_len = 1ull << params->log_2_filter_len;
-	for(uint64_t i = 0; i < n_rows; ++i){
-		if(rows[i] >= filter_len || (i && rows[i] <= rows[i - 1])){
-			return fail(KWAGE_ERR_ARG, "kwage_group_create_sparse: rows must be strictly ascending and below 2^%u", params->log_2_filter_len);
-		}
-	}
-	kwage_group *g = nullptr;
-	if((rc = group_allocate(ctx, params, column_capacity, n_rows, &g))){ return rc; }
-	g->h_row_map.assign(rows, rows + n_rows);
-	hipError_t e = hipMalloc((void**)&g->d_row_map, n_rows*sizeof(uint32_t));
-	if(e == hipSuccess){ e = hipMemcpy(g->d_row_map, rows, n_rows*sizeof(uint32_t), hipMemcpyHostToDevice); }
-	if(e != hipSuccess){
-		kwage_group_destroy(g);
-		return fail(KWAGE_ERR_DEVICE, "kwage_group_create_sparse: %s", hipGetErrorString(e));
-	}
-	*out = g;
-	return KWAGE_OK;
-}
-
-extern "C" void kwage_group_destroy(kwage_group *g)
-{
-	if(!g){ return; }
-	(void)hipSetDevice(g->ctx->device);
-	release_mapping(g->ctx);
-	(void)hipStreamSynchronize(g->ctx->slot[0].stream);
-	(void)hipStreamSynchronize(g->ctx->slot[1].stream);
-	if(g->d_bits){ (void)hipFree(g->d_bits); }
-	if(g->d_valid){ (void)hipFree(g->d_valid); }
-	if(g->d_row_map){ (void)hipFree(g->d_row_map); }
-	delete g;
-}
-
-namespace {
-
-// Reserve a 16-byte aligned byte range for `num_filter` new columns; mark them valid.
-int group_reserve_columns(kwage_group *g, uint64_t num_filter, uint64_t *byte0)
-{
-	if(g->finalized){ return fail(KWAGE_ERR_STATE, "group is finalized; no more columns can be added"); }
-	if(num_filter == 0){ return fail(KWAGE_ERR_ARG, "cannot add 0 columns"); }
-	const uint64_t start = (g->next_byte + 15)/16*16;
-	const uint64_t width = (num_filter + 7)/8;
-	if(start + width > g->stride){
-		return fail(KWAGE_ERR_ARG, "group capacity exceeded: need byte %llu of a %llu-byte row",
-		            (unsigned long long)(start + width), (unsigned long long)g->stride);
-	}
-	for(uint64_t c = 0; c < num_filter; ++c){ g->h_valid[start + c/8] |= (uint8_t)(1u << (c%8)); }
-	g->next_byte = start + width;
-	g->num_columns += num_filter;
-	*byte0 = start;
-	return KWAGE_OK;
-}
-
-}  // namespace
-
-extern "C" int kwage_group_add_columns(kwage_group *g, const void *host_rows, uint64_t host_row_stride,
-                                       uint32_t num_filter, uint64_t *first_column)
-{
-	if(!g || !host_rows){ return fail(KWAGE_ERR_ARG, "kwage_group_add_columns: NULL argument"); }
-	const uint64_t width = ((uint64_t)num_filter + 7)/8;
-	if(host_row_stride < width){ return fail(KWAGE_ERR_ARG, "kwage_group_add_columns: host_row_stride < ceil(num_filter/8)"); }
-	kwage_ctx *ctx = g->ctx;
-	int rc = set_device(ctx);
-	if(rc){ return rc; }
-	uint64_t byte0 = 0;
-	if((rc = group_reserve_columns(g, num_filter, &byte0))){ return rc; }
-
-	// stage through a device buffer in chunks of rows, then scatter into the strided matrix
-	const uint64_t chunk_rows = std::max<uint64_t>(1, std::min<uint64_t>(g->nrows, (64ull << 20)/host_row_stride));
-	DevBuf stage;
-	if((rc = stage.reserve(chunk_rows*host_row_stride))){ return rc; }
-	const uint8_t *src = (const uint8_t*)host_rows;
-	for(uint64_t r0 = 0; r0 < g->nrows; r0 += chunk_rows){
-		const uint64_t nr = std::min(chunk_rows, g->nrows - r0);
-		hipError_t e = hipMemcpyAsync(stage.p, src + r0*host_row_stride, (nr - 1)*host_row_stride + width,
-		                              hipMemcpyHostToDevice, ctx->stream);
-		if(e == hipSuccess){
-			hipLaunchKernelGGL(place_rows_kernel, dim3(grid_for(nr*width/4 + 1, 256)), dim3(256), 0, ctx->stream,
-			                   g->d_bits, g->stride, r0, byte0, (const uint8_t*)stage.p, host_row_stride, width, nr);
-			e = hipGetLastError();
-		}
-		if(e == hipSuccess){ e = hipStreamSynchronize(ctx->stream); }
-		if(e != hipSuccess){ stage.release(); return fail(KWAGE_ERR_DEVICE, "kwage_group_add_columns: %s", hipGetErrorString(e)); }
-	}
-	stage.release();
-	if(first_column){ *first_column = byte0*8; }
-	return KWAGE_OK;
-}
-
-namespace {
-
-static const uint32_t LOAD_GANG = LOAD_GANG_MAX;      // files whose rows one copy kernel writes side by side (16 x 256 B = 4 KiB per matrix row)
-
-bool load_env_flag(const char *name, bool fallback)
-{
-	const char *e = getenv(name);
-	return e ? atoi(e) != 0 : fallback;
-}
-
-uint64_t load_env_kb(const char *name, uint64_t fallback_bytes)
-{
-	const char *e = getenv(name);
-	return (e && atoll(e) > 0) ? (uint64_t)atoll(e) << 10 : fallback_bytes;
-}
-
-// Open a database file for loading into `g`: header checks, optional CRC check, column reservation.
-int open_source_for_group(kwage_group *g, const char *path, DbSliceSource &src, uint64_t *byte0)
-{
-	std::string err;
-	if(!src.open(path, err)){ return fail(KWAGE_ERR_IO, "%s", err.c_str()); }
-	const kwage_db_header &h = src.header;
-	if(h.kmer_len != g->params.kmer_len || h.num_hash != g->params.num_hash ||
-	   h.log_2_filter_len != g->params.log_2_filter_len || h.hash_func != g->params.hash_func){
-		return fail(KWAGE_ERR_ARG, "%s: parameters (k=%u, hashes=%u, log2 len=%u, func=%d) differ from the group's",
-		            path, h.kmer_len, h.num_hash, h.log_2_filter_len, h.hash_func);
-	}
-	if(h.num_filter == 0){ return fail(KWAGE_ERR_FORMAT, "%s: num_filter is 0", path); }
-	// KWAGE_VERIFY_CRC=1: refuse a file whose slice block does not match the CRC32 in its header, as the reference's
-	// merge does for its sources (merge_db.cpp:608-614; its `kwage` checks nothing, kwage.cpp:99-105).  A separate
-	// pass over the file on the host, so off by default.
-	static const bool verify_crc = load_env_flag("KWAGE_VERIFY_CRC", false);
-	if(verify_crc){
-		uint32_t crc = 0;
-		if(!src.slice_crc32(crc, err)){ return fail(KWAGE_ERR_IO, "%s: %s", path, err.c_str()); }
-		if(crc != h.crc32){ return fail(KWAGE_ERR_FORMAT, "%s: Invalid CRC32 value (header %08x, slices %08x)", path, h.crc32, crc); }
-	}
-	return group_reserve_columns(g, h.num_filter, byte0);
-}
-
-// Can the direct path take this file?  Raw layout, rows a multiple of 4 bytes, HSA lock available, and asked for
-// (KWAGE_LOAD_DIRECT=1: it is NOT the default, see load_gang_direct).
-bool direct_loadable(const DbSliceSource &src)
-{
-	static const bool mmap_ok = load_env_flag("KWAGE_LOAD_MMAP", true), direct_ok = load_env_flag("KWAGE_LOAD_DIRECT", false);
-	return mmap_ok && direct_ok && src.header.compression == KWAGE_COMPRESSION_NONE && src.slice_size % 4 == 0 && hsa_lock().lock != nullptr;
-}
-
-// Direct path (opt-in, KWAGE_LOAD_DIRECT=1): rows of up to KWAGE_LOAD_GANG (default 16) raw files go from the page cache
-// straight into the strided matrix.  Windows of the files are mapped and locked through HSA (no
-// hipHostRegister/Unregister, which wait for the device), ONE copy kernel per window reads them over PCIe and writes
-// the rows where they belong -- no staging buffer, no second pass over HBM.  The windows of up to two launches stay
-// locked behind the one being queued and are released as their kernels finish.
-// Why it is not the default (profiles/r02_loader_probe.txt, r02_e2e_cli_32files.txt, r02_load_105gb.txt):
-//   32 x 268 MB files (8.6 GB matrix, 8 KiB stride): one file per launch 38-47 GB/s, gangs of 16 35 GB/s, staged path
-//     40-41 GB/s -- the kernel's 64-byte PCIe reads cap it below the copy engine's 57 GB/s, so dropping the staging
-//     hop buys little (an SDMA rect copy straight into the matrix reaches 33 GB/s, and hipMemcpyAsync does not
-//     recognise HSA-locked memory: 19 GB/s);
-//   392 files (105 GB matrix, 100 KB stride): 24 GB/s warm and 11 GB/s in the first runs after the files were
-//     written, against 30-33 GB/s for the staged path, every time -- 256-byte pieces 100 KB apart miss the TLB and
-//     the open DRAM page on every store, which hurts a kernel that holds PCIe reads in flight more than the staged
-//     path's short HBM-to-HBM scatter bursts.
-// *rows_done = rows of every file that are on their way when the call returns (all of them unless a window could not
-// be mapped or locked; the caller finishes the rest through the staged paths).
-int load_gang_direct(kwage_group *g, DbSliceSource *const *srcs, const uint64_t *byte0, uint32_t n, uint64_t *rows_done)
-{
-	kwage_ctx *ctx = g->ctx;
-	static const uint64_t window_target = load_env_kb("KWAGE_LOAD_WINDOW_KB", 512ull << 20);
-	const long page = sysconf(_SC_PAGESIZE);
-	uint64_t total_width = 0;
-	bool vec16 = true;
-	for(uint32_t i = 0; i < n; ++i){ total_width += srcs[i]->slice_size; vec16 = vec16 && (srcs[i]->slice_size % 16 == 0); }
-	const uint32_t ub = vec16 ? 16 : 4;
-	// rows per launch: 512 MiB of file windows for one file, up to 2 GiB for a gang (a lock has a fixed cost too)
-	const uint64_t win_rows = std::max<uint64_t>(1, std::min<uint64_t>(g->nrows, window_target*std::min<uint32_t>(n, 4)/total_width));
-	*rows_done = 0;
-	for(uint64_t r0 = 0; r0 < g->nrows; ){
-		const uint64_t wr = std::min(win_rows, g->nrows - r0);
-		GangArgs ga;
-		memset(&ga, 0, sizeof(ga));
-		ga.n = n;
-		std::vector<kwage_ctx::LockedWindow> wins;
-		bool ok = true;
-		uint64_t max_bytes = 0;
-		for(uint32_t i = 0; i < n && ok; ++i){
-			const uint64_t width = srcs[i]->slice_size;
-			const uint64_t off = DB_HEADER_BYTES + r0*width, off0 = off/page*page;
-			const size_t maplen = (size_t)(off - off0 + wr*width);
-			void *base = mmap(nullptr, maplen, PROT_READ, MAP_PRIVATE, srcs[i]->fd, (off_t)off0);      // (the lock faults the pages in)
-			if(base == MAP_FAILED){ ok = false; break; }
-			void *dev_view = nullptr;
-			if(hsa_lock().lock(base, maplen, nullptr, 0, &dev_view) != 0 || !dev_view){ (void)munmap(base, maplen); ok = false; break; }
-			wins.push_back(kwage_ctx::LockedWindow{base, maplen, nullptr, false});
-			ga.f[i].src = (const uint8_t*)dev_view + (off - off0);
-			ga.f[i].byte0 = byte0[i];
-			ga.f[i].width = width;
-			max_bytes = std::max(max_bytes, wr*width);
-		}
-		hipEvent_t ev = nullptr;
-		if(ok){
-			if(!ctx->spare_events.empty()){ ev = ctx->spare_events.back(); ctx->spare_events.pop_back(); }
-			else if(hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess){ ev = nullptr; ok = false; }
-		}
-		if(!ok){
-			for(auto &w : wins){ (void)hsa_lock().unlock(w.base); (void)munmap(w.base, w.len); }
-			return KWAGE_OK;           // *rows_done tells the caller where to go on
-		}
-		const uint64_t items = (uint64_t)n*4*((max_bytes + (uint64_t)4*WAVE*ub - 1)/((uint64_t)4*WAVE*ub));     // (256-lane stretch, file, quarter) triples
-		const uint32_t blocks = grid_for(items*WAVE, 256, 256*8);
-		if(ub == 16){ hipLaunchKernelGGL((copy_rows_gang_kernel<16>), dim3(blocks), dim3(256), 0, ctx->stream, g->d_bits, g->stride, r0, ga, wr, items); }
-		else{ hipLaunchKernelGGL((copy_rows_gang_kernel<4>), dim3(blocks), dim3(256), 0, ctx->stream, g->d_bits, g->stride, r0, ga, wr, items); }
-		hipError_t e = hipGetLastError();
-		if(e == hipSuccess){ e = hipEventRecord(ev, ctx->stream); }
-		for(auto &w : wins){ w.done = ev; }              // every window of the launch waits for the same event ...
-		wins.back().owns_event = true;                   // ... and the last one to go returns it to the pool
-		for(auto &w : wins){ ctx->locked.push_back(w); }
-		if(e != hipSuccess){
-			release_mapping(ctx);
-			return fail(KWAGE_ERR_DEVICE, "loading database rows: %s", hipGetErrorString(e));
-		}
-		release_locked(ctx, 2*(size_t)n);
-		r0 += wr;
-		*rows_done = r0;
-	}
-	return KWAGE_OK;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Copy-engine pipeline for raw files (the default): page cache -> staging buffer -> place_rows_kernel, at the copy
-// engine's rate and without hipHostRegister.  Windows of a file (<= 256 MiB) are mapped and locked through HSA -- no
-// device synchronisation, so pinning the next window and un-pinning the previous one overlap with the copy that is
-// running --, hsa_amd_memory_async_copy (SDMA, linear) moves one window at a time into one of THREE staging buffers,
-// the host waits for the copy's completion signal and launches place_rows_kernel behind it on the loading stream.
-// Three windows are in flight: one being copied, one being scattered, one being pinned.  16 files x 268 MB:
-// 48-52 GB/s; 392 files into a 105 GB matrix: 54 GB/s (tools/micro/sdma_stage_probe.hip, profiles/r02_loader_probe.txt)
-// against 40 and 33 GB/s for the hipHostRegister + hipMemcpyAsync form, which stays as the fallback.
-// ------------------------------------------------------------------------------------------------------------------
-struct SdmaPipe {
-	kwage_group *g = nullptr;
-	hsa_agent_t gpu{}, cpu{};
-	bool usable = false;
-	uint64_t chunk_bytes = 0;
-	struct Chunk { hsa_signal_t sig{}; bool sig_valid = false; int stage = 0; uint64_t row0 = 0, nr = 0, byte0 = 0, width = 0; };
-	Chunk ring[3];
-	uint64_t issued = 0, finished = 0;                     // chunk counters (ring index = counter % 3)
-	struct Window { void *base; size_t len; uint64_t last_chunk; };
-	std::deque<Window> windows;                            // locked windows, oldest first
-
-	int init(kwage_group *grp)
-	{
-		g = grp;
-		const HsaApi &h = hsa_api();
-		if(!h.ok || !hsa_lock().lock){ return KWAGE_OK; }
-		hsa_amd_pointer_info_t info;
-		memset(&info, 0, sizeof(info));
-		info.size = sizeof(info);
-		if(h.pointer_info(g->d_bits, &info, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || info.type == HSA_EXT_POINTER_TYPE_UNKNOWN){ return KWAGE_OK; }
-		gpu = info.agentOwner;                             // the HSA agent behind this context's HIP device
-		struct Find { const HsaApi *h; hsa_agent_t cpu; bool found; } f = {&h, {}, false};
-		h.iterate_agents([](hsa_agent_t a, void *p) -> hsa_status_t {
-			Find *fd = (Find*)p;
-			hsa_device_type_t t;
-			if(!fd->found && fd->h->agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) == HSA_STATUS_SUCCESS && t == HSA_DEVICE_TYPE_CPU){ fd->cpu = a; fd->found = true; }
-			return HSA_STATUS_SUCCESS;
-		}, &f);
-		if(!f.found){ return KWAGE_OK; }
-		cpu = f.cpu;
-		for(auto &c : ring){ c.sig_valid = false; }
-		for(int i = 0; i < 3; ++i){
-			if(h.signal_create(1, 0, nullptr, &ring[i].sig) != HSA_STATUS_SUCCESS){ return KWAGE_OK; }
-			ring[i].sig_valid = true;
-			ring[i].stage = i;
-		}
-		HIP_TRY(hipStreamSynchronize(g->ctx->stream));       // nothing queued earlier may still read the staging buffers
-		usable = true;
-		return KWAGE_OK;
-	}
-
-	// the oldest unfinished chunk: wait for its copy, scatter it, release windows whose last chunk it was
-	int finish_one()
-	{
-		kwage_ctx *ctx = g->ctx;
-		Chunk &c = ring[finished % 3];
-		hsa_api().signal_wait(c.sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
-		hipLaunchKernelGGL(place_rows_kernel, dim3(grid_for(c.nr*c.width/4 + 1, 256)), dim3(256), 0, ctx->stream,
-		                   g->d_bits, g->stride, c.row0, c.byte0, (const uint8_t*)ctx->load_dev[c.stage].p, c.width, c.width, c.nr);
-		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipEventRecord(ctx->load_done[c.stage], ctx->stream));
-		while(!windows.empty() && windows.front().last_chunk == finished){
-			(void)hsa_lock().unlock(windows.front().base);
-			(void)munmap(windows.front().base, windows.front().len);
-			windows.pop_front();
-		}
-		++finished;
-		return KWAGE_OK;
-	}
-
-	// Queue every row of `src` (raw layout): one window = one copy.  *rows_done = rows that are on their way (all of them
-	// unless a window could not be mapped or locked, or the copy engine refused: the caller finishes the rest through the
-	// other paths).
-	int add_file(DbSliceSource &src, uint64_t byte0, uint64_t *rows_done)
-	{
-		kwage_ctx *ctx = g->ctx;
-		const HsaApi &h = hsa_api();
-		// 256 MiB per copy: pinning the next window (~12 us per MB) then takes less time than the copy that is running
-		static const uint64_t window_target = load_env_kb("KWAGE_LOAD_WINDOW_KB", 256ull << 20);
-		const uint64_t width = src.slice_size;
-		const uint64_t win_rows = std::max<uint64_t>(1, std::min<uint64_t>(g->nrows, window_target/width));
-		const long page = sysconf(_SC_PAGESIZE);
-		int rc;
-		for(int i = 0; i < 3; ++i){
-			if(ctx->load_dev[i].cap < win_rows*width){
-				// growing a staging buffer: every copy into the old one and every kernel that reads it must be done first
-				if((rc = flush())){ return rc; }
-				HIP_TRY(hipStreamSynchronize(ctx->stream));
-				if((rc = ctx->load_dev[i].reserve(win_rows*width))){ return rc; }
-			}
-			if(!ctx->load_done[i]){ HIP_TRY(hipEventCreateWithFlags(&ctx->load_done[i], hipEventDisableTiming)); HIP_TRY(hipEventRecord(ctx->load_done[i], ctx->stream)); }
-		}
-		*rows_done = 0;
-		for(uint64_t r0 = 0; r0 < g->nrows; ){
-			const uint64_t wr = std::min(win_rows, g->nrows - r0);
-			const uint64_t off = DB_HEADER_BYTES + r0*width, off0 = off/page*page;
-			const size_t maplen = (size_t)(off - off0 + wr*width);
-			// pages that are not in the page cache yet: have the kernel read the next two windows while this one is pinned
-			// and copied (the lock below faults pages in one by one, at half the rate of a plain sequential read)
-			(void)posix_fadvise(src.fd, (off_t)(off0 + maplen), (off_t)(2*win_rows*width), POSIX_FADV_WILLNEED);
-			void *base = mmap(nullptr, maplen, PROT_READ, MAP_PRIVATE, src.fd, (off_t)off0);      // (the lock faults the pages in)
-			if(base == MAP_FAILED){ return KWAGE_OK; }
-			void *dev_view = nullptr;
-			if(hsa_lock().lock(base, maplen, nullptr, 0, &dev_view) != 0 || !dev_view){ (void)munmap(base, maplen); return KWAGE_OK; }
-			Chunk &c = ring[issued % 3];
-			HIP_TRY(hipEventSynchronize(ctx->load_done[c.stage]));          // the scatter kernel that last read this staging buffer
-			c.row0 = r0; c.nr = wr; c.byte0 = byte0; c.width = width;
-			h.signal_store(c.sig, 1);
-			if(h.async_copy(ctx->load_dev[c.stage].p, gpu, (const char*)dev_view + (off - off0), cpu, wr*width, 0, nullptr, c.sig) != HSA_STATUS_SUCCESS){
-				(void)hsa_lock().unlock(base);
-				(void)munmap(base, maplen);
-				usable = false;                                 // the caller flushes and goes on with the staged paths
-				return KWAGE_OK;
-			}
-			windows.push_back(Window{base, maplen, issued});
-			++issued;
-			if(ctx->load_progress){ __atomic_fetch_add(ctx->load_progress, wr*width, __ATOMIC_RELAXED); }      // pinned: no longer the reader's business
-			r0 += wr;
-			*rows_done = r0;
-			if(issued - finished >= 2){ if((rc = finish_one())){ return rc; } }       // one copy stays in flight while the next window is pinned
-		}
-		return KWAGE_OK;
-	}
-
-	int flush()
-	{
-		int rc;
-		while(finished < issued){ if((rc = finish_one())){ return rc; } }
-		return KWAGE_OK;
-	}
-
-	~SdmaPipe()
-	{
-		if(g){ (void)flush(); }
-		while(!windows.empty()){ (void)hsa_lock().unlock(windows.front().base); (void)munmap(windows.front().base, windows.front().len); windows.pop_front(); }
-		for(auto &c : ring){ if(c.sig_valid){ (void)hsa_api().signal_destroy(c.sig); } }
-	}
-};
-
-// Staged paths for rows first_row.. of one file: the pinned file mapping feeding the copy engine (raw files, from row 0)
-// or pread / inflate into pinned buffers, each followed by place_rows_kernel.
-int load_source_rows_staged(kwage_group *g, DbSliceSource &src, const char *path, uint64_t byte0, uint64_t first_row)
-{
-	kwage_ctx *ctx = g->ctx;
-	const kwage_db_header &h = src.header;
-	const uint64_t width = src.slice_size;
-	std::string err;
-	int rc = KWAGE_OK;
-	// Raw files: map the file read-only, pin the mapping (hipHostRegister) and let the copy engine read the
-	// page cache directly -- no pread copy into a staging buffer (that copy, not PCIe, limited the loader to
-	// 30 GB/s; the mapping feeds H2D at the box's 57 GB/s, tools/micro/hostreg_probe.hip).  The copies of THIS
-	// file are left in flight when the call returns, so the next file's mmap + pinning (3-4 ms per 256 MB)
-	// overlaps with them; the mapping is released by the next call, by finalize, or when the group goes.
-	// KWAGE_LOAD_MMAP=0, a compressed file, or a failure to map or pin falls back to the pread path below.
-	static const bool mmap_ok = load_env_flag("KWAGE_LOAD_MMAP", true);
-	uint64_t first_row_pread = first_row;
-	// (KWAGE_LOAD_CHUNK_KB / KWAGE_LOAD_WINDOW_KB shrink the 64 MiB staging chunk and the 512 MiB window: tests)
-	static const uint64_t chunk_target = load_env_kb("KWAGE_LOAD_CHUNK_KB", 64ull << 20);
-	static const uint64_t window_target = load_env_kb("KWAGE_LOAD_WINDOW_KB", 512ull << 20);
-	const uint64_t chunk_rows = std::max<uint64_t>(1, std::min<uint64_t>(g->nrows, chunk_target/width));
-	const uint64_t chunk_bytes = chunk_rows*width;
-	PinBuf *pin = ctx->load_pin;
-	DevBuf *dev = ctx->load_dev;
-	hipEvent_t *done = ctx->load_done;
-	hipError_t e = hipSuccess;
-	for(int i = 0; i < 2 && rc == KWAGE_OK; ++i){
-		rc = dev[i].reserve(chunk_bytes);
-		if(!rc && !done[i] && hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess){ rc = fail(KWAGE_ERR_DEVICE, "hipEventCreate failed"); }
-	}
-	if(rc){ return rc; }
-	if(first_row == 0 && mmap_ok && h.compression == KWAGE_COMPRESSION_NONE){
-		// windows of at most 512 MiB (whole chunks): pinned page-cache pages cannot be evicted, so a file larger
-		// than host memory must never be pinned as a whole; two windows are alive at most (one being copied from)
-		const uint64_t win_rows = std::max<uint64_t>(chunk_rows, (window_target/chunk_bytes)*chunk_rows);
-		const long page = sysconf(_SC_PAGESIZE);
-		bool fell_back = false;
-		uint64_t r0 = 0;
-		int cur = 0;
-		for(; r0 < g->nrows; ){
-			const uint64_t wr = std::min(win_rows, g->nrows - r0);
-			const uint64_t off = DB_HEADER_BYTES + r0*width, off0 = off/page*page;
-			const size_t maplen = (size_t)(off - off0 + wr*width);
-			void *base = mmap(nullptr, maplen, PROT_READ, MAP_PRIVATE | MAP_POPULATE, src.fd, (off_t)off0);
-			if(base == MAP_FAILED){ fell_back = true; break; }
-			if(hipHostRegister(base, maplen, hipHostRegisterReadOnly) != hipSuccess){
-				(void)hipGetLastError();
-				(void)munmap(base, maplen);
-				fell_back = true;
-				break;
-			}
-			// Give up the previous window BEFORE queueing this one's copies: hipHostUnregister synchronises the device,
-			// so doing it with the new copies in flight would serialise everything (measured: 28 instead of 40 GB/s).
-			// The previous copies have had this window's whole mmap + pinning time to finish.
-			release_mapping(ctx);
-			ctx->map_base = base; ctx->map_len = maplen;
-			const unsigned char *rows0 = (const unsigned char*)base + (off - off0);
-			for(uint64_t c0 = 0; c0 < wr; c0 += chunk_rows, cur ^= 1){
-				const uint64_t nr = std::min(chunk_rows, wr - c0);
-				const uint64_t nb = nr*width;
-				// staging buffer reuse is safe by stream order: this copy is queued behind the scatter kernel that read it
-				e = hipMemcpyAsync(dev[cur].p, rows0 + c0*width, nb, hipMemcpyHostToDevice, ctx->stream);
-				if(e == hipSuccess){
-					hipLaunchKernelGGL(place_rows_kernel, dim3(grid_for(nb/4 + 1, 256)), dim3(256), 0, ctx->stream,
-					                   g->d_bits, g->stride, r0 + c0, byte0, (const uint8_t*)dev[cur].p, width, width, nr);
-					e = hipGetLastError();
-				}
-				if(e != hipSuccess){
-					release_mapping(ctx);
-					return fail(KWAGE_ERR_DEVICE, "kwage_group_add_db_file: %s", hipGetErrorString(e));
-				}
-			}
-			if(!ctx->map_done && hipEventCreateWithFlags(&ctx->map_done, hipEventDisableTiming) != hipSuccess){ ctx->map_done = nullptr; }
-			if(ctx->map_done){ (void)hipEventRecord(ctx->map_done, ctx->stream); }
-			r0 += wr;
-		}
-		if(!fell_back){ return KWAGE_OK; }
-		// could not map or pin a window (rows below r0 are already on their way): the pread path does the rest
-		first_row_pread = r0;
-	}
-	release_mapping(ctx);       // the staging buffers below are shared with copies that may still be in flight
-
-	// pread path, double-buffered: fill pinned buffer A (parallel pread / inflate) while buffer B is copied + scattered
-	bool used[2] = {false, false};
-	for(int i = 0; i < 2 && rc == KWAGE_OK; ++i){ rc = pin[i].reserve(chunk_bytes); }
-	int cur = 0;
-	for(uint64_t r0 = first_row_pread; r0 < g->nrows && rc == KWAGE_OK; r0 += chunk_rows, cur ^= 1){
-		const uint64_t nr = std::min(chunk_rows, g->nrows - r0);
-		const uint64_t nb = nr*width;
-		if(used[cur]){ e = hipEventSynchronize(done[cur]); if(e != hipSuccess){ rc = fail(KWAGE_ERR_DEVICE, "%s", hipGetErrorString(e)); break; } }
-		if(!src.read_rows(r0, nr, (unsigned char*)pin[cur].p, err)){ rc = fail(KWAGE_ERR_IO, "%s: %s", path, err.c_str()); break; }
-		e = hipMemcpyAsync(dev[cur].p, pin[cur].p, nb, hipMemcpyHostToDevice, ctx->stream);
-		if(e == hipSuccess){
-			hipLaunchKernelGGL(place_rows_kernel, dim3(grid_for(nb/4 + 1, 256)), dim3(256), 0, ctx->stream,
-			                   g->d_bits, g->stride, r0, byte0, (const uint8_t*)dev[cur].p, width, width, nr);
-			e = hipGetLastError();
-		}
-		if(e == hipSuccess){ e = hipEventRecord(done[cur], ctx->stream); }
-		if(e != hipSuccess){ rc = fail(KWAGE_ERR_DEVICE, "kwage_group_add_db_file: %s", hipGetErrorString(e)); break; }
-		used[cur] = true;
-	}
-	(void)hipStreamSynchronize(ctx->stream);
-	return rc;
-}
-
-// Sparse group: fetch only the listed slices of up to LOAD_GANG files -- I/O proportional to what the queries address,
-// like the reference's seekg + read per slice (kwage.cpp:414-416) -- one host thread per file (several per file when
-// the list is long) into ONE pinned staging buffer, one copy, then place_rows_kernel per file.
-int load_gang_sparse(kwage_group *g, DbSliceSource *const *srcs, const char *const *paths, const uint64_t *byte0, uint32_t n)
-{
-	kwage_ctx *ctx = g->ctx;
-	static const uint64_t chunk_target = load_env_kb("KWAGE_LOAD_CHUNK_KB", 64ull << 20);
-	uint64_t total_width = 0;
-	for(uint32_t i = 0; i < n; ++i){ total_width += srcs[i]->slice_size; }
-	const uint64_t chunk_rows = std::max<uint64_t>(1, std::min<uint64_t>(g->nrows, chunk_target/total_width));
-	const uint64_t chunk_bytes = chunk_rows*total_width;
-	PinBuf *pin = ctx->load_pin;
-	DevBuf *dev = ctx->load_dev;
-	hipEvent_t *done = ctx->load_done;
-	int rc = KWAGE_OK;
-	release_mapping(ctx);       // the staging buffers are shared with copies of an earlier (dense) load
-	for(int i = 0; i < 2 && rc == KWAGE_OK; ++i){
-		rc = dev[i].reserve(chunk_bytes);
-		if(!rc){ rc = pin[i].reserve(chunk_bytes); }
-		if(!rc && !done[i] && hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess){ rc = fail(KWAGE_ERR_DEVICE, "hipEventCreate failed"); }
-	}
-	if(rc){ return rc; }
-	bool used[2] = {false, false};
-	int cur = 0;
-	hipError_t e = hipSuccess;
-	for(uint64_t r0 = 0; r0 < g->nrows && rc == KWAGE_OK; r0 += chunk_rows, cur ^= 1){
-		const uint64_t nr = std::min(chunk_rows, g->nrows - r0);
-		if(used[cur]){ e = hipEventSynchronize(done[cur]); if(e != hipSuccess){ rc = fail(KWAGE_ERR_DEVICE, "%s", hipGetErrorString(e)); break; } }
-		// file i's nr slices land at offset nr * (widths of the files before it)
-		std::vector<uint64_t> off(n + 1, 0);
-		for(uint32_t i = 0; i < n; ++i){ off[i + 1] = off[i] + nr*srcs[i]->slice_size; }
-		std::vector<std::string> errs(n);
-		std::vector<char> ok(n, 1);
-		const unsigned inner = (n == 1) ? 16u : 1u;      // one file: its list is split over threads; a gang: one thread per file
-		auto fetch = [&](uint32_t i) {
-			ok[i] = srcs[i]->read_row_list(g->h_row_map.data() + r0, nr, (unsigned char*)pin[cur].p + off[i], errs[i], inner) ? 1 : 0;
-		};
-		std::vector<std::thread> pool;
-		for(uint32_t i = 1; i < n; ++i){ pool.emplace_back(fetch, i); }
-		fetch(0);
-		for(auto &t : pool){ t.join(); }
-		for(uint32_t i = 0; i < n; ++i){
-			if(!ok[i]){ rc = fail(KWAGE_ERR_IO, "%s: %s", paths[i], errs[i].c_str()); break; }
-		}
-		if(rc){ break; }
-		e = hipMemcpyAsync(dev[cur].p, pin[cur].p, off[n], hipMemcpyHostToDevice, ctx->stream);
-		for(uint32_t i = 0; i < n && e == hipSuccess; ++i){
-			const uint64_t width = srcs[i]->slice_size;
-			hipLaunchKernelGGL(place_rows_kernel, dim3(grid_for(nr*width/4 + 1, 256)), dim3(256), 0, ctx->stream,
-			                   g->d_bits, g->stride, r0, byte0[i], (const uint8_t*)dev[cur].p + off[i], width, width, nr);
-			e = hipGetLastError();
-		}
-		if(e == hipSuccess){ e = hipEventRecord(done[cur], ctx->stream); }
-		if(e != hipSuccess){ rc = fail(KWAGE_ERR_DEVICE, "kwage_group_add_db_files: %s", hipGetErrorString(e)); break; }
-		used[cur] = true;
-	}
-	(void)hipStreamSynchronize(ctx->stream);
-	return rc;
-}
-
-}  // namespace
-
-extern "C" int kwage_group_add_db_file(kwage_group *g, const char *path, uint64_t *first_column, uint32_t *num_filter)
-{
-	if(!g || !path){ return fail(KWAGE_ERR_ARG, "kwage_group_add_db_file: NULL argument"); }
-	return kwage_group_add_db_files(g, &path, 1, first_column, num_filter);
-}
-
-extern "C" int kwage_group_add_db_files(kwage_group *g, const char *const *paths, uint32_t n, uint64_t *first_columns, uint32_t *num_filters)
-{
-	if(!g || !paths || n == 0){ return fail(KWAGE_ERR_ARG, "kwage_group_add_db_files: NULL argument"); }
-	for(uint32_t i = 0; i < n; ++i){ if(!paths[i]){ return fail(KWAGE_ERR_ARG, "kwage_group_add_db_files: path %u is NULL", i); } }
-	int rc = set_device(g->ctx);
-	if(rc){ return rc; }
-	const NumaScope on_the_gpus_node(g->ctx);      // this thread and the reader threads it starts, until the call returns
-	// Files are taken in the order given (that is the column order).  Raw files go through the copy-engine pipeline
-	// (SdmaPipe; KWAGE_LOAD_SDMA=0 disables it), or -- opt-in -- LOAD_GANG at a time through the direct copy kernel;
-	// compressed files, sparse groups and whatever those paths cannot take go through the staged paths file by file.
-	static const bool sdma_ok = load_env_flag("KWAGE_LOAD_SDMA", true) && load_env_flag("KWAGE_LOAD_MMAP", true);
-	SdmaPipe pipe;
-	if(sdma_ok && !g->d_row_map && !load_env_flag("KWAGE_LOAD_DIRECT", false)){ if((rc = pipe.init(g))){ return rc; } }
-	for(uint32_t i0 = 0; i0 < n; ){
-		DbSliceSource srcs[LOAD_GANG];
-		DbSliceSource *ptrs[LOAD_GANG];
-		uint64_t byte0[LOAD_GANG];
-		uint32_t cnt = 0, n_direct = 0;
-		static const uint32_t gang_max = []() { const char *e = getenv("KWAGE_LOAD_GANG"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= (int)LOAD_GANG) ? (uint32_t)v : LOAD_GANG; }();
-		while(i0 + cnt < n && cnt < gang_max){
-			DbSliceSource &src = srcs[cnt];
-			if((rc = open_source_for_group(g, paths[i0 + cnt], src, &byte0[cnt]))){ return rc; }
-			if(first_columns){ first_columns[i0 + cnt] = byte0[cnt]*8; }
-			if(num_filters){ num_filters[i0 + cnt] = src.header.num_filter; }
-			ptrs[cnt] = &src;
-			++cnt;
-			if(g->d_row_map){ continue; }                // sparse group: gangs of any files
-			// whole-file loading: start reading the head of every file of the gang now (no-op for pages already cached)
-			if(src.fd >= 0){ (void)posix_fadvise(src.fd, 0, (off_t)(512ull << 20), POSIX_FADV_WILLNEED); }
-			if(!direct_loadable(src)){ break; }          // this file ends the gang and is staged on its own
-			n_direct = cnt;
-		}
-		if(g->d_row_map){          // sparse group: only the listed slices of these files
-			const char *gp[LOAD_GANG];
-			for(uint32_t k = 0; k < cnt; ++k){ gp[k] = paths[i0 + k]; }
-			if((rc = load_gang_sparse(g, ptrs, gp, byte0, cnt))){ return rc; }
-			i0 += cnt;
-			continue;
-		}
-		uint64_t rows_done = 0;
-		if(n_direct){
-			if((rc = load_gang_direct(g, ptrs, byte0, n_direct, &rows_done))){ return rc; }
-		}
-		for(uint32_t k = 0; k < cnt; ++k){
-			const uint64_t progress_before = g->ctx->load_progress ? __atomic_load_n(g->ctx->load_progress, __ATOMIC_RELAXED) : 0;
-			uint64_t from = (k < n_direct) ? rows_done : 0;
-			if(from == 0 && pipe.usable && srcs[k].header.compression == KWAGE_COMPRESSION_NONE){
-				if((rc = pipe.add_file(srcs[k], byte0[k], &from))){ return rc; }
-				if(from < g->nrows){ if((rc = pipe.flush())){ return rc; } }       // the staged paths share the staging buffers
-			}
-			else if(pipe.usable){ if((rc = pipe.flush())){ return rc; } }
-			if(from < g->nrows){
-				if((rc = load_source_rows_staged(g, srcs[k], paths[i0 + k], byte0[k], from))){ return rc; }
-				// its mapped path returns with copies and scatter kernels still in flight on the staging buffers the
-				// copy-engine pipeline shares (and records no load_done event): nothing of it may be left when the pipe
-				// writes into them again
-				if(pipe.usable){ HIP_TRY(hipStreamSynchronize(g->ctx->stream)); }
-			}
-			if(g->ctx->load_progress){       // the whole file has been passed now (windows reported themselves as they were pinned)
-				struct stat st;
-				if(fstat(srcs[k].fd, &st) == 0 && st.st_size > 0){
-					const uint64_t now = __atomic_load_n(g->ctx->load_progress, __ATOMIC_RELAXED), end = progress_before + (uint64_t)st.st_size;
-					if(end > now){ __atomic_fetch_add(g->ctx->load_progress, end - now, __ATOMIC_RELAXED); }
-				}
-			}
-		}
-		i0 += cnt;
-	}
-	if(pipe.usable || pipe.issued){ if((rc = pipe.flush())){ return rc; } }
-	return KWAGE_OK;
-}
-
-extern "C" int kwage_group_add_random_columns(kwage_group *g, uint64_t num_columns, uint64_t seed,
-                                              uint32_t density_q8, uint64_t *first_column)
-{
-	if(!g){ return fail(KWAGE_ERR_ARG, "kwage_group_add_random_columns: NULL group"); }
-	if(density_q8 > 256){ return fail(KWAGE_ERR_ARG, "density_q8 must be in [0,256]"); }
-	kwage_ctx *ctx = g->ctx;
-	int rc = set_device(ctx);
-	if(rc){ return rc; }
-	uint64_t byte0 = 0;
-	if((rc = group_reserve_columns(g, num_columns, &byte0))){ return rc; }
-	const uint64_t width = (num_columns + 7)/8;
-	const uint64_t words = g->nrows*((width + 7)/8);
-	hipLaunchKernelGGL(fill_random_kernel, dim3(grid_for(words, 256, 256*16)), dim3(256), 0, ctx->stream,
-	                   g->d_bits, g->stride, g->nrows, byte0, width, seed, density_q8);
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipStreamSynchronize(ctx->stream));
-	if(first_column){ *first_column = byte0*8; }
-	return KWAGE_OK;
-}
-
-extern "C" int kwage_group_set_bits(kwage_group *g, const uint32_t *rows, const uint64_t *columns, uint64_t n)
-{
-	if(!g || (n && (!rows || !columns))){ return fail(KWAGE_ERR_ARG, "kwage_group_set_bits: NULL argument"); }
-	if(n == 0){ return KWAGE_OK; }
-	kwage_ctx *ctx = g->ctx;
-	int rc = set_device(ctx);
-	if(rc){ return rc; }
-	for(uint64_t i = 0; i < n; ++i){
-		if(rows[i] >= g->nrows || columns[i] >= g->next_byte*8){
-			return fail(KWAGE_ERR_ARG, "kwage_group_set_bits: (row %u, column %llu) outside the matrix", rows[i], (unsigned long long)columns[i]);
-		}
-	}
-	DevBuf dr, dc;
-	if((rc = dr.reserve(n*sizeof(uint32_t))) || (rc = dc.reserve(n*sizeof(uint64_t)))){ dr.release(); dc.release(); return rc; }
-	hipError_t e = hipMemcpyAsync(dr.p, rows, n*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-	if(e == hipSuccess){ e = hipMemcpyAsync(dc.p, columns, n*sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream); }
-	if(e == hipSuccess){
-		hipLaunchKernelGGL(set_bits_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream,
-		                   g->d_bits, g->stride, (const uint32_t*)dr.p, (const uint64_t*)dc.p, n);
-		e = hipGetLastError();
-	}
-	if(e == hipSuccess){ e = hipStreamSynchronize(ctx->stream); }
-	dr.release(); dc.release();
-	if(e != hipSuccess){ return fail(KWAGE_ERR_DEVICE, "kwage_group_set_bits: %s", hipGetErrorString(e)); }
-	return KWAGE_OK;
-}
-
-extern "C" int kwage_group_read_rows(kwage_group *g, const uint32_t *rows, uint64_t n, void *out, uint64_t out_stride)
-{
-	if(!g || (n && (!rows || !out))){ return fail(KWAGE_ERR_ARG, "kwage_group_read_rows: NULL argument"); }
-	if(n == 0){ return KWAGE_OK; }
-	const uint64_t row_bytes = g->next_byte;
-	if(row_bytes == 0){ return fail(KWAGE_ERR_STATE, "kwage_group_read_rows: group has no columns"); }
-	if(out_stride < row_bytes){ return fail(KWAGE_ERR_ARG, "kwage_group_read_rows: out_stride < row_bytes"); }
-	for(uint64_t i = 0; i < n; ++i){
-		if(rows[i] >= g->nrows){ return fail(KWAGE_ERR_ARG, "kwage_group_read_rows: row %u out of range", rows[i]); }
-	}
-	kwage_ctx *ctx = g->ctx;
-	int rc = set_device(ctx);
-	if(rc){ return rc; }
-	DevBuf dr, dout;
-	if((rc = dr.reserve(n*sizeof(uint32_t))) || (rc = dout.reserve(n*row_bytes))){ dr.release(); dout.release(); return rc; }
-	hipError_t e = hipMemcpyAsync(dr.p, rows, n*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-	if(e == hipSuccess){
-		hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n*row_bytes, 256)), dim3(256), 0, ctx->stream,
-		                   (const uint8_t*)g->d_bits, g->stride, (const uint32_t*)dr.p, n, row_bytes, (uint8_t*)dout.p);
-		e = hipGetLastError();
-	}
-	if(e == hipSuccess){
-		e = hipMemcpy2DAsync(out, out_stride, dout.p, row_bytes, row_bytes, n, hipMemcpyDeviceToHost, ctx->stream);
-	}
-	if(e == hipSuccess){ e = hipStreamSynchronize(ctx->stream); }
-	dr.release(); dout.release();
-	if(e != hipSuccess){ return fail(KWAGE_ERR_DEVICE, "kwage_group_read_rows: %s", hipGetErrorString(e)); }
-	return KWAGE_OK;
-}
-
-extern "C" int kwage_group_finalize(kwage_group *g)
-{
-	if(!g){ return fail(KWAGE_ERR_ARG, "kwage_group_finalize: NULL group"); }
-	kwage_ctx *ctx = g->ctx;
-	int rc = set_device(ctx);
-	if(rc){ return rc; }
-	HIP_TRY(hipMemcpyAsync(g->d_valid, g->h_valid.data(), g->stride, hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(hipStreamSynchronize(ctx->stream));
-	release_mapping(ctx);          // the last file's copies are done
-	g->finalized = true;
-	return KWAGE_OK;
-}
-
-extern "C" uint64_t kwage_group_num_columns(const kwage_group *g) { return g ? g->num_columns : 0; }
-extern "C" uint64_t kwage_group_column_span(const kwage_group *g) { return g ? g->next_byte*8 : 0; }
-extern "C" uint64_t kwage_group_row_bytes(const kwage_group *g) { return g ? g->next_byte : 0; }
-extern "C" uint64_t kwage_group_row_stride(const kwage_group *g) { return g ? g->stride : 0; }
-extern "C" uint64_t kwage_group_device_bytes(const kwage_group *g) { return g ? g->alloc_bytes : 0; }
-
-extern "C" int kwage_group_params(const kwage_group *g, kwage_params *out)
-{
-	if(!g || !out){ return fail(KWAGE_ERR_ARG, "kwage_group_params: NULL argument"); }
-	*out = g->params;
-	return KWAGE_OK;
-}
-
 // ------------------------------------------------------------------------------------------
 // query batch
 // ------------------------------------------------------------------------------------------

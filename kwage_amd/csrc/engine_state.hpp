@@ -1,0 +1,303 @@
+// kwage_amd/csrc/engine_state.hpp -- what the translation units of the device library share: the context, the
+// database group, the query batch and the buffers they own.  Private to kwage_amd/csrc (the C ABI exposes these types
+// as opaque pointers only).
+//
+//   engine.hip   contexts, tuning knobs, query batches, the search pipeline (k-mer stage, gather kernels, hit lists)
+//   loader.hip   database groups: allocation, the loaders (.db files raw and compressed, sparse groups), synthetic columns
+#ifndef KWAGE_AMD_ENGINE_STATE_HPP
+#define KWAGE_AMD_ENGINE_STATE_HPP
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "internal.h"
+
+#define HIP_TRY(expr)                                                                          \
+	do {                                                                                       \
+		hipError_t _e = (expr);                                                                \
+		if(_e != hipSuccess){                                                                  \
+			return fail(KWAGE_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+			            __FILE__, __LINE__);                                                   \
+		}                                                                                      \
+	} while(0)
+
+struct kwage_group;
+struct kwage_batch;
+struct kwage_ctx;
+
+namespace kwage {
+
+struct KmerLayout;
+
+// A device buffer that only ever grows (scratch reused across searches).
+struct DevBuf {
+	void *p = nullptr;
+	uint64_t cap = 0;
+	int reserve(uint64_t bytes)
+	{
+		if(bytes <= cap){ return KWAGE_OK; }
+		if(p){ (void)hipFree(p); p = nullptr; cap = 0; }
+		const uint64_t want = std::max<uint64_t>(bytes + bytes/4, 4096);
+		HIP_TRY(hipMalloc(&p, want));
+		cap = want;
+		return KWAGE_OK;
+	}
+	void release()
+	{
+		if(p){ (void)hipFree(p); }
+		p = nullptr; cap = 0;
+	}
+};
+
+struct PinBuf {
+	void *p = nullptr;
+	uint64_t cap = 0;
+	int reserve(uint64_t bytes)
+	{
+		if(bytes <= cap){ return KWAGE_OK; }
+		if(p){ (void)hipHostFree(p); p = nullptr; cap = 0; }
+		const uint64_t want = std::max<uint64_t>(bytes + bytes/4, 4096);
+		HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+		cap = want;
+		return KWAGE_OK;
+	}
+	void release()
+	{
+		if(p){ (void)hipHostFree(p); }
+		p = nullptr; cap = 0;
+	}
+};
+
+// Pinned host blocks for LONG hit lists, recycled between searches: a list of 100 M records (1.2 GB) crosses PCIe in
+// 22 ms, but landing it in fresh pageable memory cost 0.2 s (a page fault per 4 KiB, one thread's memcpy) -- so the
+// result array of a long list IS a pinned block, the D2H copy's destination, and kwage_result_free hands it back for
+// the next search.  Results may outlive their context: the pool is shared, kwage_shutdown closes it.
+struct PinnedPool {
+	static const size_t MAX_CACHED_BLOCKS = 2;
+	static const uint64_t MAX_CACHED_BYTES = 8ull << 30;
+	std::mutex mu;
+	bool open = true;
+	std::vector<PinBuf> cached;
+	int acquire(uint64_t bytes, PinBuf *out)
+	{
+		{
+			std::lock_guard<std::mutex> lock(mu);
+			size_t best = cached.size();
+			for(size_t i = 0; i < cached.size(); ++i){
+				if(cached[i].cap >= bytes && (best == cached.size() || cached[i].cap < cached[best].cap)){ best = i; }
+			}
+			if(best != cached.size()){
+				*out = cached[best];
+				cached.erase(cached.begin() + (long)best);
+				return KWAGE_OK;
+			}
+		}
+		out->p = nullptr; out->cap = 0;
+		return out->reserve(bytes);
+	}
+	void release(PinBuf &b)
+	{
+		if(!b.p){ return; }
+		{
+			std::lock_guard<std::mutex> lock(mu);
+			uint64_t held = 0;
+			for(const PinBuf &c : cached){ held += c.cap; }
+			if(open && cached.size() < MAX_CACHED_BLOCKS && held + b.cap <= MAX_CACHED_BYTES){
+				cached.push_back(b);
+				b.p = nullptr; b.cap = 0;
+				return;
+			}
+		}
+		b.release();
+	}
+	void close()
+	{
+		std::lock_guard<std::mutex> lock(mu);
+		open = false;
+		for(PinBuf &c : cached){ c.release(); }
+		cached.clear();
+	}
+};
+
+// (SEARCH_THREADS / WAVE of kernels.hpp, which this header does not need otherwise; engine.hip asserts they agree)
+static const int64_t TUNING_DEFAULT_BLOCK_WAVES = 4;
+
+// Everything one in-flight search owns.  A context has two slots so that a second search can be
+// submitted (and its k-mer stage run) while the first one's results are still being collected.
+struct Slot {
+	hipStream_t stream = nullptr;
+	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t search_done = nullptr;   // recorded behind the slot's gather kernel(s)
+	bool search_done_valid = false;
+	// scratch, grown on demand and reused
+	DevBuf rows, tables, partial;
+	// One contiguous result block per search, so that a single D2H copy returns everything:
+	//   [counters: 4 x u64 (hits, -, -, sink)] [nkmer: n x u32] [qthr: n x u32] [pad to 16] [hits: cap x 12 B]
+	DevBuf result;
+	uint64_t *d_counters = nullptr;
+	uint32_t *d_nkmer = nullptr, *d_qthr = nullptr;
+	kwage_hit *d_hits = nullptr;
+	uint64_t hit_cap = 0, head_bytes = 0;
+	PinBuf h_stage;        // host image of the head of the result block + the first SPEC_HITS records
+	DevBuf sort_scratch;   // key / value buffers of the device hit sort (lists beyond SPEC_HITS only)
+	// the submission occupying the slot
+	bool busy = false;
+	kwage_group *g = nullptr;
+	kwage_batch *b = nullptr;
+	const KmerLayout *lay = nullptr;     // the batch's layout for the group's k-mer length
+	float threshold = 1.0f;
+	uint32_t flags = 0;
+	uint32_t launches = 0;
+	char kernel_name[64] = "";          // the gather kernel launch_search_stage picked, with its template shape
+	// and_walk_kernel's meeting place for (query, tile) pairs cut by a wave-share boundary: all zero between searches
+	DevBuf walk_or, walk_done;
+	// count_walk_kernel's: partial counters of cut pairs (overwritten before they are read) and the arrival counters of their trees (zero between searches)
+	DevBuf cwalk_slab, cwalk_arrived;
+	uint64_t staged_hits = 0;
+	kwage_hit *ext_hits = nullptr;      // caller-owned device buffer (kwage_search_device) or null
+	uint64_t ext_cap = 0;
+	uint64_t *ext_count = nullptr;      // optional device word that receives the hit count in stream order
+	// append mode (kwage_search_device_append_submit): *ext_count IS the hit counter -- not zeroed unless asked, so the
+	// searches of several groups fill one list -- and col_base is added to every reported column
+	bool append = false, append_reset = false;
+	uint32_t col_base = 0;
+};
+
+// Kernel-selection knobs.  They are parsed ONCE, from the environment, when a context is created, and changed afterwards
+// only through kwage_ctx_set_tuning (tests and tuning tools): nothing on the search path reads the environment.
+struct Tuning {
+	int64_t walk = 4;               // KWAGE_WALK: and_walk_kernel's rows in flight (4 or 2); 0 = always the tiled kernel
+	int64_t walk_min_rows = -1;     // KWAGE_WALK_MIN_ROWS: batches with fewer rows use the tiled kernel (-1: 64 rows per wave of the chip)
+	int64_t walk_max_kib = 16;      // KWAGE_WALK_MAX_KIB: widest row the walk form takes
+	int64_t walk_early_exit = 0;    // KWAGE_WALK_EARLY_EXIT: use the walk form with early exit too (the tiled kernel stops sooner)
+	int64_t walk_waves = 0;         // KWAGE_WALK_WAVES: exactly this many waves (tests: shares of every size); 0 = from the CU count
+	int64_t walk_fences = 0;        // KWAGE_WALK_FENCES: agent-scope fences around the cut-pair count (measurement only)
+	int64_t walk_one_wg_per_cu = 1; // KWAGE_WALK_ONE_WG_PER_CU: chip-filling launches of the persistent kernels use one workgroup of 8 waves per CU (0: workgroups of 4 waves, placed by the dispatcher)
+	int64_t and_vec = 0;            // KWAGE_AND_CFG="vec,unroll,nt[,ldsKB[,block waves]]": shape of the tiled AND kernel (0 = by row width)
+	int64_t and_unroll = 8;
+	int64_t and_nt = 1;
+	int64_t and_lds_kb = 0;         //   dynamic LDS per workgroup caps the waves per CU (tuning only)
+	int64_t and_block_waves = TUNING_DEFAULT_BLOCK_WAVES;
+	int64_t narrow = 1;             // KWAGE_NARROW: several queries per wave for rows <= 512 B
+	int64_t narrow_unroll = 0;      // KWAGE_NARROW_UNROLL: rows in flight per wave of the narrow AND kernel (0 = by the number of waves; 8, 16)
+	int64_t force_segs = 0;         // KWAGE_FORCE_SEGS: cut every query's k-mer list into this many segments (tests)
+	int64_t count_walk = 1;         // KWAGE_COUNT_WALK: the persistent count kernel where it applies
+	int64_t count_walk_wpc = 8;     // KWAGE_COUNT_WALK_WPC: its waves per CU (8: 6335 GB/s at C2's shape, 12: 6271, 16: 6250, 20: 5876)
+	int64_t count_walk_waves = 0;   // KWAGE_COUNT_WALK_WAVES: exactly this many waves (tests)
+	int64_t count_walk_min_rows = -1;   // KWAGE_COUNT_WALK_MIN_ROWS: smaller batches use the tiled kernel (-1: 64 rows for each of its waves)
+	int64_t count_walk_prefetch = 1;    // KWAGE_COUNT_WALK_PREFETCH: request the next four k-mers' rows before adding the current four (+1.3 % at C2's shape)
+	int64_t count_narrow_kps = 8;   // KWAGE_COUNT_NARROW_KPS: k-mers per step of the narrow count kernel (8 or 4)
+	int64_t hit_sort_host = 0;      // KWAGE_HIT_SORT=host: order long hit lists on the host (A/B runs, the fallback)
+	int64_t hit_copy_piece_kb = 0;  // KWAGE_HIT_COPY_PIECE_KB: piece size of the copy-back of a long hit list (0 = default)
+	int64_t shared_table_log2 = 0;  // KWAGE_SHARED_TABLE_LOG2: at least this many slots in a sample's shared distinct set (tests)
+};
+
+}  // namespace kwage
+
+struct kwage_ctx {
+	int device = -1;
+	int ncu = 0;                        // compute units of the device (persistent grids are sized from it)
+	kwage::Tuning tune;
+	hipStream_t stream = nullptr;       // == slot[0].stream; loading, building and the synchronous calls use it
+	kwage::Slot slot[2];
+	kwage::DevBuf kmers;                       // kwage_hash_batch output
+	// database loading: two pinned + two device staging buffers, kept across files
+	kwage::PinBuf load_pin[2];
+	kwage::DevBuf load_dev[3];                 // [2] is used by the copy-engine pipeline only (three chunks in flight)
+	hipEvent_t load_done[3] = {nullptr, nullptr, nullptr};
+	// zero-copy loading: the file mapping whose H2D copies may still be in flight on `stream`
+	void *map_base = nullptr;
+	size_t map_len = 0;
+	hipEvent_t map_done = nullptr;      // recorded behind the last copy that reads the mapping
+	// direct loading: file windows locked through HSA whose copy kernels may still be running, oldest first
+	struct LockedWindow { void *base; size_t len; hipEvent_t done; bool owns_event; };     // the windows of one launch share its event; the last one owns it
+	std::deque<LockedWindow> locked;
+	std::vector<hipEvent_t> spare_events;
+	volatile uint64_t *load_progress = nullptr;      // kwage_set_load_progress
+	std::shared_ptr<kwage::PinnedPool> result_pool = std::make_shared<kwage::PinnedPool>();      // result arrays of long hit lists
+	// CPUs of the NUMA node the device hangs on (empty: unknown, or the process may not run there): database loading
+	// runs on them (the page-cache pages it pins and the staging traffic then stay on the GPU's side of the host)
+	std::vector<int> numa_cpus;
+	int numa_node = -1;
+};
+
+struct kwage_group {
+	kwage_ctx *ctx = nullptr;
+	kwage_params params{};
+	uint64_t nrows = 0;
+	uint64_t stride = 0;           // bytes, multiple of 128
+	uint64_t next_byte = 0;        // next free byte column within a row
+	uint64_t num_columns = 0;      // valid columns
+	uint8_t *d_bits = nullptr;
+	uint8_t *d_valid = nullptr;
+	uint64_t alloc_bytes = 0;
+	std::vector<uint8_t> h_valid;
+	bool finalized = false;
+	// sparse group (kwage_group_create_sparse): the matrix holds only the listed rows of every file, in this order
+	// (sorted, distinct); row indices from the k-mer stage are translated to positions in the list before the gather
+	std::vector<uint32_t> h_row_map;
+	uint32_t *d_row_map = nullptr;
+};
+
+namespace kwage {
+
+// Where the k-mer positions of a batch's queries lie for ONE k-mer length: what the k-mer stage and the gather kernels
+// index their row lists with.
+struct KmerLayout {
+	uint32_t k = 0;
+	uint64_t total_pos = 0;        // sum over the queries of max(len - k + 1, 0)
+	uint64_t max_pos = 0;
+	uint64_t table_slots = 0;      // global hash-set slots needed by long queries
+	uint64_t *d_pos_off = nullptr; // n+1: position prefix
+	uint64_t *d_tab_off = nullptr; // n: slot offset of a long query's global distinct set
+	// k-mer stage work list: one workgroup per chunk; a query above KM_LDS_SLOTS/2 positions is cut into chunks of
+	// KM_CHUNK positions that share its global distinct set, everything shorter is one chunk
+	uint32_t *d_chunk_q = nullptr;     // n_chunks: query of the chunk
+	uint64_t *d_chunk_t0 = nullptr;    // n_chunks: its first position within the query
+	uint64_t n_chunks = 0;
+	bool multi_chunk = false;          // some query has more than one chunk
+	std::vector<uint64_t> h_pos_off;
+	~KmerLayout()
+	{
+		if(d_pos_off){ (void)hipFree(d_pos_off); }
+		if(d_tab_off){ (void)hipFree(d_tab_off); }
+		if(d_chunk_q){ (void)hipFree(d_chunk_q); }
+		if(d_chunk_t0){ (void)hipFree(d_chunk_t0); }
+	}
+};
+
+}  // namespace kwage
+
+struct kwage_batch {
+	kwage_ctx *ctx = nullptr;
+	uint32_t n = 0;
+	uint64_t total_len = 0;
+	char *d_seqs = nullptr;
+	uint64_t *d_seq_off = nullptr;
+	std::vector<uint64_t> h_seq_off;
+	// One layout per k-mer length the batch has been searched with (a database directory may hold files of several
+	// k: two or three in practice).  A layout never changes once built, so searches with different k-mer lengths can
+	// be in flight on the same batch side by side.
+	std::vector<std::unique_ptr<kwage::KmerLayout>> layouts;
+};
+
+namespace kwage {
+
+inline int set_device(kwage_ctx *ctx)
+{
+	HIP_TRY(hipSetDevice(ctx->device));
+	return KWAGE_OK;
+}
+
+// loader.hip, called where a context is created and destroyed
+void find_numa_cpus(int device, int *node, std::vector<int> *cpus);
+void release_mapping(kwage_ctx *ctx);
+
+}  // namespace kwage
+
+#endif

@@ -1150,141 +1150,6 @@ __global__ __launch_bounds__(COMBINE_WAVES*WAVE) void count_combine_kernel(Searc
 	if(w == 0){ emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q], on); }
 }
 
-// ------------------------------------------------------------------------------------------
-// database construction / inspection kernels
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t splitmix64(uint64_t &x)
-{
-	x += 0x9E3779B97F4A7C15ull;
-	uint64_t z = x;
-	z = (z ^ (z >> 30))*0xBF58476D1CE4E5B9ull;
-	z = (z ^ (z >> 27))*0x94D049BB133111EBull;
-	return z ^ (z >> 31);
-}
-
-// 64 i.i.d. Bernoulli(q8/256) bits: fold random words along the binary expansion of q8
-// (bit set -> OR, bit clear -> AND), least significant set bit first.
-__device__ __forceinline__ uint64_t bernoulli64(uint64_t key, uint32_t q8)
-{
-	if(q8 >= 256){ return ~0ull; }
-	if(q8 == 0){ return 0; }
-	uint64_t x = key;
-	uint64_t r = 0;
-	bool started = false;
-	for(int b = 0; b < 8; ++b){
-		const bool bit = (q8 >> b) & 1u;
-		if(!started){
-			if(bit){ r = splitmix64(x); started = true; }
-		}
-		else{
-			const uint64_t d = splitmix64(x);
-			r = bit ? (r | d) : (r & d);
-		}
-	}
-	return r;
-}
-
-// Fill bytes [byte0, byte0+nbytes) of every row with random bits. byte0 is 8-byte aligned.
-__global__ void fill_random_kernel(uint8_t *db, uint64_t stride, uint64_t nrows, uint64_t byte0,
-                                   uint64_t nbytes, uint64_t seed, uint32_t q8)
-{
-	const uint64_t words_per_row = (nbytes + 7)/8;
-	const uint64_t total = nrows*words_per_row;
-	for(uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x*blockDim.x){
-		const uint64_t r = i / words_per_row;
-		const uint64_t w = i % words_per_row;
-		const uint64_t key = seed ^ (r*0xD1342543DE82EF95ull) ^ ((byte0/8 + w)*0xA24BAED4963EE407ull);
-		const uint64_t bits = bernoulli64(key, q8);
-		uint8_t *dst = db + r*stride + byte0 + w*8;
-		const uint64_t remain = nbytes - w*8;
-		if(remain >= 8){
-			*reinterpret_cast<uint64_t*>(dst) = bits;
-		}
-		else{
-			for(uint64_t b = 0; b < remain; ++b){ dst[b] = (uint8_t)(bits >> (8*b)); }
-		}
-	}
-}
-
-// Copy a contiguous block of rows (src: nrows x width) into the strided matrix at byte offset byte0.
-__global__ void place_rows_kernel(uint8_t *db, uint64_t stride, uint64_t row0, uint64_t byte0,
-                                  const uint8_t *src, uint64_t src_stride, uint64_t width, uint64_t nrows)
-{
-	if(((width | byte0 | src_stride) & 3ull) == 0 && ((uintptr_t)src & 3ull) == 0){
-		const uint64_t wpr = width/4;
-		const uint64_t total = nrows*wpr;
-		for(uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x*blockDim.x){
-			const uint64_t r = i / wpr, w = i % wpr;
-			*reinterpret_cast<uint32_t*>(db + (row0 + r)*stride + byte0 + 4*w) =
-				*reinterpret_cast<const uint32_t*>(src + r*src_stride + 4*w);
-		}
-	}
-	else{
-		const uint64_t total = nrows*width;
-		for(uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x*blockDim.x){
-			const uint64_t r = i / width, b = i % width;
-			db[(row0 + r)*stride + byte0 + b] = src[r*src_stride + b];
-		}
-	}
-}
-
-// Loader, direct path.  Rows of up to LOAD_GANG files -- windows of `.db` files locked in host memory, read over PCIe;
-// only dword aligned: the body of a file starts at byte 44 -- to rows row0.. of the strided matrix, every file at its
-// own byte column (16-byte aligned, adjacent for full 2048-column files).  UB = bytes per lane: 16 when every row
-// length is a multiple of 16, else 4.  Consecutive lanes write consecutive bytes of ONE matrix row across the files
-// of the gang, so a 100 KB-wide matrix is written 4 KiB at a time instead of 256 bytes at a time (one file per
-// kernel filled a 105 GB matrix at 14 GB/s: every 256-byte piece opened another DRAM page and another TLB entry).
-static constexpr uint32_t LOAD_GANG_MAX = 16;
-struct GangSource { const uint8_t *src; uint64_t byte0; uint64_t width; };        // window of one file, its byte column in the matrix, its row length
-struct GangArgs { GangSource f[LOAD_GANG_MAX]; uint32_t n; };
-
-typedef u32x4 u32x4_dword_aligned __attribute__((aligned(4)));
-
-// One work item = 64 lanes x UB consecutive bytes of ONE file's window, and the four waves of a workgroup take four
-// consecutive items of the same file: a workgroup reads a contiguous 4 KiB (one host page of the page cache) exactly as
-// a plain sequential copy would.  Consecutive workgroups take the same stretch of consecutive files, so the pieces that
-// are neighbours in a matrix row are written at about the same time, by neighbouring workgroups, into the same DRAM
-// pages and through the same TLB entries.
-template <int UB>
-__global__ __launch_bounds__(256) void copy_rows_gang_kernel(uint8_t *db, uint64_t stride, uint64_t row0, GangArgs ga, uint64_t nrows, uint64_t items)
-{
-	const uint32_t lane = threadIdx.x & (WAVE - 1);
-	const uint64_t nwaves = ((uint64_t)gridDim.x*blockDim.x) >> 6;
-	for(uint64_t it = ((uint64_t)blockIdx.x*blockDim.x + threadIdx.x) >> 6; it < items; it += nwaves){
-		// it = ((stretch*n + file)*4 + quarter): quarter = wave within the workgroup
-		const uint32_t fi = __builtin_amdgcn_readfirstlane((uint32_t)((it >> 2) % ga.n));
-		const uint64_t chunk = ((it >> 2) / ga.n)*4 + (it & 3);
-		const uint64_t width = ga.f[fi].width;
-		const uint64_t off = chunk*(WAVE*UB) + (uint64_t)lane*UB;        // byte offset within this file's window
-		if(off < nrows*width){
-			const uint64_t r = off / width, col = off % width;           // UB divides width: a lane never straddles two rows
-			const uint8_t *s = ga.f[fi].src + off;
-			uint8_t *d = db + (row0 + r)*stride + ga.f[fi].byte0 + col;
-			if(UB == 16){ *reinterpret_cast<u32x4*>(d) = *reinterpret_cast<const u32x4_dword_aligned*>(s); }
-			else{ *reinterpret_cast<uint32_t*>(d) = *reinterpret_cast<const uint32_t*>(s); }
-		}
-	}
-}
-
-__global__ void set_bits_kernel(uint8_t *db, uint64_t stride, const uint32_t *rows, const uint64_t *cols, uint64_t n)
-{
-	for(uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x*blockDim.x){
-		const uint64_t c = cols[i];
-		uint32_t *word = reinterpret_cast<uint32_t*>(db + (uint64_t)rows[i]*stride + (c/32)*4);
-		atomicOr(word, 1u << (c % 32));      // little endian: bit c%8 of byte c/8 (bloom.h:162)
-	}
-}
-
-__global__ void gather_rows_kernel(const uint8_t *db, uint64_t stride, const uint32_t *rows, uint64_t n,
-                                   uint64_t row_bytes, uint8_t *out)
-{
-	const uint64_t total = n*row_bytes;
-	for(uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x*blockDim.x){
-		const uint64_t r = i / row_bytes, b = i % row_bytes;
-		out[i] = db[(uint64_t)rows[r]*stride + b];
-	}
-}
-
 // Streaming read of the matrix: the box's achievable HBM read rate, reported beside every roofline number.  Every wave
 // walks a contiguous region of its own, eight 1-KiB loads in flight (tools/micro/power_probe.hip: this pattern streams
 // 6.9 TB/s where a grid-stride walk -- round 1/2's probe -- measured 6.4 on the same box; a random-row gather reaches
