@@ -76,6 +76,9 @@ Share share_of(const vector<uint32_t> &group_files, const vector<DbFileEntry> &f
 	return s;
 }
 
+// A file's columns in the global numbering of the hit records.
+struct ColumnBlock { uint64_t first_global_column; uint32_t file_index, kmer_len; };
+
 struct NodeGroup {
 	GroupKey key;
 	kwage_params params;
@@ -141,6 +144,15 @@ int run_rank(int rank, int n_ranks, const string &id_path, const Cli &cli, const
 			groups.push_back(std::move(g));
 		}
 		if(next_base > (1ull << 32)){ throw "main: more than 2^32 columns in the database"; }
+		// where every file's columns begin in the global numbering (ascending: groups, ranks and files are numbered in order)
+		vector<ColumnBlock> blocks;
+		for(const NodeGroup &g : groups){
+			for(size_t r = 0; r < (size_t)n_ranks; ++r){
+				for(size_t f = 0; f < g.share[r].files.size(); ++f){
+					blocks.push_back(ColumnBlock{g.base[r] + g.share[r].first_column[f], g.share[r].files[f], g.params.kmer_len});
+				}
+			}
+		}
 
 		// ---- this rank's device, its communicator, its matrices ---------------------------------------------------------
 		kwage_ctx *ctx = nullptr;
@@ -287,21 +299,14 @@ int run_rank(int rank, int n_ranks, const string &id_path, const Cli &cli, const
 					vector<Match> &dst = found.by_query.try_emplace(found.by_query.end(), qid)->second;
 					if(!q.deflines.empty()){ found.defline.try_emplace(found.defline.end(), qid, q.deflines[qi]); }
 					for(; i < total && hits[i].query == qi; ++i){
-						const uint64_t col = hits[i].column;
-						size_t gi = groups.size() - 1;              // the last group whose first base is <= col ...
-						while(gi > 0 && groups[gi].base[0] > col){ --gi; }
-						const NodeGroup &g = groups[gi];
-						size_t r = (size_t)n_ranks - 1;             // ... and in it the last rank whose base is <= col
-						while(r > 0 && g.base[r] > col){ --r; }
-						const Share &s = g.share[r];
-						const uint64_t local = col - g.base[r];
-						size_t f = s.files.size() - 1;
-						while(f > 0 && s.first_column[f] > local){ --f; }
+						// the last block that starts at or before the column
+						const ColumnBlock &blk = *(upper_bound(blocks.begin(), blocks.end(), (uint64_t)hits[i].column,
+						                                       [](uint64_t col, const ColumnBlock &b) { return col < b.first_global_column; }) - 1);
 						Match m;
 						m.num_kmers_found = hits[i].num_match;
-						m.num_query_kmer = nk_by_k[g.params.kmer_len][qi];
-						m.file_index = s.files[f];
-						m.column = (uint32_t)(local - s.first_column[f]);
+						m.num_query_kmer = nk_by_k[blk.kmer_len][qi];
+						m.file_index = blk.file_index;
+						m.column = (uint32_t)(hits[i].column - blk.first_global_column);
 						dst.push_back(m);
 					}
 				}

@@ -87,6 +87,12 @@ const HsaApi &hsa_api()
 	return h;
 }
 
+bool load_env_flag(const char *name, bool fallback)
+{
+	const char *e = getenv(name);
+	return e ? atoi(e) != 0 : fallback;
+}
+
 uint32_t grid_for(uint64_t work_items, uint32_t block, uint32_t cap_blocks = 256*8)
 {
 	const uint64_t b = (work_items + block - 1)/block;
@@ -210,7 +216,16 @@ int group_allocate(kwage_ctx *ctx, const kwage_params *params, uint64_t column_c
 	g->stride = (row_bytes + 127)/128*128;
 	if(g->stride/16 > 0x7FFFFFFFull){ delete g; return fail(KWAGE_ERR_ARG, "kwage_group_create: row too wide"); }
 	g->alloc_bytes = g->stride*g->nrows;
-	hipError_t e = hipMalloc((void**)&g->d_bits, g->alloc_bytes);
+	// Physically contiguous device memory where the driver can provide it (KWAGE_GROUP_CONTIGUOUS=0: plain hipMalloc):
+	// where a 105 GB matrix happens to lie decides 3-8 % of the gather kernels' rate (tools/micro/placement_probe.hip,
+	// profiles/r03_placement_probe.txt); a contiguous block was the fastest or within 0.6 % of it in every process measured.
+	static const bool contiguous = load_env_flag("KWAGE_GROUP_CONTIGUOUS", true);
+	hipError_t e = hipErrorOutOfMemory;
+	if(contiguous && g->alloc_bytes >= (64ull << 20)){
+		e = hipExtMallocWithFlags((void**)&g->d_bits, g->alloc_bytes, hipDeviceMallocContiguous);
+		if(e != hipSuccess){ (void)hipGetLastError(); g->d_bits = nullptr; }
+	}
+	if(e != hipSuccess){ e = hipMalloc((void**)&g->d_bits, g->alloc_bytes); }
 	if(e != hipSuccess){
 		const double gb = (double)g->alloc_bytes/1e9;
 		delete g;
@@ -347,12 +362,6 @@ extern "C" int kwage_group_add_columns(kwage_group *g, const void *host_rows, ui
 namespace {
 
 static const uint32_t LOAD_GANG = LOAD_GANG_MAX;      // files whose rows one copy kernel writes side by side (16 x 256 B = 4 KiB per matrix row)
-
-bool load_env_flag(const char *name, bool fallback)
-{
-	const char *e = getenv(name);
-	return e ? atoi(e) != 0 : fallback;
-}
 
 uint64_t load_env_kb(const char *name, uint64_t fallback_bytes)
 {
