@@ -6,6 +6,7 @@
 //   va2g      hipMalloc(bytes + 2 GiB), the matrix starts at the next 2 GiB boundary of the virtual address
 //   vmm<N>    hipMemAddressReserve + physical memory created in N-MiB handles, mapped side by side
 //   vmma<N>   the same, mapped from a 2 GiB boundary of a larger reservation (hipMemAddressReserve ignores its alignment argument)
+//   <variant>:<W>   all waves read from the same 1/W of the matrix at the same time (window after window)
 //   hipcc --offload-arch=gfx950 -O3 -o placement_probe placement_probe.hip ;  ./placement_probe [variant ...]
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -19,7 +20,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do{ hipError_t e=(x); if(e!=hipSuccess){ printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } }while(0)
 
 template <int R>
-__global__ __launch_bounds__(512) void gather(const u32x4 *src, uint64_t nrows, uint32_t row_kib, uint64_t stride16, uint64_t rows_per_wave, uint32_t *sink)
+__global__ __launch_bounds__(512) void gather(const u32x4 *src, uint64_t nrows, uint32_t row_kib, uint64_t stride16, uint64_t rows_per_wave, uint32_t *sink, uint32_t nwin)
 {
 	extern __shared__ uint32_t pad[];
 	u32x4 acc = (u32x4)(0u);
@@ -31,7 +32,9 @@ __global__ __launch_bounds__(512) void gather(const u32x4 *src, uint64_t nrows, 
 #pragma unroll
 		for(int u = 0; u < R; ++u){
 			x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
-			const uint64_t row = __builtin_amdgcn_readfirstlane((uint32_t)((x*0x2545F4914F6CDD1Dull) >> 33)) % nrows;
+			// nwin > 1: all waves draw their rows from the SAME 1/nwin of the matrix at the same time (window after window)
+			const uint64_t per_win = nrows/nwin, win = (r + u)*nwin/rows_per_wave;
+			const uint64_t row = win*per_win + __builtin_amdgcn_readfirstlane((uint32_t)((x*0x2545F4914F6CDD1Dull) >> 33)) % per_win;
 			p[u] = src + row*stride16 + lane;
 		}
 		for(uint32_t j = 0; j < row_kib; ++j){
@@ -120,7 +123,7 @@ int main(int argc, char **argv)
 	for(int i = 1; i < argc; ++i){ variants.push_back(argv[i]); }
 	if(variants.empty()){ variants = {"plain", "plain", "va2g", "vmm1024", "vmm2048", "vmm256", "plain"}; }
 	const uint64_t nrows = 1ull << 23, stride = 12544, row_kib = 13;            // C2: 100 000 samples = 12 500 B per row, rows 128 B aligned
-	const size_t bytes = nrows*stride;
+	const size_t bytes = nrows*stride + (2u << 20);          // (a row is READ as 13 KiB, 768 B more than the stride: slack behind the last row)
 	hipDeviceProp_t prop;
 	CK(hipGetDeviceProperties(&prop, 0));
 	const int ncu = prop.multiProcessorCount;
@@ -129,7 +132,10 @@ int main(int argc, char **argv)
 	hipEvent_t e0, e1;
 	CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 	const uint64_t waves = (uint64_t)ncu*8, rows_per_wave = 970000/waves/4*4;   // C2's batch: 970 k rows
-	for(const std::string &how : variants){
+	for(std::string how : variants){
+		uint32_t nwin = 1;
+		const size_t colon = how.find(':');          // "contig:8" = eight windows
+		if(colon != std::string::npos){ nwin = (uint32_t)atoi(how.c_str() + colon + 1); how = how.substr(0, colon); }
 		Block b;
 		if(allocate(how, bytes, 0, &b)){ return 1; }
 		CK(hipMemsetAsync(b.use, 0x5a, bytes, 0));
@@ -138,7 +144,7 @@ int main(int argc, char **argv)
 		const int reps = 9;
 		for(int i = 0; i < reps + 1; ++i){
 			CK(hipEventRecord(e0, 0));
-			hipLaunchKernelGGL(gather<4>, dim3(ncu), dim3(512), 100*1024, 0, (const u32x4*)b.use, nrows, (uint32_t)row_kib, stride/16, rows_per_wave, sink);
+			hipLaunchKernelGGL(gather<4>, dim3(ncu), dim3(512), 100*1024, 0, (const u32x4*)b.use, nrows, (uint32_t)row_kib, stride/16, rows_per_wave, sink, nwin);
 			CK(hipEventRecord(e1, 0));
 			CK(hipEventSynchronize(e1));
 			float ms = 0;
@@ -146,7 +152,7 @@ int main(int argc, char **argv)
 			if(i){ best = ms < best ? ms : best; sum += ms; }
 		}
 		const double touched = (double)waves*rows_per_wave*row_kib*1024;
-		printf("%-8s at %p  avg %.4f ms  best %.4f ms -> %.0f GB/s touched (avg)\n", how.c_str(), b.use, sum/reps, best, touched/(sum/reps)/1e6);
+		printf("%-8s windows %3u at %p  avg %.4f ms  best %.4f ms -> %.0f GB/s touched (avg)\n", how.c_str(), nwin, b.use, sum/reps, best, touched/(sum/reps)/1e6);
 		fflush(stdout);
 		if(release(&b)){ return 1; }
 	}
