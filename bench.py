@@ -518,6 +518,8 @@ def rank_main(args):
                        "groups": [[lg, ns] for lg, ns in groups] if multi else None, "sharding": "columns (samples) over %d GPU(s)" % world, "step_pipeline": pipeline_note,
                        "total_kmers_per_step": int(probe.total_kmers) if not multi else None, "hits_per_step": int(nhits),
                        "db_build_s": round(t_build, 2),
+                       # how the loader chose each matrix's device block (rank 0): candidates compared, gather-probe GB/s on the kept / released one
+                       "matrix_placement": [m.group.placement for m in multi] if multi else s.group.placement,
                        "seeds": {"queries_and_planted_genomes": 1, "columns": "rank (splitmix64 keyed by seed, row, word; kwage_amd/synth.py)"}},
             "hbm_gbps_algorithmic_whole_step": round(alg_bytes_rank * world * args.steps / dt / 1e9, 1),
             "roofline": {"bound": "hbm", "kernel": kernel,

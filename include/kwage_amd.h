@@ -155,6 +155,15 @@ uint64_t kwage_group_row_bytes(const kwage_group *g);     /* ceil(column_span/8)
 uint64_t kwage_group_row_stride(const kwage_group *g);    /* bytes between rows in HBM        */
 uint64_t kwage_group_device_bytes(const kwage_group *g);  /* HBM held by the bit matrix       */
 int kwage_group_params(const kwage_group *g, kwage_params *out);
+/* How the matrix's device block was chosen.  Where a large block lies in HBM decides a few per cent of the gather
+ * kernels' rate, so where the device has room for two candidate blocks at once, both are allocated, a few milliseconds
+ * of the gather pattern are timed on each and the faster one is kept (matrices of 4 GiB and more; context knobs
+ * "group_placement_probe" = 0: no second candidate -- releasing the other block costs seconds per 100 GB while the
+ * driver wipes it, so one-shot programs turn it off; "group_contiguous" = 0: plain hipMalloc blocks instead of
+ * physically contiguous ones; kwage_ctx_set_tuning, or KWAGE_GROUP_PLACEMENT_PROBE / KWAGE_GROUP_CONTIGUOUS in the
+ * environment when the context is created).  candidates = blocks compared (1: no choice was made); *_gbps = the probe's rate on the
+ * block kept and on the one released (0 with one candidate).  Any pointer may be NULL. */
+int kwage_group_placement(const kwage_group *g, uint32_t *candidates, double *kept_gbps, double *other_gbps);
 
 /* ------------------------------------------------------------------------------------
  * Query batch: raw sequences (any case, any characters -- exactly what the reference hands to

@@ -37,6 +37,7 @@ static const TuningName TUNING_NAMES[] = {
 	{"count_walk_min_rows", &Tuning::count_walk_min_rows}, {"count_walk_prefetch", &Tuning::count_walk_prefetch},
 	{"count_narrow_kps", &Tuning::count_narrow_kps},
 	{"hit_sort_host", &Tuning::hit_sort_host}, {"hit_copy_piece_kb", &Tuning::hit_copy_piece_kb}, {"shared_table_log2", &Tuning::shared_table_log2},
+	{"group_contiguous", &Tuning::group_contiguous}, {"group_placement_probe", &Tuning::group_placement_probe},
 };
 
 namespace {

@@ -195,6 +195,10 @@ struct Tuning {
 	int64_t hit_sort_host = 0;      // KWAGE_HIT_SORT=host: order long hit lists on the host (A/B runs, the fallback)
 	int64_t hit_copy_piece_kb = 0;  // KWAGE_HIT_COPY_PIECE_KB: piece size of the copy-back of a long hit list (0 = default)
 	int64_t shared_table_log2 = 0;  // KWAGE_SHARED_TABLE_LOG2: at least this many slots in a sample's shared distinct set (tests)
+	// where a group's matrix lies (loader.hip, allocate_matrix) -- read when a group is created
+	int64_t group_contiguous = 1;   // KWAGE_GROUP_CONTIGUOUS: ask for a physically contiguous block first (0: plain hipMalloc)
+	int64_t group_placement_probe = 1;  // KWAGE_GROUP_PLACEMENT_PROBE: where two candidate blocks fit, time the gather pattern on both and keep the
+	                                //   faster (+3-4 % at C2's shape); releasing the other costs ~3 s per 100 GB (the driver wipes it), so one-shot programs turn it off
 };
 
 }  // namespace kwage
@@ -236,6 +240,9 @@ struct kwage_group {
 	uint8_t *d_bits = nullptr;
 	uint8_t *d_valid = nullptr;
 	uint64_t alloc_bytes = 0;
+	// how the matrix's block was chosen (loader.hip, allocate_matrix): candidates compared, the gather probe's GB/s on the kept and on the released one
+	uint32_t placement_candidates = 0;
+	double placement_kept_gbps = 0, placement_other_gbps = 0;
 	std::vector<uint8_t> h_valid;
 	bool finalized = false;
 	// sparse group (kwage_group_create_sparse): the matrix holds only the listed rows of every file, in this order

@@ -821,6 +821,14 @@ uint64_t env_u64(const char *name, uint64_t fallback)
 	return e ? strtoull(e, nullptr, 10) : fallback;
 }
 
+// A command-line run loads a database once and searches it once: choosing between two candidate placements of a large
+// matrix (the library's default, +3-4 % on the gather kernels) costs seconds while the driver wipes the released block,
+// which such a run never earns back.  Off unless the environment asks for it.
+void one_shot_placement(kwage_ctx *ctx)
+{
+	if(!getenv("KWAGE_GROUP_PLACEMENT_PROBE")){ (void)kwage_ctx_set_tuning(ctx, "group_placement_probe", 0); }
+}
+
 // The number of visible devices WITHOUT starting the HIP runtime in this process: the page-cache readers are forked
 // after the devices have been chosen, and a process in which HIP is up (runtime threads, the open KFD) must not be
 // forked.  A short-lived child asks the runtime and reports over a pipe.  -1: could not be done.
@@ -998,6 +1006,7 @@ int main(int argc, char *argv[])
 			try{
 				kwage_ctx *ctx = nullptr;
 				check(kwage_init(devices[di], &ctx));
+				one_shot_placement(ctx);
 				if(verbose){ lock_guard<mutex> lk(merge_lock); cerr << "[kwage] device " << devices[di] << " ready: " << rss_mb() << endl; }
 				CacheReader &reader = readers[di];
 				if(reader.shared){ kwage_set_load_progress(ctx, &reader.shared->passed); }

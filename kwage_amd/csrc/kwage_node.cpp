@@ -157,6 +157,7 @@ int run_rank(int rank, int n_ranks, const string &id_path, const Cli &cli, const
 		// ---- this rank's device, its communicator, its matrices ---------------------------------------------------------
 		kwage_ctx *ctx = nullptr;
 		check(kwage_init(rehearsal ? 0 : rank, &ctx));
+		one_shot_placement(ctx);
 		ncclComm_t comm = nullptr;
 		hipStream_t stream;
 		NODE_HIP(hipStreamCreate(&stream));

@@ -198,6 +198,100 @@ struct NumaScope {
 // ------------------------------------------------------------------------------------------
 namespace {
 
+// One device block for a matrix: physically contiguous where the driver has such a block (knob group_contiguous = 0:
+// plain hipMalloc, also the fallback).
+hipError_t allocate_block(uint64_t bytes, bool contiguous, void **out)
+{
+	hipError_t e = hipErrorOutOfMemory;
+	*out = nullptr;
+	if(contiguous && bytes >= (64ull << 20)){
+		e = hipExtMallocWithFlags(out, bytes, hipDeviceMallocContiguous);
+		if(e != hipSuccess){ (void)hipGetLastError(); *out = nullptr; }
+	}
+	if(e != hipSuccess){ e = hipMalloc(out, bytes); }
+	if(e != hipSuccess){ (void)hipGetLastError(); *out = nullptr; }
+	return e;
+}
+
+// GB/s of the gather pattern (placement_probe_kernel) over an uninitialised block laid out like g's matrix; 0 on error.
+double probe_block(kwage_group *g, const void *block)
+{
+	kwage_ctx *ctx = g->ctx;
+	const uint64_t stride16 = g->stride/16;
+	const uint32_t lanes = (uint32_t)std::min<uint64_t>(LOADER_WAVE, stride16);
+	const uint32_t chunks = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, g->stride/1024));
+	const uint32_t rows_per_wave = 256;
+	const uint32_t wgs = (uint32_t)std::max(ctx->ncu, 1);
+	void *sink = nullptr;
+	if(hipMalloc(&sink, 4) != hipSuccess){ (void)hipGetLastError(); return 0; }
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	double best = 0;
+	if(hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess){
+		for(int i = 0; i < 4; ++i){                          // (the first launch is the warm-up)
+			(void)hipEventRecord(e0, ctx->stream);
+			hipLaunchKernelGGL(placement_probe_kernel, dim3(wgs), dim3(512), 100*1024, ctx->stream, (const dwords4*)block, g->nrows, stride16,
+			                   chunks, lanes, rows_per_wave, (uint32_t*)sink);
+			(void)hipEventRecord(e1, ctx->stream);
+			float ms = 0;
+			if(hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0){ best = 0; break; }
+			const double gbps = (double)wgs*8*rows_per_wave*chunks*lanes*16/((double)ms*1e-3)/1e9;
+			if(i){ best = std::max(best, gbps); }
+		}
+	}
+	(void)hipGetLastError();
+	if(e0){ (void)hipEventDestroy(e0); }
+	if(e1){ (void)hipEventDestroy(e1); }
+	(void)hipFree(sink);
+	return best;
+}
+
+// The matrix's device block.  WHERE a large block lies in HBM decides 3-6 % of the gather kernels' rate -- the rate is a
+// stable property of the physical region (two 105 GB blocks held at once: 6.88 and 6.64 TB/s, again and again; 23 blocks
+// of 12 GB: 18 at 6.90-6.95, five at 6.56-6.71; profiles/r03_placement_probe.txt) -- so where the device has room for
+// two candidates at once, both are allocated, the gather pattern is timed on each (a few ms) and the faster one is kept
+// (knob group_placement_probe = 0: no second candidate).  Matrices below 4 GiB are not worth it, larger than half the free
+// memory have no choice.  The price is paid after the choice: the driver wipes the released block (about 3 s per
+// 100 GB) and allocations made meanwhile may wait for it -- worth it for a host that searches a resident database for
+// hours, not for a one-shot run (the kwage command line turns the knob off).
+hipError_t allocate_matrix(kwage_group *g)
+{
+	const bool choose = g->ctx->tune.group_placement_probe != 0, contiguous = g->ctx->tune.group_contiguous != 0;
+	const auto t0 = std::chrono::steady_clock::now();
+	auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+	void *a = nullptr;
+	hipError_t e = allocate_block(g->alloc_bytes, contiguous, &a);
+	if(e != hipSuccess){ return e; }
+	const double ms_a = ms_since(t0);
+	g->d_bits = (uint8_t*)a;
+	g->placement_candidates = 1;
+	size_t free_bytes = 0, total_bytes = 0;
+	if(!choose || g->alloc_bytes < (4ull << 30) || hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess ||
+	   free_bytes < g->alloc_bytes + std::max<uint64_t>(g->alloc_bytes/8, 2ull << 30)){
+		(void)hipGetLastError();
+		return hipSuccess;
+	}
+	void *b = nullptr;
+	const auto t1 = std::chrono::steady_clock::now();
+	if(allocate_block(g->alloc_bytes, contiguous, &b) != hipSuccess){ return hipSuccess; }
+	const double ms_b = ms_since(t1);
+	const auto t2 = std::chrono::steady_clock::now();
+	const double ra = probe_block(g, a), rb = probe_block(g, b);
+	const double ms_probe = ms_since(t2);
+	g->placement_candidates = 2;
+	g->placement_kept_gbps = std::max(ra, rb);
+	g->placement_other_gbps = std::min(ra, rb);
+	if(rb > ra){ std::swap(a, b); }
+	g->d_bits = (uint8_t*)a;
+	const auto t3 = std::chrono::steady_clock::now();
+	(void)hipFree(b);
+	if(getenv("KWAGE_VERBOSE")){
+		fprintf(stderr, "[kwage] matrix of %.1f GB: gather probe %.0f GB/s on the block kept, %.0f GB/s on the other candidate "
+		        "(allocations %.0f + %.0f ms, probes %.0f ms, release %.0f ms)\n",
+		        (double)g->alloc_bytes/1e9, g->placement_kept_gbps, g->placement_other_gbps, ms_a, ms_b, ms_probe, ms_since(t3));
+	}
+	return hipSuccess;
+}
+
 // Allocate and clear a group's matrix of `nrows` rows for `column_capacity` columns.
 int group_allocate(kwage_ctx *ctx, const kwage_params *params, uint64_t column_capacity, uint64_t nrows, kwage_group **out)
 {
@@ -216,16 +310,7 @@ int group_allocate(kwage_ctx *ctx, const kwage_params *params, uint64_t column_c
 	g->stride = (row_bytes + 127)/128*128;
 	if(g->stride/16 > 0x7FFFFFFFull){ delete g; return fail(KWAGE_ERR_ARG, "kwage_group_create: row too wide"); }
 	g->alloc_bytes = g->stride*g->nrows;
-	// Physically contiguous device memory where the driver can provide it (KWAGE_GROUP_CONTIGUOUS=0: plain hipMalloc):
-	// where a 105 GB matrix happens to lie decides 3-8 % of the gather kernels' rate (tools/micro/placement_probe.hip,
-	// profiles/r03_placement_probe.txt); a contiguous block was the fastest or within 0.6 % of it in every process measured.
-	static const bool contiguous = load_env_flag("KWAGE_GROUP_CONTIGUOUS", true);
-	hipError_t e = hipErrorOutOfMemory;
-	if(contiguous && g->alloc_bytes >= (64ull << 20)){
-		e = hipExtMallocWithFlags((void**)&g->d_bits, g->alloc_bytes, hipDeviceMallocContiguous);
-		if(e != hipSuccess){ (void)hipGetLastError(); g->d_bits = nullptr; }
-	}
-	if(e != hipSuccess){ e = hipMalloc((void**)&g->d_bits, g->alloc_bytes); }
+	hipError_t e = allocate_matrix(g);
 	if(e != hipSuccess){
 		const double gb = (double)g->alloc_bytes/1e9;
 		delete g;
@@ -959,6 +1044,15 @@ extern "C" uint64_t kwage_group_column_span(const kwage_group *g) { return g ? g
 extern "C" uint64_t kwage_group_row_bytes(const kwage_group *g) { return g ? g->next_byte : 0; }
 extern "C" uint64_t kwage_group_row_stride(const kwage_group *g) { return g ? g->stride : 0; }
 extern "C" uint64_t kwage_group_device_bytes(const kwage_group *g) { return g ? g->alloc_bytes : 0; }
+
+extern "C" int kwage_group_placement(const kwage_group *g, uint32_t *candidates, double *kept_gbps, double *other_gbps)
+{
+	if(!g){ return fail(KWAGE_ERR_ARG, "kwage_group_placement: g is NULL"); }
+	if(candidates){ *candidates = g->placement_candidates; }
+	if(kept_gbps){ *kept_gbps = g->placement_kept_gbps; }
+	if(other_gbps){ *other_gbps = g->placement_other_gbps; }
+	return KWAGE_OK;
+}
 
 extern "C" int kwage_group_params(const kwage_group *g, kwage_params *out)
 {

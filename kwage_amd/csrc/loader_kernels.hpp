@@ -146,6 +146,37 @@ __global__ void gather_rows_kernel(const uint8_t *db, uint64_t stride, const uin
 	}
 }
 
+
+// The gather kernels' access pattern on an empty block, to compare candidate PLACEMENTS of a matrix (loader.hip,
+// choose_placement): every wave reads `rows_per_wave` pseudo-random rows, four at a time, `chunks` KiB-steps of each
+// (`lanes` lanes x 16 B per step, never past the row's stride).  One workgroup of 8 waves per CU (dynamic LDS pad).
+__global__ __launch_bounds__(512) void placement_probe_kernel(const dwords4 *base, uint64_t nrows, uint64_t stride16, uint32_t chunks, uint32_t lanes,
+                                                              uint32_t rows_per_wave, uint32_t *sink)
+{
+	extern __shared__ uint32_t placement_pad[];
+	dwords4 acc = (dwords4)(0u);
+	const uint64_t wave = (uint64_t)blockIdx.x*(blockDim.x/LOADER_WAVE) + (threadIdx.x/LOADER_WAVE);
+	const uint32_t lane = threadIdx.x & (LOADER_WAVE - 1);
+	uint64_t x = wave*0x9E3779B97F4A7C15ull + 12345;
+	for(uint32_t r = 0; r < rows_per_wave; r += 4){
+		const dwords4 *p[4];
+#pragma unroll
+		for(int u = 0; u < 4; ++u){
+			x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+			const uint64_t row = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)((x*0x2545F4914F6CDD1Dull) >> 33)) % nrows;
+			p[u] = base + row*stride16 + (lane < lanes ? lane : 0);
+		}
+		for(uint32_t j = 0; j < chunks; ++j){
+			dwords4 a[4];
+#pragma unroll
+			for(int u = 0; u < 4; ++u){ a[u] = __builtin_nontemporal_load(p[u] + (uint64_t)j*LOADER_WAVE); }
+#pragma unroll
+			for(int u = 0; u < 4; ++u){ acc ^= a[u]; }
+		}
+	}
+	if((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u){ *sink = placement_pad[0]; }   // keep the loads alive
+}
+
 }  // namespace kwage
 
 #endif

@@ -155,6 +155,14 @@ class Group:
     row_stride = property(lambda self: lib().kwage_group_row_stride(self._h))
     device_bytes = property(lambda self: lib().kwage_group_device_bytes(self._h))
 
+    @property
+    def placement(self) -> dict:
+        """How the matrix's device block was chosen (kwage_group_placement): candidates compared and the gather probe's
+        GB/s on the block kept / released."""
+        n, kept, other = C.c_uint32(), C.c_double(), C.c_double()
+        check(lib().kwage_group_placement(self._h, C.byref(n), C.byref(kept), C.byref(other)))
+        return {"candidates": n.value, "kept_probe_gbps": round(kept.value, 1), "other_probe_gbps": round(other.value, 1)}
+
     def stream_read_gbps(self, nbytes: int, iters: int = 3) -> float:
         g = C.c_double()
         check(lib().kwage_stream_read_gbps(self._h, nbytes, iters, C.byref(g)))

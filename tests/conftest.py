@@ -10,6 +10,10 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Choosing between two candidate placements of a large matrix costs seconds per matrix (the driver wipes the released
+# block): off for the suite, switched on where it is the thing tested (test_gpu_fullsize.py, C2).
+os.environ.setdefault("KWAGE_GROUP_PLACEMENT_PROBE", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

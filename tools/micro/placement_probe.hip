@@ -6,6 +6,7 @@
 //   va2g      hipMalloc(bytes + 2 GiB), the matrix starts at the next 2 GiB boundary of the virtual address
 //   vmm<N>    hipMemAddressReserve + physical memory created in N-MiB handles, mapped side by side
 //   vmma<N>   the same, mapped from a 2 GiB boundary of a larger reservation (hipMemAddressReserve ignores its alignment argument)
+//   +<variant>      the block stays allocated until the end (later blocks must lie elsewhere) and is measured again then
 //   <variant>:<W>   all waves read from the same 1/W of the matrix at the same time (window after window)
 //   hipcc --offload-arch=gfx950 -O3 -o placement_probe placement_probe.hip ;  ./placement_probe [variant ...]
 #include <hip/hip_runtime.h>
@@ -122,7 +123,9 @@ int main(int argc, char **argv)
 	std::vector<std::string> variants;
 	for(int i = 1; i < argc; ++i){ variants.push_back(argv[i]); }
 	if(variants.empty()){ variants = {"plain", "plain", "va2g", "vmm1024", "vmm2048", "vmm256", "plain"}; }
-	const uint64_t nrows = 1ull << 23, stride = 12544, row_kib = 13;            // C2: 100 000 samples = 12 500 B per row, rows 128 B aligned
+	// PROBE_GB: block size (default: C2's 105 GB = 2^23 rows)
+	const uint64_t stride = 12544, row_kib = 13;
+	const uint64_t nrows = getenv("PROBE_GB") ? (uint64_t)(atof(getenv("PROBE_GB"))*1e9/stride) : 1ull << 23;            // C2: 100 000 samples = 12 500 B per row, rows 128 B aligned
 	const size_t bytes = nrows*stride + (2u << 20);          // (a row is READ as 13 KiB, 768 B more than the stride: slack behind the last row)
 	hipDeviceProp_t prop;
 	CK(hipGetDeviceProperties(&prop, 0));
@@ -132,7 +135,11 @@ int main(int argc, char **argv)
 	hipEvent_t e0, e1;
 	CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 	const uint64_t waves = (uint64_t)ncu*8, rows_per_wave = 970000/waves/4*4;   // C2's batch: 970 k rows
+	std::vector<Block> kept;
+	std::vector<std::string> kept_names;
 	for(std::string how : variants){
+		bool keep = false;
+		if(!how.empty() && how[0] == '+'){ keep = true; how = how.substr(1); }          // "+contig": the block stays allocated (later ones lie elsewhere) and is measured again at the end
 		uint32_t nwin = 1;
 		const size_t colon = how.find(':');          // "contig:8" = eight windows
 		if(colon != std::string::npos){ nwin = (uint32_t)atoi(how.c_str() + colon + 1); how = how.substr(0, colon); }
@@ -154,7 +161,24 @@ int main(int argc, char **argv)
 		const double touched = (double)waves*rows_per_wave*row_kib*1024;
 		printf("%-8s windows %3u at %p  avg %.4f ms  best %.4f ms -> %.0f GB/s touched (avg)\n", how.c_str(), nwin, b.use, sum/reps, best, touched/(sum/reps)/1e6);
 		fflush(stdout);
-		if(release(&b)){ return 1; }
+		if(keep){ kept.push_back(b); kept_names.push_back(how); }
+		else if(release(&b)){ return 1; }
 	}
+	for(int round = 0; round < 2; ++round){
+		for(size_t k = 0; k < kept.size(); ++k){
+			float sum = 0;
+			for(int i = 0; i < 6; ++i){
+				CK(hipEventRecord(e0, 0));
+				hipLaunchKernelGGL(gather<4>, dim3(ncu), dim3(512), 100*1024, 0, (const u32x4*)kept[k].use, nrows, (uint32_t)row_kib, stride/16, rows_per_wave, sink, 1u);
+				CK(hipEventRecord(e1, 0));
+				CK(hipEventSynchronize(e1));
+				float ms = 0;
+				CK(hipEventElapsedTime(&ms, e0, e1));
+				if(i){ sum += ms; }
+			}
+			printf("again: kept block %zu (%s at %p)  avg %.4f ms -> %.0f GB/s\n", k, kept_names[k].c_str(), kept[k].use, sum/5, (double)waves*rows_per_wave*row_kib*1024/(sum/5)/1e6);
+		}
+	}
+	for(Block &b : kept){ if(release(&b)){ return 1; } }
 	return 0;
 }
