@@ -238,7 +238,7 @@ double probe_block(kwage_group *g, const void *block)
 			if(i){ best = std::max(best, gbps); }
 		}
 	}
-	(void)hipGetLastError();
+	if(hipGetLastError() != hipSuccess){ best = 0; }          // (a launch that failed says nothing about the block)
 	if(e0){ (void)hipEventDestroy(e0); }
 	if(e1){ (void)hipEventDestroy(e1); }
 	(void)hipFree(sink);
