@@ -195,7 +195,10 @@ def measured_traffic(workload, kernel, early_exit):
     used that kernel AND the kernel sources + engine are byte for byte what the pass profiled; otherwise null, with
     the reason in traffic_source.  tools/pmc_refresh.py regenerates every entry in one GPU session."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(workload)
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        # (a workload whose kernel depends on where its matrix lies -- and_walk_kernel or, band after band,
+        # and_band_walk_kernel -- has one pass per kernel: "c2" and "c2@and_band_walk_kernel<13,4>")
+        t = rec.get("%s@%s" % (workload, kernel)) or rec.get(workload)
     except Exception as exc:
         return None, {"file": "profiles/pmc_traffic.json", "status": "unreadable: %r" % (exc,)}
     if not t:

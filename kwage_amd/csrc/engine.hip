@@ -31,6 +31,7 @@ struct TuningName { const char *name; int64_t Tuning::*field; };
 static const TuningName TUNING_NAMES[] = {
 	{"walk", &Tuning::walk}, {"walk_min_rows", &Tuning::walk_min_rows}, {"walk_max_kib", &Tuning::walk_max_kib},
 	{"walk_early_exit", &Tuning::walk_early_exit}, {"walk_waves", &Tuning::walk_waves}, {"walk_fences", &Tuning::walk_fences}, {"walk_one_wg_per_cu", &Tuning::walk_one_wg_per_cu},
+	{"walk_bands", &Tuning::walk_bands}, {"walk_bands_min_gib", &Tuning::walk_bands_min_gib},
 	{"and_vec", &Tuning::and_vec}, {"and_unroll", &Tuning::and_unroll}, {"and_nt", &Tuning::and_nt}, {"and_lds_kb", &Tuning::and_lds_kb},
 	{"and_block_waves", &Tuning::and_block_waves}, {"narrow", &Tuning::narrow}, {"narrow_unroll", &Tuning::narrow_unroll}, {"force_segs", &Tuning::force_segs},
 	{"count_walk", &Tuning::count_walk}, {"count_walk_wpc", &Tuning::count_walk_wpc}, {"count_walk_waves", &Tuning::count_walk_waves},
@@ -475,6 +476,49 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 			const WalkShape shape = walk_shape(tn, want_waves, ncu);
 			const uint32_t wgs = shape.wgs;
 			const uint64_t waves = (uint64_t)wgs*shape.wg_waves;
+			// Band after band (and_band_walk_kernel): matrices large enough to span several regions of the device's memory,
+			// one column tile, a slot of 16 KiB per query affordable.  (With early exit the tiled kernel is the default anyway.)
+			const uint64_t band_items = L->total_pos*a.num_hash;
+			const uint32_t bands = (tn.walk_bands < 0) ? (g->mixes_regions ? 3u : 0u)
+				: (g->alloc_bytes >= ((uint64_t)std::max<int64_t>(tn.walk_bands_min_gib, 0) << 30)) ? (uint32_t)std::min<int64_t>(tn.walk_bands, BAND_MAX) : 0u;
+			if(bands >= 2 && coltiles == 1 &&
+			   (uint64_t)a.n_queries*16*1024 <= (256ull << 20) && band_items < 0x7FFFFFFFull){
+				BandArgs ba;
+				ba.bands = bands;
+				ba.rows_per_band = (uint32_t)((g->nrows + bands - 1)/bands);
+				if((rc = sl->band_rows.reserve(band_items*sizeof(uint32_t)))){ return rc; }
+				if((rc = sl->band_prefix.reserve((uint64_t)bands*(a.n_queries + 1)*sizeof(uint32_t)))){ return rc; }
+				if((rc = reserve_zeroed(sl->band_or, (uint64_t)a.n_queries*16*1024, sl->stream))){ return rc; }
+				if((rc = reserve_zeroed(sl->band_state, (uint64_t)a.n_queries*sizeof(uint32_t), sl->stream))){ return rc; }
+				ba.orbuf = (uint32_t*)sl->band_or.p;
+				ba.state = (uint32_t*)sl->band_state.p;
+				uint32_t *prefix = (uint32_t*)sl->band_prefix.p, *rows2 = (uint32_t*)sl->band_rows.p;
+				hipLaunchKernelGGL(band_hist_kernel, dim3(a.n_queries), dim3(256), 0, sl->stream, a.rows, a.pos_off, a.nkmer, a.num_hash, a.n_queries,
+				                   ba.bands, ba.rows_per_band, prefix);
+				hipLaunchKernelGGL(band_scan_kernel, dim3(ba.bands), dim3(256), 0, sl->stream, prefix, a.n_queries);
+				hipLaunchKernelGGL(band_scatter_kernel, dim3(a.n_queries), dim3(256), 0, sl->stream, a.rows, a.pos_off, a.nkmer, a.num_hash, a.n_queries,
+				                   ba.bands, ba.rows_per_band, (const uint32_t*)prefix, rows2);
+				a.segs = 1;
+				a.chunks = 1;
+				snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_band_walk_kernel<%u,%d>", walk_ch, walk_unroll == 2 ? 2 : 4);
+				const dim3 grid(wgs), block(shape.wg_waves*WAVE), fgrid((a.n_queries + 3)/4);
+#define KWAGE_BAND_LAUNCH(CH, U) do { \
+					if(shape.lds > 48*1024){ (void)hipFuncSetAttribute((const void*)and_band_walk_kernel<CH, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shape.lds); } \
+					hipLaunchKernelGGL((and_band_walk_kernel<CH, U>), grid, block, shape.lds, sl->stream, a, ba, (const uint32_t*)rows2, (const uint32_t*)prefix); \
+					hipLaunchKernelGGL((and_band_finish_kernel<CH>), fgrid, dim3(256), 0, sl->stream, a, ba, a.nkmer); } while(0)
+#define KWAGE_BAND_CASE(CH) case CH: \
+					if(walk_unroll == 2){ KWAGE_BAND_LAUNCH(CH, 2); } else{ KWAGE_BAND_LAUNCH(CH, 4); } break;
+				switch(walk_ch){
+					KWAGE_BAND_CASE(3) KWAGE_BAND_CASE(4) KWAGE_BAND_CASE(5) KWAGE_BAND_CASE(6) KWAGE_BAND_CASE(7)
+					KWAGE_BAND_CASE(8) KWAGE_BAND_CASE(9) KWAGE_BAND_CASE(10) KWAGE_BAND_CASE(11) KWAGE_BAND_CASE(12)
+					KWAGE_BAND_CASE(13) KWAGE_BAND_CASE(14) KWAGE_BAND_CASE(15)
+					default: KWAGE_BAND_CASE(16)
+				}
+#undef KWAGE_BAND_CASE
+#undef KWAGE_BAND_LAUNCH
+				HIP_TRY(hipGetLastError());
+				return KWAGE_OK;
+			}
 			WalkArgs wa;
 			wa.total_slots = walk_slots;
 			wa.per_wave = (walk_slots + waves - 1)/waves;
@@ -863,7 +907,8 @@ extern "C" void kwage_shutdown(kwage_ctx *ctx)
 		if(sl->stream){ (void)hipStreamSynchronize(sl->stream); }
 		sl->rows.release(); sl->tables.release(); sl->result.release();
 		sl->partial.release(); sl->h_stage.release(); sl->sort_scratch.release();
-		sl->walk_or.release(); sl->walk_done.release(); sl->cwalk_slab.release(); sl->cwalk_arrived.release();
+		sl->walk_or.release(); sl->walk_done.release();
+		sl->band_rows.release(); sl->band_prefix.release(); sl->band_or.release(); sl->band_state.release(); sl->cwalk_slab.release(); sl->cwalk_arrived.release();
 		for(int i = 0; i < 4; ++i){ if(sl->ev[i]){ (void)hipEventDestroy(sl->ev[i]); } }
 		if(sl->search_done){ (void)hipEventDestroy(sl->search_done); }
 		if(sl->stream){ (void)hipStreamDestroy(sl->stream); }

@@ -156,6 +156,9 @@ struct Slot {
 	char kernel_name[64] = "";          // the gather kernel launch_search_stage picked, with its template shape
 	// and_walk_kernel's meeting place for (query, tile) pairs cut by a wave-share boundary: all zero between searches
 	DevBuf walk_or, walk_done;
+	// and_band_walk_kernel's: the batch's rows regrouped by band of the matrix, the per-band prefix over the queries, and
+	// the queries' meeting slots (masks + flags: zero between searches)
+	DevBuf band_rows, band_prefix, band_or, band_state;
 	// count_walk_kernel's: partial counters of cut pairs (overwritten before they are read) and the arrival counters of their trees (zero between searches)
 	DevBuf cwalk_slab, cwalk_arrived;
 	uint64_t staged_hits = 0;
@@ -178,6 +181,10 @@ struct Tuning {
 	int64_t walk_waves = 0;         // KWAGE_WALK_WAVES: exactly this many waves (tests: shares of every size); 0 = from the CU count
 	int64_t walk_fences = 0;        // KWAGE_WALK_FENCES: agent-scope fences around the cut-pair count (measurement only)
 	int64_t walk_one_wg_per_cu = 1; // KWAGE_WALK_ONE_WG_PER_CU: chip-filling launches of the persistent kernels use one workgroup of 8 waves per CU (0: workgroups of 4 waves, placed by the dispatcher)
+	int64_t walk_bands = -1;        // KWAGE_WALK_BANDS: the walk form takes the rows band after band of the matrix, all waves together (and_band_walk_kernel):
+	                                //   -1 = three bands where the loader's probe found that the matrix's block mixes regions of the device's memory
+	                                //   (the windowed probe > 2 % faster than the plain one), 0 = never, 2..64 = always, that many
+	int64_t walk_bands_min_gib = 48;    // KWAGE_WALK_BANDS_MIN_GIB: a forced band count applies to matrices of at least this size
 	int64_t and_vec = 0;            // KWAGE_AND_CFG="vec,unroll,nt[,ldsKB[,block waves]]": shape of the tiled AND kernel (0 = by row width)
 	int64_t and_unroll = 8;
 	int64_t and_nt = 1;
@@ -243,6 +250,10 @@ struct kwage_group {
 	// how the matrix's block was chosen (loader.hip, allocate_matrix): candidates compared, the gather probe's GB/s on the kept and on the released one
 	uint32_t placement_candidates = 0;
 	double placement_kept_gbps = 0, placement_other_gbps = 0;
+	// the same probe on the block kept with all waves reading from the same quarter of it at the same time: where that
+	// is clearly faster the block mixes regions of the device's memory, and the walk form goes band after band (knob walk_bands = -1)
+	double placement_windowed_gbps = 0;
+	bool mixes_regions = false;
 	std::vector<uint8_t> h_valid;
 	bool finalized = false;
 	// sparse group (kwage_group_create_sparse): the matrix holds only the listed rows of every file, in this order

@@ -632,6 +632,217 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void and_walk_kernel(SearchArgs
 	}
 }
 
+// ---- the walk form, ADDRESS BAND after ADDRESS BAND ---------------------------------------------------------------
+// A random-row gather over a matrix of ~100 GB reads 3-4 % faster when, at any moment, all waves read from the same
+// narrow part of it: concurrent accesses to different large regions of the device's memory cost each other
+// (tools/micro/placement_probe.hip: a 105 GB block that reads 6.66 TB/s reads 6.91 when the rows are taken window after
+// window; every 4 GiB window alone reads 6.95; profiles/r03_placement_probe.txt).  AND is order independent, so the
+// batch's rows are regrouped by BAND of the matrix (band_hist / band_scan / band_scatter: `rows2` is band-major,
+// query-minor; prefix[b][q] = rows of the queries before q in band b) and every wave walks its equal share of band 0's
+// list, then of band 1's, ... -- all waves move up the matrix together.  A (query, band) part is reduced in registers
+// as before; parts meet in the query's slot: an all-zero part (the rule after a few dozen random rows) only raises the
+// slot's DEAD flag, a part with surviving columns ORs its complemented mask in (DIRTY).  Nothing waits for anything:
+// and_band_finish_kernel, queued behind, reads the slots of the queries that are DIRTY and not DEAD, reports their
+// columns and leaves every slot zero again.  One column tile only (rows up to 16 KiB).
+struct BandArgs {
+	uint32_t bands;                 // B <= BAND_MAX
+	uint32_t rows_per_band;         // matrix rows per band: ceil(rows of the matrix / B)
+	uint32_t *orbuf;                // [n_queries][CH*4*64] complemented partial masks; zero between searches
+	uint32_t *state;                // [n_queries] WALK_DEAD | WALK_DIRTY; zero between searches
+};
+static constexpr uint32_t BAND_MAX = 64;
+
+// rows of query q per band -> cnt[b][q]   (cnt is [bands][n_queries + 1]; one workgroup per query)
+__global__ __launch_bounds__(256) void band_hist_kernel(const uint32_t *__restrict__ rows, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ nkmer,
+                                                       uint32_t num_hash, uint32_t n_queries, uint32_t bands, uint32_t rows_per_band, uint32_t *__restrict__ cnt)
+{
+	__shared__ uint32_t h[BAND_MAX];
+	const uint32_t q = blockIdx.x;
+	if(threadIdx.x < BAND_MAX){ h[threadIdx.x] = 0; }
+	__syncthreads();
+	const uint64_t base = pos_off[q]*num_hash;
+	const uint32_t n = nkmer[q]*num_hash;
+	for(uint32_t i = threadIdx.x; i < n; i += blockDim.x){
+		atomicAdd(&h[min(rows[base + i]/rows_per_band, bands - 1)], 1u);
+	}
+	__syncthreads();
+	if(threadIdx.x < bands){ cnt[(uint64_t)threadIdx.x*(n_queries + 1) + q] = h[threadIdx.x]; }
+}
+
+// cnt[b][0 .. n_queries) -> exclusive prefix sums in place, cnt[b][n_queries] = the band's total   (one workgroup per band)
+__global__ __launch_bounds__(256) void band_scan_kernel(uint32_t *cnt, uint32_t n_queries)
+{
+	__shared__ uint32_t part[256];
+	uint32_t *p = cnt + (uint64_t)blockIdx.x*(n_queries + 1);
+	const uint32_t chunk = (n_queries + 255)/256;
+	const uint32_t lo = min(threadIdx.x*chunk, n_queries), hi = min(lo + chunk, n_queries);
+	uint32_t sum = 0;
+	for(uint32_t i = lo; i < hi; ++i){ sum += p[i]; }
+	part[threadIdx.x] = sum;
+	__syncthreads();
+	if(threadIdx.x == 0){
+		uint32_t run = 0;
+		for(int t = 0; t < 256; ++t){ const uint32_t x = part[t]; part[t] = run; run += x; }
+		p[n_queries] = run;
+	}
+	__syncthreads();
+	uint32_t run = part[threadIdx.x];
+	for(uint32_t i = lo; i < hi; ++i){ const uint32_t x = p[i]; p[i] = run; run += x; }
+}
+
+// rows -> rows2: band-major, query-minor   (one workgroup per query; the order inside a (query, band) part is free)
+__global__ __launch_bounds__(256) void band_scatter_kernel(const uint32_t *__restrict__ rows, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ nkmer,
+                                                          uint32_t num_hash, uint32_t n_queries, uint32_t bands, uint32_t rows_per_band,
+                                                          const uint32_t *__restrict__ prefix, uint32_t *__restrict__ rows2)
+{
+	__shared__ uint32_t cur[BAND_MAX];
+	const uint32_t q = blockIdx.x;
+	if(threadIdx.x == 0){
+		uint32_t base = 0;
+		for(uint32_t b = 0; b < bands; ++b){
+			const uint32_t *pf = prefix + (uint64_t)b*(n_queries + 1);
+			cur[b] = base + pf[q];
+			base += pf[n_queries];
+		}
+	}
+	__syncthreads();
+	const uint64_t base = pos_off[q]*num_hash;
+	const uint32_t n = nkmer[q]*num_hash;
+	for(uint32_t i = threadIdx.x; i < n; i += blockDim.x){
+		const uint32_t r = rows[base + i];
+		rows2[atomicAdd(&cur[min(r/rows_per_band, bands - 1)], 1u)] = r;
+	}
+}
+
+template <int CH, int UNROLL>
+__global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void and_band_walk_kernel(SearchArgs a, BandArgs ba, const uint32_t *__restrict__ rows2,
+                                                                           const uint32_t *__restrict__ prefix)
+{
+	const uint32_t lane = threadIdx.x & (WAVE - 1);
+	const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x*(blockDim.x/WAVE) + (threadIdx.x >> 6));
+	const uint32_t nw = gridDim.x*(blockDim.x/WAVE);
+	const uint32_t row_bytes = a.units_per_row*16u;
+	const uint32_t q1 = a.n_queries + 1;
+	uint32_t band_base = 0;
+	uint32_t q_start = 0xFFFFFFFFu;          // where this wave's share of the previous band began: the next band's begins nearby
+	for(uint32_t b = 0; b < ba.bands; ++b){
+		const uint32_t *pf = prefix + (uint64_t)b*q1;
+		const uint32_t total = pf[a.n_queries];
+		const uint32_t per = (uint32_t)(((uint64_t)total + nw - 1)/nw);
+		uint64_t s = (uint64_t)gw*per;
+		const uint64_t s1 = min((uint64_t)total, s + per);
+		if(s < s1){
+			// the query that holds the band's slot s: the largest q with pf[q] <= s (queries without rows in this band
+			// share their successor's prefix, so the largest one is the one that has rows)
+			// (a binary search in the first band -- ten dependent scalar loads --, a step or two from the previous band's
+			// start afterwards: every band holds about the same share of every query's rows)
+			uint32_t q = 0;
+			if(q_start == 0xFFFFFFFFu){
+				uint32_t hi = a.n_queries;
+				while(hi - q > 1){
+					const uint32_t mid = q + (hi - q)/2;
+					if(pf[mid] <= s){ q = mid; } else { hi = mid; }
+				}
+			}
+			else{
+				q = q_start;
+				while(q > 0 && pf[q] > s){ --q; }
+			}
+			while(pf[q + 1] <= s){ ++q; }                            // (pf[n_queries] = total > s)
+			q_start = q;
+			while(s < s1){
+				while(pf[q + 1] <= s){ ++q; }
+				const uint32_t j0 = (uint32_t)(s - pf[q]);
+				const uint32_t nrows = (uint32_t)min((uint64_t)(pf[q + 1] - pf[q] - j0), s1 - s);
+				const uint32_t *rq = rows2 + band_base + s;
+				u32x4 acc[CH];
+#pragma unroll
+				for(int j = 0; j < CH; ++j){ acc[j] = ~(u32x4)(0u); }
+				for(uint32_t i = 0; i < nrows; i += UNROLL){
+					// (parts are short here -- a band's share of a query -- so a group past the part's end does not read its last
+					// row again as in and_walk_kernel: its descriptors are EMPTY, the loads touch no memory and return 0, and
+					// `fill` turns that into all ones)
+					__amdgpu_buffer_rsrc_t rs[UNROLL];
+					uint32_t fill[UNROLL];
+#pragma unroll
+					for(int u = 0; u < UNROLL; ++u){
+						const bool in = i + u < nrows;
+						const uint32_t r = rq[min(i + u, nrows - 1)];
+						rs[u] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.db + (uint64_t)r*a.stride), 0, in ? row_bytes : 0u, 0x00020000);
+						fill[u] = in ? 0u : ~0u;
+					}
+#pragma unroll
+					for(int j = 0; j < CH; ++j){
+						u32x4 x[UNROLL];
+#pragma unroll
+						for(int u = 0; u < UNROLL; ++u){ x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs[u], lane*16u, j*1024, 2 /* nt */); }
+#pragma unroll
+						for(int u = 0; u < UNROLL; ++u){ acc[j] &= (x[u] | fill[u]); }
+						__builtin_amdgcn_sched_barrier(0);               // one KiB-step of UNROLL rows at a time (and_walk_kernel)
+					}
+					if(a.early_exit){     // kwage.cpp:466-470: this part alone already rules every column out
+						bool nz = false;
+#pragma unroll
+						for(int j = 0; j < CH; ++j){ nz |= ((acc[j].x | acc[j].y | acc[j].z | acc[j].w) != 0); }
+						if(!__any(nz)){ break; }
+					}
+				}
+				bool nz = false;
+#pragma unroll
+				for(int j = 0; j < CH; ++j){ nz |= ((acc[j].x | acc[j].y | acc[j].z | acc[j].w) != 0); }
+				const bool live = __any(nz);
+				if(live){
+					uint32_t *ob = ba.orbuf + (uint64_t)q*(CH*4*WAVE) + lane;
+#pragma unroll
+					for(int j = 0; j < CH; ++j){
+#pragma unroll
+						for(int d = 0; d < 4; ++d){
+							const uint32_t v = ~acc[j][d];
+							if(v){ __hip_atomic_fetch_or(ob + (j*4 + d)*WAVE, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+						}
+					}
+				}
+				if(lane == 0){ __hip_atomic_fetch_or(ba.state + q, live ? WALK_DIRTY : WALK_DEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+				s += nrows;
+			}
+		}
+		band_base += total;
+	}
+}
+
+// One wave per query: report the columns that survived in every part, leave the query's slot zero.
+template <int CH>
+__global__ __launch_bounds__(256) void and_band_finish_kernel(SearchArgs a, BandArgs ba, const uint32_t *__restrict__ nkmer)
+{
+	const uint32_t lane = threadIdx.x & (WAVE - 1);
+	const uint32_t q = __builtin_amdgcn_readfirstlane(blockIdx.x*(blockDim.x/WAVE) + (threadIdx.x >> 6));
+	if(q >= a.n_queries){ return; }
+	const uint32_t fl = __builtin_amdgcn_readfirstlane(ba.state[q]);
+	if(fl == 0){ return; }                                           // a query without rows
+	const bool emit = (fl & WALK_DIRTY) && !(fl & WALK_DEAD);
+	u32x4 acc[CH];
+	if(fl & WALK_DIRTY){
+		uint32_t *ob = ba.orbuf + (uint64_t)q*(CH*4*WAVE) + lane;
+#pragma unroll
+		for(int j = 0; j < CH; ++j){
+#pragma unroll
+			for(int d = 0; d < 4; ++d){
+				acc[j][d] = ~ob[(j*4 + d)*WAVE];
+				ob[(j*4 + d)*WAVE] = 0u;
+			}
+		}
+	}
+	if(lane == 0){ ba.state[q] = 0u; }
+	if(emit){
+		const uint32_t n = nkmer[q];
+		const uint32_t umax = a.units_per_row - 1;
+#pragma unroll
+		for(int j = 0; j < CH; ++j){
+			emit_mask_hits(a, q, min(lane + (uint32_t)j*WAVE, umax), acc[j], n, lane + (uint32_t)j*WAVE <= umax);
+		}
+	}
+}
+
 // Narrow databases (a row is at most 64/G 16-byte units, e.g. one 2048-column file = 16 units): G queries
 // share a wave, 64/G lanes each, so a wave-load still moves up to 1 KiB.  Row indices are per lane group
 // (vector loads, broadcast within the group).  Shorter row lists are padded by re-reading their last row

@@ -214,7 +214,7 @@ hipError_t allocate_block(uint64_t bytes, bool contiguous, void **out)
 }
 
 // GB/s of the gather pattern (placement_probe_kernel) over an uninitialised block laid out like g's matrix; 0 on error.
-double probe_block(kwage_group *g, const void *block)
+double probe_block(kwage_group *g, const void *block, uint32_t windows = 1)
 {
 	kwage_ctx *ctx = g->ctx;
 	const uint64_t stride16 = g->stride/16;
@@ -230,7 +230,7 @@ double probe_block(kwage_group *g, const void *block)
 		for(int i = 0; i < 4; ++i){                          // (the first launch is the warm-up)
 			(void)hipEventRecord(e0, ctx->stream);
 			hipLaunchKernelGGL(placement_probe_kernel, dim3(wgs), dim3(512), 100*1024, ctx->stream, (const dwords4*)block, g->nrows, stride16,
-			                   chunks, lanes, rows_per_wave, (uint32_t*)sink);
+			                   chunks, lanes, rows_per_wave, windows, (uint32_t*)sink);
 			(void)hipEventRecord(e1, ctx->stream);
 			float ms = 0;
 			if(hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0){ best = 0; break; }
@@ -264,30 +264,41 @@ hipError_t allocate_matrix(kwage_group *g)
 	const double ms_a = ms_since(t0);
 	g->d_bits = (uint8_t*)a;
 	g->placement_candidates = 1;
+	if(!choose || g->alloc_bytes < (4ull << 30)){ return hipSuccess; }
 	size_t free_bytes = 0, total_bytes = 0;
-	if(!choose || g->alloc_bytes < (4ull << 30) || hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess ||
-	   free_bytes < g->alloc_bytes + std::max<uint64_t>(g->alloc_bytes/8, 2ull << 30)){
-		(void)hipGetLastError();
-		return hipSuccess;
-	}
+	double ms_b = 0, ms_probe = 0, ms_release = 0;
 	void *b = nullptr;
-	const auto t1 = std::chrono::steady_clock::now();
-	if(allocate_block(g->alloc_bytes, contiguous, &b) != hipSuccess){ return hipSuccess; }
-	const double ms_b = ms_since(t1);
+	if(hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess && free_bytes >= g->alloc_bytes + std::max<uint64_t>(g->alloc_bytes/8, 2ull << 30)){
+		const auto t1 = std::chrono::steady_clock::now();
+		(void)allocate_block(g->alloc_bytes, contiguous, &b);
+		ms_b = ms_since(t1);
+	}
+	(void)hipGetLastError();
 	const auto t2 = std::chrono::steady_clock::now();
-	const double ra = probe_block(g, a), rb = probe_block(g, b);
-	const double ms_probe = ms_since(t2);
-	g->placement_candidates = 2;
-	g->placement_kept_gbps = std::max(ra, rb);
-	g->placement_other_gbps = std::min(ra, rb);
-	if(rb > ra){ std::swap(a, b); }
+	double ra = probe_block(g, a);
+	if(b){
+		const double rb = probe_block(g, b);
+		g->placement_candidates = 2;
+		const bool keep_b = (rb > ra) != (g->ctx->tune.group_placement_probe < 0);     // (knob < 0: keep the SLOWER block -- measurements of what placement costs)
+		g->placement_other_gbps = keep_b ? ra : rb;
+		if(keep_b){ std::swap(a, b); ra = rb; }
+	}
+	g->placement_kept_gbps = ra;
+	// does the block kept mix regions of the device's memory?  the same pattern, all waves in the same quarter at a time
+	g->placement_windowed_gbps = probe_block(g, a, 4);
+	g->mixes_regions = ra > 0 && g->placement_windowed_gbps > 1.02*ra;
+	ms_probe = ms_since(t2);
 	g->d_bits = (uint8_t*)a;
-	const auto t3 = std::chrono::steady_clock::now();
-	(void)hipFree(b);
+	if(b){
+		const auto t3 = std::chrono::steady_clock::now();
+		(void)hipFree(b);
+		ms_release = ms_since(t3);
+	}
 	if(getenv("KWAGE_VERBOSE")){
-		fprintf(stderr, "[kwage] matrix of %.1f GB: gather probe %.0f GB/s on the block kept, %.0f GB/s on the other candidate "
+		fprintf(stderr, "[kwage] matrix of %.1f GB: gather probe %.0f GB/s on the block kept (%.0f GB/s window after window%s), %.0f GB/s on the other candidate "
 		        "(allocations %.0f + %.0f ms, probes %.0f ms, release %.0f ms)\n",
-		        (double)g->alloc_bytes/1e9, g->placement_kept_gbps, g->placement_other_gbps, ms_a, ms_b, ms_probe, ms_since(t3));
+		        (double)g->alloc_bytes/1e9, g->placement_kept_gbps, g->placement_windowed_gbps, g->mixes_regions ? ": it mixes memory regions" : "",
+		        g->placement_other_gbps, ms_a, ms_b, ms_probe, ms_release);
 	}
 	return hipSuccess;
 }
@@ -1045,12 +1056,13 @@ extern "C" uint64_t kwage_group_row_bytes(const kwage_group *g) { return g ? g->
 extern "C" uint64_t kwage_group_row_stride(const kwage_group *g) { return g ? g->stride : 0; }
 extern "C" uint64_t kwage_group_device_bytes(const kwage_group *g) { return g ? g->alloc_bytes : 0; }
 
-extern "C" int kwage_group_placement(const kwage_group *g, uint32_t *candidates, double *kept_gbps, double *other_gbps)
+extern "C" int kwage_group_placement(const kwage_group *g, uint32_t *candidates, double *kept_gbps, double *other_gbps, double *windowed_gbps)
 {
 	if(!g){ return fail(KWAGE_ERR_ARG, "kwage_group_placement: g is NULL"); }
 	if(candidates){ *candidates = g->placement_candidates; }
 	if(kept_gbps){ *kept_gbps = g->placement_kept_gbps; }
 	if(other_gbps){ *other_gbps = g->placement_other_gbps; }
+	if(windowed_gbps){ *windowed_gbps = g->placement_windowed_gbps; }
 	return KWAGE_OK;
 }
 

@@ -151,7 +151,7 @@ __global__ void gather_rows_kernel(const uint8_t *db, uint64_t stride, const uin
 // choose_placement): every wave reads `rows_per_wave` pseudo-random rows, four at a time, `chunks` KiB-steps of each
 // (`lanes` lanes x 16 B per step, never past the row's stride).  One workgroup of 8 waves per CU (dynamic LDS pad).
 __global__ __launch_bounds__(512) void placement_probe_kernel(const dwords4 *base, uint64_t nrows, uint64_t stride16, uint32_t chunks, uint32_t lanes,
-                                                              uint32_t rows_per_wave, uint32_t *sink)
+                                                              uint32_t rows_per_wave, uint32_t windows, uint32_t *sink)
 {
 	extern __shared__ uint32_t placement_pad[];
 	dwords4 acc = (dwords4)(0u);
@@ -163,7 +163,9 @@ __global__ __launch_bounds__(512) void placement_probe_kernel(const dwords4 *bas
 #pragma unroll
 		for(int u = 0; u < 4; ++u){
 			x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
-			const uint64_t row = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)((x*0x2545F4914F6CDD1Dull) >> 33)) % nrows;
+			// windows > 1: all waves draw from the same 1/windows of the block at the same time, window after window
+			const uint64_t per_win = nrows/windows, win = (uint64_t)(r + u)*windows/rows_per_wave;
+			const uint64_t row = win*per_win + (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)((x*0x2545F4914F6CDD1Dull) >> 33)) % per_win;
 			p[u] = base + row*stride16 + (lane < lanes ? lane : 0);
 		}
 		for(uint32_t j = 0; j < chunks; ++j){

@@ -159,9 +159,10 @@ class Group:
     def placement(self) -> dict:
         """How the matrix's device block was chosen (kwage_group_placement): candidates compared and the gather probe's
         GB/s on the block kept / released."""
-        n, kept, other = C.c_uint32(), C.c_double(), C.c_double()
-        check(lib().kwage_group_placement(self._h, C.byref(n), C.byref(kept), C.byref(other)))
-        return {"candidates": n.value, "kept_probe_gbps": round(kept.value, 1), "other_probe_gbps": round(other.value, 1)}
+        n, kept, other, win = C.c_uint32(), C.c_double(), C.c_double(), C.c_double()
+        check(lib().kwage_group_placement(self._h, C.byref(n), C.byref(kept), C.byref(other), C.byref(win)))
+        return {"candidates": n.value, "kept_probe_gbps": round(kept.value, 1), "other_probe_gbps": round(other.value, 1),
+                "kept_windowed_probe_gbps": round(win.value, 1)}
 
     def stream_read_gbps(self, nbytes: int, iters: int = 3) -> float:
         g = C.c_double()

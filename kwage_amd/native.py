@@ -121,7 +121,7 @@ _SIGNATURES = [
     ("kwage_group_row_bytes", C.c_uint64, [_P]),
     ("kwage_group_row_stride", C.c_uint64, [_P]),
     ("kwage_group_device_bytes", C.c_uint64, [_P]),
-    ("kwage_group_placement", C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("kwage_group_placement", C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("kwage_group_params", C.c_int, [_P, C.POINTER(Params)]),
     ("kwage_batch_create", C.c_int, [_P, C.c_char_p, _P, C.c_uint32, C.POINTER(_P)]),
     ("kwage_batch_destroy", None, [_P]),

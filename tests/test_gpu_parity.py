@@ -787,6 +787,20 @@ def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, request):
                 assert r.per_query() == exp, (n_cols, flags, waves)           # against the oracle once ...
             else:                                                            # ... then hit list against hit list (millions of records)
                 assert np.array_equal(r.hits, first.hits) and np.array_equal(r.num_query_kmer, first.num_query_kmer), (n_cols, flags, waves)
+    # band after band of the matrix (and_band_walk_kernel: rows regrouped by band, parts meet in per-query slots, a finish
+    # kernel reports): 2, 5 and 64 bands, the natural number of waves and shares of a handful of rows, twice each (the
+    # slots must be left zero), with and without early exit inside a part
+    if n_cols <= 131072:
+        with ctx.tuning(walk_bands_min_gib=0, walk_early_exit=1):
+            for bands in (2, 5, 64):
+                for waves in (0, 3001):
+                    ctx.set_tuning("walk_bands", bands)
+                    ctx.set_tuning("walk_waves", waves)
+                    for flags in (0, 0, ka.SEARCH_EARLY_EXIT):
+                        r = g.search(b, 1.0, flags)
+                        assert r.search_kernel.startswith("and_band_walk_kernel<"), r.search_kernel
+                        assert np.array_equal(r.hits, first.hits) and np.array_equal(r.num_query_kmer, first.num_query_kmer), (n_cols, bands, waves, flags)
+            ctx.set_tuning("walk_bands", 0)
     ctx.set_tuning("walk_waves", 0)
     ctx.set_tuning("walk", 0)
     r = g.search(b, 1.0, 0)

@@ -164,6 +164,44 @@ int main(int argc, char **argv)
 		if(keep){ kept.push_back(b); kept_names.push_back(how); }
 		else if(release(&b)){ return 1; }
 	}
+	// PROBE_FOOTPRINTS="1,4,16": the kept blocks again with the rows drawn from their first F GB only
+	std::vector<double> footprints;
+	if(const char *e = getenv("PROBE_FOOTPRINTS")){ for(const char *c = e; *c; ){ footprints.push_back(atof(c)); c = strchr(c, ','); if(!c){ break; } ++c; } }
+	for(double f : footprints){
+		const uint64_t fr = (uint64_t)(f*1e9/stride) < nrows ? (uint64_t)(f*1e9/stride) : nrows;
+		for(size_t k = 0; k < kept.size(); ++k){
+			float sum = 0;
+			for(int i = 0; i < 6; ++i){
+				CK(hipEventRecord(e0, 0));
+				hipLaunchKernelGGL(gather<4>, dim3(ncu), dim3(512), 100*1024, 0, (const u32x4*)kept[k].use, fr, (uint32_t)row_kib, stride/16, rows_per_wave, sink, 1u);
+				CK(hipEventRecord(e1, 0));
+				CK(hipEventSynchronize(e1));
+				float ms = 0;
+				CK(hipEventElapsedTime(&ms, e0, e1));
+				if(i){ sum += ms; }
+			}
+			printf("footprint %6.1f GB of kept block %zu  avg %.4f ms -> %.0f GB/s\n", f, k, sum/5, (double)waves*rows_per_wave*row_kib*1024/(sum/5)/1e6);
+		}
+	}
+	// PROBE_WINDOW_GB=8: the kept blocks again, window by window (rows drawn from [off, off + W) GB only)
+	if(const char *e = getenv("PROBE_WINDOW_GB")){
+		const uint64_t wr = (uint64_t)(atof(e)*1e9/stride);
+		for(size_t k = 0; k < kept.size(); ++k){
+			for(uint64_t r0 = 0; r0 + wr <= nrows; r0 += wr){
+				float sum = 0;
+				for(int i = 0; i < 4; ++i){
+					CK(hipEventRecord(e0, 0));
+					hipLaunchKernelGGL(gather<4>, dim3(ncu), dim3(512), 100*1024, 0, (const u32x4*)kept[k].use + r0*(stride/16), wr, (uint32_t)row_kib, stride/16, rows_per_wave, sink, 1u);
+					CK(hipEventRecord(e1, 0));
+					CK(hipEventSynchronize(e1));
+					float ms = 0;
+					CK(hipEventElapsedTime(&ms, e0, e1));
+					if(i){ sum += ms; }
+				}
+				printf("block %zu window at %6.1f GB (+%s GB)  avg %.4f ms -> %.0f GB/s\n", k, (double)r0*stride/1e9, e, sum/3, (double)waves*rows_per_wave*row_kib*1024/(sum/3)/1e6);
+			}
+		}
+	}
 	for(int round = 0; round < 2; ++round){
 		for(size_t k = 0; k < kept.size(); ++k){
 			float sum = 0;

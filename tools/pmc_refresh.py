@@ -5,7 +5,7 @@ tools/pmc_summary.py's rule (FETCH_SIZE is in KiB and counts half the bytes of a
 factor is CALIBRATED in each pass on stream_read_kernel's known byte count), written with the hash of the kernel sources +
 engine the pass ran on -- bench.py reports an entry as roofline.traffic only while that hash still matches.
 
-    python tools/pmc_refresh.py [--round r03] [workload ...]        (default: c2 c2t c3 c4 c5s c5)
+    python tools/pmc_refresh.py [--round r03] [workload ...]        (default: c2 c2+bands c2t c3 c4 c5s c5)
 
 This script never touches the GPU itself: every pass is a child process (`rocprofv3 ... -- python3 bench.py ...`)."""
 import collections
@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (pure Python at import time: no torch, no HIP)
 
 N_GROUPS = {"c5": 8}
-GATHER = ("and_kernel", "and_walk_kernel", "and_narrow_kernel", "count_kernel", "count_walk_kernel", "count_narrow_kernel")
+GATHER = ("and_kernel", "and_walk_kernel", "and_band_walk_kernel", "and_narrow_kernel", "count_kernel", "count_walk_kernel", "count_narrow_kernel")
 
 
 def short(kernel_name):
@@ -36,18 +36,21 @@ def main():
     rnd = "r03"
     if args[:1] == ["--round"]:
         rnd, args = args[1], args[2:]
-    workloads = args or ["c2", "c2t", "c3", "c4", "c5s", "c5"]
+    # "c2+bands": the same workload with the walk kernel forced band after band (its entry is keyed "c2@<kernel>")
+    workloads = args or ["c2", "c2+bands", "c2t", "c3", "c4", "c5s", "c5"]
     out_root = os.path.join(ROOT, "gpurun_out", "pmc_" + rnd)
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     rec = json.load(open(path))
     code = bench.kernel_code_hash()
-    for wl in workloads:
-        d = os.path.join(out_root, wl)
+    for spec in workloads:
+        wl, banded = spec.split("+")[0], spec.endswith("+bands")
+        knobs = {"KWAGE_WALK_BANDS": "3", "KWAGE_WALK_BANDS_MIN_GIB": "0"} if banded else {"KWAGE_WALK_BANDS": "0"}
+        d = os.path.join(out_root, spec.replace("+", "_"))
         os.makedirs(d, exist_ok=True)
         cmd = ["rocprofv3", "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", d, "--",
                sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--no-cpu-baseline", "--no-sustained", "--steps", "5", "--warmup", "1"]
         t0 = time.time()
-        r = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", **knobs))
         print("[pmc_refresh] %s: rc %d in %.0f s" % (wl, r.returncode, time.time() - t0), flush=True)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
         if r.returncode != 0 or not lines:
@@ -79,7 +82,7 @@ def main():
         dominant = max(gather, key=lambda k: sum(gather[k]))
         summary = {"workload": wl, "bench_line": line, "calibration": {"stream_read_dispatches": len(cal), "known_bytes": known, "factor": factor},
                    "kernels": {short(k): {"dispatches": len(v), "FETCH_SIZE_avg_KiB": sum(v) / len(v)} for k, v in agg.items()}}
-        sfile = os.path.join(ROOT, "profiles", "%s_%s_pmc_fetch_size.json" % (rnd, wl))
+        sfile = os.path.join(ROOT, "profiles", "%s_%s_pmc_fetch_size.json" % (rnd, spec.replace("+", "_")))
         json.dump(summary, open(sfile, "w"), indent=1)
         entry = {"kernel": line["roofline"]["kernel"], "profiled_kernels": {short(k): len(v) for k, v in gather.items()},
                  "hbm_read_bytes_per_launch": int(per_step), "algorithmic_bytes_per_launch": int(line["roofline"]["algorithmic_bytes_per_launch"]),
@@ -87,7 +90,7 @@ def main():
                  "source": os.path.relpath(sfile, ROOT), "code_hash": code, "round": rnd}
         if ng > 1:
             entry["note"] = "per STEP = the %d groups' launches together, as bench.py sums kernel time and algorithmic bytes over the groups" % ng
-        rec[wl] = entry
+        rec["%s@%s" % (wl, entry["kernel"]) if banded else wl] = entry
         print("[pmc_refresh] %s: %s  %.3f GB per step for %.3f GB algorithmic = %.4fx (factor %.4f)" %
               (wl, short(dominant), per_step / 1e9, entry["algorithmic_bytes_per_launch"] / 1e9, entry["ratio"], factor), flush=True)
         json.dump(rec, open(path, "w"), indent=1)
