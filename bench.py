@@ -240,6 +240,8 @@ def rank_main(args):
     backend = os.environ.get("KWAGE_BENCH_BACKEND", "nccl")
     if os.environ.get("KWAGE_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
+        # ranks that share a device must not each hold a second candidate block for their matrix while the others allocate theirs
+        os.environ.setdefault("KWAGE_GROUP_PLACEMENT_PROBE", "0")
     # KWAGE_BENCH_FORCE_SHARDED=1: take the multi-GPU code path (device-resident hits + RCCL exchange)
     # even with one rank, to measure its per-step overhead on a one-GPU box
     force_sharded = os.environ.get("KWAGE_BENCH_FORCE_SHARDED") == "1"
