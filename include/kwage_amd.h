@@ -163,7 +163,7 @@ int kwage_group_params(const kwage_group *g, kwage_params *out);
  * physically contiguous ones; kwage_ctx_set_tuning, or KWAGE_GROUP_PLACEMENT_PROBE / KWAGE_GROUP_CONTIGUOUS in the
  * environment when the context is created).  candidates = blocks compared (1: no choice was made); *_gbps = the probe's rate on the
  * block kept and on the one released (0 with one candidate); windowed_gbps = the probe on the block kept with all waves
- * reading from the same quarter of it at a time -- where that is more than 2 % faster the block mixes regions of the
+ * reading from the same quarter of it at a time -- where that is more than 3 % faster the block mixes regions of the
  * device's memory and the t = 1 walk kernel takes its rows band after band of the matrix (knob "walk_bands" = -1).
  * Any pointer may be NULL. */
 int kwage_group_placement(const kwage_group *g, uint32_t *candidates, double *kept_gbps, double *other_gbps, double *windowed_gbps);

@@ -183,7 +183,7 @@ struct Tuning {
 	int64_t walk_one_wg_per_cu = 1; // KWAGE_WALK_ONE_WG_PER_CU: chip-filling launches of the persistent kernels use one workgroup of 8 waves per CU (0: workgroups of 4 waves, placed by the dispatcher)
 	int64_t walk_bands = -1;        // KWAGE_WALK_BANDS: the walk form takes the rows band after band of the matrix, all waves together (and_band_walk_kernel):
 	                                //   -1 = three bands where the loader's probe found that the matrix's block mixes regions of the device's memory
-	                                //   (the windowed probe > 2 % faster than the plain one), 0 = never, 2..64 = always, that many
+	                                //   (the windowed probe > 3 % faster than the plain one), 0 = never, 2..64 = always, that many
 	int64_t walk_bands_min_gib = 48;    // KWAGE_WALK_BANDS_MIN_GIB: a forced band count applies to matrices of at least this size
 	int64_t and_vec = 0;            // KWAGE_AND_CFG="vec,unroll,nt[,ldsKB[,block waves]]": shape of the tiled AND kernel (0 = by row width)
 	int64_t and_unroll = 8;

@@ -286,7 +286,9 @@ hipError_t allocate_matrix(kwage_group *g)
 	g->placement_kept_gbps = ra;
 	// does the block kept mix regions of the device's memory?  the same pattern, all waves in the same quarter at a time
 	g->placement_windowed_gbps = probe_block(g, a, 4);
-	g->mixes_regions = ra > 0 && g->placement_windowed_gbps > 1.02*ra;
+	// (3 % : the band form's regrouping and finish launches cost about 2 % of a C2 search -- 43 us, rocprofv3 -- so a block
+	// whose windowed rate is only 1-2 % above the plain one is better served by the plain walk)
+	g->mixes_regions = ra > 0 && g->placement_windowed_gbps > 1.03*ra;
 	ms_probe = ms_since(t2);
 	g->d_bits = (uint8_t*)a;
 	if(b){
