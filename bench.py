@@ -531,6 +531,9 @@ def rank_main(args):
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": round(k_ms, 4), "kernel_ms_min": round(per_rank[0][1], 4), "kernel_ms_max": round(per_rank[0][2], 4),
+                         # HIP events on the search's stream around the gather STAGE: one launch, except for and_band_walk_kernel,
+                         # whose three regrouping launches and finish launch are inside (rocprofv3's average for that kernel alone is ~2 % less)
+                         "kernel_ms_scope": "gather stage" + (" = regrouping launches + and_band_walk_kernel + finish launch" if kernel.startswith("and_band_walk") else " = one launch"),
                          "algorithmic_bytes_per_launch": alg_bytes_rank,
                          "measured_stream_read_gbps": round(stream_gbps, 1),
                          "frac_of_measured_stream": round(achieved / stream_gbps, 4) if stream_gbps else None},
