@@ -73,9 +73,13 @@ def test_c2_full_size_properties(ka, oracle):
         s = synth.build(ctx, w)
         assert s.group.device_bytes == (1 << 23) * 12544
         pl = s.group.placement
-        assert pl["candidates"] == 2 and pl["kept_probe_gbps"] >= pl["other_probe_gbps"] > 1000, pl
+        assert pl["candidates"] == 2 and pl["kept_probe_gbps"] >= pl["other_probe_gbps"] > 1000 and pl["kept_windowed_probe_gbps"] > 1000, pl
         r1 = s.group.search(s.batch, 1.0)
         assert r1.total_kmers == 970 * 1000 and r1.algorithmic_bytes == 970 * 1000 * 12500
+        # whichever form the loader's probe chose for this block, the other one must report the same columns
+        with ctx.tuning(walk_bands=0 if r1.search_kernel.startswith("and_band_walk") else 3, walk_bands_min_gib=0):
+            r1b = s.group.search(s.batch, 1.0)
+            assert r1b.search_kernel != r1.search_kernel and np.array_equal(r1.hits, r1b.hits), (r1.search_kernel, r1b.search_kernel)
         _check_planted(s, r1)
         hitq = [i for i, g in enumerate(s.query_genome) if g >= 0][:3]
         missq = [i for i, g in enumerate(s.query_genome) if g < 0][:3]
