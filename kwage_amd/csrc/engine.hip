@@ -487,24 +487,26 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 				ba.bands = bands;
 				ba.rows_per_band = (uint32_t)((g->nrows + bands - 1)/bands);
 				if((rc = sl->band_rows.reserve(band_items*sizeof(uint32_t)))){ return rc; }
-				if((rc = sl->band_prefix.reserve((uint64_t)bands*(a.n_queries + 1)*sizeof(uint32_t)))){ return rc; }
+				if((rc = sl->band_prefix.reserve((uint64_t)a.n_queries*(bands + 1)*sizeof(uint32_t)))){ return rc; }
 				if((rc = reserve_zeroed(sl->band_or, (uint64_t)a.n_queries*16*1024, sl->stream))){ return rc; }
 				if((rc = reserve_zeroed(sl->band_state, (uint64_t)a.n_queries*sizeof(uint32_t), sl->stream))){ return rc; }
 				ba.orbuf = (uint32_t*)sl->band_or.p;
 				ba.state = (uint32_t*)sl->band_state.p;
-				uint32_t *prefix = (uint32_t*)sl->band_prefix.p, *rows2 = (uint32_t*)sl->band_rows.p;
-				hipLaunchKernelGGL(band_hist_kernel, dim3(a.n_queries), dim3(256), 0, sl->stream, a.rows, a.pos_off, a.nkmer, a.num_hash, a.n_queries,
-				                   ba.bands, ba.rows_per_band, prefix);
-				hipLaunchKernelGGL(band_scan_kernel, dim3(ba.bands), dim3(256), 0, sl->stream, prefix, a.n_queries);
-				hipLaunchKernelGGL(band_scatter_kernel, dim3(a.n_queries), dim3(256), 0, sl->stream, a.rows, a.pos_off, a.nkmer, a.num_hash, a.n_queries,
-				                   ba.bands, ba.rows_per_band, (const uint32_t*)prefix, rows2);
+				uint32_t *loc = (uint32_t*)sl->band_prefix.p, *rows2 = (uint32_t*)sl->band_rows.p;
+				hipLaunchKernelGGL(band_bucket_kernel, dim3(a.n_queries), dim3(256), 0, sl->stream, a.rows, a.pos_off, a.nkmer, a.num_hash,
+				                   ba.bands, ba.rows_per_band, loc, rows2);
+				WalkArgs wb;
+				wb.total_slots = walk_slots;                         // (one column tile: slots = positions)
+				wb.per_wave = (walk_slots + waves - 1)/waves;
+				wb.coltiles = 1;
+				wb.orbuf = nullptr; wb.done = nullptr; wb.full_fences = 0;
 				a.segs = 1;
 				a.chunks = 1;
 				snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_band_walk_kernel<%u,%d>", walk_ch, walk_unroll == 2 ? 2 : 4);
 				const dim3 grid(wgs), block(shape.wg_waves*WAVE), fgrid((a.n_queries + 3)/4);
 #define KWAGE_BAND_LAUNCH(CH, U) do { \
 					if(shape.lds > 48*1024){ (void)hipFuncSetAttribute((const void*)and_band_walk_kernel<CH, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shape.lds); } \
-					hipLaunchKernelGGL((and_band_walk_kernel<CH, U>), grid, block, shape.lds, sl->stream, a, ba, (const uint32_t*)rows2, (const uint32_t*)prefix); \
+					hipLaunchKernelGGL((and_band_walk_kernel<CH, U>), grid, block, shape.lds, sl->stream, a, ba, wb, (const uint32_t*)rows2, (const uint32_t*)loc, a.pos_off, a.nkmer); \
 					hipLaunchKernelGGL((and_band_finish_kernel<CH>), fgrid, dim3(256), 0, sl->stream, a, ba, a.nkmer); } while(0)
 #define KWAGE_BAND_CASE(CH) case CH: \
 					if(walk_unroll == 2){ KWAGE_BAND_LAUNCH(CH, 2); } else{ KWAGE_BAND_LAUNCH(CH, 4); } break;

@@ -637,9 +637,8 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void and_walk_kernel(SearchArgs
 // narrow part of it: concurrent accesses to different large regions of the device's memory cost each other
 // (tools/micro/placement_probe.hip: a 105 GB block that reads 6.66 TB/s reads 6.91 when the rows are taken window after
 // window; every 4 GiB window alone reads 6.95; profiles/r03_placement_probe.txt).  AND is order independent, so the
-// batch's rows are regrouped by BAND of the matrix (band_hist / band_scan / band_scatter: `rows2` is band-major,
-// query-minor; prefix[b][q] = rows of the queries before q in band b) and every wave walks its equal share of band 0's
-// list, then of band 1's, ... -- all waves move up the matrix together.  A (query, band) part is reduced in registers
+// rows of every query are bucketed by BAND of the matrix (band_bucket_kernel, one launch) and every wave walks band 0's
+// part of its share of the batch, then band 1's, ... -- all waves move up the matrix together.  A (query, band) part is reduced in registers
 // as before; parts meet in the query's slot: an all-zero part (the rule after a few dozen random rows) only raises the
 // slot's DEAD flag, a part with surviving columns ORs its complemented mask in (DIRTY).  Nothing waits for anything:
 // and_band_finish_kernel, queued behind, reads the slots of the queries that are DIRTY and not DEAD, reports their
@@ -652,11 +651,13 @@ struct BandArgs {
 };
 static constexpr uint32_t BAND_MAX = 64;
 
-// rows of query q per band -> cnt[b][q]   (cnt is [bands][n_queries + 1]; one workgroup per query)
-__global__ __launch_bounds__(256) void band_hist_kernel(const uint32_t *__restrict__ rows, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ nkmer,
-                                                       uint32_t num_hash, uint32_t n_queries, uint32_t bands, uint32_t rows_per_band, uint32_t *__restrict__ cnt)
+// The rows of query q, bucketed by band IN PLACE of the query's stretch of the row list: rows2[pos_off[q]*nh + loc[q][b] ...
+// + loc[q][b+1]) are q's rows in band b (loc is [n_queries][bands + 1], loc[q][bands] = q's rows).  One workgroup per query;
+// the order inside a bucket is free.
+__global__ __launch_bounds__(256) void band_bucket_kernel(const uint32_t *__restrict__ rows, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ nkmer,
+                                                         uint32_t num_hash, uint32_t bands, uint32_t rows_per_band, uint32_t *__restrict__ loc, uint32_t *__restrict__ rows2)
 {
-	__shared__ uint32_t h[BAND_MAX];
+	__shared__ uint32_t h[BAND_MAX], cur[BAND_MAX];
 	const uint32_t q = blockIdx.x;
 	if(threadIdx.x < BAND_MAX){ h[threadIdx.x] = 0; }
 	__syncthreads();
@@ -666,95 +667,63 @@ __global__ __launch_bounds__(256) void band_hist_kernel(const uint32_t *__restri
 		atomicAdd(&h[min(rows[base + i]/rows_per_band, bands - 1)], 1u);
 	}
 	__syncthreads();
-	if(threadIdx.x < bands){ cnt[(uint64_t)threadIdx.x*(n_queries + 1) + q] = h[threadIdx.x]; }
-}
-
-// cnt[b][0 .. n_queries) -> exclusive prefix sums in place, cnt[b][n_queries] = the band's total   (one workgroup per band)
-__global__ __launch_bounds__(256) void band_scan_kernel(uint32_t *cnt, uint32_t n_queries)
-{
-	__shared__ uint32_t part[256];
-	uint32_t *p = cnt + (uint64_t)blockIdx.x*(n_queries + 1);
-	const uint32_t chunk = (n_queries + 255)/256;
-	const uint32_t lo = min(threadIdx.x*chunk, n_queries), hi = min(lo + chunk, n_queries);
-	uint32_t sum = 0;
-	for(uint32_t i = lo; i < hi; ++i){ sum += p[i]; }
-	part[threadIdx.x] = sum;
-	__syncthreads();
 	if(threadIdx.x == 0){
+		uint32_t *lq = loc + (uint64_t)q*(bands + 1);
 		uint32_t run = 0;
-		for(int t = 0; t < 256; ++t){ const uint32_t x = part[t]; part[t] = run; run += x; }
-		p[n_queries] = run;
+		for(uint32_t b = 0; b < bands; ++b){ cur[b] = run; lq[b] = run; run += h[b]; }
+		lq[bands] = run;
 	}
 	__syncthreads();
-	uint32_t run = part[threadIdx.x];
-	for(uint32_t i = lo; i < hi; ++i){ const uint32_t x = p[i]; p[i] = run; run += x; }
-}
-
-// rows -> rows2: band-major, query-minor   (one workgroup per query; the order inside a (query, band) part is free)
-__global__ __launch_bounds__(256) void band_scatter_kernel(const uint32_t *__restrict__ rows, const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ nkmer,
-                                                          uint32_t num_hash, uint32_t n_queries, uint32_t bands, uint32_t rows_per_band,
-                                                          const uint32_t *__restrict__ prefix, uint32_t *__restrict__ rows2)
-{
-	__shared__ uint32_t cur[BAND_MAX];
-	const uint32_t q = blockIdx.x;
-	if(threadIdx.x == 0){
-		uint32_t base = 0;
-		for(uint32_t b = 0; b < bands; ++b){
-			const uint32_t *pf = prefix + (uint64_t)b*(n_queries + 1);
-			cur[b] = base + pf[q];
-			base += pf[n_queries];
-		}
-	}
-	__syncthreads();
-	const uint64_t base = pos_off[q]*num_hash;
-	const uint32_t n = nkmer[q]*num_hash;
 	for(uint32_t i = threadIdx.x; i < n; i += blockDim.x){
 		const uint32_t r = rows[base + i];
-		rows2[atomicAdd(&cur[min(r/rows_per_band, bands - 1)], 1u)] = r;
+		rows2[base + atomicAdd(&cur[min(r/rows_per_band, bands - 1)], 1u)] = r;
 	}
 }
 
+// (the grid and a wave's share of the batch's POSITIONS are and_walk_kernel's: wa.total_slots, wa.per_wave; in band b a
+// wave takes, of every query piece it holds, the same fraction of the query's band-b bucket as the piece is of the query)
 template <int CH, int UNROLL>
-__global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void and_band_walk_kernel(SearchArgs a, BandArgs ba, const uint32_t *__restrict__ rows2,
-                                                                           const uint32_t *__restrict__ prefix)
+__global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void and_band_walk_kernel(SearchArgs a, BandArgs ba, WalkArgs wa, const uint32_t *__restrict__ rows2,
+                                                                           const uint32_t *__restrict__ loc, const uint64_t *__restrict__ pos_off,
+                                                                           const uint32_t *__restrict__ nkmer)
 {
 	const uint32_t lane = threadIdx.x & (WAVE - 1);
 	const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x*(blockDim.x/WAVE) + (threadIdx.x >> 6));
-	const uint32_t nw = gridDim.x*(blockDim.x/WAVE);
+	const uint64_t s_begin = (uint64_t)gw*wa.per_wave;
+	const uint64_t s_end = min(wa.total_slots, s_begin + wa.per_wave);
+	if(s_begin >= s_end){ return; }
 	const uint32_t row_bytes = a.units_per_row*16u;
-	const uint32_t q1 = a.n_queries + 1;
-	uint32_t band_base = 0;
-	uint32_t q_start = 0xFFFFFFFFu;          // where this wave's share of the previous band began: the next band's begins nearby
+	const uint32_t b1 = ba.bands + 1;
+	// the query that holds position s_begin: the largest q with pos_off[q] <= s_begin
+	uint32_t q_begin = 0;
+	{
+		uint32_t hi = a.n_queries;
+		while(hi - q_begin > 1){
+			const uint32_t mid = q_begin + (hi - q_begin)/2;
+			if(pos_off[mid] <= s_begin){ q_begin = mid; } else { hi = mid; }
+		}
+	}
 	for(uint32_t b = 0; b < ba.bands; ++b){
-		const uint32_t *pf = prefix + (uint64_t)b*q1;
-		const uint32_t total = pf[a.n_queries];
-		const uint32_t per = (uint32_t)(((uint64_t)total + nw - 1)/nw);
-		uint64_t s = (uint64_t)gw*per;
-		const uint64_t s1 = min((uint64_t)total, s + per);
-		if(s < s1){
-			// the query that holds the band's slot s: the largest q with pf[q] <= s (queries without rows in this band
-			// share their successor's prefix, so the largest one is the one that has rows)
-			// (a binary search in the first band -- ten dependent scalar loads --, a step or two from the previous band's
-			// start afterwards: every band holds about the same share of every query's rows)
-			uint32_t q = 0;
-			if(q_start == 0xFFFFFFFFu){
-				uint32_t hi = a.n_queries;
-				while(hi - q > 1){
-					const uint32_t mid = q + (hi - q)/2;
-					if(pf[mid] <= s){ q = mid; } else { hi = mid; }
-				}
+		uint64_t s = s_begin;
+		uint32_t q = q_begin;
+		while(s < s_end){
+			const uint64_t p0 = pos_off[q];
+			const uint64_t npos = pos_off[q + 1] - p0;
+			if(npos == 0){ ++q; continue; }                  // a query shorter than k (q stays in range: s < total_slots)
+			const uint32_t j0 = (uint32_t)(s - p0);
+			const uint32_t take = (uint32_t)min(npos - j0, s_end - s);
+			const uint32_t n = nkmer[q];
+			const uint32_t jv1 = min(j0 + take, n);              // positions past the distinct k-mers hold no rows
+			uint32_t nrows = 0;
+			const uint32_t *rq = rows2;
+			if(j0 < jv1){
+				const uint32_t *lq = loc + (uint64_t)q*b1;
+				const uint32_t c0 = lq[b], cnt = lq[b + 1] - c0;
+				const uint32_t lo = (uint32_t)((uint64_t)cnt*j0/n), hi = (uint32_t)((uint64_t)cnt*jv1/n);
+				nrows = hi - lo;
+				rq = rows2 + p0*a.num_hash + c0 + lo;
 			}
-			else{
-				q = q_start;
-				while(q > 0 && pf[q] > s){ --q; }
-			}
-			while(pf[q + 1] <= s){ ++q; }                            // (pf[n_queries] = total > s)
-			q_start = q;
-			while(s < s1){
-				while(pf[q + 1] <= s){ ++q; }
-				const uint32_t j0 = (uint32_t)(s - pf[q]);
-				const uint32_t nrows = (uint32_t)min((uint64_t)(pf[q + 1] - pf[q] - j0), s1 - s);
-				const uint32_t *rq = rows2 + band_base + s;
+			if(nrows){
 				u32x4 acc[CH];
 #pragma unroll
 				for(int j = 0; j < CH; ++j){ acc[j] = ~(u32x4)(0u); }
@@ -803,10 +772,10 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void and_band_walk_kernel(Searc
 					}
 				}
 				if(lane == 0){ __hip_atomic_fetch_or(ba.state + q, live ? WALK_DIRTY : WALK_DEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-				s += nrows;
 			}
+			s += take;
+			if(j0 + take == npos){ ++q; }
 		}
-		band_base += total;
 	}
 }
 
