@@ -487,12 +487,12 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 				ba.bands = bands;
 				ba.rows_per_band = (uint32_t)((g->nrows + bands - 1)/bands);
 				if((rc = sl->band_rows.reserve(band_items*sizeof(uint32_t)))){ return rc; }
-				if((rc = sl->band_prefix.reserve((uint64_t)a.n_queries*(bands + 1)*sizeof(uint32_t)))){ return rc; }
+				if((rc = sl->band_loc.reserve((uint64_t)a.n_queries*(bands + 1)*sizeof(uint32_t)))){ return rc; }
 				if((rc = reserve_zeroed(sl->band_or, (uint64_t)a.n_queries*16*1024, sl->stream))){ return rc; }
 				if((rc = reserve_zeroed(sl->band_state, (uint64_t)a.n_queries*sizeof(uint32_t), sl->stream))){ return rc; }
 				ba.orbuf = (uint32_t*)sl->band_or.p;
 				ba.state = (uint32_t*)sl->band_state.p;
-				uint32_t *loc = (uint32_t*)sl->band_prefix.p, *rows2 = (uint32_t*)sl->band_rows.p;
+				uint32_t *loc = (uint32_t*)sl->band_loc.p, *rows2 = (uint32_t*)sl->band_rows.p;
 				hipLaunchKernelGGL(band_bucket_kernel, dim3(a.n_queries), dim3(256), 0, sl->stream, a.rows, a.pos_off, a.nkmer, a.num_hash,
 				                   ba.bands, ba.rows_per_band, loc, rows2);
 				WalkArgs wb;
@@ -910,7 +910,7 @@ extern "C" void kwage_shutdown(kwage_ctx *ctx)
 		sl->rows.release(); sl->tables.release(); sl->result.release();
 		sl->partial.release(); sl->h_stage.release(); sl->sort_scratch.release();
 		sl->walk_or.release(); sl->walk_done.release();
-		sl->band_rows.release(); sl->band_prefix.release(); sl->band_or.release(); sl->band_state.release(); sl->cwalk_slab.release(); sl->cwalk_arrived.release();
+		sl->band_rows.release(); sl->band_loc.release(); sl->band_or.release(); sl->band_state.release(); sl->cwalk_slab.release(); sl->cwalk_arrived.release();
 		for(int i = 0; i < 4; ++i){ if(sl->ev[i]){ (void)hipEventDestroy(sl->ev[i]); } }
 		if(sl->search_done){ (void)hipEventDestroy(sl->search_done); }
 		if(sl->stream){ (void)hipStreamDestroy(sl->stream); }

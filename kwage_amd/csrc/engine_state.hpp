@@ -156,9 +156,9 @@ struct Slot {
 	char kernel_name[64] = "";          // the gather kernel launch_search_stage picked, with its template shape
 	// and_walk_kernel's meeting place for (query, tile) pairs cut by a wave-share boundary: all zero between searches
 	DevBuf walk_or, walk_done;
-	// and_band_walk_kernel's: the batch's rows regrouped by band of the matrix, the per-band prefix over the queries, and
+	// and_band_walk_kernel's: every query's rows bucketed by band of the matrix, the buckets' offsets per query, and
 	// the queries' meeting slots (masks + flags: zero between searches)
-	DevBuf band_rows, band_prefix, band_or, band_state;
+	DevBuf band_rows, band_loc, band_or, band_state;
 	// count_walk_kernel's: partial counters of cut pairs (overwritten before they are read) and the arrival counters of their trees (zero between searches)
 	DevBuf cwalk_slab, cwalk_arrived;
 	uint64_t staged_hits = 0;
