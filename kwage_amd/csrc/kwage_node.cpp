@@ -20,6 +20,7 @@
 // only this program links it.  No row data ever crosses xGMI.
 //
 //   KWAGE_NODE_RANKS    number of ranks (default: the number of visible devices); rank r uses device r
+//   KWAGE_NODE_PLAN     1: print the plan (groups, every rank's files, global column bases) as JSON and stop; no device is touched
 //   KWAGE_NODE_REHEARSE 1: rehearsal on a machine with fewer GPUs than ranks -- every rank uses device 0 and the records
 //                       travel through a shared host segment instead of RCCL (which refuses two ranks on one device).
 //                       The searches still run on the GPU; sharding, global numbering, gather and report are the same
@@ -95,6 +96,70 @@ struct Rehearsal {
 	kwage_hit *records() { return reinterpret_cast<kwage_hit*>(this + 1); }
 };
 
+// The node's plan: the database files grouped by parameters, every group's files dealt to the ranks (share_of), and
+// the global column number of every rank's column 0 -- group after group, inside a group rank after rank.  A pure
+// function of the file headers: every rank computes the same plan (and KWAGE_NODE_PLAN=1 prints it without a device).
+vector<NodeGroup> plan_groups(const vector<DbFileEntry> &files, int n_ranks)
+{
+	map<GroupKey, vector<uint32_t> > by_key;
+	for(size_t i = 0; i < files.size(); ++i){
+		const kwage_db_header &h = files[i].header;
+		by_key[GroupKey{h.kmer_len, h.num_hash, h.log_2_filter_len, h.hash_func}].push_back((uint32_t)i);
+	}
+	vector<NodeGroup> groups;
+	uint64_t next_base = 0;
+	for(const auto &kv : by_key){
+		NodeGroup g;
+		g.key = kv.first;
+		g.params = kwage_params{kv.first.kmer_len, kv.first.num_hash, kv.first.log_2_filter_len, kv.first.hash_func};
+		for(int r = 0; r < n_ranks; ++r){
+			g.share.push_back(share_of(kv.second, files, (size_t)r, (size_t)n_ranks));
+			g.base.push_back(next_base);
+			next_base += g.share.back().span_columns;
+		}
+		groups.push_back(std::move(g));
+	}
+	if(next_base > (1ull << 32)){ throw "main: more than 2^32 columns in the database"; }
+	return groups;
+}
+
+// KWAGE_NODE_PLAN=1: print the plan for n_ranks ranks and stop -- no device is touched (tests; a dry run before a long job)
+int print_plan(const vector<string> &db_paths, int n_ranks)
+{
+	try{
+		vector<DbFileEntry> files(db_paths.size());
+		for(size_t i = 0; i < db_paths.size(); ++i){
+			files[i].path = db_paths[i];
+			if(kwage_db_read_header(files[i].path.c_str(), &files[i].header) != KWAGE_OK){
+				cerr << kwage_last_error() << endl;
+				throw "main: I/O error";
+			}
+		}
+		const vector<NodeGroup> groups = plan_groups(files, n_ranks);
+		cout << "{\"ranks\": " << n_ranks << ", \"groups\": [";
+		for(size_t gi = 0; gi < groups.size(); ++gi){
+			const NodeGroup &g = groups[gi];
+			cout << (gi ? ", " : "") << "{\"kmer_len\": " << g.key.kmer_len << ", \"num_hash\": " << g.key.num_hash << ", \"log_2_filter_len\": "
+			     << g.key.log_2_filter_len << ", \"hash_func\": " << g.key.hash_func << ", \"shares\": [";
+			for(size_t r = 0; r < g.share.size(); ++r){
+				cout << (r ? ", " : "") << "{\"rank\": " << r << ", \"global_base\": " << g.base[r] << ", \"span_columns\": " << g.share[r].span_columns << ", \"files\": [";
+				for(size_t f = 0; f < g.share[r].files.size(); ++f){
+					cout << (f ? ", " : "") << "{\"path\": \"" << files[g.share[r].files[f]].path << "\", \"first_column\": " << g.share[r].first_column[f]
+					     << ", \"num_filter\": " << files[g.share[r].files[f]].header.num_filter << "}";
+				}
+				cout << "]}";
+			}
+			cout << "]}";
+		}
+		cout << "]}" << endl;
+	}
+	catch(const char *error){
+		cerr << "Caught the error " << error << endl;
+		return EXIT_FAILURE;
+	}
+	return EXIT_SUCCESS;
+}
+
 int run_rank(int rank, int n_ranks, const string &id_path, const Cli &cli, const vector<string> &db_paths, Rehearsal *rehearsal)
 {
 	try{
@@ -124,26 +189,7 @@ int run_rank(int rank, int n_ranks, const string &id_path, const Cli &cli, const
 				throw "main: Unable to read header";
 			}
 		}
-		map<GroupKey, vector<uint32_t> > by_key;
-		for(size_t i = 0; i < files.size(); ++i){
-			const kwage_db_header &h = files[i].header;
-			by_key[GroupKey{h.kmer_len, h.num_hash, h.log_2_filter_len, h.hash_func}].push_back((uint32_t)i);
-		}
-		// global column numbers: group after group, inside a group rank after rank
-		vector<NodeGroup> groups;
-		uint64_t next_base = 0;
-		for(const auto &kv : by_key){
-			NodeGroup g;
-			g.key = kv.first;
-			g.params = kwage_params{kv.first.kmer_len, kv.first.num_hash, kv.first.log_2_filter_len, kv.first.hash_func};
-			for(int r = 0; r < n_ranks; ++r){
-				g.share.push_back(share_of(kv.second, files, (size_t)r, (size_t)n_ranks));
-				g.base.push_back(next_base);
-				next_base += g.share.back().span_columns;
-			}
-			groups.push_back(std::move(g));
-		}
-		if(next_base > (1ull << 32)){ throw "main: more than 2^32 columns in the database"; }
+		vector<NodeGroup> groups = plan_groups(files, n_ranks);
 		// where every file's columns begin in the global numbering (ascending: groups, ranks and files are numbered in order)
 		vector<ColumnBlock> blocks;
 		for(const NodeGroup &g : groups){
@@ -391,6 +437,7 @@ int main(int argc, char *argv[])
 		cerr << "kwage_node: no usable device count (" << n_ranks << "); set KWAGE_NODE_RANKS" << endl;
 		return EXIT_FAILURE;
 	}
+	if(env_u64("KWAGE_NODE_PLAN", 0)){ return print_plan(db_paths, n_ranks); }
 	Rehearsal *rehearsal = nullptr;
 	if(env_u64("KWAGE_NODE_REHEARSE", 0)){
 		const uint64_t capacity = env_u64("KWAGE_NODE_REHEARSE_RECORDS", 64ull << 20);

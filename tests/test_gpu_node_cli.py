@@ -108,3 +108,47 @@ def test_node_cli_a_failing_rank_ends_the_run(tmp_path):
     r = subprocess.run([NODE, "-d", "dbs", "-i", "reads.fastq", "-t", "0.5", "--o.csv", "-o", "/no_such_dir/out.csv"], cwd=cdir, capture_output=True,
                        timeout=120, env=_env(KWAGE_NODE_RANKS="2", KWAGE_NODE_REHEARSE="1"))
     assert r.returncode != 0 and b"Unable to open" in r.stderr
+
+
+def test_node_plan_is_the_python_hosts_partition(tmp_path, oracle):
+    """KWAGE_NODE_PLAN=1 prints kwage_node's plan without touching a device: files of ragged widths in two parameter
+    groups, 1 ... 9 ranks.  Every group's files must be dealt to the ranks exactly as kwage_amd.distributed.partition_files
+    deals them (the file that holds a rank's middle column), every file's block must start on a 16-byte boundary behind its
+    predecessor, and the global column bases must number groups and ranks in order without overlap."""
+    import numpy as np
+    from kwage_amd.distributed import partition_files
+    rng = np.random.default_rng(5)
+    widths = {"a": [int(x) for x in rng.integers(1, 300, size=17)], "b": [2048, 1, 2048, 7, 640]}
+    for sub, (L, nh) in (("a", (10, 1)), ("b", (11, 2))):
+        os.makedirs(tmp_path / "db" / sub)
+        for f, n in enumerate(widths[sub]):
+            rows = rng.integers(0, 256, size=(1 << L, (n + 7) // 8), dtype=np.uint8)
+            infos = [oracle.FilterInfo(run_accession=oracle.str_to_accession("SRR%07d" % (1000 * f + j))) for j in range(n)]
+            oracle.write_db(str(tmp_path / "db" / sub / ("f%02d.db" % f)), 31, nh, L, rows, n, infos)
+    for ranks in (1, 2, 3, 5, 9):
+        r = subprocess.run([NODE, "-d", "db", "-t", "1", "ACGTACGTACGTACGTACGTACGTACGTACGTAAA"], cwd=tmp_path, capture_output=True, timeout=60,
+                           env=_env(KWAGE_NODE_RANKS=str(ranks), KWAGE_NODE_PLAN="1"))
+        assert r.returncode == 0, r.stderr.decode()
+        plan = json.loads(r.stdout)
+        assert plan["ranks"] == ranks and len(plan["groups"]) == 2
+        next_base = 0
+        for g in plan["groups"]:
+            sub = "a" if g["log_2_filter_len"] == 10 else "b"
+            files = sorted(os.path.join("db", sub, "f%02d.db" % f) for f in range(len(widths[sub])))       # the CLI's order within a directory
+            listed = [f["path"] for s in g["shares"] for f in s["files"]]
+            assert sorted(listed) == files
+            order = [p for p in listed]                       # rank after rank = the order the files were found in
+            nf = [widths[sub][int(os.path.basename(p)[1:3])] for p in order]
+            want = partition_files(nf, ranks)
+            at = 0
+            for s, (lo, hi) in zip(g["shares"], want):
+                assert [f["path"] for f in s["files"]] == order[lo:hi], (ranks, sub, s["rank"])
+                assert s["global_base"] == next_base
+                span = 0
+                for f in s["files"]:
+                    span = (span + 15) // 16 * 16
+                    assert f["first_column"] == span * 8 and f["num_filter"] == nf[at]
+                    span += (f["num_filter"] + 7) // 8
+                    at += 1
+                assert s["span_columns"] == span * 8
+                next_base += s["span_columns"]
