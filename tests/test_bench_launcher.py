@@ -86,6 +86,16 @@ def test_traffic_is_reported_only_for_the_kernel_and_code_that_were_profiled(mon
         assert t is None and src["status"].startswith("stale: the kernel sources / engine changed")
     assert n >= 4
     assert bench.measured_traffic("no-such-workload", "k", False)[0] is None
+    # a workload whose kernel depends on where its matrix lies has one pass per kernel ("c2" and "c2@<the band form>"):
+    # the run's kernel picks the pass
+    keyed = [k for k in rec if "@" in k]
+    assert keyed
+    for key in keyed:
+        workload, kern = key.split("@", 1)
+        monkeypatch.setattr(bench, "kernel_code_hash", lambda e=rec[key]: e["code_hash"])
+        assert rec[key]["kernel"] == kern and rec[workload]["kernel"] != kern
+        assert bench.measured_traffic(workload, kern, False)[0] == rec[key]["hbm_read_bytes_per_launch"]
+        assert bench.measured_traffic(workload, rec[workload]["kernel"], False)[0] == rec[workload]["hbm_read_bytes_per_launch"]
 
 
 @pytest.mark.gpu
