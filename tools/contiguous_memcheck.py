@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Does a physically contiguous matrix cost more device memory than its size?  Free memory before / after groups of
+105, 164 and 193 GB (hipExtMallocWithFlags(hipDeviceMallocContiguous) does not round up).   python tools/contiguous_memcheck.py"""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import kwage_amd as ka

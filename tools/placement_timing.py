@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""What the loader's choice between two candidate placements costs at load time: group creation timed for matrices of
+105, 105, 26 and 131 GB in one process; with KWAGE_VERBOSE=1 the loader prints allocation / probe / release times and
+the probe's rates.   KWAGE_VERBOSE=1 python tools/placement_timing.py"""
 import sys, os, time
 sys.path.insert(0, os.getcwd())
 import kwage_amd as ka
