@@ -227,7 +227,7 @@ double probe_block(kwage_group *g, const void *block, uint32_t windows = 1)
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	double best = 0;
 	if(hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess){
-		for(int i = 0; i < 4; ++i){                          // (the first launch is the warm-up)
+		for(int i = 0; i < 6; ++i){                          // (the first launch is the warm-up; the best of five counts)
 			(void)hipEventRecord(e0, ctx->stream);
 			hipLaunchKernelGGL(placement_probe_kernel, dim3(wgs), dim3(512), 100*1024, ctx->stream, (const dwords4*)block, g->nrows, stride16,
 			                   chunks, lanes, rows_per_wave, windows, (uint32_t*)sink);
