@@ -2,6 +2,7 @@
 """bench.py -- throughput of the kwage search path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5|c5s|c2t|c1]
+                    [--scaling weak|strong] [--also auto|none|c3,c4,...] [--share-of K [--share-rank R]]
 
 A "step" is one pass of the hot path over one batch of synthetic queries against the
 HBM-resident synthetic database (k-mer pack + MurmurHash3 + row gather + AND/count + hit
@@ -9,15 +10,31 @@ compaction + D2H of the sorted hit list).  Inputs (database and query strings) a
 HBM before the timed region.  Metric = BASELINE.json's: G k-mer.sample bit-tests/s, with the
 achieved HBM GB/s of the gather kernel against the 8 TB/s roofline beside it.
 
+The line the driver reads (ONE JSON line, the last of stdout) is the headline workload -- C2, the configuration
+BASELINE.json quotes the metric on, unchanged from round to round -- and carries, beside `roofline`, `sustained`,
+`aggregate` and `cpu_baseline`:
+
+  * `result_check`: AFTER the timed region the hit lists the timed kernel produced are checked -- every query cut from
+    a planted genome reports the genome's columns, and three sampled queries are bit-exact against the CPU oracle on the
+    rows they address, read back from HBM.  The oracle is used here as the checker only, never inside a timed region;
+    a mismatch ends the run with a non-zero status on every rank.
+  * `also`: the other BASELINE.json configurations this launch can hold, each measured like the headline (own
+    `ms_per_step`, `roofline`, `result_check`, at N > 1 `exchange_check`) after the headline's matrix was freed:
+    at N = 1 **C3** (the largest 1-GPU configuration), at N > 1 the per-GPU shares of **C4** and **C5**.
+
 N > 1: one process per GPU.  Either the caller starts the ranks (`python -m torch.distributed.run
 --nproc-per-node N ... bench.py --gpus N`: RANK / LOCAL_RANK / WORLD_SIZE come from the environment), or
 plain `python bench.py --gpus N` starts them itself: the parent process -- which never touches the GPU --
 runs torch.distributed.run as a child and relays its output and exit code.  The sample (column) axis is
-sharded: every rank holds its own block of `num_samples` columns (weak scaling), searches it independently,
-and the per-rank hit lists are concatenated on rank 0 by one padded RCCL gather per step.  No row data ever
-crosses xGMI.  Every rank's gather-kernel time goes into the line (`aggregate`): the north-star figure is
-the fraction of the AGGREGATE HBM bandwidth, i.e. all ranks' algorithmic bytes over the slowest rank's
-kernel time.  `--workload c4` / `c5` are the per-GPU shares of BASELINE.json's 8-GPU configurations.
+sharded, queries are replicated, every rank searches its block independently and the per-rank hit lists are
+concatenated on rank 0 by one small RCCL exchange per step.  No row data ever crosses xGMI.
+  --scaling weak   (default) every rank holds `num_samples` columns of its own: per-GPU work is fixed.
+  --scaling strong the workload's columns are SPLIT over the ranks at 1024-column boundaries (partition_columns):
+                   total work is fixed, rows get narrower as N grows -- SURVEY 8(e)'s real limiter.
+  --share-of K     on ONE GPU, hold what rank R (--share-rank, default 0) of a K-way strong split would hold: the
+                   one-GPU proxy of the strong-scaling curve (tools/strong_scaling_proxy.py).
+Every rank's gather-kernel time goes into the line (`aggregate`): the north-star figure is the fraction of the
+AGGREGATE HBM bandwidth, i.e. all ranks' algorithmic bytes over the slowest rank's kernel time.
 
 The CPU baseline (rank 0, N=1 only) times the REFERENCE binary (oracle/_ref/kwage, OpenMP over
 <=2048-column .db files) when it travelled with the snapshot, else the repo's C restatement, on
@@ -41,6 +58,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 SUSTAINED_SECONDS = 2.0  # back-to-back steps after the timed region (DVFS: a 40 ms window could be a burst)
+MULTI_GROUPS = {"c5": "C5_GROUPS", "c5tiny": "C5_TEST_GROUPS"}     # workloads of several filter-size groups (kwage_amd/synth.py)
 
 
 def parse_args(argv=None):
@@ -49,7 +67,14 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=os.environ.get("KWAGE_BENCH_WORKLOAD", "c2"))
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("KWAGE_BENCH_SCALING", "weak"),
+                    help="weak: every rank holds the workload's columns; strong: the workload's columns are split over the ranks")
+    ap.add_argument("--share-of", type=int, default=0, help="one GPU holding one rank's share of a K-way strong split (the strong-scaling proxy)")
+    ap.add_argument("--share-rank", type=int, default=0, help="which rank's share --share-of holds")
+    ap.add_argument("--also", default=os.environ.get("KWAGE_BENCH_ALSO", "auto"),
+                    help="other configurations measured after the headline: auto (N=1: c3; N>1: c4,c5 -- only when the headline is c2), none, or a comma list")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-result-check", action="store_true", help="skip the post-timing check of the hit lists against the oracle")
     ap.add_argument("--no-sustained", action="store_true", help="skip the %.0f s sustained block after the timed steps" % SUSTAINED_SECONDS)
     ap.add_argument("--early-exit", action="store_true", help="enable the reference's early exit (not the nominal figure)")
     ap.add_argument("--cpu-files", type=int, default=0, help="number of 2048-column .db files of the CPU sample (default: host cores, max 16)")
@@ -218,61 +243,146 @@ def measured_traffic(workload, kernel, early_exit):
     return t["hbm_read_bytes_per_launch"], src
 
 
-def rank_main(args):
-    import numpy as np
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    args.gpus = world
+# ------------------------------------------------------------------------------------------------------
+# which columns a rank holds; which other configurations a launch measures
+# ------------------------------------------------------------------------------------------------------
+def rank_share(name, scaling, split, part):
+    """-> (Workload, groups-or-None, total samples) of workload `name` for rank `part` of `split`.
+    weak: every rank holds the workload's own column count.  strong: the workload's columns -- for a multi-group
+    workload every group's -- are cut into `split` contiguous blocks at 1024-column boundaries (partition_columns,
+    the rule the sharded hosts use) and the rank holds block `part`."""
+    from dataclasses import replace
+    from kwage_amd import synth
+    from kwage_amd.distributed import partition_columns
+    w = synth.WORKLOADS[name]
+    groups = getattr(synth, MULTI_GROUPS[name]) if name in MULTI_GROUPS else None
+    total = int(sum(ns for _, ns in groups)) if groups else int(w.num_samples)
+    if scaling == "strong" and split > 1:
+        def share(n):
+            s, e = partition_columns(int(n), split)[part]
+            return e - s
+        if groups:
+            groups = [(lg, share(ns)) for lg, ns in groups]
+            if any(ns <= 0 for _, ns in groups):
+                raise ValueError("strong split %d-way leaves rank %d without columns in some group of %s" % (split, part, name))
+        else:
+            if share(w.num_samples) <= 0:
+                raise ValueError("strong split %d-way leaves rank %d without columns of %s" % (split, part, name))
+            w = replace(w, num_samples=share(w.num_samples))
+    return w, groups, total
 
+
+def also_workloads(args, world):
+    """The BASELINE.json configurations measured after the headline.  auto: only behind the default headline (C2, weak) --
+    at N = 1 C3, the largest 1-GPU configuration; at N > 1 the per-GPU shares of the two 8-GPU configurations."""
+    sel = (args.also or "none").strip().lower()
+    if sel in ("none", "", "0", "off"):
+        return []
+    if sel == "auto":
+        if args.workload != "c2" or args.scaling != "weak" or args.share_of or args.early_exit:
+            return []
+        return ["c3"] if world == 1 else ["c4", "c5"]
+    return [x for x in (s.strip() for s in sel.split(",")) if x and x != args.workload]
+
+
+# ------------------------------------------------------------------------------------------------------
+# result_check: the hit lists of the timed kernel against planted positives and the CPU oracle
+# ------------------------------------------------------------------------------------------------------
+def result_check(members, results, threshold, n_hit=2, n_miss=1):
+    """After the timed region: what the kernel that was timed reported is (a) complete on the planted positives -- every
+    query cut from a planted genome reports the genome's columns with every k-mer found -- and (b) bit-exact, false
+    positives included, for sampled queries against the CPU oracle reducing the ADDRESSED rows read back from HBM
+    (tests/test_gpu_fullsize.py's size-independent checks).  The oracle is the checker here, nothing it does is timed.
+    -> dict; ["ok"] False on any mismatch."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import kwage_oracle as oracle
+    oracle.build()
+    t0 = time.perf_counter()
+    thr = float(np.float32(threshold))
+    out = {"ok": True, "planted_queries": 0, "planted_columns_found": 0, "planted_columns_expected": 0,
+           "sampled_queries": 0, "sampled_hits_compared": 0, "sampled_rows_read_back": 0, "mismatches": []}
+    for gi, (m, res) in enumerate(zip(members, results)):
+        w = m.workload
+        # records grouped by query without a Python loop over all of them (C3: 150 k hits)
+        order = np.argsort(res.hits["query"], kind="stable")
+        hq = res.hits["query"][order]
+        starts = np.searchsorted(hq, np.arange(len(m.queries) + 1))
+
+        def per_query(qi):
+            sl = order[starts[qi]:starts[qi + 1]]
+            return [(int(c), int(n)) for c, n in zip(res.hits["column"][sl], res.hits["num_match"][sl])]
+        for qi, src in enumerate(m.query_genome):
+            if src < 0:
+                continue
+            found = dict(per_query(qi))
+            nk = int(res.num_query_kmer[qi])
+            want = m.planted[src]
+            out["planted_queries"] += 1
+            out["planted_columns_expected"] += len(want)
+            got = sum(1 for c in want if found.get(c) == nk)
+            out["planted_columns_found"] += got
+            if got != len(want) and len(out["mismatches"]) < 8:
+                out["mismatches"].append({"group": gi, "query": qi, "kind": "planted column missing or short of num_query_kmer"})
+            lo = nk if threshold == 1.0 else int(res.query_threshold[qi])
+            if any(not (lo <= n <= nk) for n in found.values()) and len(out["mismatches"]) < 8:
+                out["mismatches"].append({"group": gi, "query": qi, "kind": "num_match outside [threshold, num_query_kmer]"})
+        hitq = [i for i, g in enumerate(m.query_genome) if g >= 0]
+        missq = [i for i, g in enumerate(m.query_genome) if g < 0]
+        pick = lambda xs, n: [xs[(len(xs) - 1) * j // max(n - 1, 1)] for j in range(min(n, len(xs)))]     # first ... last
+        for qi in pick(hitq, n_hit) + pick(missq, n_miss):
+            kmers = oracle.unique_kmers(m.queries[qi], w.kmer_len)
+            rows = oracle.row_indices(kmers, w.kmer_len, w.num_hash, w.log_2_filter_len).reshape(-1)
+            matrix = m.group.read_rows(rows)                      # only the rows this query addresses
+            exp = oracle.search_row_matrix(matrix, w.num_hash, w.num_samples, len(kmers), thr)
+            got = per_query(qi)
+            out["sampled_queries"] += 1
+            out["sampled_hits_compared"] += len(exp)
+            out["sampled_rows_read_back"] += int(len(rows))
+            if int(res.num_query_kmer[qi]) != len(kmers) or got != exp:
+                if len(out["mismatches"]) < 8:
+                    out["mismatches"].append({"group": gi, "query": qi, "kind": "hit list differs from the oracle's",
+                                              "device_hits": len(got), "oracle_hits": len(exp)})
+    out["ok"] = (not out["mismatches"]) and out["planted_columns_found"] == out["planted_columns_expected"] and out["sampled_queries"] > 0
+    out["groups"] = len(members)
+    out["oracle"] = "oracle/kwage_oracle.c (kwo_search_rows) on rows read back with kwage_group_read_rows"
+    out["seconds"] = round(time.perf_counter() - t0, 2)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------
+# one rank
+# ------------------------------------------------------------------------------------------------------
+class Env:
+    """What every measurement of a launch shares: the rank's place in the job, its context, the process group."""
+    pass
+
+
+def measure(env, args, name, headline):
+    """Build workload `name` on this rank, run warm-up + EXACTLY args.steps timed steps (+ the sustained block for the
+    headline), check the results, free everything.  -> the JSON block on rank 0, None elsewhere.  Raises SystemExit(3/4)
+    on every rank when the exchange or the results fail their check."""
+    import numpy as np
     import torch
     import kwage_amd as ka
-    from kwage_amd import native, synth
-    if local_rank == 0:
-        native.ensure_built()          # artefacts are git-ignored; normally they travel with the snapshot
-    else:
-        for _ in range(600):           # other ranks wait for rank 0's build instead of racing it
-            if os.path.exists(native.lib_path()) and os.path.exists(native.KWAGE_BIN):
-                break
-            time.sleep(0.5)
+    from kwage_amd import synth
+    rank, local_rank, world, backend, cdev, dist, ctx = env.rank, env.local_rank, env.world, env.backend, env.cdev, env.dist, env.ctx
+    sharded, force_sharded = env.sharded, env.force_sharded
+    want_sustained = headline and not args.no_sustained
 
-    # KWAGE_BENCH_BACKEND=gloo + KWAGE_BENCH_ONE_DEVICE=1 rehearse the N>1 code path on a one-GPU box
-    backend = os.environ.get("KWAGE_BENCH_BACKEND", "nccl")
-    if os.environ.get("KWAGE_BENCH_ONE_DEVICE") == "1":
-        local_rank = 0
-        # ranks that share a device must not each hold a second candidate block for their matrix while the others allocate theirs
-        os.environ.setdefault("KWAGE_GROUP_PLACEMENT_PROBE", "0")
-    # KWAGE_BENCH_FORCE_SHARDED=1: take the multi-GPU code path (device-resident hits + RCCL exchange)
-    # even with one rank, to measure its per-step overhead on a one-GPU box
-    force_sharded = os.environ.get("KWAGE_BENCH_FORCE_SHARDED") == "1"
-    if force_sharded and world == 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-    sharded = world > 1 or force_sharded
-    dist = None
-    ctx = ka.Context(local_rank)       # before torch.distributed creates its streams (hardware-queue assignment is first come, first served)
-    cdev = ("cuda:%d" % local_rank) if backend == "nccl" else "cpu"       # where the collectives' tensors live
-    if sharded:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-
-    w = synth.WORKLOADS[args.workload]
+    split = args.share_of if args.share_of > 1 else world
+    part = (args.share_rank if args.share_of > 1 else rank)
+    scaling = "strong" if (args.scaling == "strong" or args.share_of > 1) else "weak"
+    w, groups, total_samples = rank_share(name, scaling, split, part)
     t_build = time.perf_counter()
     multi = None
-    groups = {"c5": synth.C5_GROUPS, "c5tiny": synth.C5_TEST_GROUPS}.get(args.workload)
     if groups is not None:
         # adaptive filter sizes: several groups searched back to back; everything below treats the first
         # group as `s` for the shared query batch and sums work / kernel time over the groups
-        multi = synth.build_multi(ctx, groups, w, seed=1, column_seed=rank)
+        multi = synth.build_multi(ctx, groups, w, seed=1, column_seed=part)
         s = multi[0]
     else:
-        s = synth.build(ctx, w, seed=1, column_seed=rank)
+        s = synth.build(ctx, w, seed=1, column_seed=part)
     t_build = time.perf_counter() - t_build
     flags = ka.SEARCH_TIMING | (ka.SEARCH_EARLY_EXIT if args.early_exit else 0)
     threshold = w.threshold
@@ -388,7 +498,7 @@ def rank_main(args):
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
                 if rank == 0:
-                    print(json.dumps({"metric": "exchange_check failed", "exchange_check": exchange_check}), flush=True)
+                    print(json.dumps({"metric": "exchange_check failed", "workload": w.name, "exchange_check": exchange_check}), flush=True)
                 sys.exit(3)
 
     last_results = []
@@ -458,7 +568,8 @@ def rank_main(args):
     # ---- sustained block: the same steps back to back for >= SUSTAINED_SECONDS (the count is derived from the agreed
     # max-over-ranks step time, so every rank runs the same number of steps and collectives) ------------------------
     sustained = None
-    if not args.no_sustained:
+    sus_kernel_ms = []
+    if want_sustained:
         n_sus = int(max(args.steps, min(20000, SUSTAINED_SECONDS / max(dt / args.steps, 1e-6)))) + 1
         sync_all()
         kernel_ms.clear()
@@ -473,73 +584,95 @@ def rank_main(args):
         sus_kernel_ms = list(kernel_ms)
         sustained = {"steps": n_sus, "seconds": round(dts, 3), "ms_per_step": round(dts / n_sus * 1e3, 4)}
 
-    # work per step (identical on every rank: same queries, same column count)
+    # work per step on THIS rank (weak scaling: identical on every rank; strong: the ranks' column counts differ)
     probe = list(last_results) or [m.group.search(s.batch, threshold, flags) for m in members]
     bit_tests_rank = int(sum(r.bit_tests for r in probe))
     alg_bytes_rank = int(sum(r.algorithmic_bytes for r in probe))
-    probe = probe[0]
     if sharded and pipe is None:
         # the synchronous sharded path does not return kernel times: measure them with three local searches
         timed_kernel_ms = [sum(m.group.search(s.batch, threshold, flags).search_kernel_ms for m in members) for _ in range(3)]
         sus_kernel_ms = []
 
+    # ---- result_check: the lists the timed kernel produced (rank-local, before any exchange) ------------------------
+    rcheck = None
+    if not args.no_result_check:
+        try:
+            rcheck = result_check(members, probe, threshold)
+        except Exception as exc:          # a checker that cannot run is a failed check, not a skipped one
+            rcheck = {"ok": False, "error": repr(exc)}
+    probe = probe[0]
+
     def stats(xs):
         xs = [float(x) for x in xs if x > 0]
         return [float(np.mean(xs)), float(np.min(xs)), float(np.max(xs))] if xs else [0.0, 0.0, 0.0]
 
-    # every rank's kernel time (timed region: mean/min/max; sustained block: mean/min/max), gathered on all ranks
-    mine = stats(timed_kernel_ms) + (stats(sus_kernel_ms) if sustained else [0.0, 0.0, 0.0])
+    # every rank's kernel time (timed region: mean/min/max; sustained block: mean/min/max), its work per step and the
+    # verdict of its result check, gathered on all ranks
+    mine = stats(timed_kernel_ms) + (stats(sus_kernel_ms) if sustained else [0.0, 0.0, 0.0]) \
+        + [float(bit_tests_rank), float(alg_bytes_rank), 1.0 if (rcheck is None or rcheck.get("ok")) else 0.0]
     per_rank = [mine]
     if dist is not None:
         t = torch.tensor(mine, dtype=torch.float64, device=cdev)
         outs = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(outs, t)
         per_rank = [[float(x) for x in o.tolist()] for o in outs]
+    checks_ok = all(r[8] == 1.0 for r in per_rank)
 
+    out = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = bit_tests_rank * world * args.steps / dt / 1e9
+        bit_tests_all = int(sum(r[6] for r in per_rank))
+        alg_bytes_all = int(sum(r[7] for r in per_rank))
+        value = bit_tests_all * args.steps / dt / 1e9
         k_ms = per_rank[0][0]
         achieved = alg_bytes_rank / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         stream_gbps = s.group.stream_read_gbps(min(s.group.device_bytes, 8 << 30), 3)
         kernel = getattr(probe, "search_kernel", "") or ("and_kernel" if threshold == 1.0 else "count_kernel")
-        traffic, traffic_source = measured_traffic(args.workload, kernel, args.early_exit)
+        traffic, traffic_source = (None, {"status": "no PMC pass for a %d-way share" % split}) if scaling == "strong" and split > 1 \
+            else measured_traffic(name, kernel, args.early_exit)
         k_means = [r[0] for r in per_rank]
         k_max, k_mean = max(k_means), float(np.mean(k_means))
-        agg_achieved = alg_bytes_rank * world / (k_max * 1e-3) / 1e9 if k_max > 0 else 0.0
+        # every GPU's algorithmic bytes over the SLOWEST rank's mean kernel time
+        agg_achieved = alg_bytes_all / (k_max * 1e-3) / 1e9 if k_max > 0 else 0.0
         out = {
             "metric": "G k-mer·sample bit-tests/sec (+ achieved HBM GB/s of the gather kernel in `roofline`)",
             "value": round(value, 3),
             "unit": "G bit-tests/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling if (world > 1 or split > 1) else "weak", "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": w.name, "samples_per_gpu": int(sum(ns for _, ns in groups)) if multi else w.num_samples, "log_2_filter_len": w.log_2_filter_len,
+            "config": {"workload": w.name, "samples_per_gpu": int(sum(ns for _, ns in groups)) if multi else w.num_samples,
+                       "total_samples": (total_samples if scaling == "strong" else (total_samples * world)),
+                       "log_2_filter_len": w.log_2_filter_len,
                        "kmer_len": w.kmer_len, "num_hash": w.num_hash, "queries": w.num_queries, "query_len": w.query_len,
                        "threshold": w.threshold, "early_exit": bool(args.early_exit), "density": w.density_q8 / 256.0,
                        "db_bytes_per_gpu": int(sum(m.group.device_bytes for m in multi)) if multi else int(s.group.device_bytes),
-                       "groups": [[lg, ns] for lg, ns in groups] if multi else None, "sharding": "columns (samples) over %d GPU(s)" % world, "step_pipeline": pipeline_note,
+                       "row_bytes": None if multi else int(s.group.row_bytes),
+                       "groups": [[lg, ns] for lg, ns in groups] if multi else None,
+                       "sharding": ("columns (samples) over %d GPU(s)" % world) + ("; strong: this GPU holds share %d of %d" % (part, split) if split > 1 and scaling == "strong" else ""),
+                       "step_pipeline": pipeline_note,
                        "total_kmers_per_step": int(probe.total_kmers) if not multi else None, "hits_per_step": int(nhits),
                        "db_build_s": round(t_build, 2),
                        # how the loader chose each matrix's device block (rank 0): candidates compared, gather-probe GB/s on the kept / released one
                        "matrix_placement": [m.group.placement for m in multi] if multi else s.group.placement,
                        "seeds": {"queries_and_planted_genomes": 1, "columns": "rank (splitmix64 keyed by seed, row, word; kwage_amd/synth.py)"}},
-            "hbm_gbps_algorithmic_whole_step": round(alg_bytes_rank * world * args.steps / dt / 1e9, 1),
+            "hbm_gbps_algorithmic_whole_step": round(alg_bytes_all * args.steps / dt / 1e9, 1),
             "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": round(k_ms, 4), "kernel_ms_min": round(per_rank[0][1], 4), "kernel_ms_max": round(per_rank[0][2], 4),
                          # HIP events on the search's stream around the gather STAGE: one launch, except for and_band_walk_kernel,
-                         # whose three regrouping launches and finish launch are inside (rocprofv3's average for that kernel alone is ~2 % less)
-                         "kernel_ms_scope": "gather stage" + (" = regrouping launches + and_band_walk_kernel + finish launch" if kernel.startswith("and_band_walk") else " = one launch"),
+                         # whose bucketing launch and finish launch are inside (rocprofv3's average for that kernel alone is ~2 % less)
+                         "kernel_ms_scope": "gather stage" + (" = bucketing launch + and_band_walk_kernel + finish launch" if kernel.startswith("and_band_walk") else " = one launch"),
                          "algorithmic_bytes_per_launch": alg_bytes_rank,
                          "measured_stream_read_gbps": round(stream_gbps, 1),
                          "frac_of_measured_stream": round(achieved / stream_gbps, 4) if stream_gbps else None},
             # all ranks: every GPU's algorithmic bytes over the SLOWEST rank's mean kernel time, against N x 8 TB/s
             "aggregate": {"n_gpus": world, "kernel_ms_per_rank": [round(x, 4) for x in k_means],
                           "kernel_ms_max": round(k_max, 4), "kernel_ms_mean": round(k_mean, 4),
+                          "algorithmic_bytes_per_rank": [int(r[7]) for r in per_rank],
                           "achieved": round(agg_achieved, 1), "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
                           "aggregate_frac": round(agg_achieved / (HBM_PEAK_GBPS * world), 4)},
         }
@@ -548,7 +681,7 @@ def rank_main(args):
             sustained.update({"kernel_ms_mean": round(sk[0], 4), "kernel_ms_min": round(sk[1], 4), "kernel_ms_max": round(sk[2], 4),
                               "achieved": round(alg_bytes_rank / (sk[0] * 1e-3) / 1e9, 1) if sk[0] > 0 else None,
                               "frac": round(alg_bytes_rank / (sk[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if sk[0] > 0 else None,
-                              "value": round(bit_tests_rank * world / (sustained["ms_per_step"] * 1e-3) / 1e9, 3),
+                              "value": round(bit_tests_all / (sustained["ms_per_step"] * 1e-3) / 1e9, 3),
                               "kernel_ms_mean_per_rank": [round(r[3], 4) for r in per_rank]})
             out["sustained"] = sustained
         if sharded:
@@ -564,23 +697,115 @@ def rank_main(args):
                            "searches_per_step": n_groups}
             if exchange_check is not None:
                 out["exchange_check"] = exchange_check
+        if rcheck is not None:
+            rcheck["ranks_ok"] = [bool(r[8] == 1.0) for r in per_rank]
+            rcheck["checked"] = "rank-local hit lists of the kernel that was timed (%s), after the timed region" % kernel
+            out["result_check"] = rcheck
         if force_sharded:
             out["config"]["note"] = "KWAGE_BENCH_FORCE_SHARDED: multi-GPU code path on one rank"
-        if world == 1 and not args.no_cpu_baseline:
+        if headline and world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(w, s.queries, args.cpu_files)
             except Exception as e:   # the baseline is informative; never lose the GPU number over it
                 out["cpu_baseline"] = {"value": None, "unit": "G bit-tests/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
-        print(json.dumps(out), flush=True)
 
     for m in members:
         m.batch.close()
         m.group.close()
-    ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if not checks_ok:
+        if rank == 0:
+            print(json.dumps({"metric": "result_check failed", "workload": w.name, "result_check": out.get("result_check") if out else None}), flush=True)
+        else:
+            print("[bench] rank %d: result_check %r" % (rank, rcheck), file=sys.stderr, flush=True)
+        sys.exit(4)
+    return out
+
+
+ALSO_KEYS = ("value", "unit", "ms_per_step", "steps", "warmup", "scaling", "config", "hbm_gbps_algorithmic_whole_step", "roofline",
+             "aggregate", "rccl", "exchange_check", "result_check")
+
+
+def rank_main(args):
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    args.gpus = world
+    if args.share_of > 1 and (world > 1 or not (0 <= args.share_rank < args.share_of)):
+        raise SystemExit("--share-of K is a ONE-GPU proxy (N = 1) and needs 0 <= --share-rank < K")
+
+    import torch
+    import kwage_amd as ka
+    from kwage_amd import native
+    if local_rank == 0:
+        native.ensure_built()          # artefacts are git-ignored; normally they travel with the snapshot
+    else:
+        for _ in range(600):           # other ranks wait for rank 0's build instead of racing it
+            if os.path.exists(native.lib_path()) and os.path.exists(native.KWAGE_BIN):
+                break
+            time.sleep(0.5)
+
+    env = Env()
+    env.rank, env.world = rank, world
+    # KWAGE_BENCH_BACKEND=gloo + KWAGE_BENCH_ONE_DEVICE=1 rehearse the N>1 code path on a one-GPU box
+    env.backend = os.environ.get("KWAGE_BENCH_BACKEND", "nccl")
+    if os.environ.get("KWAGE_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+        # ranks that share a device must not each hold a second candidate block for their matrix while the others allocate theirs
+        os.environ.setdefault("KWAGE_GROUP_PLACEMENT_PROBE", "0")
+    env.local_rank = local_rank
+    # KWAGE_BENCH_FORCE_SHARDED=1: take the multi-GPU code path (device-resident hits + RCCL exchange)
+    # even with one rank, to measure its per-step overhead on a one-GPU box
+    env.force_sharded = os.environ.get("KWAGE_BENCH_FORCE_SHARDED") == "1"
+    if env.force_sharded and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    env.sharded = world > 1 or env.force_sharded
+    env.dist = None
+    env.ctx = ka.Context(local_rank)       # before torch.distributed creates its streams (hardware-queue assignment is first come, first served)
+    env.cdev = ("cuda:%d" % local_rank) if env.backend == "nccl" else "cpu"       # where the collectives' tensors live
+    if env.sharded:
+        import torch.distributed as dist
+        env.dist = dist
+        torch.cuda.set_device(local_rank)
+        if env.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(env.backend)
+
+    out = measure(env, args, args.workload, True)
+
+    # ---- the other BASELINE.json configurations this launch can hold, after the headline's matrix was freed ------------
+    names = also_workloads(args, world)
+    if names:
+        if rank == 0:     # a copy of the headline on stderr first: whatever happens below, the number is on record
+            print("[bench] headline (the `also` blocks follow): " + json.dumps(out), file=sys.stderr, flush=True)
+        also = {}
+        for name in names:
+            t0 = time.perf_counter()
+            if world == 1:
+                try:
+                    blk = measure(env, args, name, False)
+                except SystemExit:
+                    raise
+                except Exception as exc:          # e.g. the matrix does not fit beside another tenant of the device
+                    blk = {"error": repr(exc)}
+            else:
+                blk = measure(env, args, name, False)       # ranks stay in step: an exception ends the job (the headline is on stderr)
+            if rank == 0:
+                also[name] = {k: blk[k] for k in ALSO_KEYS if k in blk} if "error" not in blk else blk
+                also[name]["wall_s"] = round(time.perf_counter() - t0, 2)
+        if rank == 0:
+            out["also"] = also
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+    env.ctx.close()
+    if env.dist is not None:
+        env.dist.barrier()
+        env.dist.destroy_process_group()
 
 
 def main():

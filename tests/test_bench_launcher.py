@@ -142,3 +142,85 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     assert l5["rccl"]["collectives"] == 6 and l5["rccl"]["p2p_batches"] == 0
     e5 = l5["exchange_check"]
     assert e5["ok"] and e5["hits"] == sum(e5["hits_per_rank"]) == l5["config"]["hits_per_step"] and e5["hits"] > 0
+
+
+def test_strong_split_is_the_sharded_hosts_partition():
+    """--scaling strong / --share-of K: a rank holds block `part` of partition_columns(total, K) -- the shares add up to
+    the workload's columns, every boundary but the last is a 1024-column multiple, and a multi-group workload (C5) is
+    cut group by group.  weak: every rank holds the workload as it stands."""
+    import bench
+    from kwage_amd import synth
+    for name in ("c2", "c3"):
+        total = synth.WORKLOADS[name].num_samples
+        for k in (2, 4, 8):
+            shares = [bench.rank_share(name, "strong", k, r) for r in range(k)]
+            assert sum(w.num_samples for w, _, _ in shares) == total and all(t == total for _, _, t in shares)
+            assert all(w.num_samples % 1024 == 0 for w, _, _ in shares[:-1])
+            assert max(w.num_samples for w, _, _ in shares) - min(w.num_samples for w, _, _ in shares) <= 2 * 1024
+            assert all(g is None for _, g, _ in shares)
+        w, g, t = bench.rank_share(name, "weak", 8, 3)
+        assert w.num_samples == total and g is None and t == total
+        assert bench.rank_share(name, "strong", 1, 0)[0].num_samples == total
+    per_rank = [bench.rank_share("c5", "strong", 4, r)[1] for r in range(4)]
+    for gi, (lg, ns) in enumerate(synth.C5_GROUPS):
+        assert [g[gi][0] for g in per_rank] == [lg] * 4 and sum(g[gi][1] for g in per_rank) == ns
+    with pytest.raises(ValueError):
+        bench.rank_share("c5", "strong", 8, 7)            # its smallest group (6000 samples) has six 1024-column units
+    assert bench.rank_share("c5", "weak", 8, 0)[1] == synth.C5_GROUPS
+    with pytest.raises(ValueError):
+        bench.rank_share("tiny", "strong", 8, 7)          # 5000 columns are five 1024-column units: rank 7 of 8 gets none
+
+
+def test_also_blocks_follow_the_default_headline_only():
+    import bench
+    a = bench.parse_args([])
+    assert bench.also_workloads(a, 1) == ["c3"] and bench.also_workloads(a, 8) == ["c4", "c5"] and bench.also_workloads(a, 2) == ["c4", "c5"]
+    for argv in (["--workload", "c3"], ["--scaling", "strong"], ["--share-of", "4"], ["--early-exit"], ["--also", "none"]):
+        assert bench.also_workloads(bench.parse_args(argv), 1) == [], argv
+    assert bench.also_workloads(bench.parse_args(["--also", "c5s,c2t,c2"]), 1) == ["c5s", "c2t"]      # never the headline twice
+
+
+def test_result_check_accepts_the_oracles_lists_and_refuses_anything_else(oracle):
+    """bench.py's post-timing check on a matrix small enough for the CPU: a stand-in group whose rows come from a numpy
+    image, hit lists computed by the oracle itself -> ok; one record dropped, altered or added -> not ok."""
+    import numpy as np
+    import bench
+    from types import SimpleNamespace
+    from kwage_amd import synth
+    from kwage_amd.engine import HIT_DTYPE, SearchResult
+    k, nh, L, ncol = 31, 2, 12, 700
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seq = lambda n: acgt[rng.integers(0, 4, size=n)].tobytes().decode()
+    genomes = [seq(600), seq(600)]
+    planted = [[3, 400], [77, 699]]
+    image = (rng.integers(0, 256, size=(1 << L, (ncol + 7) // 8), dtype=np.uint8) & rng.integers(0, 256, size=(1 << L, (ncol + 7) // 8), dtype=np.uint8))
+    image[:, -1] &= np.uint8((1 << (ncol % 8)) - 1)
+    for g, cols in zip(genomes, planted):
+        rows = oracle.row_indices(oracle.unique_kmers(g, k), k, nh, L).reshape(-1)
+        for c in cols:
+            image[rows, c // 8] |= np.uint8(1 << (c % 8))
+    queries = [genomes[0][:300], seq(300), genomes[1][100:400], seq(300), genomes[0][300:600]]
+    qsrc = [0, -1, 1, -1, 0]
+    for thr in (1.0, 0.8):
+        w = synth.Workload("stub", ncol, L, k, nh, len(queries), 300, thr)
+        recs, nk, qt = [], [], []
+        for qi, q in enumerate(queries):
+            kmers = oracle.unique_kmers(q, k)
+            hits, _ = oracle.search_image(image, image.shape[1], k, nh, L, ncol, kmers, float(np.float32(thr)))
+            recs += [(qi, c, n) for c, n in hits]
+            nk.append(len(kmers))
+            qt.append(0 if thr == 1.0 else oracle.query_threshold(float(np.float32(thr)), len(kmers)))
+        group = SimpleNamespace(read_rows=lambda rows: np.ascontiguousarray(image[np.asarray(rows, dtype=np.int64)]))
+        member = SimpleNamespace(workload=w, group=group, queries=queries, query_genome=qsrc, planted=planted)
+        mk = lambda rr: SearchResult(np.array(rr, dtype=HIT_DTYPE), np.array(nk, np.uint32), np.array(qt, np.uint32), sum(nk), 0, 0, 0.0, 0.0, 1, "stub")
+        good = bench.result_check([member], [mk(recs)], thr)
+        assert good["ok"] and good["planted_queries"] == 3 and good["planted_columns_found"] == good["planted_columns_expected"] == 6
+        assert good["sampled_queries"] == 3 and good["sampled_hits_compared"] > 0 and not good["mismatches"]
+        first_planted = next(i for i, r in enumerate(recs) if r[0] == 0 and r[1] == 3)
+        dropped = recs[:first_planted] + recs[first_planted + 1:]
+        altered = [(q, c, n - 1) if i == first_planted else (q, c, n) for i, (q, c, n) in enumerate(recs)]
+        added = sorted(recs + [(1, 5, nk[1])]) if not any(r[0] == 1 and r[1] == 5 for r in recs) else None
+        for bad in (dropped, altered, added):
+            if bad is not None:
+                assert not bench.result_check([member], [mk(bad)], thr)["ok"]
