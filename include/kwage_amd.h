@@ -74,6 +74,12 @@ int kwage_sync(kwage_ctx *ctx);
  * environment.  For tests and tuning tools: no knob changes any result.  Not while a search is pending. */
 int kwage_ctx_set_tuning(kwage_ctx *ctx, const char *name, int64_t value);
 int kwage_ctx_get_tuning(kwage_ctx *ctx, const char *name, int64_t *value);
+/* Diagnostic: the persistent gather kernels (and_walk_kernel, and_band_walk_kernel, count_walk_kernel) finish the (query,
+ * tile) pairs their wave shares cut through small exchange buffers in HBM that they must leave ALL ZERO -- they are
+ * cleared when allocated, never per search.  Counts the non-zero 32-bit words of both search slots' buffers:
+ * out[0] cut-pair masks, out[1] cut-pair counts + flags (and_walk), out[2] per-query masks, out[3] per-query flags
+ * (and_band_walk), out[4] tree arrival counters (count_walk).  Waits for the context's streams first.  tools/soak_walk.py. */
+int kwage_ctx_scratch_nonzero(kwage_ctx *ctx, uint64_t out[5]);
 
 /* ------------------------------------------------------------------------------------
  * Database group: all columns (samples) that share (kmer_len, num_hash, log_2_filter_len,

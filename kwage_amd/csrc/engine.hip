@@ -845,6 +845,46 @@ extern "C" int kwage_ctx_get_tuning(kwage_ctx *ctx, const char *name, int64_t *v
 	return fail(KWAGE_ERR_ARG, "kwage_ctx_get_tuning: no knob named '%s'", name);
 }
 
+namespace {
+__global__ __launch_bounds__(256) void count_nonzero_kernel(const uint32_t *p, uint64_t n, unsigned long long *out)
+{
+	unsigned long long c = 0;
+	for(uint64_t i = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x*blockDim.x){ c += (p[i] != 0); }
+	if(c){ atomicAdd(out, c); }
+}
+}  // namespace
+
+extern "C" int kwage_ctx_scratch_nonzero(kwage_ctx *ctx, uint64_t out[5])
+{
+	if(!ctx || !out){ return fail(KWAGE_ERR_ARG, "kwage_ctx_scratch_nonzero: NULL argument"); }
+	for(int i = 0; i < 2; ++i){ if(ctx->slot[i].busy){ return fail(KWAGE_ERR_STATE, "kwage_ctx_scratch_nonzero: a search is pending on this context"); } }
+	int rc = set_device(ctx);
+	if(rc){ return rc; }
+	HIP_TRY(hipStreamSynchronize(ctx->slot[0].stream));
+	HIP_TRY(hipStreamSynchronize(ctx->slot[1].stream));
+	unsigned long long *d = nullptr;
+	HIP_TRY(hipMalloc((void**)&d, 5*sizeof(unsigned long long)));
+	hipError_t e = hipMemsetAsync(d, 0, 5*sizeof(unsigned long long), ctx->stream);
+	for(int k = 0; k < 2 && e == hipSuccess; ++k){
+		Slot *sl = &ctx->slot[k];
+		const DevBuf *bufs[5] = {&sl->walk_or, &sl->walk_done, &sl->band_or, &sl->band_state, &sl->cwalk_arrived};
+		for(int j = 0; j < 5; ++j){
+			const uint64_t n = bufs[j]->cap/sizeof(uint32_t);
+			if(!n){ continue; }
+			hipLaunchKernelGGL(count_nonzero_kernel, dim3((uint32_t)std::min<uint64_t>(2048, (n + 255)/256)), dim3(256), 0, ctx->stream,
+			                   (const uint32_t*)bufs[j]->p, n, d + j);
+		}
+		e = hipGetLastError();
+	}
+	unsigned long long h[5] = {0, 0, 0, 0, 0};
+	if(e == hipSuccess){ e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream); }
+	if(e == hipSuccess){ e = hipStreamSynchronize(ctx->stream); }
+	(void)hipFree(d);
+	if(e != hipSuccess){ return fail(KWAGE_ERR_DEVICE, "kwage_ctx_scratch_nonzero: %s", hipGetErrorString(e)); }
+	for(int j = 0; j < 5; ++j){ out[j] = h[j]; }
+	return KWAGE_OK;
+}
+
 namespace kwage {
 hipStream_t ctx_stream(kwage_ctx *ctx) { return ctx->stream; }
 int ctx_device(kwage_ctx *ctx) { return ctx->device; }

@@ -59,6 +59,13 @@ class Context:
         check(lib().kwage_ctx_get_tuning(self._h, name.encode(), C.byref(v)))
         return int(v.value)
 
+    def scratch_nonzero(self) -> dict:
+        """Non-zero words left in the exchange buffers of the persistent gather kernels (kwage_ctx_scratch_nonzero):
+        all zero between searches, or a cut pair was not finished."""
+        out = (C.c_uint64 * 5)()
+        check(lib().kwage_ctx_scratch_nonzero(self._h, out))
+        return dict(zip(("walk_or", "walk_done", "band_or", "band_state", "cwalk_arrived"), (int(x) for x in out)))
+
     def tuning(self, **knobs):
         """`with ctx.tuning(walk_waves=17, walk_min_rows=1): ...` -- the knobs are set inside the block and put back
         after it."""
