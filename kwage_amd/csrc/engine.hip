@@ -29,7 +29,7 @@ static_assert(TUNING_DEFAULT_BLOCK_WAVES == SEARCH_THREADS/WAVE, "the tiled AND 
 
 struct TuningName { const char *name; int64_t Tuning::*field; };
 static const TuningName TUNING_NAMES[] = {
-	{"walk", &Tuning::walk}, {"walk_min_rows", &Tuning::walk_min_rows}, {"walk_max_kib", &Tuning::walk_max_kib},
+	{"walk", &Tuning::walk}, {"walk_min_rows", &Tuning::walk_min_rows}, {"walk_max_kib", &Tuning::walk_max_kib}, {"walk_min_kib", &Tuning::walk_min_kib},
 	{"walk_early_exit", &Tuning::walk_early_exit}, {"walk_waves", &Tuning::walk_waves}, {"walk_fences", &Tuning::walk_fences}, {"walk_one_wg_per_cu", &Tuning::walk_one_wg_per_cu},
 	{"walk_bands", &Tuning::walk_bands}, {"walk_bands_min_gib", &Tuning::walk_bands_min_gib},
 	{"and_vec", &Tuning::and_vec}, {"and_unroll", &Tuning::and_unroll}, {"and_nt", &Tuning::and_nt}, {"and_lds_kb", &Tuning::and_lds_kb},
@@ -405,7 +405,7 @@ int reserve_zeroed(DevBuf &buf, uint64_t bytes, hipStream_t s)
 
 // Launch the gather+reduce kernel(s) for the current batch.
 int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayout *L, float threshold, uint32_t flags,
-                        kwage_hit *d_hits, uint64_t cap, unsigned long long *hit_count)
+                        kwage_hit *d_hits, uint64_t cap, unsigned long long *hit_count, hipStream_t gs)
 {
 	const Tuning &tn = g->ctx->tune;
 	const uint64_t ncu = (uint64_t)std::max(g->ctx->ncu, 1);
@@ -442,8 +442,8 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 			const int unroll = (tn.narrow_unroll == 8 || tn.narrow_unroll == 16) ? (int)tn.narrow_unroll : ((waves < ncu*16) ? 16 : 8);
 			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_narrow_kernel<%u,%d>", G, unroll);
 #define KWAGE_NARROW_CASE(GG) case GG: \
-				if(unroll == 16){ hipLaunchKernelGGL((and_narrow_kernel<GG, 16>), grid, block, 0, sl->stream, a); } \
-				else{ hipLaunchKernelGGL((and_narrow_kernel<GG, 8>), grid, block, 0, sl->stream, a); } break;
+				if(unroll == 16){ hipLaunchKernelGGL((and_narrow_kernel<GG, 16>), grid, block, 0, gs, a); } \
+				else{ hipLaunchKernelGGL((and_narrow_kernel<GG, 8>), grid, block, 0, gs, a); } break;
 			switch(G){
 				KWAGE_NARROW_CASE(16) KWAGE_NARROW_CASE(8) KWAGE_NARROW_CASE(4)
 				default: KWAGE_NARROW_CASE(2)
@@ -455,7 +455,7 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 		// rows of 3..16 KiB: the walk form (a persistent grid, every wave walks an equal share of the batch's row
 		// list over the whole width of a column tile; kernels.hpp and_walk_kernel).  Worth it once every wave of
 		// the chip gets a few dozen rows; smaller batches stay with the tiled kernel and its row-list segments.
-		const int walk_unroll = (int)tn.walk;
+		const int walk_knob = (int)tn.walk;
 		const uint64_t walk_min_rows = (tn.walk_min_rows >= 0) ? (uint64_t)tn.walk_min_rows : (uint64_t)WALK_MIN_ROWS_PER_WAVE*256*WALK_WAVES_PER_CU;
 		const uint32_t kib = (a.units_per_row + WAVE - 1)/WAVE;
 		// (the kernel handles wider rows as several balanced column tiles -- the walk_max_kib knob raises the limit --
@@ -467,7 +467,11 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 		// width and never stops (C2 with early exit: 0.64 ms tiled, 1.29 ms walk).
 		const bool walk_ee_ok = !a.early_exit || tn.walk_early_exit;
 		const uint64_t walk_slots = (uint64_t)coltiles*L->total_pos;
-		if(walk_unroll && walk_ee_ok && kib >= 3 && kib <= walk_max_kib && walk_slots*a.num_hash >= walk_min_rows && walk_slots > 0){
+		const uint32_t walk_min_kib = (uint32_t)std::max<int64_t>(tn.walk_min_kib, 1);
+		// rows in flight per wave: 4; 8 for rows of one or two KiB-steps (a group of four such rows is only 4-8 loads: C2's
+		// columns split 8 ways, 1664-byte rows, 0.2626 vs 0.2667 ms) and, by knob, up to four; 2 by knob
+		const int walk_unroll = (walk_knob == 2) ? 2 : ((walk_knob == 8 && walk_ch <= 4) || walk_ch <= 2) ? 8 : 4;
+		if(walk_knob && walk_ee_ok && kib >= walk_min_kib && kib <= walk_max_kib && walk_slots*a.num_hash >= walk_min_rows && walk_slots > 0){
 			// WALK_WAVES_PER_CU waves per CU, all resident at once (__launch_bounds__(256, 4) allows twice as many),
 			// fewer when the batch is small: a wave should have WALK_MIN_ROWS_PER_WAVE rows to walk
 			const uint64_t chip_waves = ncu*WALK_WAVES_PER_CU;
@@ -488,12 +492,12 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 				ba.rows_per_band = (uint32_t)((g->nrows + bands - 1)/bands);
 				if((rc = sl->band_rows.reserve(band_items*sizeof(uint32_t)))){ return rc; }
 				if((rc = sl->band_loc.reserve((uint64_t)a.n_queries*(bands + 1)*sizeof(uint32_t)))){ return rc; }
-				if((rc = reserve_zeroed(sl->band_or, (uint64_t)a.n_queries*16*1024, sl->stream))){ return rc; }
-				if((rc = reserve_zeroed(sl->band_state, (uint64_t)a.n_queries*sizeof(uint32_t), sl->stream))){ return rc; }
+				if((rc = reserve_zeroed(sl->band_or, (uint64_t)a.n_queries*16*1024, gs))){ return rc; }
+				if((rc = reserve_zeroed(sl->band_state, (uint64_t)a.n_queries*sizeof(uint32_t), gs))){ return rc; }
 				ba.orbuf = (uint32_t*)sl->band_or.p;
 				ba.state = (uint32_t*)sl->band_state.p;
 				uint32_t *loc = (uint32_t*)sl->band_loc.p, *rows2 = (uint32_t*)sl->band_rows.p;
-				hipLaunchKernelGGL(band_bucket_kernel, dim3(a.n_queries), dim3(256), 0, sl->stream, a.rows, a.pos_off, a.nkmer, a.num_hash,
+				hipLaunchKernelGGL(band_bucket_kernel, dim3(a.n_queries), dim3(256), 0, gs, a.rows, a.pos_off, a.nkmer, a.num_hash,
 				                   ba.bands, ba.rows_per_band, loc, rows2);
 				WalkArgs wb;
 				wb.total_slots = walk_slots;                         // (one column tile: slots = positions)
@@ -506,8 +510,8 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 				const dim3 grid(wgs), block(shape.wg_waves*WAVE), fgrid((a.n_queries + 3)/4);
 #define KWAGE_BAND_LAUNCH(CH, U) do { \
 					if(shape.lds > 48*1024){ (void)hipFuncSetAttribute((const void*)and_band_walk_kernel<CH, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shape.lds); } \
-					hipLaunchKernelGGL((and_band_walk_kernel<CH, U>), grid, block, shape.lds, sl->stream, a, ba, wb, (const uint32_t*)rows2, (const uint32_t*)loc, a.pos_off, a.nkmer); \
-					hipLaunchKernelGGL((and_band_finish_kernel<CH>), fgrid, dim3(256), 0, sl->stream, a, ba, a.nkmer); } while(0)
+					hipLaunchKernelGGL((and_band_walk_kernel<CH, U>), grid, block, shape.lds, gs, a, ba, wb, (const uint32_t*)rows2, (const uint32_t*)loc, a.pos_off, a.nkmer); \
+					hipLaunchKernelGGL((and_band_finish_kernel<CH>), fgrid, dim3(256), 0, gs, a, ba, a.nkmer); } while(0)
 #define KWAGE_BAND_CASE(CH) case CH: \
 					if(walk_unroll == 2){ KWAGE_BAND_LAUNCH(CH, 2); } else{ KWAGE_BAND_LAUNCH(CH, 4); } break;
 				switch(walk_ch){
@@ -526,26 +530,29 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 			wa.per_wave = (walk_slots + waves - 1)/waves;
 			wa.coltiles = coltiles;
 			// cut-pair slots: one per wave, 16 KiB each whatever CH is; the kernel leaves them zero
-			if((rc = reserve_zeroed(sl->walk_or, waves*16*1024, sl->stream))){ return rc; }
-			if((rc = reserve_zeroed(sl->walk_done, waves*2*sizeof(uint32_t), sl->stream))){ return rc; }
+			if((rc = reserve_zeroed(sl->walk_or, waves*16*1024, gs))){ return rc; }
+			if((rc = reserve_zeroed(sl->walk_done, waves*2*sizeof(uint32_t), gs))){ return rc; }
 			wa.orbuf = (uint32_t*)sl->walk_or.p;
 			wa.done = (uint32_t*)sl->walk_done.p;
 			wa.full_fences = tn.walk_fences ? 1 : 0;
 			a.segs = 1;
 			a.chunks = coltiles;
-			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_walk_kernel<%u,%d>", walk_ch, walk_unroll == 2 ? 2 : 4);
+			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_walk_kernel<%u,%d>", walk_ch, walk_unroll);
 			const dim3 grid(wgs), block(shape.wg_waves*WAVE);
 #define KWAGE_WALK_LAUNCH(...) do { \
 				if(shape.lds > 48*1024){ (void)hipFuncSetAttribute((const void*)and_walk_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shape.lds); } \
-				hipLaunchKernelGGL((and_walk_kernel<__VA_ARGS__>), grid, block, shape.lds, sl->stream, a, wa, a.rows, a.pos_off, a.nkmer); } while(0)
+				hipLaunchKernelGGL((and_walk_kernel<__VA_ARGS__>), grid, block, shape.lds, gs, a, wa, a.rows, a.pos_off, a.nkmer); } while(0)
 #define KWAGE_WALK_CASE(CH) case CH: \
 				if(walk_unroll == 2){ KWAGE_WALK_LAUNCH(CH, 2); } else{ KWAGE_WALK_LAUNCH(CH, 4); } break;
+#define KWAGE_WALK_CASE8(CH) case CH: \
+				if(walk_unroll == 2){ KWAGE_WALK_LAUNCH(CH, 2); } else if(walk_unroll == 8){ KWAGE_WALK_LAUNCH(CH, 8); } else{ KWAGE_WALK_LAUNCH(CH, 4); } break;
 			switch(walk_ch){
-				KWAGE_WALK_CASE(3) KWAGE_WALK_CASE(4) KWAGE_WALK_CASE(5) KWAGE_WALK_CASE(6) KWAGE_WALK_CASE(7)
+				KWAGE_WALK_CASE8(1) KWAGE_WALK_CASE8(2) KWAGE_WALK_CASE8(3) KWAGE_WALK_CASE8(4) KWAGE_WALK_CASE(5) KWAGE_WALK_CASE(6) KWAGE_WALK_CASE(7)
 				KWAGE_WALK_CASE(8) KWAGE_WALK_CASE(9) KWAGE_WALK_CASE(10) KWAGE_WALK_CASE(11) KWAGE_WALK_CASE(12)
 				KWAGE_WALK_CASE(13) KWAGE_WALK_CASE(14) KWAGE_WALK_CASE(15)
 				default: KWAGE_WALK_CASE(16)
 			}
+#undef KWAGE_WALK_CASE8
 #undef KWAGE_WALK_CASE
 #undef KWAGE_WALK_LAUNCH
 			HIP_TRY(hipGetLastError());
@@ -554,14 +561,14 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 		if(a.segs > 1){
 			const uint64_t bytes = (uint64_t)a.n_queries*g->stride;
 			if((rc = sl->partial.reserve(bytes))){ return rc; }
-			HIP_TRY(hipMemsetAsync(sl->partial.p, 0xFF, bytes, sl->stream));
+			HIP_TRY(hipMemsetAsync(sl->partial.p, 0xFF, bytes, gs));
 			a.partial = (uint32_t*)sl->partial.p;
 		}
 		snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_kernel<%d,%d,%s>%s", cfg.vec, cfg.unroll, cfg.nt ? "nt" : "t", a.segs > 1 ? "+segments" : "");
-		if(cfg.nt){ launch_and_v<true>(a, sl->stream, cfg); }
-		else{ launch_and_v<false>(a, sl->stream, cfg); }
+		if(cfg.nt){ launch_and_v<true>(a, gs, cfg); }
+		else{ launch_and_v<false>(a, gs, cfg); }
 		if(a.segs > 1){
-			hipLaunchKernelGGL(and_combine_kernel, dim3((a.units_per_row + 255)/256, a.n_queries), dim3(256), 0, sl->stream, a);
+			hipLaunchKernelGGL(and_combine_kernel, dim3((a.units_per_row + 255)/256, a.n_queries), dim3(256), 0, gs, a);
 		}
 	}
 	else{
@@ -592,13 +599,13 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 				wa.per_wave = (slots + waves - 1)/waves;
 				wa.coltiles = a.chunks;
 				if((rc = sl->cwalk_slab.reserve(waves*2*planes*1024))){ return rc; }
-				if((rc = reserve_zeroed(sl->cwalk_arrived, waves*CWALK_LEVELS*sizeof(uint32_t), sl->stream))){ return rc; }
+				if((rc = reserve_zeroed(sl->cwalk_arrived, waves*CWALK_LEVELS*sizeof(uint32_t), gs))){ return rc; }
 				wa.slab = (uint32_t*)sl->cwalk_slab.p;
 				wa.arrived = (uint32_t*)sl->cwalk_arrived.p;
 				a.segs = 1;
 				snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_walk_kernel<%u,%u%s>", planes, std::min(a.num_hash, 5u), tn.count_walk_prefetch ? ",pf" : "");
-				if(tn.count_walk_prefetch){ launch_count_walk_planes<true>(planes, a, wa, shape, sl->stream); }
-				else{ launch_count_walk_planes<false>(planes, a, wa, shape, sl->stream); }
+				if(tn.count_walk_prefetch){ launch_count_walk_planes<true>(planes, a, wa, shape, gs); }
+				else{ launch_count_walk_planes<false>(planes, a, wa, shape, gs); }
 				HIP_TRY(hipGetLastError());
 				return KWAGE_OK;
 			}
@@ -625,14 +632,14 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 			const int kps = (tn.count_narrow_kps == 4) ? 4 : 8;
 			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_narrow_kernel<%u,%u,%d,%d>", planes, a.num_hash, a.units_per_row <= 16 ? 4 : 2, kps);
 			if(a.units_per_row <= 16){
-				if(planes == 7){ launch_count_narrow_k<7, 4>(a, sl->stream, kps); }
-				else if(planes == 10){ launch_count_narrow_k<10, 4>(a, sl->stream, kps); }
-				else{ launch_count_narrow_k<14, 4>(a, sl->stream, kps); }
+				if(planes == 7){ launch_count_narrow_k<7, 4>(a, gs, kps); }
+				else if(planes == 10){ launch_count_narrow_k<10, 4>(a, gs, kps); }
+				else{ launch_count_narrow_k<14, 4>(a, gs, kps); }
 			}
 			else{
-				if(planes == 7){ launch_count_narrow_k<7, 2>(a, sl->stream, kps); }
-				else if(planes == 10){ launch_count_narrow_k<10, 2>(a, sl->stream, kps); }
-				else{ launch_count_narrow_k<14, 2>(a, sl->stream, kps); }
+				if(planes == 7){ launch_count_narrow_k<7, 2>(a, gs, kps); }
+				else if(planes == 10){ launch_count_narrow_k<10, 2>(a, gs, kps); }
+				else{ launch_count_narrow_k<14, 2>(a, gs, kps); }
 			}
 			HIP_TRY(hipGetLastError());
 			return KWAGE_OK;
@@ -643,15 +650,15 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 		else{
 			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_kernel<%u,%u>", planes, std::min(a.num_hash, 5u));
 		}
-		launch_count_planes(seg_planes, a, sl->stream);
+		launch_count_planes(seg_planes, a, gs);
 		if(a.segs > 1){
 			HIP_TRY(hipGetLastError());
 			switch(planes){
-				case 7: rc = launch_count_combine<7>(a, seg_planes, sl->stream); break;
-				case 10: rc = launch_count_combine<10>(a, seg_planes, sl->stream); break;
-				case 14: rc = launch_count_combine<14>(a, seg_planes, sl->stream); break;
-				case 20: rc = launch_count_combine<20>(a, seg_planes, sl->stream); break;
-				default: rc = launch_count_combine<32>(a, seg_planes, sl->stream); break;
+				case 7: rc = launch_count_combine<7>(a, seg_planes, gs); break;
+				case 10: rc = launch_count_combine<10>(a, seg_planes, gs); break;
+				case 14: rc = launch_count_combine<14>(a, seg_planes, gs); break;
+				case 20: rc = launch_count_combine<20>(a, seg_planes, gs); break;
+				default: rc = launch_count_combine<32>(a, seg_planes, gs); break;
 			}
 			if(rc){ return rc; }
 		}
@@ -684,21 +691,32 @@ int enqueue_search_and_copy(Slot *sl)
 	const uint64_t cap = own ? sl->hit_cap : sl->ext_cap;
 	kwage_hit *d_hits = own ? sl->d_hits : sl->ext_hits;
 	if(b->n && g->num_columns){
-		// The gather kernels of the two slots must not run side by side (they would only share the HBM
-		// bandwidth and stretch each other): this one starts when the other slot's has finished.  The
-		// k-mer stage enqueued before and the copy-back enqueued after are what overlaps.
-		Slot *other = (sl == &g->ctx->slot[0]) ? &g->ctx->slot[1] : &g->ctx->slot[0];
-		if(other->search_done_valid){ HIP_TRY(hipStreamWaitEvent(sl->stream, other->search_done, 0)); }
-		if(sl->append && sl->append_reset){ HIP_TRY(hipMemsetAsync(sl->ext_count, 0, sizeof(uint64_t), sl->stream)); }      // a new list starts here
-		if(timing){ HIP_TRY(hipEventRecord(sl->ev[2], sl->stream)); }
+		// The gather stage of both slots goes to the context's ONE gather stream, in submission order: gather kernels
+		// never run side by side (they would only share the HBM bandwidth and stretch each other), and the next one
+		// starts right behind the previous one on the same hardware queue -- a cross-queue event between two gather
+		// kernels cost ~25 us per search (rocprofv3 kernel trace, profiles/r04_*).  What the stage reads (row list,
+		// counts, zeroed counters) was queued on the slot's stream: the gather stream waits for that -- normally long
+		// done, the k-mer stage ran beside the previous gather kernel -- and the slot's stream, which carries the
+		// copy-back, waits for the gather stage.
+		hipStream_t gs = g->ctx->gather_stream;
+		HIP_TRY(hipEventRecord(sl->kmer_done, sl->stream));
+		HIP_TRY(hipStreamWaitEvent(gs, sl->kmer_done, 0));
+		if(sl->append && sl->append_reset){ HIP_TRY(hipMemsetAsync(sl->ext_count, 0, sizeof(uint64_t), gs)); }      // a new list starts here
+		if(timing){ HIP_TRY(hipEventRecord(sl->ev[2], gs)); }
 		unsigned long long *hit_count = sl->append ? (unsigned long long*)sl->ext_count : (unsigned long long*)sl->d_counters;
-		if((rc = launch_search_stage(sl, g, b, sl->lay, sl->threshold, sl->flags, d_hits, cap, hit_count))){ return rc; }
-		if(timing){ HIP_TRY(hipEventRecord(sl->ev[3], sl->stream)); }
-		HIP_TRY(hipEventRecord(sl->search_done, sl->stream));
-		sl->search_done_valid = true;
+		if((rc = launch_search_stage(sl, g, b, sl->lay, sl->threshold, sl->flags, d_hits, cap, hit_count, gs))){ return rc; }
+		if(timing){ HIP_TRY(hipEventRecord(sl->ev[3], gs)); }
+		HIP_TRY(hipEventRecord(sl->gather_done, gs));
+		HIP_TRY(hipStreamWaitEvent(sl->stream, sl->gather_done, 0));
 		++sl->launches;
 	}
-	else if(sl->append && sl->append_reset){ HIP_TRY(hipMemsetAsync(sl->ext_count, 0, sizeof(uint64_t), sl->stream)); }      // nothing to search: an empty list all the same
+	else if(sl->append && sl->append_reset){
+		// nothing to search: an empty list all the same (on the gather stream, where the list's other searches append)
+		hipStream_t gs = g->ctx->gather_stream;
+		HIP_TRY(hipMemsetAsync(sl->ext_count, 0, sizeof(uint64_t), gs));
+		HIP_TRY(hipEventRecord(sl->gather_done, gs));
+		HIP_TRY(hipStreamWaitEvent(sl->stream, sl->gather_done, 0));
+	}
 	if(sl->append){         // the running total of the caller's list comes back with the head of the result block
 		HIP_TRY(hipMemcpyAsync(sl->d_counters, sl->ext_count, sizeof(uint64_t), hipMemcpyDeviceToDevice, sl->stream));
 	}
@@ -860,6 +878,7 @@ extern "C" int kwage_ctx_scratch_nonzero(kwage_ctx *ctx, uint64_t out[5])
 	for(int i = 0; i < 2; ++i){ if(ctx->slot[i].busy){ return fail(KWAGE_ERR_STATE, "kwage_ctx_scratch_nonzero: a search is pending on this context"); } }
 	int rc = set_device(ctx);
 	if(rc){ return rc; }
+	HIP_TRY(hipStreamSynchronize(ctx->gather_stream));
 	HIP_TRY(hipStreamSynchronize(ctx->slot[0].stream));
 	HIP_TRY(hipStreamSynchronize(ctx->slot[1].stream));
 	unsigned long long *d = nullptr;
@@ -930,8 +949,10 @@ extern "C" int kwage_init(int device, kwage_ctx **out)
 		// kernel's workgroups: no measurable difference on gfx950, tools/shard_pipe_probe.py)
 		HIP_TRY(hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking));
 		for(int i = 0; i < 4; ++i){ HIP_TRY(hipEventCreate(&sl->ev[i])); }
-		HIP_TRY(hipEventCreateWithFlags(&sl->search_done, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&sl->kmer_done, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&sl->gather_done, hipEventDisableTiming));
 	}
+	HIP_TRY(hipStreamCreateWithFlags(&ctx->gather_stream, hipStreamNonBlocking));
 	ctx->stream = ctx->slot[0].stream;
 	*out = ctx;
 	return KWAGE_OK;
@@ -944,6 +965,7 @@ extern "C" void kwage_shutdown(kwage_ctx *ctx)
 	release_mapping(ctx);
 	if(ctx->map_done){ (void)hipEventDestroy(ctx->map_done); }
 	for(hipEvent_t e : ctx->spare_events){ (void)hipEventDestroy(e); }
+	if(ctx->gather_stream){ (void)hipStreamSynchronize(ctx->gather_stream); }
 	for(int k = 0; k < 2; ++k){
 		Slot *sl = &ctx->slot[k];
 		if(sl->stream){ (void)hipStreamSynchronize(sl->stream); }
@@ -952,9 +974,11 @@ extern "C" void kwage_shutdown(kwage_ctx *ctx)
 		sl->walk_or.release(); sl->walk_done.release();
 		sl->band_rows.release(); sl->band_loc.release(); sl->band_or.release(); sl->band_state.release(); sl->cwalk_slab.release(); sl->cwalk_arrived.release();
 		for(int i = 0; i < 4; ++i){ if(sl->ev[i]){ (void)hipEventDestroy(sl->ev[i]); } }
-		if(sl->search_done){ (void)hipEventDestroy(sl->search_done); }
+		if(sl->kmer_done){ (void)hipEventDestroy(sl->kmer_done); }
+		if(sl->gather_done){ (void)hipEventDestroy(sl->gather_done); }
 		if(sl->stream){ (void)hipStreamDestroy(sl->stream); }
 	}
+	if(ctx->gather_stream){ (void)hipStreamDestroy(ctx->gather_stream); }
 	ctx->kmers.release();
 	ctx->result_pool->close();
 	for(int i = 0; i < 2; ++i){
@@ -987,6 +1011,7 @@ extern "C" int kwage_sync(kwage_ctx *ctx)
 	if(!ctx){ return fail(KWAGE_ERR_ARG, "kwage_sync: ctx is NULL"); }
 	int rc = set_device(ctx);
 	if(rc){ return rc; }
+	HIP_TRY(hipStreamSynchronize(ctx->gather_stream));
 	HIP_TRY(hipStreamSynchronize(ctx->slot[0].stream));
 	HIP_TRY(hipStreamSynchronize(ctx->slot[1].stream));
 	return KWAGE_OK;
@@ -1032,6 +1057,7 @@ extern "C" void kwage_batch_destroy(kwage_batch *b)
 {
 	if(!b){ return; }
 	(void)hipSetDevice(b->ctx->device);
+	(void)hipStreamSynchronize(b->ctx->gather_stream);
 	(void)hipStreamSynchronize(b->ctx->slot[0].stream);
 	(void)hipStreamSynchronize(b->ctx->slot[1].stream);
 	if(b->d_seqs){ (void)hipFree(b->d_seqs); }

@@ -132,8 +132,11 @@ static const int64_t TUNING_DEFAULT_BLOCK_WAVES = 4;
 struct Slot {
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-	hipEvent_t search_done = nullptr;   // recorded behind the slot's gather kernel(s)
-	bool search_done_valid = false;
+	// the gather stage of BOTH slots runs on the context's one gather stream (kwage_ctx::gather_stream), so that gather
+	// kernels follow each other on one hardware queue without a cross-queue dependency between them (~25 us each on
+	// gfx950); the slot's own stream carries the k-mer stage before it and the copy-back after it:
+	hipEvent_t kmer_done = nullptr;     // recorded on `stream` behind the k-mer stage: the gather stream waits for it
+	hipEvent_t gather_done = nullptr;   // recorded on the gather stream behind the slot's gather kernel(s): `stream` waits for it
 	// scratch, grown on demand and reused
 	DevBuf rows, tables, partial;
 	// One contiguous result block per search, so that a single D2H copy returns everything:
@@ -177,6 +180,8 @@ struct Tuning {
 	int64_t walk = 4;               // KWAGE_WALK: and_walk_kernel's rows in flight (4 or 2); 0 = always the tiled kernel
 	int64_t walk_min_rows = -1;     // KWAGE_WALK_MIN_ROWS: batches with fewer rows use the tiled kernel (-1: 64 rows per wave of the chip)
 	int64_t walk_max_kib = 16;      // KWAGE_WALK_MAX_KIB: widest row the walk form takes
+	int64_t walk_min_kib = 2;       // KWAGE_WALK_MIN_KIB: narrowest row (in KiB-steps) the walk form takes (round 4: 2 -- rows of 1-2 KiB no
+	                                //   longer need the tiled kernel's segments + combine pass: 0.263 vs 0.284 ms at C2's columns split 8 ways)
 	int64_t walk_early_exit = 0;    // KWAGE_WALK_EARLY_EXIT: use the walk form with early exit too (the tiled kernel stops sooner)
 	int64_t walk_waves = 0;         // KWAGE_WALK_WAVES: exactly this many waves (tests: shares of every size); 0 = from the CU count
 	int64_t walk_fences = 0;        // KWAGE_WALK_FENCES: agent-scope fences around the cut-pair count (measurement only)
@@ -215,6 +220,7 @@ struct kwage_ctx {
 	int ncu = 0;                        // compute units of the device (persistent grids are sized from it)
 	kwage::Tuning tune;
 	hipStream_t stream = nullptr;       // == slot[0].stream; loading, building and the synchronous calls use it
+	hipStream_t gather_stream = nullptr;    // the gather kernels of both slots, in submission order (see Slot)
 	kwage::Slot slot[2];
 	kwage::DevBuf kmers;                       // kwage_hash_batch output
 	// database loading: two pinned + two device staging buffers, kept across files

@@ -2,8 +2,8 @@
 // per-GPU hit lists concatenated on rank 0 by a variable-length gather over RCCL.
 //
 // Same options, same database files, same CSV / JSON bytes as `kwage` (and therefore as the reference): the option
-// parser, query readers, hit filing and report writers ARE kwage_main.cpp's -- this translation unit includes that file
-// with its `main` renamed, so the two programs cannot drift apart.  What differs is how a node's GPUs are used:
+// parser, query readers, hit records and report writers are the ones `kwage` uses (cli_common.hpp), so the two programs
+// cannot drift apart.  What differs is how a node's GPUs are used:
 //
 //   kwage  (KWAGE_DEVICES=all)   one process, a host thread + context per GPU, hit lists merged in host memory
 //   kwage_node                   one process per GPU (forked before anything touches a device), the sample (column)
@@ -20,7 +20,9 @@
 // only this program links it.  No row data ever crosses xGMI.
 //
 //   KWAGE_NODE_RANKS    number of ranks (default: the number of visible devices); rank r uses device r
-//   KWAGE_NODE_PLAN     1: print the plan (groups, every rank's files, global column bases) as JSON and stop; no device is touched
+//   KWAGE_NODE_PLAN     1: print the plan (groups, every rank's files, global column bases) as JSON and stop; no device is
+//                       touched or counted -- the number of ranks must come from KWAGE_NODE_RANKS
+//   KWAGE_NODE_STATS    1: rank 0 reports on stderr what the search phase took: wall, sum of gather-kernel time, exchange, filing
 //   KWAGE_NODE_REHEARSE 1: rehearsal on a machine with fewer GPUs than ranks -- every rank uses device 0 and the records
 //                       travel through a shared host segment instead of RCCL (which refuses two ranks on one device).
 //                       The searches still run on the GPU; sharding, global numbering, gather and report are the same
@@ -31,10 +33,9 @@
 #include <rccl/rccl.h>
 #include <pthread.h>
 #include <sys/mman.h>
+#include <new>
 
-#define main kwage_single_process_main        // kwage_main.cpp's main(): not used here, but its parts are
-#include "kwage_main.cpp"
-#undef main
+#include "cli_common.hpp"
 
 namespace {
 
@@ -87,6 +88,14 @@ struct NodeGroup {
 	vector<uint64_t> base;               // per rank: global number of the rank's column 0 of this group
 	kwage_group *mine = nullptr;         // this rank's matrix (null: no file of the group here)
 };
+
+// How rank 0 hands the communicator's unique id to the other ranks: anonymous shared memory mapped before the fork.
+struct Bootstrap {
+	ncclUniqueId id;
+	volatile int ready = 0;
+};
+
+double now_seconds() { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // KWAGE_NODE_REHEARSE: what the ranks share instead of a communicator (mapped before the fork)
 struct Rehearsal {
@@ -160,7 +169,136 @@ int print_plan(const vector<string> &db_paths, int n_ranks)
 	return EXIT_SUCCESS;
 }
 
-int run_rank(int rank, int n_ranks, const string &id_path, const Cli &cli, const vector<string> &db_paths, Rehearsal *rehearsal)
+// One rank's software pipeline over query batches (what kwage_amd/distributed.py's StepPipeline is for the Python host).
+// A STEP = one query batch against every group this rank holds; all of a step's searches append to ONE device list
+// (kwage_search_device_append_submit: the first search of a step zeroes the list's counter in stream order, every record
+// carries a GLOBAL column number).  The context runs two searches at a time: begin() queues a step's searches, finish()
+// completes the oldest step, feeding the slots as they come free -- so the next batch's first gather kernels are already
+// running while the finished batch's hits are exchanged over RCCL and filed on rank 0.  Two lists alternate.
+struct HitList {
+	uint64_t *d_count = nullptr;         // the list's record counter (what the gather kernels add to)
+	kwage_hit *d_hits = nullptr;
+	uint64_t cap = 0;
+};
+
+struct Step {
+	QueryBatch q;
+	kwage_batch *b = nullptr;
+	int list = 0;
+	size_t searches = 0, done = 0;
+	uint64_t n = 0;                      // records in the list (the running total the last search leaves)
+	double kernel_ms = 0;
+	map<uint32_t, vector<uint32_t> > nk; // rank 0: num_query_kmer per k-mer length, taken from this rank's own searches
+	Findings *found = nullptr;
+};
+
+struct RankPipeline {
+	kwage_ctx *ctx;
+	vector<NodeGroup> &groups;
+	int rank;
+	float threshold;
+	uint32_t flags;
+	HitList lists[2];
+	uint32_t *d_nk = nullptr;            // where a search leaves num_query_kmer for the host (rank 0)
+	uint64_t nk_cap = 0;
+	struct Todo { Step *step; size_t gi; bool first; };
+	struct Flying { kwage_pending *p; Step *step; size_t gi; };
+	deque<Todo> todo;
+	deque<Flying> flying;
+	int next_list = 0;
+
+	RankPipeline(kwage_ctx *c, vector<NodeGroup> &g, int r, float t, uint32_t f) : ctx(c), groups(g), rank(r), threshold(t), flags(f)
+	{
+		for(HitList &l : lists){
+			l.cap = 1u << 18;
+			NODE_HIP(hipMalloc((void**)&l.d_count, sizeof(uint64_t)));
+			NODE_HIP(hipMemset(l.d_count, 0, sizeof(uint64_t)));
+			NODE_HIP(hipMalloc((void**)&l.d_hits, l.cap*sizeof(kwage_hit)));
+		}
+	}
+	~RankPipeline()
+	{
+		for(Flying &f : flying){ uint64_t n = 0; (void)kwage_search_device_collect(f.p, &n, nullptr, nullptr); }
+		for(HitList &l : lists){ (void)hipFree(l.d_count); (void)hipFree(l.d_hits); }
+		if(d_nk){ (void)hipFree(d_nk); }
+	}
+	void submit(const Todo &t)
+	{
+		NodeGroup &g = groups[t.gi];
+		HitList &l = lists[t.step->list];
+		kwage_pending *p = nullptr;
+		check(kwage_search_device_append_submit(g.mine, t.step->b, threshold, flags | KWAGE_SEARCH_TIMING, l.d_hits, l.cap, l.d_count,
+		                                        (uint32_t)g.base[(size_t)rank], t.first ? 1 : 0, &p));
+		flying.push_back(Flying{p, t.step, t.gi});
+	}
+	void pump() { while(!todo.empty() && flying.size() < 2){ submit(todo.front()); todo.pop_front(); } }
+	void collect_oldest()
+	{
+		Flying f = flying.front();
+		flying.pop_front();
+		Step *st = f.step;
+		const uint32_t k = groups[f.gi].params.kmer_len;
+		// rank 0 files the hits and needs num_query_kmer of every query: it comes with the search (one device-to-host copy
+		// per distinct k-mer length and batch), not from a k-mer stage of its own
+		const bool want_nk = (rank == 0) && st->q.size() && !st->nk.count(k);
+		if(want_nk && st->q.size() > nk_cap){
+			if(d_nk){ (void)hipFree(d_nk); d_nk = nullptr; }
+			nk_cap = st->q.size() + st->q.size()/4;
+			NODE_HIP(hipMalloc((void**)&d_nk, nk_cap*sizeof(uint32_t)));
+		}
+		uint64_t n = 0;
+		float ms = 0;
+		check(kwage_search_device_collect(f.p, &n, want_nk ? d_nk : nullptr, &ms));
+		if(want_nk){
+			vector<uint32_t> &nk = st->nk[k];
+			nk.resize(st->q.size());
+			NODE_HIP(hipMemcpy(nk.data(), d_nk, nk.size()*sizeof(uint32_t), hipMemcpyDeviceToHost));
+		}
+		st->n = n;
+		st->kernel_ms += ms;
+		++st->done;
+	}
+	void begin(Step *st)
+	{
+		st->list = next_list;
+		next_list ^= 1;
+		check(kwage_batch_create(ctx, st->q.bases.data(), st->q.offsets.data(), (uint32_t)st->q.size(), &st->b));
+		bool first = true;
+		for(size_t gi = 0; gi < groups.size(); ++gi){
+			if(!groups[gi].mine){ continue; }
+			todo.push_back(Todo{st, gi, first});
+			first = false;
+			++st->searches;
+		}
+		pump();
+	}
+	// Complete every search of `st` (the oldest open step).  A list that outgrew its buffer is redone after growing it.
+	void finish(Step *st)
+	{
+		while(st->done < st->searches){ collect_oldest(); pump(); }
+		HitList &l = lists[st->list];
+		if(st->n > l.cap){
+			while(!flying.empty()){ collect_oldest(); }       // the next step's searches write the OTHER list: let them finish
+			while(st->n > l.cap){
+				(void)hipFree(l.d_hits);
+				l.cap = st->n + st->n/4;
+				NODE_HIP(hipMalloc((void**)&l.d_hits, l.cap*sizeof(kwage_hit)));
+				st->done = 0;
+				st->kernel_ms = 0;
+				bool first = true;
+				for(size_t gi = 0; gi < groups.size(); ++gi){
+					if(!groups[gi].mine){ continue; }
+					submit(Todo{st, gi, first});
+					first = false;
+					collect_oldest();
+				}
+			}
+			pump();
+		}
+	}
+};
+
+int run_rank(int rank, int n_ranks, Bootstrap *boot, const Cli &cli, const vector<string> &db_paths, Rehearsal *rehearsal)
 {
 	try{
 		const time_t started = time(nullptr);
@@ -206,27 +344,28 @@ int run_rank(int rank, int n_ranks, const string &id_path, const Cli &cli, const
 		one_shot_placement(ctx);
 		ncclComm_t comm = nullptr;
 		hipStream_t stream;
-		NODE_HIP(hipStreamCreate(&stream));
+		NODE_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
 		if(!rehearsal){
 			// stdout is the report: whatever RCCL prints while a communicator comes up (its version banner under
 			// NCCL_DEBUG=VERSION goes to stdout whatever NCCL_DEBUG_FILE says) is sent to stderr instead
 			cout.flush(); fflush(stdout);
 			const int report_fd = dup(STDOUT_FILENO);
 			if(report_fd < 0 || dup2(STDERR_FILENO, STDOUT_FILENO) < 0){ throw string("cannot redirect stdout"); }
+			// the communicator's id travels through memory the ranks have shared since before the fork: nothing another
+			// user of the machine could plant or read (round 3 used a file under /tmp)
 			ncclUniqueId id;
 			if(rank == 0){
 				NODE_NCCL(ncclGetUniqueId(&id));
-				const string tmp = id_path + ".tmp";
-				FILE *f = fopen(tmp.c_str(), "wb");
-				if(!f || fwrite(&id, sizeof(id), 1, f) != 1){ throw string("cannot write ") + tmp; }
-				fclose(f);
-				rename(tmp.c_str(), id_path.c_str());
+				memcpy(&boot->id, &id, sizeof(id));
+				__sync_synchronize();
+				boot->ready = 1;
 			}
 			else{
-				FILE *f = nullptr;
-				for(int tries = 0; tries < 6000 && !(f = fopen(id_path.c_str(), "rb")); ++tries){ usleep(10000); }
-				if(!f || fread(&id, sizeof(id), 1, f) != 1){ throw string("no RCCL unique id from rank 0"); }
-				fclose(f);
+				int tries = 0;
+				while(!boot->ready && tries++ < 60000){ usleep(1000); }
+				if(!boot->ready){ throw string("no RCCL unique id from rank 0"); }
+				__sync_synchronize();
+				memcpy(&id, &boot->id, sizeof(id));
 			}
 			const ncclResult_t comm_up = ncclCommInitRank(&comm, n_ranks, id, rank);
 			fflush(stdout);
@@ -247,41 +386,31 @@ int run_rank(int rank, int n_ranks, const string &id_path, const Cli &cli, const
 			check(kwage_group_finalize(g.mine));
 		}
 
-		// ---- the exchange's buffers: this rank's list (counter word + records), every rank's count, rank 0's gathered list --
+		// ---- the exchange's buffers: every rank's count, rank 0's gathered list (device + pinned host) ------------------
 		const uint32_t flags = env_u64("KWAGE_EARLY_EXIT", 1) ? KWAGE_SEARCH_EARLY_EXIT : 0u;
 		const uint64_t max_batch_bases = env_u64("KWAGE_BATCH_BASES", 64ull << 20);
-		uint64_t cap = 1u << 18, all_cap = 0;
-		uint64_t *d_count = nullptr, *d_counts = nullptr;
-		kwage_hit *d_hits = nullptr, *d_all = nullptr;
-		NODE_HIP(hipMalloc((void**)&d_count, sizeof(uint64_t)));
+		const bool stats = env_u64("KWAGE_NODE_STATS", 0) != 0;
+		uint64_t all_cap = 0, host_cap = 0;
+		uint64_t *d_counts = nullptr, *h_counts = nullptr;
+		kwage_hit *d_all = nullptr, *h_all = nullptr;
 		NODE_HIP(hipMalloc((void**)&d_counts, (size_t)n_ranks*sizeof(uint64_t)));
-		NODE_HIP(hipMalloc((void**)&d_hits, cap*sizeof(kwage_hit)));
+		NODE_HIP(hipHostMalloc((void**)&h_counts, (size_t)n_ranks*sizeof(uint64_t)));
+		double sum_kernel_ms = 0, t_exchange = 0, t_file = 0;
+		uint64_t n_batches = 0, n_records = 0;
+		const double t_search0 = now_seconds();
 
-		Findings from_command_line, from_files;
-		auto search_batch = [&](const QueryBatch &q, Findings &found) {
-			kwage_batch *b = nullptr;
-			check(kwage_batch_create(ctx, q.bases.data(), q.offsets.data(), (uint32_t)q.size(), &b));
-			// all of this rank's groups append to ONE list; records carry global column numbers
-			uint64_t n_mine = 0;
-			for(;;){
-				NODE_HIP(hipMemset(d_count, 0, sizeof(uint64_t)));
-				bool first_search = true;
-				for(NodeGroup &g : groups){
-					if(!g.mine){ continue; }
-					kwage_pending *p = nullptr;
-					check(kwage_search_device_append_submit(g.mine, b, cli.threshold, flags, d_hits, cap, d_count, (uint32_t)g.base[(size_t)rank],
-					                                        first_search ? 1 : 0, &p));
-					check(kwage_search_device_collect(p, &n_mine, nullptr, nullptr));
-					first_search = false;
-				}
-				if(n_mine <= cap){ break; }
-				(void)hipFree(d_hits);                               // rare: the list outgrew its buffer; grow and search again
-				cap = n_mine + n_mine/4;
-				NODE_HIP(hipMalloc((void**)&d_hits, cap*sizeof(kwage_hit)));
-			}
-			// the gatherv: counts to everyone, records in exact sizes to rank 0
+		{
+		RankPipeline pipe(ctx, groups, rank, cli.threshold, flags);
+
+		// The gatherv of one finished step: counts to everyone (one ncclAllGather straight from the lists' counter words),
+		// records in exact sizes to rank 0 (one grouped ncclSend / ncclRecv; RCCL has no gatherv); rank 0 files them.
+		// The next step's searches are running on the device meanwhile.
+		auto exchange_and_file = [&](Step *st) {
+			const double t0 = now_seconds();
+			const HitList &l = pipe.lists[st->list];
+			const uint64_t n_mine = st->n;
 			vector<uint64_t> counts((size_t)n_ranks);
-			vector<kwage_hit> hits;
+			const kwage_hit *hits = nullptr;
 			uint64_t total = 0;
 			if(rehearsal){
 				rehearsal->counts[rank] = n_mine;
@@ -293,53 +422,76 @@ int run_rank(int rank, int n_ranks, const string &id_path, const Cli &cli, const
 					total += counts[(size_t)r];
 				}
 				if(total > rehearsal->capacity){ throw string("the rehearsal segment is too small for this hit list"); }
-				if(n_mine){ NODE_HIP(hipMemcpy(rehearsal->records() + at, d_hits, n_mine*sizeof(kwage_hit), hipMemcpyDeviceToHost)); }
+				if(n_mine){ NODE_HIP(hipMemcpy(rehearsal->records() + at, l.d_hits, n_mine*sizeof(kwage_hit), hipMemcpyDeviceToHost)); }
 				pthread_barrier_wait(&rehearsal->barrier);
-				if(rank == 0){ hits.assign(rehearsal->records(), rehearsal->records() + total); }
+				if(rank == 0 && total){
+					if(total > host_cap){
+						if(h_all){ (void)hipHostFree(h_all); }
+						host_cap = total + total/4;
+						NODE_HIP(hipHostMalloc((void**)&h_all, host_cap*sizeof(kwage_hit)));
+					}
+					memcpy(h_all, rehearsal->records(), total*sizeof(kwage_hit));
+					hits = h_all;
+				}
 				pthread_barrier_wait(&rehearsal->barrier);            // (the segment is free for the next batch)
 			}
 			else{
-				NODE_HIP(hipMemcpy(d_counts + rank, &n_mine, sizeof(uint64_t), hipMemcpyHostToDevice));
-				NODE_NCCL(ncclAllGather(d_counts + rank, d_counts, 1, ncclUint64, comm, stream));
+				// (the step's searches have been collected: the counter word holds the list's final count)
+				NODE_NCCL(ncclAllGather(l.d_count, d_counts, 1, ncclUint64, comm, stream));
+				NODE_HIP(hipMemcpyAsync(h_counts, d_counts, (size_t)n_ranks*sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
 				NODE_HIP(hipStreamSynchronize(stream));
-				NODE_HIP(hipMemcpy(counts.data(), d_counts, counts.size()*sizeof(uint64_t), hipMemcpyDeviceToHost));
-				for(uint64_t c : counts){ total += c; }
+				for(int r = 0; r < n_ranks; ++r){ counts[(size_t)r] = h_counts[r]; total += h_counts[r]; }
+				if(counts[(size_t)rank] != n_mine){ throw string("the list's counter word disagrees with the count the search returned"); }
 				if(rank == 0 && total > all_cap){
 					if(d_all){ (void)hipFree(d_all); }
 					all_cap = total + total/4;
 					NODE_HIP(hipMalloc((void**)&d_all, all_cap*sizeof(kwage_hit)));
 				}
-				NODE_NCCL(ncclGroupStart());
-				if(rank == 0){
-					uint64_t at = counts[0];
-					for(int r = 1; r < n_ranks; ++r){
-						if(counts[(size_t)r]){ NODE_NCCL(ncclRecv(d_all + at, counts[(size_t)r]*3, ncclUint32, r, comm, stream)); }
-						at += counts[(size_t)r];
+				if(rank == 0 && total > host_cap){
+					if(h_all){ (void)hipHostFree(h_all); }
+					host_cap = total + total/4;
+					NODE_HIP(hipHostMalloc((void**)&h_all, host_cap*sizeof(kwage_hit)));
+				}
+				{
+					NODE_NCCL(ncclGroupStart());
+					if(rank == 0){
+						uint64_t at = counts[0];
+						for(int r = 1; r < n_ranks; ++r){
+							if(counts[(size_t)r]){ NODE_NCCL(ncclRecv(d_all + at, counts[(size_t)r]*3, ncclUint32, r, comm, stream)); }
+							at += counts[(size_t)r];
+						}
 					}
+					else if(n_mine){
+						NODE_NCCL(ncclSend(l.d_hits, n_mine*3, ncclUint32, 0, comm, stream));
+					}
+					NODE_NCCL(ncclGroupEnd());
 				}
-				else if(n_mine){
-					NODE_NCCL(ncclSend(d_hits, n_mine*3, ncclUint32, 0, comm, stream));
-				}
-				NODE_NCCL(ncclGroupEnd());
-				if(rank == 0 && n_mine){ NODE_HIP(hipMemcpyAsync(d_all, d_hits, n_mine*sizeof(kwage_hit), hipMemcpyDeviceToDevice, stream)); }
-				NODE_HIP(hipStreamSynchronize(stream));
 				if(rank == 0 && total){
-					hits.resize(total);
-					NODE_HIP(hipMemcpy(hits.data(), d_all, total*sizeof(kwage_hit), hipMemcpyDeviceToHost));
+					// rank 0's own records go to the host straight from its list, the other ranks' from the gathered block
+					if(n_mine){ NODE_HIP(hipMemcpyAsync(h_all, l.d_hits, n_mine*sizeof(kwage_hit), hipMemcpyDeviceToHost, stream)); }
+					if(total > n_mine){ NODE_HIP(hipMemcpyAsync(h_all + n_mine, d_all + n_mine, (total - n_mine)*sizeof(kwage_hit), hipMemcpyDeviceToHost, stream)); }
+					hits = h_all;
 				}
+				NODE_HIP(hipStreamSynchronize(stream));      // (a sender's list is refilled two steps on: the send has left it)
 			}
+			const double t1 = now_seconds();
+			t_exchange += t1 - t0;
 
 			if(rank == 0 && total){
-				kwage_sort_hits(hits.data(), total);               // by (query, global column): groups, ranks and files in order
-				// num_query_kmer depends on the k-mer length only: one k-mer stage per distinct length of the database
-				map<uint32_t, vector<uint32_t> > nk_by_k;
+				kwage_sort_hits(h_all, total);                     // by (query, global column): groups, ranks and files in order
+				const QueryBatch &q = st->q;
+				// num_query_kmer depends on the k-mer length only; lengths of which this rank holds no group (it searched none
+				// of them) are the one case that still needs a k-mer stage of its own
 				for(const NodeGroup &g : groups){
-					if(nk_by_k.count(g.params.kmer_len)){ continue; }
+					if(st->nk.count(g.params.kmer_len)){ continue; }
+					while(!pipe.flying.empty()){ pipe.collect_oldest(); }      // (kwage_hash_batch wants the context's slots idle)
 					vector<uint64_t> off(q.size() + 1);
 					vector<uint32_t> nk(q.size());
-					check(kwage_hash_batch(ctx, &g.params, b, off.data(), nk.data(), nullptr, nullptr));
-					nk_by_k[g.params.kmer_len] = std::move(nk);
+					check(kwage_hash_batch(ctx, &g.params, st->b, off.data(), nk.data(), nullptr, nullptr));
+					st->nk[g.params.kmer_len] = std::move(nk);
 				}
+				pipe.pump();
+				Findings &found = *st->found;
 				for(uint64_t i = 0; i < total; ){
 					const uint32_t qi = hits[i].query;
 					const size_t qid = q.ids[qi];
@@ -351,37 +503,67 @@ int run_rank(int rank, int n_ranks, const string &id_path, const Cli &cli, const
 						                                       [](uint64_t col, const ColumnBlock &b) { return col < b.first_global_column; }) - 1);
 						Match m;
 						m.num_kmers_found = hits[i].num_match;
-						m.num_query_kmer = nk_by_k[blk.kmer_len][qi];
+						m.num_query_kmer = st->nk[blk.kmer_len][qi];
 						m.file_index = blk.file_index;
 						m.column = (uint32_t)(hits[i].column - blk.first_global_column);
 						dst.push_back(m);
 					}
 				}
 			}
-			kwage_batch_destroy(b);
+			t_file += now_seconds() - t1;
+			sum_kernel_ms += st->kernel_ms;
+			n_records += total;
+			++n_batches;
 		};
 
+		// batches stream through: batch i+1 is parsed (on its own thread) and its searches queued BEFORE batch i is
+		// finished, exchanged and filed
+		unique_ptr<Step> open_step;
+		auto retire = [&](unique_ptr<Step> &st) {
+			pipe.finish(st.get());
+			exchange_and_file(st.get());
+			kwage_batch_destroy(st->b);
+			st.reset();
+		};
+		auto run_source = [&](QuerySource &source, Findings &found) {
+			PrefetchedQueries ahead(source, max_batch_bases);
+			for(;;){
+				unique_ptr<Step> st(new Step());
+				if(!ahead.fill(st->q, max_batch_bases)){ break; }
+				st->found = &found;
+				pipe.begin(st.get());
+				if(open_step){ retire(open_step); }
+				open_step = std::move(st);
+				open_step->q.bases = string();                      // resident on the device now
+			}
+		};
+		Findings from_command_line_, from_files_;
 		{
 			CommandLineQueries typed(cli.query_seqs);
-			QueryBatch q;
-			while(typed.fill(q, max_batch_bases)){ search_batch(q, from_command_line); }
+			run_source(typed, from_command_line_);
 		}
 		if(!cli.query_files.empty()){
 			FileQueries disk(cli.query_files);
-			QueryBatch q;
-			while(disk.fill(q, max_batch_bases)){ search_batch(q, from_files); }
+			run_source(disk, from_files_);
+		}
+		if(open_step){ retire(open_step); }
+		const double t_search = now_seconds() - t_search0;
+		if(stats && rank == 0){
+			fprintf(stderr, "[kwage_node] %llu batches, %llu records: search phase %.3f ms wall, sum of gather-kernel time (rank 0) %.3f ms, "
+			                "exchange %.3f ms, filing %.3f ms\n", (unsigned long long)n_batches, (unsigned long long)n_records, t_search*1e3,
+			        sum_kernel_ms, t_exchange*1e3, t_file*1e3);
 		}
 
+		// (pipe is destroyed before the context)
 		if(comm){ NODE_NCCL(ncclCommDestroy(comm)); }
-		(void)hipFree(d_count); (void)hipFree(d_counts); (void)hipFree(d_hits);
+		(void)hipFree(d_counts); (void)hipHostFree(h_counts);
 		if(d_all){ (void)hipFree(d_all); }
+		if(h_all){ (void)hipHostFree(h_all); }
 		(void)hipStreamDestroy(stream);
-		for(NodeGroup &g : groups){ if(g.mine){ kwage_group_destroy(g.mine); } }
-		kwage_shutdown(ctx);
 
 		if(rank == 0){
 			// order and report exactly as kwage does (kwage_main.cpp; reference kwage.cpp:191-315)
-			for(Findings *f : {&from_command_line, &from_files}){
+			for(Findings *f : {&from_command_line_, &from_files_}){
 				for(auto &kv : f->by_query){
 					sort(kv.second.begin(), kv.second.end(), [](const Match &a, const Match &b) {
 						return (a.file_index != b.file_index) ? (a.file_index < b.file_index) : (a.column < b.column);
@@ -392,12 +574,15 @@ int run_rank(int rank, int n_ranks, const string &id_path, const Cli &cli, const
 			unique_ptr<Report> report;
 			if(cli.format == Cli::CSV){ report.reset(new CsvReport(out, infos)); }
 			else{ report.reset(new JsonReport(out, cli.threshold, infos)); }
-			report->begin(from_command_line.by_query.size() + from_files.by_query.size());
-			for(const auto &kv : from_command_line.by_query){ report->query("command line seq " + to_string(kv.first), kv.second); }
-			for(const auto &kv : from_files.by_query){ report->query(from_files.defline[kv.first], kv.second); }
+			report->begin(from_command_line_.by_query.size() + from_files_.by_query.size());
+			for(const auto &kv : from_command_line_.by_query){ report->query("command line seq " + to_string(kv.first), kv.second); }
+			for(const auto &kv : from_files_.by_query){ report->query(from_files_.defline[kv.first], kv.second); }
 			report->end();
 			cerr << "Search complete in " << (time(nullptr) - started) << " sec" << endl;
 		}
+		}
+		for(NodeGroup &g : groups){ if(g.mine){ kwage_group_destroy(g.mine); } }
+		kwage_shutdown(ctx);
 	}
 	catch(const char *error){
 		cerr << "Caught the error " << error << endl;
@@ -430,14 +615,21 @@ int main(int argc, char *argv[])
 		cerr << "Caught the error " << error << endl;
 		return EXIT_FAILURE;
 	}
-	// the parent touches no GPU: the devices are counted by a short-lived child, the ranks forked before any HIP call
 	int n_ranks = (int)env_u64("KWAGE_NODE_RANKS", 0);
+	// the plan is a function of the file headers and the rank count: it is printed before anything looks for a device
+	if(env_u64("KWAGE_NODE_PLAN", 0)){
+		if(n_ranks < 1 || n_ranks > 64){
+			cerr << "kwage_node: KWAGE_NODE_PLAN needs the number of ranks in KWAGE_NODE_RANKS (1..64); no device is asked" << endl;
+			return EXIT_FAILURE;
+		}
+		return print_plan(db_paths, n_ranks);
+	}
+	// the parent touches no GPU: the devices are counted by a short-lived child, the ranks forked before any HIP call
 	if(n_ranks <= 0){ n_ranks = device_count_in_child(); }
 	if(n_ranks < 1 || n_ranks > 64){
 		cerr << "kwage_node: no usable device count (" << n_ranks << "); set KWAGE_NODE_RANKS" << endl;
 		return EXIT_FAILURE;
 	}
-	if(env_u64("KWAGE_NODE_PLAN", 0)){ return print_plan(db_paths, n_ranks); }
 	Rehearsal *rehearsal = nullptr;
 	if(env_u64("KWAGE_NODE_REHEARSE", 0)){
 		const uint64_t capacity = env_u64("KWAGE_NODE_REHEARSE_RECORDS", 64ull << 20);
@@ -450,25 +642,30 @@ int main(int argc, char *argv[])
 		pthread_barrierattr_setpshared(&shared, PTHREAD_PROCESS_SHARED);
 		pthread_barrier_init(&rehearsal->barrier, &shared, (unsigned)n_ranks);
 	}
-	char id_path[] = "/tmp/kwage_node_id_XXXXXX";
-	const int fd = mkstemp(id_path);
-	if(fd < 0){ perror("mkstemp"); return EXIT_FAILURE; }
-	close(fd);
-	unlink(id_path);                                       // rank 0 creates it when the id is complete
+	// where rank 0 leaves the communicator's id for the others: anonymous memory shared with the ranks through the fork
+	void *bseg = mmap(nullptr, sizeof(Bootstrap), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+	if(bseg == MAP_FAILED){ perror("mmap"); return EXIT_FAILURE; }
+	Bootstrap *boot = new (bseg) Bootstrap();
 	vector<pid_t> kids;
+	int rc = EXIT_SUCCESS;
 	for(int r = 0; r < n_ranks; ++r){
 		const pid_t pid = fork();
-		if(pid < 0){ perror("fork"); return EXIT_FAILURE; }
+		if(pid < 0){
+			// the ranks already started would wait for this one in the communicator's set-up or the first exchange: end them
+			perror("fork");
+			rc = EXIT_FAILURE;
+			for(pid_t k : kids){ kill(k, SIGTERM); }
+			break;
+		}
 		if(pid == 0){
-			const int rc = run_rank(r, n_ranks, id_path, cli, db_paths, rehearsal);
+			const int rank_rc = run_rank(r, n_ranks, boot, cli, db_paths, rehearsal);
 			cout.flush();
 			fflush(nullptr);
-			_exit(rc);
+			_exit(rank_rc);
 		}
 		kids.push_back(pid);
 	}
 	// a rank that fails would leave the others waiting in the exchange: end them too
-	int rc = EXIT_SUCCESS;
 	for(size_t left = kids.size(); left; ){
 		int st = 0;
 		const pid_t done = waitpid(-1, &st, 0);
@@ -482,6 +679,6 @@ int main(int argc, char *argv[])
 			for(pid_t k : kids){ if(k > 0){ kill(k, SIGTERM); } }
 		}
 	}
-	unlink(id_path);
+	(void)munmap(bseg, sizeof(Bootstrap));
 	return rc;
 }

@@ -393,6 +393,7 @@ extern "C" void kwage_group_destroy(kwage_group *g)
 	if(!g){ return; }
 	(void)hipSetDevice(g->ctx->device);
 	release_mapping(g->ctx);
+	(void)hipStreamSynchronize(g->ctx->gather_stream);
 	(void)hipStreamSynchronize(g->ctx->slot[0].stream);
 	(void)hipStreamSynchronize(g->ctx->slot[1].stream);
 	if(g->d_bits){ (void)hipFree(g->d_bits); }

@@ -151,6 +151,127 @@ __global__ __launch_bounds__(512) void walk_like(const uint8_t *db, uint64_t str
 	if((t.x ^ t.y ^ t.z ^ t.w) == 0x12345678u){ *sink = pad[0]; }
 }
 
+
+// ---- LDS-DMA forms (round 4): do rows landing in LDS (global_load_lds_dwordx4: no VGPR destination, so the bytes in flight
+// per wave are not bounded by the register budget) gather faster than rows landing in registers?
+//   walk_lds<R, P, CH>   and_walk_kernel's pattern (MODE 2 above) with every KiB-step of R rows DMA'd into a per-wave LDS
+//                        ring P steps ahead of the step being ANDed: P*R KiB in flight per wave, read back with ds_read_b128
+//   narrow_reg<U> / narrow_lds<P>   the narrow shape (256-byte rows = one 2048-column file, four lane groups of 16 per wave,
+//                        every group its own row list): U rows per group in registers vs P KiB-instructions ahead in LDS
+// Every form writes a per-wave checksum of what it read (XOR-accumulated: the AND of fifty Bernoulli(1/4) rows is all zero and would
+// say nothing), so that the host can tell that the LDS forms read the same bytes.
+__device__ __forceinline__ void glds16_nt(const void *gsrc, uint32_t lds_dst)
+{
+	// M0 = wave-uniform LDS byte address; every lane's 16 bytes land at M0 + lane*16 (cdna_hip_programming.md section 7: the
+	// LDS-DMA recipe).  The lgkmcnt(0) makes sure this wave's earlier ds_reads of the slot have returned before it is refilled.
+	unsigned keep;
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+	             : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <int R, int P, int CH>
+__global__ __launch_bounds__(512) void walk_lds(const uint8_t *db, uint64_t stride, const uint32_t *__restrict__ rows, uint64_t rows_per_wave, uint32_t *check)
+{
+	extern __shared__ __attribute__((aligned(1024))) uint8_t ring[];       // per wave (P + 1) slots of R KiB
+	const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const uint64_t wave = __builtin_amdgcn_readfirstlane((uint32_t)(blockIdx.x*(blockDim.x/64) + w));
+	const uint32_t *rq = rows + wave*rows_per_wave;
+	constexpr uint32_t SLOT = R*1024, NSLOT = P + 1;
+	uint8_t *mine = ring + (size_t)w*NSLOT*SLOT;
+	const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)mine);
+	const uint64_t groups = rows_per_wave/R, steps = groups*CH;
+	u32x4 acc[CH];
+#pragma unroll
+	for(int j = 0; j < CH; ++j){ acc[j] = ~(u32x4)(0u); }
+	// issue side: step ti = (group gi, KiB-step ji) into slot si
+	uint64_t gi = 0; uint32_t ji = 0, si = 0;
+	auto issue = [&]() {
+#pragma unroll
+		for(int u = 0; u < R; ++u){
+			const uint32_t r = rq[gi*R + u];
+			glds16_nt(db + (uint64_t)r*stride + ji*1024u + lane*16u, lds0 + si*SLOT + u*1024u);
+		}
+		if(++ji == CH){ ji = 0; ++gi; }
+		if(++si == NSLOT){ si = 0; }
+	};
+	uint64_t issued = 0;
+	for(; issued < (uint64_t)P && issued < steps; ++issued){ issue(); }
+	uint32_t sr = 0;
+	for(uint64_t g = 0; g < groups; ++g){
+#pragma unroll
+		for(int j = 0; j < CH; ++j){
+			if(issued < steps){ issue(); ++issued; wait_vm<P*R>(); }       // P steps stay in flight behind the one read now
+			else{ wait_vm<0>(); }
+			const u32x4 *sl = reinterpret_cast<const u32x4*>(mine + sr*SLOT) + lane;
+#pragma unroll
+			for(int u = 0; u < R; ++u){ acc[j] ^= sl[u*64]; }
+			if(++sr == NSLOT){ sr = 0; }
+		}
+	}
+	u32x4 t = acc[0];
+#pragma unroll
+	for(int j = 1; j < CH; ++j){ t ^= acc[j]; }
+	uint32_t c = t.x ^ t.y ^ t.z ^ t.w;
+	for(int d = 32; d; d >>= 1){ c ^= __shfl_xor(c, d); }
+	if(lane == 0){ check[wave] = c; }
+}
+
+__device__ __forceinline__ uint32_t narrow_row(uint64_t &x, uint64_t nrows)
+{
+	x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+	return (uint32_t)(((x*0x2545F4914F6CDD1Dull) >> 33) % nrows);
+}
+
+// one wave = four queries of `n` rows each (lane group of 16 = one 256-byte row per load)
+template <int U>
+__global__ __launch_bounds__(256) void narrow_reg(const uint8_t *db, uint64_t nrows, uint32_t n, uint32_t *check)
+{
+	const uint32_t lane = threadIdx.x & 63, l = lane & 15;
+	const uint64_t wave = (uint64_t)blockIdx.x*(blockDim.x/64) + (threadIdx.x >> 6);
+	uint64_t x = (wave*4 + lane/16)*0x9E3779B97F4A7C15ull + 31337;
+	u32x4 acc = ~(u32x4)(0u);
+	for(uint32_t i = 0; i < n; i += U){
+		u32x4 v[U];
+#pragma unroll
+		for(int u = 0; u < U; ++u){ v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(db + (uint64_t)narrow_row(x, nrows)*256) + l); }
+#pragma unroll
+		for(int u = 0; u < U; ++u){ acc ^= v[u]; }
+	}
+	uint32_t c = acc.x ^ acc.y ^ acc.z ^ acc.w;
+	for(int d = 32; d; d >>= 1){ c ^= __shfl_xor(c, d); }
+	if(lane == 0){ check[wave] = c; }
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void narrow_lds(const uint8_t *db, uint64_t nrows, uint32_t n, uint32_t *check)
+{
+	extern __shared__ __attribute__((aligned(1024))) uint8_t ring[];       // per wave (P + 1) slots of 1 KiB
+	const uint32_t lane = threadIdx.x & 63, l = lane & 15, w = threadIdx.x >> 6;
+	const uint64_t wave = (uint64_t)blockIdx.x*(blockDim.x/64) + w;
+	uint64_t x = (wave*4 + lane/16)*0x9E3779B97F4A7C15ull + 31337;
+	constexpr uint32_t NSLOT = P + 1;
+	uint8_t *mine = ring + (size_t)w*NSLOT*1024;
+	const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)mine);
+	u32x4 acc = ~(u32x4)(0u);
+	uint32_t si = 0, sr = 0, issued = 0;
+	auto issue = [&]() {
+		glds16_nt(db + (uint64_t)narrow_row(x, nrows)*256 + l*16u, lds0 + si*1024u);
+		if(++si == NSLOT){ si = 0; }
+	};
+	for(; issued < (uint32_t)P && issued < n; ++issued){ issue(); }
+	for(uint32_t i = 0; i < n; ++i){
+		if(issued < n){ issue(); ++issued; wait_vm<P>(); }
+		else{ wait_vm<0>(); }
+		acc ^= reinterpret_cast<const u32x4*>(mine + sr*1024u)[lane];
+		if(++sr == NSLOT){ sr = 0; }
+	}
+	uint32_t c = acc.x ^ acc.y ^ acc.z ^ acc.w;
+	for(int d = 32; d; d >>= 1){ c ^= __shfl_xor(c, d); }
+	if(lane == 0){ check[wave] = c; }
+}
+
 // Wide rows (C3: 125 000-byte rows).  PIECES: every wave reads random 8 KiB pieces (row, piece) on its own, R in flight --
 // what the tiled kernel and the column-tiled walk do to the memory: a row's pieces are fetched by different waves at
 // different times.  COOP: the 16 waves of a workgroup take the SAME row at the same time, wave w its w-th 8 KiB -- the row
@@ -299,6 +420,145 @@ int run(const char *name, int wgs, int threads, size_t lds, const u32x4 *buf, ui
 	return 0;
 }
 
+
+// run `launch` for `seconds`, print GB/s second by second; -> checksum over the per-wave checks of the last launch
+template <typename F>
+int timed(const char *name, double seconds, double bytes_per_launch, int reps, uint32_t *check, uint64_t nwaves, uint32_t *sum_out, F launch)
+{
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+	printf("%-72s", name);
+	const auto t0 = std::chrono::steady_clock::now();
+	double last_report = 0, best = 0;
+	while(true){
+		CK(hipEventRecord(e0, 0));
+		for(int r = 0; r < reps; ++r){ launch(); }
+		CK(hipEventRecord(e1, 0));
+		CK(hipEventSynchronize(e1));
+		CK(hipGetLastError());
+		float ms = 0;
+		CK(hipEventElapsedTime(&ms, e0, e1));
+		const double gbps = reps*bytes_per_launch/ms/1e6;
+		best = gbps > best ? gbps : best;
+		const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		if(el - last_report >= 1.0){ printf(" %5.0f", gbps); fflush(stdout); last_report = el; }
+		if(el >= seconds){ break; }
+	}
+	uint32_t *h = (uint32_t*)malloc(nwaves*4);
+	CK(hipMemcpy(h, check, nwaves*4, hipMemcpyDeviceToHost));
+	uint32_t sum = 0;
+	for(uint64_t i = 0; i < nwaves; ++i){ sum = sum*31u + h[i]; }
+	free(h);
+	*sum_out = sum;
+	printf("  GB/s  (best %5.0f, checksum %08x)\n", best, sum);
+	return 0;
+}
+
+// walk_like<.., 2> with a per-wave checksum (the register reference of the LDS forms)
+template <int R, int CH>
+__global__ __launch_bounds__(512) void walk_reg_check(const uint8_t *db, uint64_t stride, uint32_t row_bytes, const uint32_t *__restrict__ rows, uint64_t rows_per_wave, uint32_t *check)
+{
+	extern __shared__ uint32_t pad[];
+	const uint32_t lane = threadIdx.x & 63;
+	const uint64_t wave = __builtin_amdgcn_readfirstlane((uint32_t)(blockIdx.x*(blockDim.x/64) + (threadIdx.x >> 6)));
+	const uint32_t *rq = rows + wave*rows_per_wave;
+	u32x4 acc[CH];
+#pragma unroll
+	for(int j = 0; j < CH; ++j){ acc[j] = ~(u32x4)(0u); }
+	for(uint64_t r = 0; r < rows_per_wave; r += R){
+		__amdgpu_buffer_rsrc_t rs[R];
+#pragma unroll
+		for(int u = 0; u < R; ++u){ rs[u] = __builtin_amdgcn_make_buffer_rsrc((void*)(db + (uint64_t)rq[r + u]*stride), 0, row_bytes, 0x00020000); }
+#pragma unroll
+		for(int j = 0; j < CH; ++j){
+			u32x4 x[R];
+#pragma unroll
+			for(int u = 0; u < R; ++u){ x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs[u], lane*16u, j*1024, 2); }
+#pragma unroll
+			for(int u = 0; u < R; ++u){ acc[j] ^= x[u]; }
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	}
+	u32x4 t = acc[0];
+#pragma unroll
+	for(int j = 1; j < CH; ++j){ t ^= acc[j]; }
+	uint32_t c = t.x ^ t.y ^ t.z ^ t.w;
+	for(int d = 32; d; d >>= 1){ c ^= __shfl_xor(c, d); }
+	if(lane == 0){ check[wave] = c; }
+}
+
+template <int R, int P>
+int run_walk_lds(const char *name, int wg_waves, const uint8_t *buf, uint64_t bytes, uint32_t *rows, uint32_t *check, double seconds, uint32_t *sum)
+{
+	const uint64_t stride = 12544, nrows = bytes/stride, total_rows = 970000;
+	const int wgs = 256;
+	const uint64_t waves = (uint64_t)wgs*wg_waves;
+	const uint64_t rpw = (total_rows + waves - 1)/waves/8*8 + 8;            // (a multiple of every R used, the same for every form of one wave count)
+	const size_t lds = (size_t)wg_waves*(P + 1)*R*1024;
+	CK(hipFuncSetAttribute((const void*)walk_lds<R, P, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	hipLaunchKernelGGL(fill_rows, dim3(1024), dim3(256), 0, 0, rows, waves*rpw, nrows);
+	return timed(name, seconds, (double)waves*rpw*12544, 8, check, waves, sum, [&]{
+		hipLaunchKernelGGL((walk_lds<R, P, 13>), dim3(wgs), dim3(wg_waves*64), lds, 0, buf, stride, rows, rpw, check); });
+}
+
+int run_walk_reg(const char *name, int wg_waves, const uint8_t *buf, uint64_t bytes, uint32_t *rows, uint32_t *check, double seconds, uint32_t *sum)
+{
+	const uint64_t stride = 12544, nrows = bytes/stride, total_rows = 970000;
+	const int wgs = 256;
+	const uint64_t waves = (uint64_t)wgs*wg_waves;
+	const uint64_t rpw = (total_rows + waves - 1)/waves/8*8 + 8;
+	CK(hipFuncSetAttribute((const void*)walk_reg_check<4, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, 100*1024));
+	hipLaunchKernelGGL(fill_rows, dim3(1024), dim3(256), 0, 0, rows, waves*rpw, nrows);
+	return timed(name, seconds, (double)waves*rpw*12544, 8, check, waves, sum, [&]{
+		hipLaunchKernelGGL((walk_reg_check<4, 13>), dim3(wgs), dim3(wg_waves*64), 100*1024, 0, buf, stride, (uint32_t)stride, rows, rpw, check); });
+}
+
+int lds_section(const uint8_t *buf, uint64_t bytes, uint32_t *rows, uint32_t *check, double seconds)
+{
+	uint32_t ref8 = 0, ref4 = 0, got = 0;
+	printf("---- C2's gather (970 k rows of 12 544 B, row numbers from memory): rows into REGISTERS vs rows into LDS by DMA\n");
+	for(int rep = 0; rep < 2; ++rep){
+		if(run_walk_reg("registers: buffer loads, 4 rows x 1 KiB in flight, 8 waves/CU  [= mode 2]", 8, buf, bytes, rows, check, seconds, &ref8)) return 1;
+		if(run_walk_lds<4, 3>("LDS-DMA: 4 rows x 3 KiB-steps ahead = 12 KiB in flight/wave, 8 waves/CU", 8, buf, bytes, rows, check, seconds, &got)) return 1;
+		if(got != ref8){ printf("!! checksum differs from the register form\n"); return 1; }
+		if(run_walk_lds<2, 7>("LDS-DMA: 2 rows x 7 steps ahead = 14 KiB in flight/wave, 8 waves/CU", 8, buf, bytes, rows, check, seconds, &got)) return 1;
+		if(got != ref8){ printf("!! checksum differs from the register form\n"); return 1; }
+		if(run_walk_reg("registers: 4 rows x 1 KiB in flight, 4 waves/CU", 4, buf, bytes, rows, check, seconds, &ref4)) return 1;
+		if(run_walk_lds<4, 7>("LDS-DMA: 4 rows x 7 steps ahead = 28 KiB in flight/wave, 4 waves/CU", 4, buf, bytes, rows, check, seconds, &got)) return 1;
+		if(got != ref4){ printf("!! checksum differs from the register form\n"); return 1; }
+		if(run_walk_lds<8, 3>("LDS-DMA: 8 rows x 3 steps ahead = 24 KiB in flight/wave, 4 waves/CU", 4, buf, bytes, rows, check, seconds, &got)) return 1;
+		if(got != ref4){ printf("!! checksum differs from the register form\n"); return 1; }
+	}
+	printf("---- the narrow shape (10 k queries x 970 rows of 256 B = one 2048-column file; 2500 waves, four queries each)\n");
+	const uint64_t nrows_n = (8ull << 30)/256;       // 2^25 rows x 256 B = 8 GiB, as the `narrow` workload
+	const uint64_t nw = 2500;
+	const double nbytes = (double)nw*4*970*256;
+	uint32_t refn = 0;
+	for(int rep = 0; rep < 2; ++rep){
+		if(timed("registers: 8 rows in flight per lane group (8 KiB/wave)", seconds, nbytes, 8, check, nw, &refn, [&]{
+			hipLaunchKernelGGL((narrow_reg<8>), dim3(nw/4), dim3(256), 0, 0, buf, nrows_n, 970u, check); })) return 1;
+		if(timed("registers: 16 rows in flight (16 KiB/wave)  [= and_narrow_kernel<4,16>]", seconds, nbytes, 8, check, nw, &got, [&]{
+			hipLaunchKernelGGL((narrow_reg<16>), dim3(nw/4), dim3(256), 0, 0, buf, nrows_n, 970u, check); })) return 1;
+		if(got != refn){ printf("!! checksum differs\n"); return 1; }
+		if(timed("registers: 32 rows in flight (32 KiB/wave)", seconds, nbytes, 8, check, nw, &got, [&]{
+			hipLaunchKernelGGL((narrow_reg<32>), dim3(nw/4), dim3(256), 0, 0, buf, nrows_n, 970u, check); })) return 1;
+		if(got != refn){ printf("!! checksum differs\n"); return 1; }
+		CK(hipFuncSetAttribute((const void*)narrow_lds<15>, hipFuncAttributeMaxDynamicSharedMemorySize, 4*16*1024));
+		if(timed("LDS-DMA: 15 KiB in flight per wave", seconds, nbytes, 8, check, nw, &got, [&]{
+			hipLaunchKernelGGL((narrow_lds<15>), dim3(nw/4), dim3(256), 4*16*1024, 0, buf, nrows_n, 970u, check); })) return 1;
+		if(got != refn){ printf("!! checksum differs from the register form\n"); return 1; }
+		CK(hipFuncSetAttribute((const void*)narrow_lds<31>, hipFuncAttributeMaxDynamicSharedMemorySize, 4*32*1024));
+		if(timed("LDS-DMA: 31 KiB in flight per wave (one workgroup per CU)", seconds, nbytes, 8, check, nw, &got, [&]{
+			hipLaunchKernelGGL((narrow_lds<31>), dim3(nw/4), dim3(256), 4*32*1024, 0, buf, nrows_n, 970u, check); })) return 1;
+		if(got != refn){ printf("!! checksum differs from the register form\n"); return 1; }
+		CK(hipFuncSetAttribute((const void*)narrow_lds<62>, hipFuncAttributeMaxDynamicSharedMemorySize, 2*63*1024));
+		if(timed("LDS-DMA: 62 KiB in flight per wave, workgroups of 2 waves", seconds, nbytes, 8, check, nw, &got, [&]{
+			hipLaunchKernelGGL((narrow_lds<62>), dim3(nw/2), dim3(128), 2*63*1024, 0, buf, nrows_n, 970u, check); })) return 1;
+		if(got != refn){ printf("!! checksum differs from the register form\n"); return 1; }
+	}
+	return 0;
+}
+
 int main(int argc, char **argv)
 {
 	const double seconds = argc > 1 ? atof(argv[1]) : 6.0;
@@ -309,6 +569,15 @@ int main(int argc, char **argv)
 	const uint64_t n16 = (32ull << 30)/16;
 	const size_t big = 100*1024;     // more than half a CU's LDS: one workgroup per CU
 	if(run<4>("stream: 2048 WGs x 256 thr, 4 KiB/wave", 2048, 256, 0, buf, n16, sink, seconds)) return 1;
+	if(argc > 2 && argv[2][0] == 'l'){        // round 4: rows into LDS by DMA against rows into registers, Bernoulli(1/4) matrix
+		uint32_t *check;
+		CK(hipMalloc(&check, 1u << 20));
+		hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, buf, bytes/16);
+		CK(hipDeviceSynchronize());
+		if(run_gather<4>("bare gather: random rows from a register RNG, 13 KiB/row", 256, 512, big, buf, bytes, sink, seconds)) return 1;
+		if(run_walk_like<2>("2: buffer descriptors, 13 unrolled paced KiB-steps (no checksum)", (const uint8_t*)buf, bytes, rows, sink, seconds)) return 1;
+		return lds_section((const uint8_t*)buf, bytes, rows, check, seconds);
+	}
 	if(argc > 2 && argv[2][0] == 'w'){
 		for(int rep = 0; rep < 2; ++rep){
 			if(run_wide<4, false>("wide rows: independent waves, random 8 KiB pieces, 4 in flight (8/CU)", 256, 512, big, buf, bytes, sink, seconds)) return 1;
