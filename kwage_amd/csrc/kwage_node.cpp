@@ -398,6 +398,7 @@ int run_rank(int rank, int n_ranks, Bootstrap *boot, const Cli &cli, const vecto
 		double sum_kernel_ms = 0, t_exchange = 0, t_file = 0;
 		uint64_t n_batches = 0, n_records = 0;
 		const double t_search0 = now_seconds();
+		double t_first_begin = 0;
 
 		{
 		RankPipeline pipe(ctx, groups, rank, cli.threshold, flags);
@@ -531,6 +532,7 @@ int run_rank(int rank, int n_ranks, Bootstrap *boot, const Cli &cli, const vecto
 				unique_ptr<Step> st(new Step());
 				if(!ahead.fill(st->q, max_batch_bases)){ break; }
 				st->found = &found;
+				if(t_first_begin == 0){ t_first_begin = now_seconds(); }
 				pipe.begin(st.get());
 				if(open_step){ retire(open_step); }
 				open_step = std::move(st);
@@ -549,9 +551,11 @@ int run_rank(int rank, int n_ranks, Bootstrap *boot, const Cli &cli, const vecto
 		if(open_step){ retire(open_step); }
 		const double t_search = now_seconds() - t_search0;
 		if(stats && rank == 0){
-			fprintf(stderr, "[kwage_node] %llu batches, %llu records: search phase %.3f ms wall, sum of gather-kernel time (rank 0) %.3f ms, "
-			                "exchange %.3f ms, filing %.3f ms\n", (unsigned long long)n_batches, (unsigned long long)n_records, t_search*1e3,
-			        sum_kernel_ms, t_exchange*1e3, t_file*1e3);
+			const double t_pipe = t_first_begin ? now_seconds() - t_first_begin : 0;
+			fprintf(stderr, "[kwage_node] %llu batches, %llu records: first batch queued -> last batch filed %.3f ms wall (with the first batch's parsing %.3f ms); "
+			                "sum of gather-kernel time (rank 0) %.3f ms = %.1f %% of it; exchange %.3f ms, filing %.3f ms (both beside the next batch's searches)\n",
+			        (unsigned long long)n_batches, (unsigned long long)n_records, t_pipe*1e3, t_search*1e3,
+			        sum_kernel_ms, t_pipe > 0 ? 100.0*sum_kernel_ms/(t_pipe*1e3) : 0.0, t_exchange*1e3, t_file*1e3);
 		}
 
 		// (pipe is destroyed before the context)
