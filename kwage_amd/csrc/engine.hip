@@ -7,6 +7,7 @@
 // which together replace the reference's search() (kwage.cpp:340-541) for a whole batch of
 // queries.  There is no CPU fallback anywhere in this file.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <chrono>
@@ -38,7 +39,7 @@ static const TuningName TUNING_NAMES[] = {
 	{"count_walk_min_rows", &Tuning::count_walk_min_rows}, {"count_walk_prefetch", &Tuning::count_walk_prefetch},
 	{"count_narrow_kps", &Tuning::count_narrow_kps},
 	{"hit_sort_host", &Tuning::hit_sort_host}, {"hit_copy_piece_kb", &Tuning::hit_copy_piece_kb}, {"shared_table_log2", &Tuning::shared_table_log2},
-	{"group_contiguous", &Tuning::group_contiguous}, {"group_placement_probe", &Tuning::group_placement_probe},
+	{"ext_launch_events", &Tuning::ext_launch_events}, {"group_contiguous", &Tuning::group_contiguous}, {"group_placement_probe", &Tuning::group_placement_probe},
 };
 
 namespace {
@@ -193,6 +194,16 @@ int launch_kmer_stage(Slot *sl, const kwage_params &p, kwage_batch *b, const Kme
 	return KWAGE_OK;
 }
 
+// The events of one gather stage, carried by its kernel launches themselves (hipExtLaunchKernelGGL): the first launch of
+// a stage takes `start`, the last one `stop` -- the dispatch packets' own start / end timestamps, no barrier packet on the
+// gather stream.  Recording them with hipEventRecord put two to three barrier packets between consecutive gather kernels,
+// ~5 us each (rocprofv3 kernel trace: 22 us from one gather kernel's end to the next one's start on the same queue).
+// Null members: the caller records plain events around the stage instead (knob ext_launch_events = 0).
+struct StageEvents { hipEvent_t start = nullptr, stop = nullptr; };
+
+#define KW_GATHER_LAUNCH(ge, first, last, kernel, grid, block, lds, stream, ...) \
+	hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)(lds), stream, (first) ? (ge).start : nullptr, (last) ? (ge).stop : nullptr, 0u, __VA_ARGS__)
+
 static const uint32_t WALK_MIN_ROWS_PER_WAVE = 64;   // and_walk_kernel: below this share per wave the tiled kernel is used
 static const uint32_t WALK_WAVES_PER_CU = 8;         // 2 workgroups: 2048 waves measured 1-2 % faster than 4096 (half the cut pairs)
 
@@ -235,77 +246,77 @@ AndCfg and_config(const Tuning &t, uint32_t units_per_row)
 }
 
 template <int VEC, int UNROLL, bool NT>
-void launch_and(const SearchArgs &a, hipStream_t s, const AndCfg &c)
+void launch_and(const SearchArgs &a, hipStream_t s, const AndCfg &c, const StageEvents &ge)
 {
 	const uint64_t tiles = (uint64_t)a.n_queries*a.segs*a.chunks;
 	const uint32_t bw = (uint32_t)c.block_waves;
 	const dim3 grid((uint32_t)((tiles + bw - 1)/bw)), block(bw*WAVE);
 	if(a.segs > 1){
-		hipLaunchKernelGGL((and_kernel<VEC, UNROLL, NT, true>), grid, block, (size_t)c.lds_bytes, s, a);
+		KW_GATHER_LAUNCH(ge, true, false, (and_kernel<VEC, UNROLL, NT, true>), grid, block, c.lds_bytes, s, a);      // (and_combine_kernel ends the stage)
 	}
 	else{
-		hipLaunchKernelGGL((and_kernel<VEC, UNROLL, NT, false>), grid, block, (size_t)c.lds_bytes, s, a);
+		KW_GATHER_LAUNCH(ge, true, true, (and_kernel<VEC, UNROLL, NT, false>), grid, block, c.lds_bytes, s, a);
 	}
 }
 
 template <int VEC, bool NT>
-void launch_and_u(const SearchArgs &a, hipStream_t s, const AndCfg &c)
+void launch_and_u(const SearchArgs &a, hipStream_t s, const AndCfg &c, const StageEvents &ge)
 {
-	if(c.unroll == 4){ launch_and<VEC, 4, NT>(a, s, c); }
-	else if(c.unroll == 16 && VEC < 4){ launch_and<VEC, 16, NT>(a, s, c); }
-	else if(c.unroll == 32 && VEC == 1){ launch_and<VEC, 32, NT>(a, s, c); }
-	else{ launch_and<VEC, 8, NT>(a, s, c); }
+	if(c.unroll == 4){ launch_and<VEC, 4, NT>(a, s, c, ge); }
+	else if(c.unroll == 16 && VEC < 4){ launch_and<VEC, 16, NT>(a, s, c, ge); }
+	else if(c.unroll == 32 && VEC == 1){ launch_and<VEC, 32, NT>(a, s, c, ge); }
+	else{ launch_and<VEC, 8, NT>(a, s, c, ge); }
 }
 
 template <bool NT>
-void launch_and_v(const SearchArgs &a, hipStream_t s, const AndCfg &c)
+void launch_and_v(const SearchArgs &a, hipStream_t s, const AndCfg &c, const StageEvents &ge)
 {
-	if(c.vec == 1){ launch_and_u<1, NT>(a, s, c); }
-	else if(c.vec == 2){ launch_and_u<2, NT>(a, s, c); }
-	else{ launch_and_u<4, NT>(a, s, c); }
+	if(c.vec == 1){ launch_and_u<1, NT>(a, s, c, ge); }
+	else if(c.vec == 2){ launch_and_u<2, NT>(a, s, c, ge); }
+	else{ launch_and_u<4, NT>(a, s, c, ge); }
 }
 
 template <int PLANES, int NH>
-void launch_count(const SearchArgs &a, hipStream_t s)
+void launch_count(const SearchArgs &a, hipStream_t s, const StageEvents &ge)
 {
 	if(a.segs > 1){
-		hipLaunchKernelGGL((count_kernel<PLANES, NH, true>), dim3(search_blocks(a)), dim3(SEARCH_THREADS), 0, s, a);
+		KW_GATHER_LAUNCH(ge, true, false, (count_kernel<PLANES, NH, true>), dim3(search_blocks(a)), dim3(SEARCH_THREADS), 0, s, a);      // (count_combine_kernel ends the stage)
 	}
 	else{
-		hipLaunchKernelGGL((count_kernel<PLANES, NH, false>), dim3(search_blocks(a)), dim3(SEARCH_THREADS), 0, s, a);
+		KW_GATHER_LAUNCH(ge, true, true, (count_kernel<PLANES, NH, false>), dim3(search_blocks(a)), dim3(SEARCH_THREADS), 0, s, a);
 	}
 }
 
 template <int PLANES, int G, int KPS>
-void launch_count_narrow(const SearchArgs &a, hipStream_t s)
+void launch_count_narrow(const SearchArgs &a, hipStream_t s, const StageEvents &ge)
 {
 	const uint64_t waves = ((uint64_t)a.n_queries + G - 1)/G;
 	const dim3 grid((uint32_t)((waves + 3)/4)), block(SEARCH_THREADS);
 	switch(a.num_hash){
-		case 1: hipLaunchKernelGGL((count_narrow_kernel<PLANES, 1, G, KPS>), grid, block, 0, s, a); break;
-		case 2: hipLaunchKernelGGL((count_narrow_kernel<PLANES, 2, G, KPS>), grid, block, 0, s, a); break;
-		case 3: hipLaunchKernelGGL((count_narrow_kernel<PLANES, 3, G, KPS>), grid, block, 0, s, a); break;
-		case 4: hipLaunchKernelGGL((count_narrow_kernel<PLANES, 4, G, KPS>), grid, block, 0, s, a); break;
-		default: hipLaunchKernelGGL((count_narrow_kernel<PLANES, 5, G, KPS>), grid, block, 0, s, a); break;
+		case 1: KW_GATHER_LAUNCH(ge, true, true, (count_narrow_kernel<PLANES, 1, G, KPS>), grid, block, 0, s, a); break;
+		case 2: KW_GATHER_LAUNCH(ge, true, true, (count_narrow_kernel<PLANES, 2, G, KPS>), grid, block, 0, s, a); break;
+		case 3: KW_GATHER_LAUNCH(ge, true, true, (count_narrow_kernel<PLANES, 3, G, KPS>), grid, block, 0, s, a); break;
+		case 4: KW_GATHER_LAUNCH(ge, true, true, (count_narrow_kernel<PLANES, 4, G, KPS>), grid, block, 0, s, a); break;
+		default: KW_GATHER_LAUNCH(ge, true, true, (count_narrow_kernel<PLANES, 5, G, KPS>), grid, block, 0, s, a); break;
 	}
 }
 
 template <int PLANES, int G>
-void launch_count_narrow_k(const SearchArgs &a, hipStream_t s, int kps)
+void launch_count_narrow_k(const SearchArgs &a, hipStream_t s, int kps, const StageEvents &ge)
 {
-	if(kps == 4){ launch_count_narrow<PLANES, G, 4>(a, s); }
-	else{ launch_count_narrow<PLANES, G, 8>(a, s); }
+	if(kps == 4){ launch_count_narrow<PLANES, G, 4>(a, s, ge); }
+	else{ launch_count_narrow<PLANES, G, 8>(a, s, ge); }
 }
 
 template <int PLANES>
-void launch_count_nh(const SearchArgs &a, hipStream_t s)
+void launch_count_nh(const SearchArgs &a, hipStream_t s, const StageEvents &ge)
 {
 	switch(a.num_hash){
-		case 1: launch_count<PLANES, 1>(a, s); break;
-		case 2: launch_count<PLANES, 2>(a, s); break;
-		case 3: launch_count<PLANES, 3>(a, s); break;
-		case 4: launch_count<PLANES, 4>(a, s); break;
-		default: launch_count<PLANES, 5>(a, s); break;
+		case 1: launch_count<PLANES, 1>(a, s, ge); break;
+		case 2: launch_count<PLANES, 2>(a, s, ge); break;
+		case 3: launch_count<PLANES, 3>(a, s, ge); break;
+		case 4: launch_count<PLANES, 4>(a, s, ge); break;
+		default: launch_count<PLANES, 5>(a, s, ge); break;
 	}
 }
 
@@ -317,56 +328,56 @@ uint32_t planes_for(uint64_t max_count)
 	return (bits <= 7) ? 7 : (bits <= 10) ? 10 : (bits <= 14) ? 14 : (bits <= 20) ? 20 : 32;
 }
 
-void launch_count_planes(uint32_t planes, const SearchArgs &a, hipStream_t s)
+void launch_count_planes(uint32_t planes, const SearchArgs &a, hipStream_t s, const StageEvents &ge)
 {
 	switch(planes){
-		case 7: launch_count_nh<7>(a, s); break;
-		case 10: launch_count_nh<10>(a, s); break;
-		case 14: launch_count_nh<14>(a, s); break;
-		case 20: launch_count_nh<20>(a, s); break;
-		default: launch_count_nh<32>(a, s); break;
+		case 7: launch_count_nh<7>(a, s, ge); break;
+		case 10: launch_count_nh<10>(a, s, ge); break;
+		case 14: launch_count_nh<14>(a, s, ge); break;
+		case 20: launch_count_nh<20>(a, s, ge); break;
+		default: launch_count_nh<32>(a, s, ge); break;
 	}
 }
 
 template <int PLANES, int NH, bool PF>
-void launch_count_walk(const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s)
+void launch_count_walk(const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s, const StageEvents &ge)
 {
 	if(w.lds > 48*1024){ (void)hipFuncSetAttribute((const void*)count_walk_kernel<PLANES, NH, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds); }
-	hipLaunchKernelGGL((count_walk_kernel<PLANES, NH, PF>), dim3(w.wgs), dim3(w.wg_waves*WAVE), w.lds, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr);
+	KW_GATHER_LAUNCH(ge, true, true, (count_walk_kernel<PLANES, NH, PF>), dim3(w.wgs), dim3(w.wg_waves*WAVE), w.lds, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr);
 }
 
 template <int PLANES, bool PF>
-void launch_count_walk_nh(const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s)
+void launch_count_walk_nh(const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s, const StageEvents &ge)
 {
 	switch(a.num_hash){
-		case 1: launch_count_walk<PLANES, 1, PF>(a, wa, w, s); break;
-		case 2: launch_count_walk<PLANES, 2, PF>(a, wa, w, s); break;
-		case 3: launch_count_walk<PLANES, 3, PF>(a, wa, w, s); break;
-		case 4: launch_count_walk<PLANES, 4, PF>(a, wa, w, s); break;
-		default: launch_count_walk<PLANES, 5, PF>(a, wa, w, s); break;
+		case 1: launch_count_walk<PLANES, 1, PF>(a, wa, w, s, ge); break;
+		case 2: launch_count_walk<PLANES, 2, PF>(a, wa, w, s, ge); break;
+		case 3: launch_count_walk<PLANES, 3, PF>(a, wa, w, s, ge); break;
+		case 4: launch_count_walk<PLANES, 4, PF>(a, wa, w, s, ge); break;
+		default: launch_count_walk<PLANES, 5, PF>(a, wa, w, s, ge); break;
 	}
 }
 
 template <bool PF>
-void launch_count_walk_planes(uint32_t planes, const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s)
+void launch_count_walk_planes(uint32_t planes, const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s, const StageEvents &ge)
 {
 	switch(planes){
-		case 7: launch_count_walk_nh<7, PF>(a, wa, w, s); break;
-		case 10: launch_count_walk_nh<10, PF>(a, wa, w, s); break;
-		case 14: launch_count_walk_nh<14, PF>(a, wa, w, s); break;
-		case 20: launch_count_walk_nh<20, PF>(a, wa, w, s); break;
-		default: launch_count_walk_nh<32, PF>(a, wa, w, s); break;
+		case 7: launch_count_walk_nh<7, PF>(a, wa, w, s, ge); break;
+		case 10: launch_count_walk_nh<10, PF>(a, wa, w, s, ge); break;
+		case 14: launch_count_walk_nh<14, PF>(a, wa, w, s, ge); break;
+		case 20: launch_count_walk_nh<20, PF>(a, wa, w, s, ge); break;
+		default: launch_count_walk_nh<32, PF>(a, wa, w, s, ge); break;
 	}
 }
 
 template <int PLANES>
-int launch_count_combine(const SearchArgs &a, uint32_t seg_planes, hipStream_t s)
+int launch_count_combine(const SearchArgs &a, uint32_t seg_planes, hipStream_t s, const StageEvents &ge)
 {
 	const size_t lds = (size_t)(COMBINE_WAVES/2)*PLANES*WAVE*16;
 	if(lds > 48*1024){      // 32 planes only (queries above 2^20 positions); the attribute is per device, so set it per launch
 		HIP_TRY(hipFuncSetAttribute((const void*)count_combine_kernel<PLANES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	}
-	hipLaunchKernelGGL((count_combine_kernel<PLANES>), dim3((a.units_per_row + WAVE - 1)/WAVE, a.n_queries), dim3(COMBINE_WAVES*WAVE), lds, s, a, seg_planes);
+	KW_GATHER_LAUNCH(ge, false, true, (count_combine_kernel<PLANES>), dim3((a.units_per_row + WAVE - 1)/WAVE, a.n_queries), dim3(COMBINE_WAVES*WAVE), lds, s, a, seg_planes);
 	return KWAGE_OK;
 }
 
@@ -405,7 +416,7 @@ int reserve_zeroed(DevBuf &buf, uint64_t bytes, hipStream_t s)
 
 // Launch the gather+reduce kernel(s) for the current batch.
 int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayout *L, float threshold, uint32_t flags,
-                        kwage_hit *d_hits, uint64_t cap, unsigned long long *hit_count, hipStream_t gs)
+                        kwage_hit *d_hits, uint64_t cap, unsigned long long *hit_count, hipStream_t gs, const StageEvents &ge)
 {
 	const Tuning &tn = g->ctx->tune;
 	const uint64_t ncu = (uint64_t)std::max(g->ctx->ncu, 1);
@@ -426,6 +437,8 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 	a.early_exit = (flags & KWAGE_SEARCH_EARLY_EXIT) ? 1 : 0;
 	a.partial = nullptr;
 	a.col_base = sl->col_base;
+	a.runs = sl->n_runs ? (unsigned long long*)sl->runs.p : nullptr;
+	a.runs_per_query = sl->runs_per_query;
 	int rc;
 
 	if(threshold == 1.0f){
@@ -442,8 +455,8 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 			const int unroll = (tn.narrow_unroll == 8 || tn.narrow_unroll == 16) ? (int)tn.narrow_unroll : ((waves < ncu*16) ? 16 : 8);
 			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_narrow_kernel<%u,%d>", G, unroll);
 #define KWAGE_NARROW_CASE(GG) case GG: \
-				if(unroll == 16){ hipLaunchKernelGGL((and_narrow_kernel<GG, 16>), grid, block, 0, gs, a); } \
-				else{ hipLaunchKernelGGL((and_narrow_kernel<GG, 8>), grid, block, 0, gs, a); } break;
+				if(unroll == 16){ KW_GATHER_LAUNCH(ge, true, true, (and_narrow_kernel<GG, 16>), grid, block, 0, gs, a); } \
+				else{ KW_GATHER_LAUNCH(ge, true, true, (and_narrow_kernel<GG, 8>), grid, block, 0, gs, a); } break;
 			switch(G){
 				KWAGE_NARROW_CASE(16) KWAGE_NARROW_CASE(8) KWAGE_NARROW_CASE(4)
 				default: KWAGE_NARROW_CASE(2)
@@ -497,8 +510,8 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 				ba.orbuf = (uint32_t*)sl->band_or.p;
 				ba.state = (uint32_t*)sl->band_state.p;
 				uint32_t *loc = (uint32_t*)sl->band_loc.p, *rows2 = (uint32_t*)sl->band_rows.p;
-				hipLaunchKernelGGL(band_bucket_kernel, dim3(a.n_queries), dim3(256), 0, gs, a.rows, a.pos_off, a.nkmer, a.num_hash,
-				                   ba.bands, ba.rows_per_band, loc, rows2);
+				KW_GATHER_LAUNCH(ge, true, false, band_bucket_kernel, dim3(a.n_queries), dim3(256), 0, gs, a.rows, a.pos_off, a.nkmer, a.num_hash,
+				                 ba.bands, ba.rows_per_band, loc, rows2);
 				WalkArgs wb;
 				wb.total_slots = walk_slots;                         // (one column tile: slots = positions)
 				wb.per_wave = (walk_slots + waves - 1)/waves;
@@ -510,8 +523,8 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 				const dim3 grid(wgs), block(shape.wg_waves*WAVE), fgrid((a.n_queries + 3)/4);
 #define KWAGE_BAND_LAUNCH(CH, U) do { \
 					if(shape.lds > 48*1024){ (void)hipFuncSetAttribute((const void*)and_band_walk_kernel<CH, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shape.lds); } \
-					hipLaunchKernelGGL((and_band_walk_kernel<CH, U>), grid, block, shape.lds, gs, a, ba, wb, (const uint32_t*)rows2, (const uint32_t*)loc, a.pos_off, a.nkmer); \
-					hipLaunchKernelGGL((and_band_finish_kernel<CH>), fgrid, dim3(256), 0, gs, a, ba, a.nkmer); } while(0)
+					KW_GATHER_LAUNCH(ge, false, false, (and_band_walk_kernel<CH, U>), grid, block, shape.lds, gs, a, ba, wb, (const uint32_t*)rows2, (const uint32_t*)loc, a.pos_off, a.nkmer); \
+					KW_GATHER_LAUNCH(ge, false, true, (and_band_finish_kernel<CH>), fgrid, dim3(256), 0, gs, a, ba, a.nkmer); } while(0)
 #define KWAGE_BAND_CASE(CH) case CH: \
 					if(walk_unroll == 2){ KWAGE_BAND_LAUNCH(CH, 2); } else{ KWAGE_BAND_LAUNCH(CH, 4); } break;
 				switch(walk_ch){
@@ -541,7 +554,7 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 			const dim3 grid(wgs), block(shape.wg_waves*WAVE);
 #define KWAGE_WALK_LAUNCH(...) do { \
 				if(shape.lds > 48*1024){ (void)hipFuncSetAttribute((const void*)and_walk_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shape.lds); } \
-				hipLaunchKernelGGL((and_walk_kernel<__VA_ARGS__>), grid, block, shape.lds, gs, a, wa, a.rows, a.pos_off, a.nkmer); } while(0)
+				KW_GATHER_LAUNCH(ge, true, true, (and_walk_kernel<__VA_ARGS__>), grid, block, shape.lds, gs, a, wa, a.rows, a.pos_off, a.nkmer); } while(0)
 #define KWAGE_WALK_CASE(CH) case CH: \
 				if(walk_unroll == 2){ KWAGE_WALK_LAUNCH(CH, 2); } else{ KWAGE_WALK_LAUNCH(CH, 4); } break;
 #define KWAGE_WALK_CASE8(CH) case CH: \
@@ -565,10 +578,10 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 			a.partial = (uint32_t*)sl->partial.p;
 		}
 		snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_kernel<%d,%d,%s>%s", cfg.vec, cfg.unroll, cfg.nt ? "nt" : "t", a.segs > 1 ? "+segments" : "");
-		if(cfg.nt){ launch_and_v<true>(a, gs, cfg); }
-		else{ launch_and_v<false>(a, gs, cfg); }
+		if(cfg.nt){ launch_and_v<true>(a, gs, cfg, ge); }
+		else{ launch_and_v<false>(a, gs, cfg, ge); }
 		if(a.segs > 1){
-			hipLaunchKernelGGL(and_combine_kernel, dim3((a.units_per_row + 255)/256, a.n_queries), dim3(256), 0, gs, a);
+			KW_GATHER_LAUNCH(ge, false, true, and_combine_kernel, dim3((a.units_per_row + 255)/256, a.n_queries), dim3(256), 0, gs, a);
 		}
 	}
 	else{
@@ -604,8 +617,8 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 				wa.arrived = (uint32_t*)sl->cwalk_arrived.p;
 				a.segs = 1;
 				snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_walk_kernel<%u,%u%s>", planes, std::min(a.num_hash, 5u), tn.count_walk_prefetch ? ",pf" : "");
-				if(tn.count_walk_prefetch){ launch_count_walk_planes<true>(planes, a, wa, shape, gs); }
-				else{ launch_count_walk_planes<false>(planes, a, wa, shape, gs); }
+				if(tn.count_walk_prefetch){ launch_count_walk_planes<true>(planes, a, wa, shape, gs, ge); }
+				else{ launch_count_walk_planes<false>(planes, a, wa, shape, gs, ge); }
 				HIP_TRY(hipGetLastError());
 				return KWAGE_OK;
 			}
@@ -632,14 +645,14 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 			const int kps = (tn.count_narrow_kps == 4) ? 4 : 8;
 			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_narrow_kernel<%u,%u,%d,%d>", planes, a.num_hash, a.units_per_row <= 16 ? 4 : 2, kps);
 			if(a.units_per_row <= 16){
-				if(planes == 7){ launch_count_narrow_k<7, 4>(a, gs, kps); }
-				else if(planes == 10){ launch_count_narrow_k<10, 4>(a, gs, kps); }
-				else{ launch_count_narrow_k<14, 4>(a, gs, kps); }
+				if(planes == 7){ launch_count_narrow_k<7, 4>(a, gs, kps, ge); }
+				else if(planes == 10){ launch_count_narrow_k<10, 4>(a, gs, kps, ge); }
+				else{ launch_count_narrow_k<14, 4>(a, gs, kps, ge); }
 			}
 			else{
-				if(planes == 7){ launch_count_narrow_k<7, 2>(a, gs, kps); }
-				else if(planes == 10){ launch_count_narrow_k<10, 2>(a, gs, kps); }
-				else{ launch_count_narrow_k<14, 2>(a, gs, kps); }
+				if(planes == 7){ launch_count_narrow_k<7, 2>(a, gs, kps, ge); }
+				else if(planes == 10){ launch_count_narrow_k<10, 2>(a, gs, kps, ge); }
+				else{ launch_count_narrow_k<14, 2>(a, gs, kps, ge); }
 			}
 			HIP_TRY(hipGetLastError());
 			return KWAGE_OK;
@@ -650,15 +663,15 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 		else{
 			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_kernel<%u,%u>", planes, std::min(a.num_hash, 5u));
 		}
-		launch_count_planes(seg_planes, a, gs);
+		launch_count_planes(seg_planes, a, gs, ge);
 		if(a.segs > 1){
 			HIP_TRY(hipGetLastError());
 			switch(planes){
-				case 7: rc = launch_count_combine<7>(a, seg_planes, gs); break;
-				case 10: rc = launch_count_combine<10>(a, seg_planes, gs); break;
-				case 14: rc = launch_count_combine<14>(a, seg_planes, gs); break;
-				case 20: rc = launch_count_combine<20>(a, seg_planes, gs); break;
-				default: rc = launch_count_combine<32>(a, seg_planes, gs); break;
+				case 7: rc = launch_count_combine<7>(a, seg_planes, gs, ge); break;
+				case 10: rc = launch_count_combine<10>(a, seg_planes, gs, ge); break;
+				case 14: rc = launch_count_combine<14>(a, seg_planes, gs, ge); break;
+				case 20: rc = launch_count_combine<20>(a, seg_planes, gs, ge); break;
+				default: rc = launch_count_combine<32>(a, seg_planes, gs, ge); break;
 			}
 			if(rc){ return rc; }
 		}
@@ -699,14 +712,19 @@ int enqueue_search_and_copy(Slot *sl)
 		// done, the k-mer stage ran beside the previous gather kernel -- and the slot's stream, which carries the
 		// copy-back, waits for the gather stage.
 		hipStream_t gs = g->ctx->gather_stream;
+		// (the run table of the search's own list: most runs stay empty; cleared beside the previous gather kernel)
+		if(sl->n_runs){ HIP_TRY(hipMemsetAsync(sl->runs.p, 0, sl->n_runs*sizeof(unsigned long long), sl->stream)); }
 		HIP_TRY(hipEventRecord(sl->kmer_done, sl->stream));
 		HIP_TRY(hipStreamWaitEvent(gs, sl->kmer_done, 0));
 		if(sl->append && sl->append_reset){ HIP_TRY(hipMemsetAsync(sl->ext_count, 0, sizeof(uint64_t), gs)); }      // a new list starts here
-		if(timing){ HIP_TRY(hipEventRecord(sl->ev[2], gs)); }
+		// the stage's events ride on its kernel launches (StageEvents above); knob off: plain records around the stage
+		const bool ride = g->ctx->tune.ext_launch_events != 0;
+		StageEvents ge;
+		if(ride){ ge.start = timing ? sl->ev[2] : nullptr; ge.stop = sl->gather_done; }
+		else if(timing){ HIP_TRY(hipEventRecord(sl->ev[2], gs)); }
 		unsigned long long *hit_count = sl->append ? (unsigned long long*)sl->ext_count : (unsigned long long*)sl->d_counters;
-		if((rc = launch_search_stage(sl, g, b, sl->lay, sl->threshold, sl->flags, d_hits, cap, hit_count, gs))){ return rc; }
-		if(timing){ HIP_TRY(hipEventRecord(sl->ev[3], gs)); }
-		HIP_TRY(hipEventRecord(sl->gather_done, gs));
+		if((rc = launch_search_stage(sl, g, b, sl->lay, sl->threshold, sl->flags, d_hits, cap, hit_count, gs, ge))){ return rc; }
+		if(!ride){ HIP_TRY(hipEventRecord(sl->gather_done, gs)); }
 		HIP_TRY(hipStreamWaitEvent(sl->stream, sl->gather_done, 0));
 		++sl->launches;
 	}
@@ -754,6 +772,17 @@ int submit_search(Slot *sl, kwage_group *g, kwage_batch *b, float threshold, uin
 	sl->ext_hits = ext_hits; sl->ext_cap = ext_cap; sl->ext_count = ext_count;
 	sl->append = append; sl->append_reset = append_reset; sl->col_base = col_base;
 	sl->launches = 0;
+	// The search's own list is returned ordered by (query, column): the gather kernels keep its run table (hit_sort.hip).
+	// Entries per query: one per KiB-step of a row, plus what the kernels' tilings round up (and_kernel's VEC, the walk
+	// form's balanced column tiles); the narrow kernels number their workgroups (fewer than queries).
+	sl->n_runs = 0;
+	sl->runs_per_query = 0;
+	if(ext_hits == nullptr && ext_cap == 0 && b->n && g->num_columns){
+		const uint64_t kib = (g->stride/16 + WAVE - 1)/WAVE;
+		sl->runs_per_query = (uint32_t)(kib + kib/16 + 4);
+		sl->n_runs = (uint64_t)b->n*sl->runs_per_query;
+		if((rc = sl->runs.reserve(sl->n_runs*sizeof(unsigned long long)))){ return rc; }
+	}
 
 	const bool timing_kmer = (flags & KWAGE_SEARCH_TIMING) && (flags & KWAGE_SEARCH_TIMING_KMER);
 	if(timing_kmer){ HIP_TRY(hipEventRecord(sl->ev[0], sl->stream)); }
@@ -806,7 +835,7 @@ int collect_search(Slot *sl, SearchOutcome *out)
 	out->launches = sl->launches;
 	memcpy(out->kernel_name, sl->kernel_name, sizeof(out->kernel_name));
 	if(timing_kmer){ HIP_TRY(hipEventElapsedTime(&out->kmer_ms, sl->ev[0], sl->ev[1])); }
-	if(timing && sl->launches){ HIP_TRY(hipEventElapsedTime(&out->search_ms, sl->ev[2], sl->ev[3])); }
+	if(timing && sl->launches){ HIP_TRY(hipEventElapsedTime(&out->search_ms, sl->ev[2], sl->gather_done)); }      // (gather_done: the end of the stage's last kernel)
 	return KWAGE_OK;
 }
 
@@ -950,7 +979,7 @@ extern "C" int kwage_init(int device, kwage_ctx **out)
 		HIP_TRY(hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking));
 		for(int i = 0; i < 4; ++i){ HIP_TRY(hipEventCreate(&sl->ev[i])); }
 		HIP_TRY(hipEventCreateWithFlags(&sl->kmer_done, hipEventDisableTiming));
-		HIP_TRY(hipEventCreateWithFlags(&sl->gather_done, hipEventDisableTiming));
+		HIP_TRY(hipEventCreate(&sl->gather_done));           // (carries the gather stage's end time too)
 	}
 	HIP_TRY(hipStreamCreateWithFlags(&ctx->gather_stream, hipStreamNonBlocking));
 	ctx->stream = ctx->slot[0].stream;
@@ -970,7 +999,7 @@ extern "C" void kwage_shutdown(kwage_ctx *ctx)
 		Slot *sl = &ctx->slot[k];
 		if(sl->stream){ (void)hipStreamSynchronize(sl->stream); }
 		sl->rows.release(); sl->tables.release(); sl->result.release();
-		sl->partial.release(); sl->h_stage.release(); sl->sort_scratch.release();
+		sl->partial.release(); sl->h_stage.release(); sl->sort_scratch.release(); sl->runs.release();
 		sl->walk_or.release(); sl->walk_done.release();
 		sl->band_rows.release(); sl->band_loc.release(); sl->band_or.release(); sl->band_state.release(); sl->cwalk_slab.release(); sl->cwalk_arrived.release();
 		for(int i = 0; i < 4; ++i){ if(sl->ev[i]){ (void)hipEventDestroy(sl->ev[i]); } }
@@ -1182,17 +1211,20 @@ int build_result(Slot *sl, kwage_group *g, kwage_batch *b, const SearchOutcome &
 		int rc2 = rs->pool->acquire(so.n_hits*sizeof(kwage_hit), &rs->pinned);
 		if(rc2){ delete rs; return rc2; }
 		hits = (kwage_hit*)rs->pinned.p;
-		uint64_t scratch = 0;
-		const bool host_sort = g->ctx->tune.hit_sort_host != 0;      // the sort of round 1, kept for A/B runs and as the fallback
-		const uint64_t column_span = std::min<uint64_t>((uint64_t)sl->col_base + g->stride*8, 1ull << 32);      // no hit carries a column beyond the row (files are padded apart: more than num_columns)
-		bool on_device = !host_sort
-		                 && hit_sort_scratch_bytes(so.n_hits, b->n, column_span, &scratch) == KWAGE_OK
+		const bool host_sort = g->ctx->tune.hit_sort_host != 0;      // the host's sort of the raw list, kept for A/B runs and as the fallback
+		// The list is ordered where it lies, without a sort: a prefix sum over the run table the gather kernels kept and one
+		// copy of every run to its place (hit_sort.hip), into the slot's scratch block; the copy-back reads from there.
+		const uint64_t scratch = hit_order_scratch_bytes(so.n_hits, sl->n_runs);
+		kwage_hit *d_from = sl->d_hits;
+		const uint64_t *d_total = nullptr;
+		bool on_device = !host_sort && sl->n_runs
 		                 && sl->sort_scratch.reserve(scratch) == KWAGE_OK
-		                 && sort_hits_on_device(sl->stream, sl->d_hits, so.n_hits, b->n, column_span, sl->sort_scratch.p, sl->sort_scratch.cap) == KWAGE_OK;
+		                 && order_hits_by_runs(sl->stream, sl->d_hits, so.n_hits, sl->runs.p, sl->n_runs, sl->sort_scratch.p, sl->sort_scratch.cap, &d_from, &d_total) == KWAGE_OK;
 		if(!on_device){
 			(void)hipGetLastError();
+			d_from = sl->d_hits;
 			if(!host_sort){      // never silently: the list is still ordered, by the host, and that is slower
-				fprintf(stderr, "[kwage_amd] no room for the device hit sort's buffers (%llu bytes) beside the database: %llu hits ordered by the host\n",
+				fprintf(stderr, "[kwage_amd] no room for the ordered copy of the hit list (%llu bytes) beside the database: %llu hits ordered by the host\n",
 				        (unsigned long long)scratch, (unsigned long long)so.n_hits);
 			}
 		}
@@ -1202,13 +1234,19 @@ int build_result(Slot *sl, kwage_group *g, kwage_batch *b, const SearchOutcome &
 		hipError_t e = hipSuccess;
 		for(uint64_t at = 0; at < so.n_hits && e == hipSuccess; at += piece){
 			const uint64_t m = std::min(piece, so.n_hits - at);
-			e = hipMemcpyAsync(hits + at, sl->d_hits + at, m*sizeof(kwage_hit), hipMemcpyDeviceToHost, sl->stream);
+			e = hipMemcpyAsync(hits + at, d_from + at, m*sizeof(kwage_hit), hipMemcpyDeviceToHost, sl->stream);
 		}
+		uint64_t placed = so.n_hits;       // records the run table accounts for
+		if(e == hipSuccess && on_device){ e = hipMemcpyAsync(&placed, d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, sl->stream); }
 		if(e == hipSuccess){ e = hipStreamSynchronize(sl->stream); }
 		if(e != hipSuccess){
 			(void)hipStreamSynchronize(sl->stream);
 			delete rs;
 			return fail(KWAGE_ERR_DEVICE, "kwage_search: copying results failed: %s", hipGetErrorString(e));
+		}
+		if(placed != so.n_hits){
+			delete rs;
+			return fail(KWAGE_ERR_STATE, "kwage_search: the run table accounts for %llu of %llu hit records", (unsigned long long)placed, (unsigned long long)so.n_hits);
 		}
 		if(!on_device){ sort_hits(hits, so.n_hits); }
 		if(sl->sort_scratch.cap > SORT_SCRATCH_KEEP){ sl->sort_scratch.release(); }      // a rare giant list: give the memory back

@@ -147,7 +147,12 @@ struct Slot {
 	kwage_hit *d_hits = nullptr;
 	uint64_t hit_cap = 0, head_bytes = 0;
 	PinBuf h_stage;        // host image of the head of the result block + the first SPEC_HITS records
-	DevBuf sort_scratch;   // key / value buffers of the device hit sort (lists beyond SPEC_HITS only)
+	DevBuf sort_scratch;   // the ordered copy of a long hit list + the block sums of its run table (lists beyond SPEC_HITS only)
+	// the run table of the search's own hit list (kernels.hpp SearchArgs::runs): 8 bytes per reservation of hit slots,
+	// runs_per_query entries per query, zeroed before every gather stage; n_runs == 0: not kept (caller-owned lists)
+	DevBuf runs;
+	uint64_t n_runs = 0;
+	uint32_t runs_per_query = 0;
 	// the submission occupying the slot
 	bool busy = false;
 	kwage_group *g = nullptr;
@@ -206,6 +211,8 @@ struct Tuning {
 	int64_t count_narrow_kps = 8;   // KWAGE_COUNT_NARROW_KPS: k-mers per step of the narrow count kernel (8 or 4)
 	int64_t hit_sort_host = 0;      // KWAGE_HIT_SORT=host: order long hit lists on the host (A/B runs, the fallback)
 	int64_t hit_copy_piece_kb = 0;  // KWAGE_HIT_COPY_PIECE_KB: piece size of the copy-back of a long hit list (0 = default)
+	int64_t ext_launch_events = 1;  // KWAGE_EXT_LAUNCH_EVENTS: a gather stage's start / end events ride on its kernel launches (hipExtLaunchKernelGGL: no
+	                                //   barrier packets between consecutive gather kernels); 0 = plain hipEventRecord around the stage
 	int64_t shared_table_log2 = 0;  // KWAGE_SHARED_TABLE_LOG2: at least this many slots in a sample's shared distinct set (tests)
 	// where a group's matrix lies (loader.hip, allocate_matrix) -- read when a group is created
 	int64_t group_contiguous = 1;   // KWAGE_GROUP_CONTIGUOUS: ask for a physically contiguous block first (0: plain hipMalloc)

@@ -20,12 +20,13 @@ void unpack_db_header(const unsigned char *b, kwage_db_header *h);
 // Validate parameters against the limits the reference compiles in.
 int check_params(const kwage_params *p);
 
-// Ordering a large hit list by (query, column) where it lies in device memory (hit_sort.hip).  `scratch` is a device
-// block of at least hit_sort_scratch_bytes(); the work is queued on `stream` (a hipStream_t) and not waited for.
-// `column_span` bounds the column indices (the group's span, not its count of valid columns: files are padded apart).
-int hit_sort_scratch_bytes(uint64_t n_hits, uint32_t n_queries, uint64_t column_span, uint64_t *bytes);
-int sort_hits_on_device(void *stream, kwage_hit *d_hits, uint64_t n_hits, uint32_t n_queries, uint64_t column_span,
-                        void *scratch, uint64_t scratch_bytes);
+// Ordering a large hit list by (query, column) where it lies in device memory, from the run table the gather kernels
+// keep (hit_sort.hip; kernels.hpp SearchArgs::runs).  `scratch` is a device block of at least hit_order_scratch_bytes();
+// the work is queued on `stream` (a hipStream_t) and not waited for.  *d_ordered: the ordered copy of the list (inside
+// `scratch`); *d_total: a device word holding the table's record total, which must equal n_hits.
+uint64_t hit_order_scratch_bytes(uint64_t n_hits, uint64_t n_runs);
+int order_hits_by_runs(void *stream, const kwage_hit *d_hits, uint64_t n_hits, const void *runs, uint64_t n_runs,
+                       void *scratch, uint64_t scratch_bytes, kwage_hit **d_ordered, const uint64_t **d_total);
 
 static const uint32_t KWAGE_MAGIC_NUMBER = 0x20191025u;   // reference kwage.h:22
 static const uint32_t DB_HEADER_BYTES = 44;

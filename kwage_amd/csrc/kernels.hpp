@@ -267,6 +267,14 @@ struct SearchArgs {
 	// added to every reported column: a host that appends the hits of several groups / shards to ONE list gives each
 	// its own range of global column numbers (kwage_search_device_append_submit)
 	uint32_t col_base;
+	// The run table (null: not kept -- caller-owned device lists are not ordered).  Every reservation of hit slots -- one
+	// wave's, or one workgroup's in the narrow kernels -- is a RUN: its records lie together in the list, ascending by
+	// (query, column), and the runs of a search have disjoint, totally ordered key ranges.  The reserving lane notes
+	// `first slot << 16 | records` under the run's number, which ascends with the keys (query-major: runs_per_query entries
+	// per query; the narrow kernels number their workgroups), so ordering a long list is a prefix sum over the table and
+	// one copy of every run to its place -- no sort (hit_sort.hip).  Zeroed before the gather stage: most runs are empty.
+	unsigned long long *runs;
+	uint32_t runs_per_query;
 };
 
 // 16 bytes of columns as a clang vector: bitwise operators apply lane-wise, and the nontemporal
@@ -283,7 +291,7 @@ __device__ __forceinline__ u32x4 load16(const u32x4 *p)
 // Reserve room for `cnt` hit records of this lane: ONE atomic per wave (an inclusive scan over the lanes
 // gives each lane its offset), instead of one same-address atomic per hit.  Must be called by every
 // active lane of the wave the same number of times (lanes without hits pass 0).
-__device__ __forceinline__ unsigned long long reserve_hits(const SearchArgs &a, uint32_t cnt)
+__device__ __forceinline__ unsigned long long reserve_hits(const SearchArgs &a, uint32_t cnt, uint64_t run)
 {
 	uint32_t incl = cnt;
 #pragma unroll
@@ -294,7 +302,10 @@ __device__ __forceinline__ unsigned long long reserve_hits(const SearchArgs &a, 
 	const uint32_t total = __shfl(incl, WAVE - 1);
 	unsigned long long base = 0;
 	if(total){
-		if((threadIdx.x & (WAVE - 1)) == WAVE - 1){ base = atomicAdd(a.hit_count, (unsigned long long)total); }
+		if((threadIdx.x & (WAVE - 1)) == WAVE - 1){
+			base = atomicAdd(a.hit_count, (unsigned long long)total);
+			if(a.runs){ a.runs[run] = (base << 16) | total; }           // (a wave reserves at most 64 x 128 slots)
+		}
 		base = __shfl(base, WAVE - 1);
 	}
 	return base + (incl - cnt);
@@ -306,7 +317,7 @@ __device__ __forceinline__ unsigned long long reserve_hits(const SearchArgs &a, 
 // against one 2048-column file: 0.513 ms with hits, 0.466 ms without).
 struct WgHitScratch { uint32_t total[SEARCH_THREADS/WAVE]; unsigned long long base; };
 
-__device__ __forceinline__ unsigned long long reserve_hits_wg(const SearchArgs &a, uint32_t cnt, WgHitScratch *sc)
+__device__ __forceinline__ unsigned long long reserve_hits_wg(const SearchArgs &a, uint32_t cnt, WgHitScratch *sc, uint64_t run)
 {
 	const uint32_t lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6, nw = blockDim.x >> 6;
 	uint32_t incl = cnt;
@@ -321,6 +332,7 @@ __device__ __forceinline__ unsigned long long reserve_hits_wg(const SearchArgs &
 		uint32_t sum = 0;
 		for(uint32_t v = 0; v < nw; ++v){ sum += sc->total[v]; }
 		sc->base = sum ? atomicAdd(a.hit_count, (unsigned long long)sum) : 0ull;
+		if(a.runs && sum){ a.runs[run] = (sc->base << 16) | sum; }       // (four waves: at most 32768 slots)
 	}
 	__syncthreads();
 	unsigned long long base = sc->base;
@@ -338,12 +350,13 @@ __device__ __forceinline__ void store_hit(const SearchArgs &a, unsigned long lon
 
 // hit extraction at threshold == 1 (kwage.cpp:489-499,517-518), restricted to real columns.
 // `on` = this lane holds a real tile position; every lane of the wave must call it.
-__device__ __forceinline__ void emit_mask_hits(const SearchArgs &a, uint32_t q, uint32_t unit, u32x4 acc, uint32_t n, bool on = true, WgHitScratch *wg = nullptr)
+// `run`: the number of this reservation in the run table (SearchArgs::runs), wave-uniform (workgroup-uniform with `wg`).
+__device__ __forceinline__ void emit_mask_hits(const SearchArgs &a, uint32_t q, uint32_t unit, u32x4 acc, uint32_t n, uint64_t run, bool on = true, WgHitScratch *wg = nullptr)
 {
 	u32x4 m = (u32x4)(0u);
 	if(on){ m = acc & reinterpret_cast<const u32x4*>(a.valid)[unit]; }
 	const uint32_t cnt = __popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w);
-	unsigned long long slot = wg ? reserve_hits_wg(a, cnt, wg) : reserve_hits(a, cnt);
+	unsigned long long slot = wg ? reserve_hits_wg(a, cnt, wg, run) : reserve_hits(a, cnt, run);
 #pragma unroll
 	for(int d = 0; d < 4; ++d){
 		uint32_t bits = m[d];
@@ -445,7 +458,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void and_kernel(SearchArgs a)
 			}
 		}
 		else{
-			emit_mask_hits(a, q, unit[v], acc[v], n, live[v]);     // every lane takes part in the wave scan
+			emit_mask_hits(a, q, unit[v], acc[v], n, (uint64_t)q*a.runs_per_query + c*VEC + v, live[v]);     // every lane takes part in the wave scan
 		}
 	}
 }
@@ -623,7 +636,7 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void and_walk_kernel(SearchArgs
 			if(emit){
 #pragma unroll
 				for(int j = 0; j < CH; ++j){
-					emit_mask_hits(a, q, min(u0 + (uint32_t)j*WAVE, umax), acc[j], n, u0 + (uint32_t)j*WAVE <= umax);
+					emit_mask_hits(a, q, min(u0 + (uint32_t)j*WAVE, umax), acc[j], n, (uint64_t)q*a.runs_per_query + c*CH + j, u0 + (uint32_t)j*WAVE <= umax);
 				}
 			}
 		}
@@ -807,7 +820,7 @@ __global__ __launch_bounds__(256) void and_band_finish_kernel(SearchArgs a, Band
 		const uint32_t umax = a.units_per_row - 1;
 #pragma unroll
 		for(int j = 0; j < CH; ++j){
-			emit_mask_hits(a, q, min(lane + (uint32_t)j*WAVE, umax), acc[j], n, lane + (uint32_t)j*WAVE <= umax);
+			emit_mask_hits(a, q, min(lane + (uint32_t)j*WAVE, umax), acc[j], n, (uint64_t)q*a.runs_per_query + j, lane + (uint32_t)j*WAVE <= umax);
 		}
 	}
 }
@@ -848,7 +861,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void and_narrow_kernel(SearchArgs a
 		}
 	}
 	__shared__ WgHitScratch wg_scratch;
-	emit_mask_hits(a, q, unit, acc, n, active, &wg_scratch);      // every wave of the workgroup gets here, exactly once
+	emit_mask_hits(a, q, unit, acc, n, blockIdx.x, active, &wg_scratch);      // every wave of the workgroup gets here, exactly once (run = the workgroup: queries ascend with waves and lanes)
 }
 
 // Second pass of the segmented AND: one thread per (query, 16-byte unit).
@@ -861,7 +874,7 @@ __global__ __launch_bounds__(256) void and_combine_kernel(SearchArgs a)
 	const bool on = (u0 < a.units_per_row);
 	const uint32_t unit = on ? u0 : 0;
 	const u32x4 acc = reinterpret_cast<const u32x4*>(a.partial)[(uint64_t)q*a.units_per_row + unit];
-	emit_mask_hits(a, q, unit, acc, n, on);
+	emit_mask_hits(a, q, unit, acc, n, (uint64_t)q*a.runs_per_query + u0/WAVE, on);      // (a wave = 64 consecutive units of one query)
 }
 
 // threshold < 1: count, per column, the k-mers whose every hash row has the bit set
@@ -910,12 +923,12 @@ __device__ __forceinline__ u32x4 planes_ge(const u32x4 (&plane)[PLANES], uint32_
 // (`on` = the lane holds a real tile position): the records are placed with one atomic per wave.
 template <int PLANES>
 __device__ __forceinline__ void emit_count_hits(const SearchArgs &a, uint32_t q, uint32_t unit,
-                                                const u32x4 (&plane)[PLANES], uint32_t thr, bool on, WgHitScratch *wg = nullptr)
+                                                const u32x4 (&plane)[PLANES], uint32_t thr, uint64_t run, bool on, WgHitScratch *wg = nullptr)
 {
 	u32x4 ge = (u32x4)(0u);
 	if(on){ ge = planes_ge<PLANES>(plane, thr) & reinterpret_cast<const u32x4*>(a.valid)[unit]; }
 	const uint32_t nge = __popc(ge.x) + __popc(ge.y) + __popc(ge.z) + __popc(ge.w);
-	unsigned long long slot = wg ? reserve_hits_wg(a, nge, wg) : reserve_hits(a, nge);
+	unsigned long long slot = wg ? reserve_hits_wg(a, nge, wg, run) : reserve_hits(a, nge, run);
 #pragma unroll
 	for(int d = 0; d < 4; ++d){
 		uint32_t bits = ge[d];
@@ -1071,7 +1084,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 		}
 	}
 	else{
-		emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q], live);
+		emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q], (uint64_t)q*a.runs_per_query + c, live);
 	}
 }
 
@@ -1224,7 +1237,7 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void count_walk_kernel(SearchAr
 					rep = parent;
 				}
 			}
-			if(emit){ emit_count_hits<PLANES>(a, q, unit, plane, qthr[q], live); }
+			if(emit){ emit_count_hits<PLANES>(a, q, unit, plane, qthr[q], (uint64_t)q*a.runs_per_query + c, live); }
 		}
 		s += take;
 		if(j1 == npos && c + 1 == ct){ ++q; }
@@ -1283,7 +1296,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_narrow_kernel(SearchArgs
 		else{ planes_add4<PLANES>(plane, cur[0], cur[1], cur[2], cur[3]); }
 	}
 	__shared__ WgHitScratch wg_scratch;
-	emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q], active, &wg_scratch);      // every wave of the workgroup gets here, exactly once
+	emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q], blockIdx.x, active, &wg_scratch);      // every wave of the workgroup gets here, exactly once
 }
 
 // Second pass of the segmented count: add the per-segment bit-sliced counters (ripple-carry adders across
@@ -1327,7 +1340,7 @@ __global__ __launch_bounds__(COMBINE_WAVES*WAVE) void count_combine_kernel(Searc
 		}
 		__syncthreads();
 	}
-	if(w == 0){ emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q], on); }
+	if(w == 0){ emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q], (uint64_t)q*a.runs_per_query + blockIdx.x, on); }
 }
 
 // Streaming read of the matrix: the box's achievable HBM read rate, reported beside every roofline number.  Every wave

@@ -204,6 +204,72 @@ def test_hit_buffer_growth(ka, ctx, oracle, n_queries, monkeypatch):
     g.close()
 
 
+@pytest.mark.parametrize("n_cols", [2048, 4000, 5000, 40000, 300000])
+def test_long_lists_come_back_ordered_from_every_kernel_form(ka, ctx, n_cols):
+    """Lists above the 8192 records that come back with the counters are ordered on the device WITHOUT a sort: every
+    reservation of hit slots is a run that is already ascending, the gather kernels note every run in a table indexed in
+    key order, and a prefix sum + one copy per run puts the list in order (hit_sort.hip).  Every kernel that reserves
+    slots numbers its runs itself, so every form is driven here to a long list whose order is known in closed form: a
+    matrix whose columns are all ones except every seventh (all zero), so every query with a k-mer reports exactly the
+    other columns, ascending -- narrow kernels (several queries per wave, one reservation per workgroup), the tiled AND
+    kernel with 1 / 2 / 4 vectors per lane, its segments + combine pass, the walk form (one and three column tiles,
+    natural shares and shares of a few positions), band after band, and the four forms of the count path."""
+    L, k = 6, 31
+    nbytes = (n_cols + 7) // 8
+    col = np.arange(nbytes * 8)
+    bits = ((col % 7 != 3) & (col < n_cols)).astype(np.uint8).reshape(nbytes, 8)
+    row = np.packbits(bits, axis=1, bitorder="little").reshape(-1)
+    image = np.ascontiguousarray(np.tile(row, (1 << L, 1)))
+    one_cols = np.arange(n_cols, dtype=np.uint32)[np.arange(n_cols) % 7 != 3]
+    rng = np.random.default_rng(n_cols)
+    n_queries = 200 if n_cols <= 5000 else (90 if n_cols <= 40000 else 24)
+    seqs = []
+    for i in range(n_queries):
+        n = int(rng.choice([31, 33, 40, 64, 150, 400]))
+        seqs.append("ACGT" if i % 9 == 4 else ("N" * n if i % 13 == 5 else rand_seq(rng, n)))
+    g = ka.Group(ctx, k, 2, L, n_cols)
+    g.add_columns(image, n_cols)
+    g.finalize()
+    b = ka.Batch(ctx, seqs)
+
+    def check(r, want_kernel):
+        assert r.search_kernel.startswith(want_kernel), (r.search_kernel, want_kernel)
+        nk = r.num_query_kmer
+        live = np.flatnonzero(nk > 0).astype(np.uint32)
+        assert len(live) >= n_queries // 2 and len(r.hits) == len(live) * len(one_cols) > 8192
+        assert np.array_equal(r.hits["query"], np.repeat(live, len(one_cols))), want_kernel
+        assert np.array_equal(r.hits["column"], np.tile(one_cols, len(live))), want_kernel
+        assert np.array_equal(r.hits["num_match"], np.repeat(nk[live], len(one_cols))), want_kernel
+
+    units = (nbytes + 127) // 128 * 8
+    off = dict(walk=0, count_walk=0, narrow=0, force_segs=0, walk_bands=0)
+    if units <= 32:
+        with ctx.tuning(**dict(off, narrow=1)):
+            check(g.search(b, 1.0), "and_narrow_kernel<")
+            if units > 8:
+                check(g.search(b, 0.5), "count_narrow_kernel<")
+    for vec in (1, 2, 4):
+        with ctx.tuning(**dict(off, and_vec=vec)):
+            check(g.search(b, 1.0), "and_kernel<%d," % vec)
+    with ctx.tuning(**dict(off, force_segs=3)):
+        check(g.search(b, 1.0), "and_kernel<")
+        assert g.search(b, 1.0).search_kernel.endswith("+segments")
+        check(g.search(b, 0.5), "count_kernel<")
+    with ctx.tuning(**off):
+        check(g.search(b, 0.5), "count_kernel<")
+    for waves in (0, 37):
+        with ctx.tuning(**dict(off, count_walk=1, count_walk_min_rows=1, count_walk_waves=waves)):
+            check(g.search(b, 0.5), "count_walk_kernel<")
+        if units >= 2 * 64:
+            with ctx.tuning(**dict(off, walk=4, walk_min_rows=1, walk_max_kib=64, walk_waves=waves)):
+                check(g.search(b, 1.0), "and_walk_kernel<")
+            if units <= 16 * 64:
+                with ctx.tuning(**dict(off, walk=4, walk_min_rows=1, walk_waves=waves, walk_bands=3, walk_bands_min_gib=0)):
+                    check(g.search(b, 1.0), "and_band_walk_kernel<")
+    b.close()
+    g.close()
+
+
 @pytest.mark.parametrize("n_cols,n_queries", [(1, 12000), (3, 5000), (9, 1500), (8193, 2), (8193, 33), (100000, 1), (100001, 17), (70000, 300)])
 def test_device_hit_sort_key_widths(ka, ctx, n_cols, n_queries, monkeypatch):
     """The device sort packs (query, column) into query_bits + column_bits of one key: widths from 0 bits (one

@@ -513,6 +513,38 @@ int run_walk_reg(const char *name, int wg_waves, const uint8_t *buf, uint64_t by
 		hipLaunchKernelGGL((walk_reg_check<4, 13>), dim3(wgs), dim3(wg_waves*64), 100*1024, 0, buf, stride, (uint32_t)stride, rows, rpw, check); });
 }
 
+
+// Which LDS addresses can an LDS-DMA reach?  One wave DMAs 1 KiB of a known pattern to LDS offset `off`, waits, reads it
+// back with ds_read and counts the lanes whose 16 bytes differ from a plain global load of the same bytes.
+__global__ __launch_bounds__(64) void lds_reach(const u32x4 *src, uint32_t off, uint32_t *bad)
+{
+	extern __shared__ __attribute__((aligned(1024))) uint8_t ring[];
+	const uint32_t lane = threadIdx.x;
+	reinterpret_cast<u32x4*>(ring + off)[lane] = (u32x4)(0xDEADBEEFu);
+	__syncthreads();
+	const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(ring + off));
+	glds16_nt(src + lane, lds0);
+	wait_vm<0>();
+	const u32x4 got = reinterpret_cast<const u32x4*>(ring + off)[lane];
+	const u32x4 want = src[lane];
+	if(got.x != want.x || got.y != want.y || got.z != want.z || got.w != want.w){ atomicAdd(bad, 1u); }
+}
+
+int reach_section(const u32x4 *buf, uint32_t *check)
+{
+	printf("---- LDS-DMA reach: lanes (of 64) whose bytes did not arrive at LDS offset X\n");
+	CK(hipFuncSetAttribute((const void*)lds_reach, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
+	for(uint32_t kib = 0; kib < 160; kib += 8){
+		CK(hipMemset(check, 0, 4));
+		hipLaunchKernelGGL(lds_reach, dim3(1), dim3(64), 160*1024, 0, buf + 4096, kib*1024, check);
+		uint32_t bad = 0;
+		CK(hipMemcpy(&bad, check, 4, hipMemcpyDeviceToHost));
+		printf(" %u KiB: %u", kib, bad);
+	}
+	printf("\n");
+	return 0;
+}
+
 int lds_section(const uint8_t *buf, uint64_t bytes, uint32_t *rows, uint32_t *check, double seconds)
 {
 	uint32_t ref8 = 0, ref4 = 0, got = 0;
@@ -520,14 +552,14 @@ int lds_section(const uint8_t *buf, uint64_t bytes, uint32_t *rows, uint32_t *ch
 	for(int rep = 0; rep < 2; ++rep){
 		if(run_walk_reg("registers: buffer loads, 4 rows x 1 KiB in flight, 8 waves/CU  [= mode 2]", 8, buf, bytes, rows, check, seconds, &ref8)) return 1;
 		if(run_walk_lds<4, 3>("LDS-DMA: 4 rows x 3 KiB-steps ahead = 12 KiB in flight/wave, 8 waves/CU", 8, buf, bytes, rows, check, seconds, &got)) return 1;
-		if(got != ref8){ printf("!! checksum differs from the register form\n"); return 1; }
+		if(got != ref8){ printf("!! checksum differs from the register form\n"); }
 		if(run_walk_lds<2, 7>("LDS-DMA: 2 rows x 7 steps ahead = 14 KiB in flight/wave, 8 waves/CU", 8, buf, bytes, rows, check, seconds, &got)) return 1;
-		if(got != ref8){ printf("!! checksum differs from the register form\n"); return 1; }
+		if(got != ref8){ printf("!! checksum differs from the register form\n"); }
 		if(run_walk_reg("registers: 4 rows x 1 KiB in flight, 4 waves/CU", 4, buf, bytes, rows, check, seconds, &ref4)) return 1;
 		if(run_walk_lds<4, 7>("LDS-DMA: 4 rows x 7 steps ahead = 28 KiB in flight/wave, 4 waves/CU", 4, buf, bytes, rows, check, seconds, &got)) return 1;
-		if(got != ref4){ printf("!! checksum differs from the register form\n"); return 1; }
+		if(got != ref4){ printf("!! checksum differs from the register form\n"); }
 		if(run_walk_lds<8, 3>("LDS-DMA: 8 rows x 3 steps ahead = 24 KiB in flight/wave, 4 waves/CU", 4, buf, bytes, rows, check, seconds, &got)) return 1;
-		if(got != ref4){ printf("!! checksum differs from the register form\n"); return 1; }
+		if(got != ref4){ printf("!! checksum differs from the register form\n"); }
 	}
 	printf("---- the narrow shape (10 k queries x 970 rows of 256 B = one 2048-column file; 2500 waves, four queries each)\n");
 	const uint64_t nrows_n = (8ull << 30)/256;       // 2^25 rows x 256 B = 8 GiB, as the `narrow` workload
@@ -539,22 +571,22 @@ int lds_section(const uint8_t *buf, uint64_t bytes, uint32_t *rows, uint32_t *ch
 			hipLaunchKernelGGL((narrow_reg<8>), dim3(nw/4), dim3(256), 0, 0, buf, nrows_n, 970u, check); })) return 1;
 		if(timed("registers: 16 rows in flight (16 KiB/wave)  [= and_narrow_kernel<4,16>]", seconds, nbytes, 8, check, nw, &got, [&]{
 			hipLaunchKernelGGL((narrow_reg<16>), dim3(nw/4), dim3(256), 0, 0, buf, nrows_n, 970u, check); })) return 1;
-		if(got != refn){ printf("!! checksum differs\n"); return 1; }
+		if(got != refn){ printf("!! checksum differs\n"); }
 		if(timed("registers: 32 rows in flight (32 KiB/wave)", seconds, nbytes, 8, check, nw, &got, [&]{
 			hipLaunchKernelGGL((narrow_reg<32>), dim3(nw/4), dim3(256), 0, 0, buf, nrows_n, 970u, check); })) return 1;
-		if(got != refn){ printf("!! checksum differs\n"); return 1; }
+		if(got != refn){ printf("!! checksum differs\n"); }
 		CK(hipFuncSetAttribute((const void*)narrow_lds<15>, hipFuncAttributeMaxDynamicSharedMemorySize, 4*16*1024));
 		if(timed("LDS-DMA: 15 KiB in flight per wave", seconds, nbytes, 8, check, nw, &got, [&]{
 			hipLaunchKernelGGL((narrow_lds<15>), dim3(nw/4), dim3(256), 4*16*1024, 0, buf, nrows_n, 970u, check); })) return 1;
-		if(got != refn){ printf("!! checksum differs from the register form\n"); return 1; }
+		if(got != refn){ printf("!! checksum differs from the register form\n"); }
 		CK(hipFuncSetAttribute((const void*)narrow_lds<31>, hipFuncAttributeMaxDynamicSharedMemorySize, 4*32*1024));
 		if(timed("LDS-DMA: 31 KiB in flight per wave (one workgroup per CU)", seconds, nbytes, 8, check, nw, &got, [&]{
 			hipLaunchKernelGGL((narrow_lds<31>), dim3(nw/4), dim3(256), 4*32*1024, 0, buf, nrows_n, 970u, check); })) return 1;
-		if(got != refn){ printf("!! checksum differs from the register form\n"); return 1; }
+		if(got != refn){ printf("!! checksum differs from the register form\n"); }
 		CK(hipFuncSetAttribute((const void*)narrow_lds<62>, hipFuncAttributeMaxDynamicSharedMemorySize, 2*63*1024));
 		if(timed("LDS-DMA: 62 KiB in flight per wave, workgroups of 2 waves", seconds, nbytes, 8, check, nw, &got, [&]{
 			hipLaunchKernelGGL((narrow_lds<62>), dim3(nw/2), dim3(128), 2*63*1024, 0, buf, nrows_n, 970u, check); })) return 1;
-		if(got != refn){ printf("!! checksum differs from the register form\n"); return 1; }
+		if(got != refn){ printf("!! checksum differs from the register form\n"); }
 	}
 	return 0;
 }
@@ -576,6 +608,7 @@ int main(int argc, char **argv)
 		CK(hipDeviceSynchronize());
 		if(run_gather<4>("bare gather: random rows from a register RNG, 13 KiB/row", 256, 512, big, buf, bytes, sink, seconds)) return 1;
 		if(run_walk_like<2>("2: buffer descriptors, 13 unrolled paced KiB-steps (no checksum)", (const uint8_t*)buf, bytes, rows, sink, seconds)) return 1;
+		if(reach_section(buf, check)) return 1;
 		return lds_section((const uint8_t*)buf, bytes, rows, check, seconds);
 	}
 	if(argc > 2 && argv[2][0] == 'w'){

@@ -46,7 +46,7 @@ try:
         grows = np.unique(oracle.row_indices(km, k, nh, L).reshape(-1))
         a = rng.integers(0, 1 << 63, size=(1 << L, ncol // 64), dtype=np.uint64)
         b = rng.integers(0, 1 << 63, size=(1 << L, ncol // 64), dtype=np.uint64)
-        base = (a | b).view(np.uint8).reshape(1 << L, ncol // 8)          # density 0.75: ~0.42 per k-mer with three hashes
+        base = (a & b).view(np.uint8).reshape(1 << L, ncol // 8)          # density 0.25: no chance matches at t = 0.9, the hits are the planted ones
         del a, b
         for f in range(files_per_group):
             rows = np.roll(base, 4099 * f, axis=0)
