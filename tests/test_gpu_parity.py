@@ -225,7 +225,8 @@ def test_long_lists_come_back_ordered_from_every_kernel_form(ka, ctx, n_cols):
     n_queries = 200 if n_cols <= 5000 else (90 if n_cols <= 40000 else 24)
     seqs = []
     for i in range(n_queries):
-        n = int(rng.choice([31, 33, 40, 64, 100, 150]))            # (at most 120 k-mers: no automatic row-list segments)
+        # (at most 120 k-mers: no automatic row-list segments; at least 3: a threshold that truncates to 0 would report the zero columns too)
+        n = int(rng.choice([33, 35, 40, 64, 100, 150]))
         seqs.append("ACGT" if i % 9 == 4 else ("N" * n if i % 13 == 5 else rand_seq(rng, n)))
     g = ka.Group(ctx, k, 2, L, n_cols)
     g.add_columns(image, n_cols)
