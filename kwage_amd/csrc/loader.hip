@@ -278,14 +278,19 @@ hipError_t allocate_matrix(kwage_group *g)
 	double ra = probe_block(g, a);
 	if(b){
 		const double rb = probe_block(g, b);
-		g->placement_candidates = 2;
-		const bool keep_b = (rb > ra) != (g->ctx->tune.group_placement_probe < 0);     // (knob < 0: keep the SLOWER block -- measurements of what placement costs)
-		g->placement_other_gbps = keep_b ? ra : rb;
-		if(keep_b){ std::swap(a, b); ra = rb; }
+		// only two MEASURED rates are compared: a probe that failed (0) decides nothing -- the first block stays, and the
+		// record says that one candidate was measured
+		if(ra > 0 && rb > 0){
+			g->placement_candidates = 2;
+			const bool keep_b = (rb > ra) != (g->ctx->tune.group_placement_probe < 0);     // (knob < 0: keep the SLOWER block -- measurements of what placement costs)
+			g->placement_other_gbps = keep_b ? ra : rb;
+			if(keep_b){ std::swap(a, b); ra = rb; }
+		}
 	}
 	g->placement_kept_gbps = ra;
 	// does the block kept mix regions of the device's memory?  the same pattern, all waves in the same quarter at a time
-	g->placement_windowed_gbps = probe_block(g, a, 4);
+	// (only where the plain probe of the block worked: the band decision needs both rates)
+	g->placement_windowed_gbps = ra > 0 ? probe_block(g, a, 4) : 0;
 	// (3 % : the band form's regrouping and finish launches cost about 2 % of a C2 search -- 43 us, rocprofv3 -- so a block
 	// whose windowed rate is only 1-2 % above the plain one is better served by the plain walk)
 	g->mixes_regions = ra > 0 && g->placement_windowed_gbps > 1.03*ra;

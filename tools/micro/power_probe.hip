@@ -490,26 +490,26 @@ __global__ __launch_bounds__(512) void walk_reg_check(const uint8_t *db, uint64_
 template <int R, int P>
 int run_walk_lds(const char *name, int wg_waves, const uint8_t *buf, uint64_t bytes, uint32_t *rows, uint32_t *check, double seconds, uint32_t *sum)
 {
-	const uint64_t stride = 12544, nrows = bytes/stride, total_rows = 970000;
+	const uint64_t stride = 13312, nrows = bytes/stride, total_rows = 970000;      // rows of exactly 13 KiB: both forms read every byte of a row
 	const int wgs = 256;
 	const uint64_t waves = (uint64_t)wgs*wg_waves;
 	const uint64_t rpw = (total_rows + waves - 1)/waves/8*8 + 8;            // (a multiple of every R used, the same for every form of one wave count)
 	const size_t lds = (size_t)wg_waves*(P + 1)*R*1024;
 	CK(hipFuncSetAttribute((const void*)walk_lds<R, P, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	hipLaunchKernelGGL(fill_rows, dim3(1024), dim3(256), 0, 0, rows, waves*rpw, nrows);
-	return timed(name, seconds, (double)waves*rpw*12544, 8, check, waves, sum, [&]{
+	return timed(name, seconds, (double)waves*rpw*13312, 8, check, waves, sum, [&]{
 		hipLaunchKernelGGL((walk_lds<R, P, 13>), dim3(wgs), dim3(wg_waves*64), lds, 0, buf, stride, rows, rpw, check); });
 }
 
 int run_walk_reg(const char *name, int wg_waves, const uint8_t *buf, uint64_t bytes, uint32_t *rows, uint32_t *check, double seconds, uint32_t *sum)
 {
-	const uint64_t stride = 12544, nrows = bytes/stride, total_rows = 970000;
+	const uint64_t stride = 13312, nrows = bytes/stride, total_rows = 970000;      // rows of exactly 13 KiB: both forms read every byte of a row
 	const int wgs = 256;
 	const uint64_t waves = (uint64_t)wgs*wg_waves;
 	const uint64_t rpw = (total_rows + waves - 1)/waves/8*8 + 8;
 	CK(hipFuncSetAttribute((const void*)walk_reg_check<4, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, 100*1024));
 	hipLaunchKernelGGL(fill_rows, dim3(1024), dim3(256), 0, 0, rows, waves*rpw, nrows);
-	return timed(name, seconds, (double)waves*rpw*12544, 8, check, waves, sum, [&]{
+	return timed(name, seconds, (double)waves*rpw*13312, 8, check, waves, sum, [&]{
 		hipLaunchKernelGGL((walk_reg_check<4, 13>), dim3(wgs), dim3(wg_waves*64), 100*1024, 0, buf, stride, (uint32_t)stride, rows, rpw, check); });
 }
 
@@ -548,7 +548,7 @@ int reach_section(const u32x4 *buf, uint32_t *check)
 int lds_section(const uint8_t *buf, uint64_t bytes, uint32_t *rows, uint32_t *check, double seconds)
 {
 	uint32_t ref8 = 0, ref4 = 0, got = 0;
-	printf("---- C2's gather (970 k rows of 12 544 B, row numbers from memory): rows into REGISTERS vs rows into LDS by DMA\n");
+	printf("---- C2's gather (970 k rows of 13 KiB, row numbers from memory): rows into REGISTERS vs rows into LDS by DMA\n");
 	for(int rep = 0; rep < 2; ++rep){
 		if(run_walk_reg("registers: buffer loads, 4 rows x 1 KiB in flight, 8 waves/CU  [= mode 2]", 8, buf, bytes, rows, check, seconds, &ref8)) return 1;
 		if(run_walk_lds<4, 3>("LDS-DMA: 4 rows x 3 KiB-steps ahead = 12 KiB in flight/wave, 8 waves/CU", 8, buf, bytes, rows, check, seconds, &got)) return 1;
@@ -561,31 +561,31 @@ int lds_section(const uint8_t *buf, uint64_t bytes, uint32_t *rows, uint32_t *ch
 		if(run_walk_lds<8, 3>("LDS-DMA: 8 rows x 3 steps ahead = 24 KiB in flight/wave, 4 waves/CU", 4, buf, bytes, rows, check, seconds, &got)) return 1;
 		if(got != ref4){ printf("!! checksum differs from the register form\n"); }
 	}
-	printf("---- the narrow shape (10 k queries x 970 rows of 256 B = one 2048-column file; 2500 waves, four queries each)\n");
+	printf("---- the narrow shape (10 k queries x 960 rows of 256 B = one 2048-column file; 2500 waves, four queries each)\n");
 	const uint64_t nrows_n = (8ull << 30)/256;       // 2^25 rows x 256 B = 8 GiB, as the `narrow` workload
 	const uint64_t nw = 2500;
-	const double nbytes = (double)nw*4*970*256;
+	const double nbytes = (double)nw*4*960*256;      // (960 rows per query: a multiple of every unroll below)
 	uint32_t refn = 0;
 	for(int rep = 0; rep < 2; ++rep){
 		if(timed("registers: 8 rows in flight per lane group (8 KiB/wave)", seconds, nbytes, 8, check, nw, &refn, [&]{
-			hipLaunchKernelGGL((narrow_reg<8>), dim3(nw/4), dim3(256), 0, 0, buf, nrows_n, 970u, check); })) return 1;
+			hipLaunchKernelGGL((narrow_reg<8>), dim3(nw/4), dim3(256), 0, 0, buf, nrows_n, 960u, check); })) return 1;
 		if(timed("registers: 16 rows in flight (16 KiB/wave)  [= and_narrow_kernel<4,16>]", seconds, nbytes, 8, check, nw, &got, [&]{
-			hipLaunchKernelGGL((narrow_reg<16>), dim3(nw/4), dim3(256), 0, 0, buf, nrows_n, 970u, check); })) return 1;
+			hipLaunchKernelGGL((narrow_reg<16>), dim3(nw/4), dim3(256), 0, 0, buf, nrows_n, 960u, check); })) return 1;
 		if(got != refn){ printf("!! checksum differs\n"); }
 		if(timed("registers: 32 rows in flight (32 KiB/wave)", seconds, nbytes, 8, check, nw, &got, [&]{
-			hipLaunchKernelGGL((narrow_reg<32>), dim3(nw/4), dim3(256), 0, 0, buf, nrows_n, 970u, check); })) return 1;
+			hipLaunchKernelGGL((narrow_reg<32>), dim3(nw/4), dim3(256), 0, 0, buf, nrows_n, 960u, check); })) return 1;
 		if(got != refn){ printf("!! checksum differs\n"); }
 		CK(hipFuncSetAttribute((const void*)narrow_lds<15>, hipFuncAttributeMaxDynamicSharedMemorySize, 4*16*1024));
 		if(timed("LDS-DMA: 15 KiB in flight per wave", seconds, nbytes, 8, check, nw, &got, [&]{
-			hipLaunchKernelGGL((narrow_lds<15>), dim3(nw/4), dim3(256), 4*16*1024, 0, buf, nrows_n, 970u, check); })) return 1;
+			hipLaunchKernelGGL((narrow_lds<15>), dim3(nw/4), dim3(256), 4*16*1024, 0, buf, nrows_n, 960u, check); })) return 1;
 		if(got != refn){ printf("!! checksum differs from the register form\n"); }
 		CK(hipFuncSetAttribute((const void*)narrow_lds<31>, hipFuncAttributeMaxDynamicSharedMemorySize, 4*32*1024));
 		if(timed("LDS-DMA: 31 KiB in flight per wave (one workgroup per CU)", seconds, nbytes, 8, check, nw, &got, [&]{
-			hipLaunchKernelGGL((narrow_lds<31>), dim3(nw/4), dim3(256), 4*32*1024, 0, buf, nrows_n, 970u, check); })) return 1;
+			hipLaunchKernelGGL((narrow_lds<31>), dim3(nw/4), dim3(256), 4*32*1024, 0, buf, nrows_n, 960u, check); })) return 1;
 		if(got != refn){ printf("!! checksum differs from the register form\n"); }
 		CK(hipFuncSetAttribute((const void*)narrow_lds<62>, hipFuncAttributeMaxDynamicSharedMemorySize, 2*63*1024));
 		if(timed("LDS-DMA: 62 KiB in flight per wave, workgroups of 2 waves", seconds, nbytes, 8, check, nw, &got, [&]{
-			hipLaunchKernelGGL((narrow_lds<62>), dim3(nw/2), dim3(128), 2*63*1024, 0, buf, nrows_n, 970u, check); })) return 1;
+			hipLaunchKernelGGL((narrow_lds<62>), dim3(nw/2), dim3(128), 2*63*1024, 0, buf, nrows_n, 960u, check); })) return 1;
 		if(got != refn){ printf("!! checksum differs from the register form\n"); }
 	}
 	return 0;
