@@ -60,6 +60,9 @@ WORKLOADS: Dict[str, Workload] = {
     # one reference file (2048 columns, 256-byte rows): the several-queries-per-wave kernels (tools/tune_knob.py)
     "narrow": Workload("one 2048-column file x 2^25 rows, 10k x 1 kb queries", 2048, 25, 31, 1, 10_000, 1000, 1.0, num_genomes=16, genome_len=200_000),
     "narrowt": Workload("one 2048-column file x 2^25 rows, 10k x 1 kb queries, t=0.8", 2048, 25, 31, 1, 10_000, 1000, 0.8, num_genomes=16, genome_len=200_000),
+    # ONE long query at threshold < 1 against C2's matrix: the count path's persistent kernel with every pair cut across waves
+    "long1t": Workload("one 100 kb query against 100k samples x 2^23-bit filters, 1 hash, t=0.9", 100_000, 23, 31, 1, 1, 100_000, 0.9,
+                       num_genomes=2, genome_len=200_000, hit_fraction=1.0),
     # small shapes for tests
     "tiny": Workload("tiny", 5000, 14, 31, 2, 64, 300, 1.0, density_q8=128, num_genomes=4, genome_len=1000),
 }

@@ -5,7 +5,7 @@ tools/pmc_summary.py's rule (FETCH_SIZE is in KiB and counts half the bytes of a
 factor is CALIBRATED in each pass on stream_read_kernel's known byte count), written with the hash of the kernel sources +
 engine the pass ran on -- bench.py reports an entry as roofline.traffic only while that hash still matches.
 
-    python tools/pmc_refresh.py [--round r03] [workload ...]        (default: c2 c2+bands c2t c3 c4 c5s c5)
+    python tools/pmc_refresh.py [--round r03] [workload ...]        (default: c2 c2+bands c2t c3 c4 c5s c5; also: narrow narrowt long1t)
 
 This script never touches the GPU itself: every pass is a child process (`rocprofv3 ... -- python3 bench.py ...`)."""
 import collections
@@ -33,7 +33,7 @@ def short(kernel_name):
 
 def main():
     args = sys.argv[1:]
-    rnd = "r03"
+    rnd = "r04"
     if args[:1] == ["--round"]:
         rnd, args = args[1], args[2:]
     # "c2+bands": the same workload with the walk kernel forced band after band (its entry is keyed "c2@<kernel>")
@@ -48,7 +48,7 @@ def main():
         d = os.path.join(out_root, spec.replace("+", "_"))
         os.makedirs(d, exist_ok=True)
         cmd = ["rocprofv3", "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", d, "--",
-               sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--no-cpu-baseline", "--no-sustained", "--steps", "5", "--warmup", "1"]
+               sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--no-cpu-baseline", "--no-sustained", "--no-result-check", "--also", "none", "--steps", "5", "--warmup", "1"]
         t0 = time.time()
         r = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", **knobs))
         print("[pmc_refresh] %s: rc %d in %.0f s" % (wl, r.returncode, time.time() - t0), flush=True)
@@ -94,6 +94,10 @@ def main():
         print("[pmc_refresh] %s: %s  %.3f GB per step for %.3f GB algorithmic = %.4fx (factor %.4f)" %
               (wl, short(dominant), per_step / 1e9, entry["algorithmic_bytes_per_launch"] / 1e9, entry["ratio"], factor), flush=True)
         json.dump(rec, open(path, "w"), indent=1)
+        # (gpurun_out/ is what comes back from a GPU box)
+        import shutil
+        shutil.copyfile(path, os.path.join(out_root, "pmc_traffic.json"))
+        shutil.copyfile(sfile, os.path.join(out_root, os.path.basename(sfile)))
 
 
 if __name__ == "__main__":
