@@ -36,7 +36,7 @@ static const TuningName TUNING_NAMES[] = {
 	{"and_vec", &Tuning::and_vec}, {"and_unroll", &Tuning::and_unroll}, {"and_nt", &Tuning::and_nt}, {"and_lds_kb", &Tuning::and_lds_kb},
 	{"and_block_waves", &Tuning::and_block_waves}, {"narrow", &Tuning::narrow}, {"narrow_unroll", &Tuning::narrow_unroll}, {"force_segs", &Tuning::force_segs},
 	{"count_walk", &Tuning::count_walk}, {"count_walk_wpc", &Tuning::count_walk_wpc}, {"count_walk_waves", &Tuning::count_walk_waves},
-	{"count_walk_min_rows", &Tuning::count_walk_min_rows}, {"count_walk_prefetch", &Tuning::count_walk_prefetch},
+	{"count_walk_min_rows", &Tuning::count_walk_min_rows}, {"count_walk_prefetch", &Tuning::count_walk_prefetch}, {"count_walk_kps", &Tuning::count_walk_kps},
 	{"count_narrow_kps", &Tuning::count_narrow_kps},
 	{"hit_sort_host", &Tuning::hit_sort_host}, {"hit_copy_piece_kb", &Tuning::hit_copy_piece_kb}, {"shared_table_log2", &Tuning::shared_table_log2},
 	{"ext_launch_events", &Tuning::ext_launch_events}, {"group_contiguous", &Tuning::group_contiguous}, {"group_placement_probe", &Tuning::group_placement_probe},
@@ -340,33 +340,41 @@ void launch_count_planes(uint32_t planes, const SearchArgs &a, hipStream_t s, co
 }
 
 template <int PLANES, int NH, bool PF>
-void launch_count_walk(const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s, const StageEvents &ge)
+void launch_count_walk(const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s, const StageEvents &ge, int kps)
 {
-	if(w.lds > 48*1024){ (void)hipFuncSetAttribute((const void*)count_walk_kernel<PLANES, NH, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds); }
-	KW_GATHER_LAUNCH(ge, true, true, (count_walk_kernel<PLANES, NH, PF>), dim3(w.wgs), dim3(w.wg_waves*WAVE), w.lds, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr);
+	// (eight k-mers per step exist for the prefetching loop with 14 planes and more: where the ripple adders dominate)
+	if constexpr(PF && PLANES >= 14){
+		if(kps == 8){
+			if(w.lds > 48*1024){ (void)hipFuncSetAttribute((const void*)count_walk_kernel<PLANES, NH, PF, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds); }
+			KW_GATHER_LAUNCH(ge, true, true, (count_walk_kernel<PLANES, NH, PF, 8>), dim3(w.wgs), dim3(w.wg_waves*WAVE), w.lds, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr);
+			return;
+		}
+	}
+	if(w.lds > 48*1024){ (void)hipFuncSetAttribute((const void*)count_walk_kernel<PLANES, NH, PF, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds); }
+	KW_GATHER_LAUNCH(ge, true, true, (count_walk_kernel<PLANES, NH, PF, 4>), dim3(w.wgs), dim3(w.wg_waves*WAVE), w.lds, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr);
 }
 
 template <int PLANES, bool PF>
-void launch_count_walk_nh(const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s, const StageEvents &ge)
+void launch_count_walk_nh(const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s, const StageEvents &ge, int kps)
 {
 	switch(a.num_hash){
-		case 1: launch_count_walk<PLANES, 1, PF>(a, wa, w, s, ge); break;
-		case 2: launch_count_walk<PLANES, 2, PF>(a, wa, w, s, ge); break;
-		case 3: launch_count_walk<PLANES, 3, PF>(a, wa, w, s, ge); break;
-		case 4: launch_count_walk<PLANES, 4, PF>(a, wa, w, s, ge); break;
-		default: launch_count_walk<PLANES, 5, PF>(a, wa, w, s, ge); break;
+		case 1: launch_count_walk<PLANES, 1, PF>(a, wa, w, s, ge, kps); break;
+		case 2: launch_count_walk<PLANES, 2, PF>(a, wa, w, s, ge, kps); break;
+		case 3: launch_count_walk<PLANES, 3, PF>(a, wa, w, s, ge, kps); break;
+		case 4: launch_count_walk<PLANES, 4, PF>(a, wa, w, s, ge, kps); break;
+		default: launch_count_walk<PLANES, 5, PF>(a, wa, w, s, ge, kps); break;
 	}
 }
 
 template <bool PF>
-void launch_count_walk_planes(uint32_t planes, const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s, const StageEvents &ge)
+void launch_count_walk_planes(uint32_t planes, const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s, const StageEvents &ge, int kps)
 {
 	switch(planes){
-		case 7: launch_count_walk_nh<7, PF>(a, wa, w, s, ge); break;
-		case 10: launch_count_walk_nh<10, PF>(a, wa, w, s, ge); break;
-		case 14: launch_count_walk_nh<14, PF>(a, wa, w, s, ge); break;
-		case 20: launch_count_walk_nh<20, PF>(a, wa, w, s, ge); break;
-		default: launch_count_walk_nh<32, PF>(a, wa, w, s, ge); break;
+		case 7: launch_count_walk_nh<7, PF>(a, wa, w, s, ge, kps); break;
+		case 10: launch_count_walk_nh<10, PF>(a, wa, w, s, ge, kps); break;
+		case 14: launch_count_walk_nh<14, PF>(a, wa, w, s, ge, kps); break;
+		case 20: launch_count_walk_nh<20, PF>(a, wa, w, s, ge, kps); break;
+		default: launch_count_walk_nh<32, PF>(a, wa, w, s, ge, kps); break;
 	}
 }
 
@@ -616,9 +624,11 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 				wa.slab = (uint32_t*)sl->cwalk_slab.p;
 				wa.arrived = (uint32_t*)sl->cwalk_arrived.p;
 				a.segs = 1;
-				snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_walk_kernel<%u,%u%s>", planes, std::min(a.num_hash, 5u), tn.count_walk_prefetch ? ",pf" : "");
-				if(tn.count_walk_prefetch){ launch_count_walk_planes<true>(planes, a, wa, shape, gs, ge); }
-				else{ launch_count_walk_planes<false>(planes, a, wa, shape, gs, ge); }
+				// k-mers per step: 8 with 14 planes and more (knob count_walk_kps: 0 = this rule, 4, 8)
+				const int kps = (tn.count_walk_prefetch && planes >= 14 && (tn.count_walk_kps == 8 || tn.count_walk_kps == 0)) ? 8 : 4;
+				snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_walk_kernel<%u,%u%s%s>", planes, std::min(a.num_hash, 5u), tn.count_walk_prefetch ? ",pf" : "", kps == 8 ? ",8" : "");
+				if(tn.count_walk_prefetch){ launch_count_walk_planes<true>(planes, a, wa, shape, gs, ge, kps); }
+				else{ launch_count_walk_planes<false>(planes, a, wa, shape, gs, ge, kps); }
 				HIP_TRY(hipGetLastError());
 				return KWAGE_OK;
 			}

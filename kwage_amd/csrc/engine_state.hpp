@@ -208,6 +208,7 @@ struct Tuning {
 	int64_t count_walk_waves = 0;   // KWAGE_COUNT_WALK_WAVES: exactly this many waves (tests)
 	int64_t count_walk_min_rows = -1;   // KWAGE_COUNT_WALK_MIN_ROWS: smaller batches use the tiled kernel (-1: 64 rows for each of its waves)
 	int64_t count_walk_prefetch = 1;    // KWAGE_COUNT_WALK_PREFETCH: request the next four k-mers' rows before adding the current four (+1.3 % at C2's shape)
+	int64_t count_walk_kps = 0;     // KWAGE_COUNT_WALK_KPS: k-mers per step of the persistent count kernel (0 = 8 with 14 counter planes and more, else 4; 4; 8)
 	int64_t count_narrow_kps = 8;   // KWAGE_COUNT_NARROW_KPS: k-mers per step of the narrow count kernel (8 or 4)
 	int64_t hit_sort_host = 0;      // KWAGE_HIT_SORT=host: order long hit lists on the host (A/B runs, the fallback)
 	int64_t hit_copy_piece_kb = 0;  // KWAGE_HIT_COPY_PIECE_KB: piece size of the copy-back of a long hit list (0 = default)

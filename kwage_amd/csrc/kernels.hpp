@@ -1090,11 +1090,19 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 
 // The same loop with the NEXT four k-mers' rows requested before the current four are added up (16 more VGPRs): for the
 // persistent kernel below, whose few waves per CU leave nothing else to cover the adders' time.
-template <int PLANES, int NH>
+// KPS k-mers per step: 4, or 8 (seven carry-save adders, then ONE ripple through the upper planes per eight k-mers): with
+// 14 planes and more -- queries above 1 k positions -- the ripple is most of the kernel's instructions, and a wave of the
+// persistent grid spends 42 % of its time issuing them (one 100 kb query at t = 0.9, 20 planes: SQ_ACTIVE_INST_ANY /
+// SQ_WAVE_CYCLES, profiles/r04_long1t_pmc_occupancy.json); halving the ripples per k-mer is what eight per step buys.
+template <int PLANES, int NH, int KPS>
 __device__ __forceinline__ void count_kmers_prefetch(const uint8_t *db, uint64_t stride, const uint32_t *rq, uint32_t nk, uint32_t unit,
                                                      u32x4 (&plane)[PLANES])
 {
-	constexpr int KPS = 4;
+	static_assert(KPS == 4 || KPS == 8, "four or eight k-mers per step");
+	auto add = [&](const u32x4 (&m)[KPS]) {
+		if constexpr(KPS == 8){ planes_add8<PLANES>(plane, m); }
+		else{ planes_add4<PLANES>(plane, m[0], m[1], m[2], m[3]); }
+	};
 	auto fetch = [&](uint32_t i, u32x4 (&m)[KPS]) {
 #pragma unroll
 		for(int u = 0; u < KPS; ++u){
@@ -1115,11 +1123,11 @@ __device__ __forceinline__ void count_kmers_prefetch(const uint8_t *db, uint64_t
 		fetch(0, cur);
 		for(i = KPS; i + KPS <= nk; i += KPS){
 			fetch(i, nxt);
-			planes_add4<PLANES>(plane, cur[0], cur[1], cur[2], cur[3]);
+			add(cur);
 #pragma unroll
 			for(int u = 0; u < KPS; ++u){ cur[u] = nxt[u]; }
 		}
-		planes_add4<PLANES>(plane, cur[0], cur[1], cur[2], cur[3]);
+		add(cur);
 	}
 	for(; i < nk; ++i){
 		u32x4 mm = ~(u32x4)(0u);
@@ -1159,7 +1167,7 @@ struct CountWalkArgs {
 	uint32_t *arrived;              // [waves][CWALK_LEVELS] arrivals at the tree node (first wave of the node's subtree, level); zero between searches
 };
 
-template <int PLANES, int NH, bool PF>
+template <int PLANES, int NH, bool PF, int KPS = 4>
 __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void count_walk_kernel(SearchArgs a, CountWalkArgs wa, const uint32_t *__restrict__ rows,
                                                                     const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ nkmer,
                                                                     const uint32_t *__restrict__ qthr)
@@ -1199,7 +1207,7 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void count_walk_kernel(SearchAr
 			u32x4 plane[PLANES];
 #pragma unroll
 			for(int p = 0; p < PLANES; ++p){ plane[p] = (u32x4)(0u); }
-			if(PF){ count_kmers_prefetch<PLANES, NH>(a.db, a.stride, rows + (p0 + j0)*NH, jv1 - j0, unit, plane); }
+			if(PF){ count_kmers_prefetch<PLANES, NH, KPS>(a.db, a.stride, rows + (p0 + j0)*NH, jv1 - j0, unit, plane); }
 			else{ count_kmers<PLANES, NH>(a.db, a.stride, rows + (p0 + j0)*NH, jv1 - j0, unit, plane, [](uint32_t) -> bool { return false; }); }
 
 			bool emit = true;

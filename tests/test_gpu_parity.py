@@ -466,15 +466,16 @@ def test_long_queries_are_segmented(ka, ctx, oracle, num_hash, monkeypatch):
     b = ka.Batch(ctx, seqs)
     # (0 = the natural choice: few tiles -> segments; "cw" = the persistent count kernel with a pair spread over
     # up to 40 waves instead of the segment slab)
-    for force in (0, 1, 7, 64, "cw"):
-        knobs = dict(force_segs=0, count_walk_min_rows=1, count_walk_waves=1500) if force == "cw" else dict(force_segs=force)
+    # (the persistent kernel takes eight k-mers per step with 14 counter planes and more -- here 20 --; "cw4": four)
+    for force in (0, 1, 7, 64, "cw", "cw4"):
+        knobs = dict(force_segs=0, count_walk_min_rows=1, count_walk_waves=1500, count_walk_kps=4 if force == "cw4" else 0) if force in ("cw", "cw4") else dict(force_segs=force)
         with ctx.tuning(**knobs):
             for threshold in (1.0, 0.97, 0.5):
                 thr32 = float(np.float32(threshold))
                 for flags in (0, ka.SEARCH_EARLY_EXIT):
                     r = g.search(b, threshold, flags)
-                    if force == "cw" and threshold < 1.0 and not flags:
-                        assert r.search_kernel.startswith("count_walk_kernel<"), r.search_kernel
+                    if force in ("cw", "cw4") and threshold < 1.0 and not flags:
+                        assert r.search_kernel.startswith("count_walk_kernel<") and r.search_kernel.endswith(",8>") == (force == "cw"), r.search_kernel
                     per_q = r.per_query()
                     for i, s in enumerate(seqs):
                         kmers = oracle.unique_kmers(s, k)
