@@ -142,6 +142,28 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     assert l5["rccl"]["collectives"] == 6 and l5["rccl"]["p2p_batches"] == 0
     e5 = l5["exchange_check"]
     assert e5["ok"] and e5["hits"] == sum(e5["hits_per_rank"]) == l5["config"]["hits_per_step"] and e5["hits"] > 0
+    # every line carries the post-timing check of its hit lists (planted positives + sampled queries against the oracle), rank by rank
+    for ln in (line, single, l5):
+        rc = ln["result_check"]
+        assert rc["ok"] and all(rc["ranks_ok"]) and len(rc["ranks_ok"]) == ln["n_gpus"] and rc["sampled_queries"] >= 3 and rc["planted_columns_found"] == rc["planted_columns_expected"] > 0
+    # `also` blocks at N > 1 (the driver's 8-GPU run measures the C4 and C5 shares behind the C2 headline): the same code on
+    # toy workloads -- every block with its own exchange_check and result_check -- and strong scaling (the columns of the
+    # workload split over the ranks at 1024-column boundaries: the ranks' algorithmic bytes differ and add up)
+    ra = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "tiny", "--no-sustained",
+                         "--also", "c5tiny"], capture_output=True, text=True, env=env, timeout=900)
+    assert ra.returncode == 0, ra.stderr[-3000:]
+    la = json.loads(ra.stdout.strip().splitlines()[-1])
+    blk = la["also"]["c5tiny"]
+    assert la["scaling"] == "weak" and la["config"]["total_samples"] == 10000 and la["exchange_check"]["ok"] and la["result_check"]["ok"]
+    assert blk["exchange_check"]["ok"] and blk["result_check"]["ok"] and blk["roofline"]["kernel"].startswith("count_") and blk["rccl"]["searches_per_step"] == 4
+    rs = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "tiny", "--no-sustained",
+                         "--scaling", "strong"], capture_output=True, text=True, env=env, timeout=900)
+    assert rs.returncode == 0, rs.stderr[-3000:]
+    ls = json.loads(rs.stdout.strip().splitlines()[-1])
+    assert ls["scaling"] == "strong" and ls["config"]["total_samples"] == 5000 and ls["config"]["samples_per_gpu"] == 3072 and "also" not in ls
+    per = ls["aggregate"]["algorithmic_bytes_per_rank"]
+    assert len(per) == 2 and per[0] > per[1] > 0 and ls["exchange_check"]["ok"] and ls["result_check"]["ok"]
+    assert ls["exchange_check"]["total_columns"] >= 5000
 
 
 def test_strong_split_is_the_sharded_hosts_partition():

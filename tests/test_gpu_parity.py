@@ -809,7 +809,7 @@ def test_pipelined_device_search_and_counted_exchange(ka, ctx):
     s.group.close()
 
 
-@pytest.mark.parametrize("n_cols", [16500, 40000, 100000, 131072, 131073, 300000])
+@pytest.mark.parametrize("n_cols", [16500, 40000, 131072, 131073, 300000])
 def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, request):
     """Rows of >= 3 KiB take and_walk_kernel when the batch is large (a persistent grid, every wave walks an
     equal share of the batch's positions over a column tile's whole width; pairs cut by a share boundary meet
@@ -830,7 +830,7 @@ def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, request):
         for r in oracle.row_indices(oracle.unique_kmers(genome, k), k, nh, L).reshape(-1):
             image[r, col // 8] |= np.uint8(1 << (col % 8))
     seqs = []
-    for i in range(960):
+    for i in range(960 if n_cols <= 40000 else 384):          # (the wide matrices return millions of records per search: fewer queries)
         n = int(rng.choice([0, 30, 31, 32, 33, 34, 35, 40, 64, 150, 300]))
         if i % 2 == 0 and n >= 31:
             a = int(rng.integers(0, len(genome) - n + 1)); seqs.append(genome[a:a + n])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What `kwage_node`'s software pipeline costs beside its gather kernels, on a database of several parameter groups
-(the C5 shape at test scale: five filter sizes 2^16 .. 2^20, eight 2048-column files each, three hash functions,
-threshold 0.9) and a FASTQ of reads streamed in many batches (KWAGE_BATCH_BASES):
+(the C5 shape at test scale: five filter sizes 2^16 .. 2^20, 24 2048-column files each = 6 KB rows, 12.5 GB, three hash
+functions, threshold 0.9 -- wide enough that the device, not the FASTQ parser (2.6 M reads/s), sets the pace) and a FASTQ of reads streamed in many batches (KWAGE_BATCH_BASES):
 
   * `kwage` (one process)                                    -- the bytes every other run must reproduce
   * `kwage_node`, one rank over RCCL (KWAGE_NODE_RANKS=1)    -- communicator, all-gather of the counts, grouped send/recv
@@ -30,7 +30,7 @@ from kwage_amd import native
 
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 batch_bases = int(sys.argv[2]) if len(sys.argv) > 2 else 4 << 20
-ncol, k, nh, read_len, files_per_group = 2048, 31, 3, 100, 8
+ncol, k, nh, read_len, files_per_group = 2048, 31, 3, 100, int(os.environ.get("NODE_STATS_FILES_PER_GROUP", "24"))
 groups = (16, 17, 18, 19, 20)
 NODE_BIN = os.path.join(os.path.dirname(native.KWAGE_BIN), "kwage_node")
 tmp = tempfile.mkdtemp(prefix="kwage_node_stats_", dir="/tmp")
