@@ -89,28 +89,37 @@ def bench_table(rnd):
     return out
 
 
+def kernel_key(name):
+    """'and_kernel<2,8,nt>' / 'and_kernel<2,8,true,false>' -> ('and_kernel', '2', '8'): the kernel and its first two template arguments."""
+    base, _, rest = name.partition("<")
+    args = [x.strip() for x in rest.rstrip(">").split(",")]
+    return (base,) + tuple(args[:2])
+
+
 def rocprof_table(rnd):
-    out = ["| rocprofv3 summary | gather kernel | dispatches | average ms | HIP-event kernel ms of the same run | algorithmic bytes ÷ rocprofv3 average ÷ 8 TB/s |", "|---|---|---|---|---|---|"]
+    out = ["| rocprofv3 summary | gather kernel | dispatches | average ms | launches per step | HIP-event ms per step of the same run (`kernel_ms`) | algorithmic bytes ÷ rocprofv3 time ÷ 8 TB/s |", "|---|---|---|---|---|---|---|"]
     for path in sorted(glob.glob(os.path.join(PROF, rnd + "_*kernel_stats.csv"))):
         base = os.path.basename(path)
         ks = kernel_stats(path)
         if not ks:
             continue
         stem = base.replace("_kernel_stats.csv", "")
-        line = None
-        for cand in (stem + "_bench_under_rocprof.json",):
-            p = os.path.join(PROF, cand)
-            if os.path.exists(p):
-                line = load_line(p)
-        for i, (k, calls, avg) in enumerate(ks[:2]):
-            hip = frac = None
-            if line and i == 0:
-                r = line["roofline"]
-                ng = len(line["config"].get("groups") or [1])
-                hip = r.get("kernel_ms")
-                if r.get("algorithmic_bytes_per_launch"):
-                    frac = r["algorithmic_bytes_per_launch"] / ng / (avg * 1e-3) / 1e9 / 8000.0 if ng == 1 else None
-            out.append("| `%s` | `%s` | %d | %s | %s | %s |" % (base, k, calls, fmt(avg, 4), fmt(hip, 4), fmt(frac, 4)))
+        blocks = []
+        p = os.path.join(PROF, stem + "_bench_under_rocprof.json")
+        if os.path.exists(p):
+            line = load_line(p)
+            if line:
+                blocks = [line] + [b for b in (line.get("also") or {}).values() if isinstance(b, dict) and "roofline" in b]
+        for k, calls, avg in ks[:3]:
+            hip = frac = per = None
+            for blk in blocks:
+                r = blk["roofline"]
+                if kernel_key(r.get("kernel", "")) == kernel_key(k):
+                    per = len(blk["config"].get("groups") or [1])
+                    hip = r.get("kernel_ms")
+                    if r.get("algorithmic_bytes_per_launch"):
+                        frac = r["algorithmic_bytes_per_launch"] / (avg * per * 1e-3) / 1e9 / 8000.0
+            out.append("| `%s` | `%s` | %d | %s | %s | %s | %s |" % (base, k, calls, fmt(avg, 4), per if per else "—", fmt(hip, 4), fmt(frac, 4)))
     return out
 
 
