@@ -230,6 +230,10 @@ void kwage_result_free(kwage_result *r);
 typedef struct kwage_pending kwage_pending;
 int kwage_search_submit(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags, kwage_pending **out);
 int kwage_search_collect(kwage_pending *p, kwage_result **out);   /* consumes p, also on error */
+/* 1 when collecting `p` would not wait any more (everything the search queued on the device has finished), 0 while it
+ * would, < 0 on a device error.  For hosts that have other work to do meanwhile -- kwage_node feeds the context's slots
+ * from inside its RCCL exchange with it.  Does not consume p. */
+int kwage_search_poll(kwage_pending *p);
 
 /* Device-side variant for multi-GPU hosts that exchange hit lists themselves (RCCL): hits are
  * left UNSORTED in the caller's device buffer of `capacity` records; *n_hits receives the total

@@ -1324,6 +1324,18 @@ extern "C" int kwage_search_collect(kwage_pending *p, kwage_result **out)
 	return build_result(sl, g, b, so, out);
 }
 
+extern "C" int kwage_search_poll(kwage_pending *p)
+{
+	if(!p || !p->sl){ fail(KWAGE_ERR_ARG, "kwage_search_poll: NULL argument"); return -1; }
+	if(set_device(p->sl->g->ctx)){ return -1; }
+	const hipError_t e = hipStreamQuery(p->sl->stream);      // (the slot's stream ends with the copy-back, which waits for the gather stage)
+	if(e == hipSuccess){ return 1; }
+	(void)hipGetLastError();
+	if(e == hipErrorNotReady){ return 0; }
+	fail(KWAGE_ERR_DEVICE, "kwage_search_poll: %s", hipGetErrorString(e));
+	return -1;
+}
+
 extern "C" int kwage_search(kwage_group *g, kwage_batch *b, float threshold, uint32_t flags, kwage_result **out)
 {
 	if(!g || !b || !out){ return fail(KWAGE_ERR_ARG, "kwage_search: NULL argument"); }

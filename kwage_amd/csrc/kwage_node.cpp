@@ -258,6 +258,20 @@ struct RankPipeline {
 		st->kernel_ms += ms;
 		++st->done;
 	}
+	// Wait for `stream` (the exchange's) WITHOUT leaving the device unfed: a collective queued behind a running gather
+	// kernel can take as long as that kernel, and only two searches are queued at a time -- so while the exchange is
+	// pending, searches that have finished are collected and the step's next ones submitted.
+	void wait_feeding(hipStream_t stream)
+	{
+		for(;;){
+			const hipError_t e = hipStreamQuery(stream);
+			if(e == hipSuccess){ return; }
+			(void)hipGetLastError();
+			if(e != hipErrorNotReady){ throw string("hipStreamQuery failed: ") + hipGetErrorString(e); }
+			if(!flying.empty() && kwage_search_poll(flying.front().p) == 1){ collect_oldest(); pump(); }
+			else{ usleep(20); }
+		}
+	}
 	void begin(Step *st)
 	{
 		st->list = next_list;
@@ -440,7 +454,7 @@ int run_rank(int rank, int n_ranks, Bootstrap *boot, const Cli &cli, const vecto
 				// (the step's searches have been collected: the counter word holds the list's final count)
 				NODE_NCCL(ncclAllGather(l.d_count, d_counts, 1, ncclUint64, comm, stream));
 				NODE_HIP(hipMemcpyAsync(h_counts, d_counts, (size_t)n_ranks*sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-				NODE_HIP(hipStreamSynchronize(stream));
+				pipe.wait_feeding(stream);
 				for(int r = 0; r < n_ranks; ++r){ counts[(size_t)r] = h_counts[r]; total += h_counts[r]; }
 				if(counts[(size_t)rank] != n_mine){ throw string("the list's counter word disagrees with the count the search returned"); }
 				if(rank == 0 && total > all_cap){
@@ -473,7 +487,7 @@ int run_rank(int rank, int n_ranks, Bootstrap *boot, const Cli &cli, const vecto
 					if(total > n_mine){ NODE_HIP(hipMemcpyAsync(h_all + n_mine, d_all + n_mine, (total - n_mine)*sizeof(kwage_hit), hipMemcpyDeviceToHost, stream)); }
 					hits = h_all;
 				}
-				NODE_HIP(hipStreamSynchronize(stream));      // (a sender's list is refilled two steps on: the send has left it)
+				pipe.wait_feeding(stream);      // (a sender's list is refilled two steps on: the send has left it)
 			}
 			const double t1 = now_seconds();
 			t_exchange += t1 - t0;

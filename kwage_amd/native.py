@@ -131,6 +131,7 @@ _SIGNATURES = [
     ("kwage_result_free", None, [C.POINTER(Result)]),
     ("kwage_search_submit", C.c_int, [_P, _P, C.c_float, C.c_uint32, C.POINTER(_P)]),
     ("kwage_search_collect", C.c_int, [_P, C.POINTER(C.POINTER(Result))]),
+    ("kwage_search_poll", C.c_int, [_P]),
     ("kwage_search_device", C.c_int, [_P, _P, C.c_float, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64), _P]),
     ("kwage_search_device_submit", C.c_int, [_P, _P, C.c_float, C.c_uint32, _P, C.c_uint64, _P, C.POINTER(_P)]),
     ("kwage_search_device_append_submit", C.c_int, [_P, _P, C.c_float, C.c_uint32, _P, C.c_uint64, _P, C.c_uint32, C.c_int, C.POINTER(_P)]),
