@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sweep and_kernel shapes (the and_vec / and_unroll / and_nt / and_lds_kb / and_block_waves knobs) on one resident workload, interleaved
 rounds in ONE process (cdna_hip_programming.md section 5.4 rule 24).  Prints median/min kernel ms
-and algorithmic GB/s per variant.   python tools/tune_and.py [workload] [rounds]"""
+and algorithmic GB/s per variant.   python tools/tune_and.py [workload] [rounds] ["vec,unroll,nt,ldsKB,blockwaves;..."]"""
 import os
 import sys
 
@@ -15,6 +15,8 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 variants = [(2, 8, 1, 0, 4), (2, 8, 1, 0, 2), (2, 8, 1, 0, 1), (1, 8, 1, 0, 4), (1, 8, 1, 0, 1), (1, 16, 1, 0, 1),
             (2, 16, 1, 0, 4), (2, 16, 1, 0, 1), (4, 8, 1, 0, 4), (4, 8, 1, 0, 1), (2, 8, 0, 0, 4)]
+if len(sys.argv) > 3:
+    variants = [tuple(int(x) for x in v.split(",")) for v in sys.argv[3].split(";") if v]
 ctx = ka.Context(0)
 ctx.set_tuning("walk", 0)      # the tiled kernel is what is swept
 s = synth.build(ctx, synth.WORKLOADS[wl])
