@@ -34,7 +34,7 @@ static const TuningName TUNING_NAMES[] = {
 	{"walk_early_exit", &Tuning::walk_early_exit}, {"walk_waves", &Tuning::walk_waves}, {"walk_fences", &Tuning::walk_fences}, {"walk_one_wg_per_cu", &Tuning::walk_one_wg_per_cu},
 	{"walk_bands", &Tuning::walk_bands}, {"walk_bands_min_gib", &Tuning::walk_bands_min_gib},
 	{"and_vec", &Tuning::and_vec}, {"and_unroll", &Tuning::and_unroll}, {"and_nt", &Tuning::and_nt}, {"and_lds_kb", &Tuning::and_lds_kb},
-	{"and_block_waves", &Tuning::and_block_waves}, {"narrow", &Tuning::narrow}, {"narrow_unroll", &Tuning::narrow_unroll}, {"force_segs", &Tuning::force_segs},
+	{"and_block_waves", &Tuning::and_block_waves}, {"and_wide", &Tuning::and_wide}, {"narrow", &Tuning::narrow}, {"narrow_unroll", &Tuning::narrow_unroll}, {"force_segs", &Tuning::force_segs},
 	{"count_walk", &Tuning::count_walk}, {"count_walk_wpc", &Tuning::count_walk_wpc}, {"count_walk_waves", &Tuning::count_walk_waves},
 	{"count_walk_min_rows", &Tuning::count_walk_min_rows}, {"count_walk_prefetch", &Tuning::count_walk_prefetch}, {"count_walk_kps", &Tuning::count_walk_kps},
 	{"count_narrow_kps", &Tuning::count_narrow_kps},
@@ -233,9 +233,18 @@ WalkShape walk_shape(const Tuning &tn, uint64_t want_waves, uint64_t ncu)
 // only) dynamic LDS per workgroup and waves per workgroup.  Defaults come from measurements on MI355X.
 struct AndCfg { int vec, unroll, nt, lds_bytes, block_waves; };
 
-AndCfg and_config(const Tuning &t, uint32_t units_per_row)
+// `wide`: rows beyond the walk form's range searched without early exit by a launch that fills the chip (C3, C4 and their
+// column shares): four vectors per lane, eight rows in flight, and a dynamic-LDS pad that keeps 8 waves per CU resident
+// -- 32 KiB in flight per wave, 256 KiB per CU.  As for the persistent kernels, the memory system prefers few deep
+// streams to many: against the default shape (32 waves per CU, 16 KiB each) +1.4 % on C3 and on the C4 share in one
+// process (12 waves per CU +0.4 %, 16 and 20 the same as the default, 4 waves per CU -20 %; profiles/r04_tune_and_wide_rows.txt).
+AndCfg and_config(const Tuning &t, uint32_t units_per_row, bool wide = false)
 {
 	AndCfg c;
+	if(wide && t.and_vec == 0 && t.and_lds_kb == 0 && t.and_unroll == 8 && t.and_block_waves == TUNING_DEFAULT_BLOCK_WAVES){
+		c.vec = 4; c.unroll = 8; c.nt = t.and_nt ? 1 : 0; c.lds_bytes = 80*1024; c.block_waves = SEARCH_THREADS/WAVE;
+		return c;
+	}
 	c.vec = (t.and_vec == 1 || t.and_vec == 2 || t.and_vec == 4) ? (int)t.and_vec : ((units_per_row >= 4*WAVE) ? 2 : 1);
 	c.unroll = (t.and_unroll == 4 || t.and_unroll == 16 || t.and_unroll == 32) ? (int)t.and_unroll : 8;
 	if((c.unroll == 16 && c.vec == 4) || (c.unroll == 32 && c.vec != 1)){ c.unroll = 8; }       // shapes that are not instantiated
@@ -251,6 +260,10 @@ void launch_and(const SearchArgs &a, hipStream_t s, const AndCfg &c, const Stage
 	const uint64_t tiles = (uint64_t)a.n_queries*a.segs*a.chunks;
 	const uint32_t bw = (uint32_t)c.block_waves;
 	const dim3 grid((uint32_t)((tiles + bw - 1)/bw)), block(bw*WAVE);
+	if(c.lds_bytes > 48*1024){
+		(void)hipFuncSetAttribute((const void*)and_kernel<VEC, UNROLL, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds_bytes);
+		(void)hipFuncSetAttribute((const void*)and_kernel<VEC, UNROLL, NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds_bytes);
+	}
 	if(a.segs > 1){
 		KW_GATHER_LAUNCH(ge, true, false, (and_kernel<VEC, UNROLL, NT, true>), grid, block, c.lds_bytes, s, a);      // (and_combine_kernel ends the stage)
 	}
@@ -450,7 +463,10 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 	int rc;
 
 	if(threshold == 1.0f){
-		const AndCfg cfg = and_config(tn, a.units_per_row);
+		// (rows beyond the walk form's 16 KiB-steps, no early exit, at least 8 waves of 4 KiB tiles for every CU: the wide shape)
+		const bool wide_rows = tn.and_wide && !(flags & KWAGE_SEARCH_EARLY_EXIT) && a.units_per_row > 16*WAVE
+		                       && (uint64_t)a.n_queries*((a.units_per_row + 4*WAVE - 1)/(4*WAVE)) >= 8*ncu;
+		const AndCfg cfg = and_config(tn, a.units_per_row, wide_rows);
 		a.chunks = (a.units_per_row + WAVE*cfg.vec - 1)/(WAVE*cfg.vec);
 		choose_segments(a, L->max_pos, 4096, tn.force_segs);
 		if((uint64_t)a.n_queries*a.segs*a.chunks/4 + 1 > 0x7FFFFFFFull){ return fail(KWAGE_ERR_ARG, "batch too large for one launch"); }
