@@ -34,7 +34,7 @@ static const TuningName TUNING_NAMES[] = {
 	{"walk_early_exit", &Tuning::walk_early_exit}, {"walk_waves", &Tuning::walk_waves}, {"walk_fences", &Tuning::walk_fences}, {"walk_one_wg_per_cu", &Tuning::walk_one_wg_per_cu},
 	{"walk_bands", &Tuning::walk_bands}, {"walk_bands_min_gib", &Tuning::walk_bands_min_gib},
 	{"and_vec", &Tuning::and_vec}, {"and_unroll", &Tuning::and_unroll}, {"and_nt", &Tuning::and_nt}, {"and_lds_kb", &Tuning::and_lds_kb},
-	{"and_block_waves", &Tuning::and_block_waves}, {"and_wide", &Tuning::and_wide}, {"narrow", &Tuning::narrow}, {"narrow_unroll", &Tuning::narrow_unroll}, {"force_segs", &Tuning::force_segs},
+	{"and_block_waves", &Tuning::and_block_waves}, {"and_wide", &Tuning::and_wide}, {"and_wide_min_kib", &Tuning::and_wide_min_kib}, {"narrow", &Tuning::narrow}, {"narrow_unroll", &Tuning::narrow_unroll}, {"force_segs", &Tuning::force_segs},
 	{"count_walk", &Tuning::count_walk}, {"count_walk_wpc", &Tuning::count_walk_wpc}, {"count_walk_waves", &Tuning::count_walk_waves},
 	{"count_walk_min_rows", &Tuning::count_walk_min_rows}, {"count_walk_prefetch", &Tuning::count_walk_prefetch}, {"count_walk_kps", &Tuning::count_walk_kps},
 	{"count_narrow_kps", &Tuning::count_narrow_kps},
@@ -464,7 +464,7 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 
 	if(threshold == 1.0f){
 		// (rows beyond the walk form's 16 KiB-steps, no early exit, at least 8 waves of 4 KiB tiles for every CU: the wide shape)
-		const bool wide_rows = tn.and_wide && !(flags & KWAGE_SEARCH_EARLY_EXIT) && a.units_per_row > 16*WAVE
+		const bool wide_rows = tn.and_wide && !(flags & KWAGE_SEARCH_EARLY_EXIT) && a.units_per_row > (uint32_t)std::max<int64_t>(tn.and_wide_min_kib, 1)*WAVE
 		                       && (uint64_t)a.n_queries*((a.units_per_row + 4*WAVE - 1)/(4*WAVE)) >= 8*ncu;
 		const AndCfg cfg = and_config(tn, a.units_per_row, wide_rows);
 		a.chunks = (a.units_per_row + WAVE*cfg.vec - 1)/(WAVE*cfg.vec);

@@ -200,6 +200,7 @@ struct Tuning {
 	int64_t and_nt = 1;
 	int64_t and_lds_kb = 0;         //   dynamic LDS per workgroup caps the waves per CU (tuning only)
 	int64_t and_block_waves = TUNING_DEFAULT_BLOCK_WAVES;
+	int64_t and_wide_min_kib = 16;  // KWAGE_AND_WIDE_MIN_KIB: ... for rows above this many KiB-steps (the walk form takes rows up to walk_max_kib first)
 	int64_t and_wide = 1;           // KWAGE_AND_WIDE: rows beyond the walk form's range, no early exit, a chip-filling launch: vec 4, 8 rows, 8 waves per CU (and_config)
 	int64_t narrow = 1;             // KWAGE_NARROW: several queries per wave for rows <= 512 B
 	int64_t narrow_unroll = 0;      // KWAGE_NARROW_UNROLL: rows in flight per wave of the narrow AND kernel (0 = by the number of waves; 8, 16)
