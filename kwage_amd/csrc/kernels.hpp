@@ -293,6 +293,7 @@ __device__ __forceinline__ u32x4 load16(const u32x4 *p)
 // active lane of the wave the same number of times (lanes without hits pass 0).
 __device__ __forceinline__ unsigned long long reserve_hits(const SearchArgs &a, uint32_t cnt, uint64_t run)
 {
+	if(!__any(cnt != 0)){ return 0; }            // the rule: a (query, tile) without a single hit -- no scan, no atomic
 	uint32_t incl = cnt;
 #pragma unroll
 	for(int d = 1; d < WAVE; d <<= 1){
@@ -634,9 +635,17 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void and_walk_kernel(SearchArgs
 				}
 			}
 			if(emit){
+				// (most pairs end without a surviving column anywhere in the tile: one wave-wide test instead of CH rounds
+				// of valid-mask loads and lane counts -- what a pair costs beyond its rows matters when queries are short:
+				// 120 rows per query in C3's shape)
+				bool any_left = false;
 #pragma unroll
-				for(int j = 0; j < CH; ++j){
-					emit_mask_hits(a, q, min(u0 + (uint32_t)j*WAVE, umax), acc[j], n, (uint64_t)q*a.runs_per_query + c*CH + j, u0 + (uint32_t)j*WAVE <= umax);
+				for(int j = 0; j < CH; ++j){ any_left |= ((acc[j].x | acc[j].y | acc[j].z | acc[j].w) != 0); }
+				if(__any(any_left)){
+#pragma unroll
+					for(int j = 0; j < CH; ++j){
+						emit_mask_hits(a, q, min(u0 + (uint32_t)j*WAVE, umax), acc[j], n, (uint64_t)q*a.runs_per_query + c*CH + j, u0 + (uint32_t)j*WAVE <= umax);
+					}
 				}
 			}
 		}
