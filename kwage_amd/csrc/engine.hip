@@ -30,7 +30,7 @@ static_assert(TUNING_DEFAULT_BLOCK_WAVES == SEARCH_THREADS/WAVE, "the tiled AND 
 
 struct TuningName { const char *name; int64_t Tuning::*field; };
 static const TuningName TUNING_NAMES[] = {
-	{"walk", &Tuning::walk}, {"walk_min_rows", &Tuning::walk_min_rows}, {"walk_max_kib", &Tuning::walk_max_kib}, {"walk_min_kib", &Tuning::walk_min_kib},
+	{"walk", &Tuning::walk}, {"walk_min_rows", &Tuning::walk_min_rows}, {"walk_max_kib", &Tuning::walk_max_kib}, {"walk_min_kib", &Tuning::walk_min_kib}, {"walk_tile_kib", &Tuning::walk_tile_kib}, {"walk_paced", &Tuning::walk_paced},
 	{"walk_early_exit", &Tuning::walk_early_exit}, {"walk_waves", &Tuning::walk_waves}, {"walk_fences", &Tuning::walk_fences}, {"walk_one_wg_per_cu", &Tuning::walk_one_wg_per_cu},
 	{"walk_bands", &Tuning::walk_bands}, {"walk_bands_min_gib", &Tuning::walk_bands_min_gib},
 	{"and_vec", &Tuning::and_vec}, {"and_unroll", &Tuning::and_unroll}, {"and_nt", &Tuning::and_nt}, {"and_lds_kb", &Tuning::and_lds_kb},
@@ -498,7 +498,10 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 		// (the kernel handles wider rows as several balanced column tiles -- the walk_max_kib knob raises the limit --
 		// but 125 KB rows measured no gain over the tiled kernel)
 		const uint32_t walk_max_kib = (uint32_t)std::max<int64_t>(tn.walk_max_kib, 0);
-		const uint32_t coltiles = (kib + 15)/16, walk_ch = (kib + coltiles - 1)/coltiles;     // balanced tiles of <= 16 KiB
+		// (knob walk_tile_kib: narrower column tiles -- with 4, eight rows in flight and no pacing a wave requests 4 KiB of each
+		// of eight rows at once: the tiled kernel's wide shape on the balanced persistent grid)
+		const uint32_t walk_tile = (uint32_t)std::min<int64_t>(std::max<int64_t>(tn.walk_tile_kib, 1), 16);
+		const uint32_t coltiles = (kib + walk_tile - 1)/walk_tile, walk_ch = (kib + coltiles - 1)/coltiles;     // balanced tiles of <= walk_tile KiB
 		// With early exit the tiled kernel wins: a tile that holds no candidate column stops after a few rows even
 		// when another tile of the same query holds a hit, whereas a walking wave covers the hit column's whole row
 		// width and never stops (C2 with early exit: 0.64 ms tiled, 1.29 ms walk).
@@ -574,7 +577,7 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 			wa.full_fences = tn.walk_fences ? 1 : 0;
 			a.segs = 1;
 			a.chunks = coltiles;
-			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_walk_kernel<%u,%d>", walk_ch, walk_unroll);
+			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_walk_kernel<%u,%d%s>", walk_ch, walk_unroll, (walk_unroll == 8 && walk_ch <= 4 && !tn.walk_paced) ? ",unpaced" : "");
 			const dim3 grid(wgs), block(shape.wg_waves*WAVE);
 #define KWAGE_WALK_LAUNCH(...) do { \
 				if(shape.lds > 48*1024){ (void)hipFuncSetAttribute((const void*)and_walk_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shape.lds); } \
@@ -582,7 +585,8 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 #define KWAGE_WALK_CASE(CH) case CH: \
 				if(walk_unroll == 2){ KWAGE_WALK_LAUNCH(CH, 2); } else{ KWAGE_WALK_LAUNCH(CH, 4); } break;
 #define KWAGE_WALK_CASE8(CH) case CH: \
-				if(walk_unroll == 2){ KWAGE_WALK_LAUNCH(CH, 2); } else if(walk_unroll == 8){ KWAGE_WALK_LAUNCH(CH, 8); } else{ KWAGE_WALK_LAUNCH(CH, 4); } break;
+				if(walk_unroll == 2){ KWAGE_WALK_LAUNCH(CH, 2); } else if(walk_unroll == 8 && !tn.walk_paced){ KWAGE_WALK_LAUNCH(CH, 8, false); } \
+				else if(walk_unroll == 8){ KWAGE_WALK_LAUNCH(CH, 8); } else{ KWAGE_WALK_LAUNCH(CH, 4); } break;
 			switch(walk_ch){
 				KWAGE_WALK_CASE8(1) KWAGE_WALK_CASE8(2) KWAGE_WALK_CASE8(3) KWAGE_WALK_CASE8(4) KWAGE_WALK_CASE(5) KWAGE_WALK_CASE(6) KWAGE_WALK_CASE(7)
 				KWAGE_WALK_CASE(8) KWAGE_WALK_CASE(9) KWAGE_WALK_CASE(10) KWAGE_WALK_CASE(11) KWAGE_WALK_CASE(12)
@@ -805,7 +809,7 @@ int submit_search(Slot *sl, kwage_group *g, kwage_batch *b, float threshold, uin
 	sl->runs_per_query = 0;
 	if(ext_hits == nullptr && ext_cap == 0 && b->n && g->num_columns){
 		const uint64_t kib = (g->stride/16 + WAVE - 1)/WAVE;
-		sl->runs_per_query = (uint32_t)(kib + kib/16 + 4);
+		sl->runs_per_query = (uint32_t)(2*kib + 4);           // (column tiles of any width: tiles x steps < kib + tiles)
 		sl->n_runs = (uint64_t)b->n*sl->runs_per_query;
 		if((rc = sl->runs.reserve(sl->n_runs*sizeof(unsigned long long)))){ return rc; }
 	}

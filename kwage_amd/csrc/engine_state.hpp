@@ -185,6 +185,8 @@ struct Tuning {
 	int64_t walk = 4;               // KWAGE_WALK: and_walk_kernel's rows in flight (4 or 2); 0 = always the tiled kernel
 	int64_t walk_min_rows = -1;     // KWAGE_WALK_MIN_ROWS: batches with fewer rows use the tiled kernel (-1: 64 rows per wave of the chip)
 	int64_t walk_max_kib = 16;      // KWAGE_WALK_MAX_KIB: widest row the walk form takes
+	int64_t walk_tile_kib = 16;     // KWAGE_WALK_TILE_KIB: widest column tile of the walk form in KiB-steps (rows wider than it are walked tile after tile)
+	int64_t walk_paced = 1;         // KWAGE_WALK_PACED: one KiB-step of the rows in flight at a time (0 with 8 rows in flight and tiles of <= 4: all steps at once)
 	int64_t walk_min_kib = 2;       // KWAGE_WALK_MIN_KIB: narrowest row (in KiB-steps) the walk form takes (round 4: 2 -- rows of 1-2 KiB no
 	                                //   longer need the tiled kernel's segments + combine pass: 0.263 vs 0.284 ms at C2's columns split 8 ways)
 	int64_t walk_early_exit = 0;    // KWAGE_WALK_EARLY_EXIT: use the walk form with early exit too (the tiled kernel stops sooner)

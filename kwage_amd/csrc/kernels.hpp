@@ -502,7 +502,7 @@ struct WalkArgs {
 // fills the chip: ONE workgroup per CU, so every CU runs exactly the same number of waves -- with workgroups of four
 // waves the dispatcher's placement left some CUs with three workgroups and others with one: +0.8-0.9 % at C2's shape,
 // profiles/r03_walk_cu_shapes.txt)
-template <int CH, int UNROLL>
+template <int CH, int UNROLL, bool PACED = true>
 __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void and_walk_kernel(SearchArgs a, WalkArgs wa, const uint32_t *__restrict__ rows,
                                                                       const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ nkmer)
 {
@@ -567,7 +567,9 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void and_walk_kernel(SearchArgs
 					// memory system likes is ~8192 sequential row streams chip-wide (8 waves per CU x 4 rows), each a KiB
 					// deep; left alone the scheduler keeps 8-9 KiB per wave in flight, which measures 1 % slower, and more
 					// streams (16 waves per CU, or 8 rows) 2-3 % slower (profiles/r02_walk_sizes_schedules.txt).
-					__builtin_amdgcn_sched_barrier(0);
+					// (PACED = false, narrow column tiles: all CH steps of the UNROLL rows are requested together -- the
+					// tiled kernel's "wide" access pattern, 4 KiB of a row at once, on the balanced persistent grid)
+					if(PACED){ __builtin_amdgcn_sched_barrier(0); }
 				}
 				if(a.early_exit){     // kwage.cpp:466-470: this part alone already rules every column of the tile out
 					bool nz = false;
