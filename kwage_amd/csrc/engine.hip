@@ -30,7 +30,7 @@ static_assert(TUNING_DEFAULT_BLOCK_WAVES == SEARCH_THREADS/WAVE, "the tiled AND 
 
 struct TuningName { const char *name; int64_t Tuning::*field; };
 static const TuningName TUNING_NAMES[] = {
-	{"walk", &Tuning::walk}, {"walk_min_rows", &Tuning::walk_min_rows}, {"walk_max_kib", &Tuning::walk_max_kib}, {"walk_min_kib", &Tuning::walk_min_kib}, {"walk_tile_kib", &Tuning::walk_tile_kib}, {"walk_paced", &Tuning::walk_paced},
+	{"walk", &Tuning::walk}, {"walk_min_rows", &Tuning::walk_min_rows}, {"walk_max_kib", &Tuning::walk_max_kib}, {"walk_min_kib", &Tuning::walk_min_kib}, {"walk_short_rows", &Tuning::walk_short_rows}, {"walk_tile_kib", &Tuning::walk_tile_kib}, {"walk_paced", &Tuning::walk_paced},
 	{"walk_early_exit", &Tuning::walk_early_exit}, {"walk_waves", &Tuning::walk_waves}, {"walk_fences", &Tuning::walk_fences}, {"walk_one_wg_per_cu", &Tuning::walk_one_wg_per_cu},
 	{"walk_bands", &Tuning::walk_bands}, {"walk_bands_min_gib", &Tuning::walk_bands_min_gib},
 	{"and_vec", &Tuning::and_vec}, {"and_unroll", &Tuning::and_unroll}, {"and_nt", &Tuning::and_nt}, {"and_lds_kb", &Tuning::and_lds_kb},
@@ -463,9 +463,16 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 	int rc;
 
 	if(threshold == 1.0f){
-		// (rows beyond the walk form's 16 KiB-steps, no early exit, at least 8 waves of 4 KiB tiles for every CU: the wide shape)
-		const bool wide_rows = tn.and_wide && !(flags & KWAGE_SEARCH_EARLY_EXIT) && a.units_per_row > (uint32_t)std::max<int64_t>(tn.and_wide_min_kib, 1)*WAVE
-		                       && (uint64_t)a.n_queries*((a.units_per_row + 4*WAVE - 1)/(4*WAVE)) >= 8*ncu;
+		// The wide shape of the tiled kernel (and_config) where a launch without early exit fills the chip with 4 KiB tiles:
+		// for rows beyond the walk form's range, and -- within that range -- for batches of SHORT row lists: with 120 rows
+		// per query (150-base reads) the tiled wide shape reads 4-9 % faster than the walk form at 6-16 KB rows, with 220
+		// rows and more the walk form wins by 2-8 % (profiles/r04_walk_vs_tiled_wide_grid.txt; crossover ~170 rows).
+		const uint32_t kib_rows = (a.units_per_row + WAVE - 1)/WAVE;
+		const uint64_t wide_tiles = (uint64_t)a.n_queries*((a.units_per_row + 4*WAVE - 1)/(4*WAVE));
+		const bool wide_ok = tn.and_wide && !(flags & KWAGE_SEARCH_EARLY_EXIT) && wide_tiles >= 8*ncu;
+		const bool short_lists = wide_ok && kib_rows >= 5 && wide_tiles >= 128*ncu
+		                         && L->total_pos*a.num_hash < (uint64_t)std::max<int64_t>(tn.walk_short_rows, 0)*a.n_queries;
+		const bool wide_rows = wide_ok && (a.units_per_row > (uint32_t)std::max<int64_t>(tn.and_wide_min_kib, 1)*WAVE || short_lists);
 		const AndCfg cfg = and_config(tn, a.units_per_row, wide_rows);
 		a.chunks = (a.units_per_row + WAVE*cfg.vec - 1)/(WAVE*cfg.vec);
 		choose_segments(a, L->max_pos, 4096, tn.force_segs);
@@ -511,7 +518,7 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 		// rows in flight per wave: 4; 8 for rows of one or two KiB-steps (a group of four such rows is only 4-8 loads: C2's
 		// columns split 8 ways, 1664-byte rows, 0.2626 vs 0.2667 ms) and, by knob, up to four; 2 by knob
 		const int walk_unroll = (walk_knob == 2) ? 2 : ((walk_knob == 8 && walk_ch <= 4) || walk_ch <= 2) ? 8 : 4;
-		if(walk_knob && walk_ee_ok && kib >= walk_min_kib && kib <= walk_max_kib && walk_slots*a.num_hash >= walk_min_rows && walk_slots > 0){
+		if(walk_knob && walk_ee_ok && !short_lists && kib >= walk_min_kib && kib <= walk_max_kib && walk_slots*a.num_hash >= walk_min_rows && walk_slots > 0){
 			// WALK_WAVES_PER_CU waves per CU, all resident at once (__launch_bounds__(256, 4) allows twice as many),
 			// fewer when the batch is small: a wave should have WALK_MIN_ROWS_PER_WAVE rows to walk
 			const uint64_t chip_waves = ncu*WALK_WAVES_PER_CU;
