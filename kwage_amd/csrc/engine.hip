@@ -34,7 +34,7 @@ static const TuningName TUNING_NAMES[] = {
 	{"walk_early_exit", &Tuning::walk_early_exit}, {"walk_waves", &Tuning::walk_waves}, {"walk_fences", &Tuning::walk_fences}, {"walk_one_wg_per_cu", &Tuning::walk_one_wg_per_cu},
 	{"walk_bands", &Tuning::walk_bands}, {"walk_bands_min_gib", &Tuning::walk_bands_min_gib},
 	{"and_vec", &Tuning::and_vec}, {"and_unroll", &Tuning::and_unroll}, {"and_nt", &Tuning::and_nt}, {"and_lds_kb", &Tuning::and_lds_kb},
-	{"and_block_waves", &Tuning::and_block_waves}, {"and_wide", &Tuning::and_wide}, {"and_wide_min_kib", &Tuning::and_wide_min_kib}, {"narrow", &Tuning::narrow}, {"narrow_unroll", &Tuning::narrow_unroll}, {"narrow_prefetch", &Tuning::narrow_prefetch}, {"force_segs", &Tuning::force_segs},
+	{"and_block_waves", &Tuning::and_block_waves}, {"and_wide", &Tuning::and_wide}, {"and_wide_min_kib", &Tuning::and_wide_min_kib}, {"narrow", &Tuning::narrow}, {"narrow_unroll", &Tuning::narrow_unroll}, {"force_segs", &Tuning::force_segs},
 	{"count_walk", &Tuning::count_walk}, {"count_walk_wpc", &Tuning::count_walk_wpc}, {"count_walk_waves", &Tuning::count_walk_waves},
 	{"count_walk_min_rows", &Tuning::count_walk_min_rows}, {"count_walk_prefetch", &Tuning::count_walk_prefetch}, {"count_walk_kps", &Tuning::count_walk_kps},
 	{"count_narrow_kps", &Tuning::count_narrow_kps},
@@ -486,10 +486,8 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 			const int unroll = (tn.narrow_unroll == 8 || tn.narrow_unroll == 16) ? (int)tn.narrow_unroll : ((waves < ncu*16) ? 16 : 8);
 			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_narrow_kernel<%u,%d>", G, unroll);
 #define KWAGE_NARROW_CASE(GG) case GG: \
-				if(unroll == 16 && tn.narrow_prefetch){ KW_GATHER_LAUNCH(ge, true, true, (and_narrow_kernel<GG, 16, true>), grid, block, 0, gs, a); } \
-				else if(unroll == 16){ KW_GATHER_LAUNCH(ge, true, true, (and_narrow_kernel<GG, 16, false>), grid, block, 0, gs, a); } \
-				else if(tn.narrow_prefetch){ KW_GATHER_LAUNCH(ge, true, true, (and_narrow_kernel<GG, 8, true>), grid, block, 0, gs, a); } \
-				else{ KW_GATHER_LAUNCH(ge, true, true, (and_narrow_kernel<GG, 8, false>), grid, block, 0, gs, a); } break;
+				if(unroll == 16){ KW_GATHER_LAUNCH(ge, true, true, (and_narrow_kernel<GG, 16>), grid, block, 0, gs, a); } \
+				else{ KW_GATHER_LAUNCH(ge, true, true, (and_narrow_kernel<GG, 8>), grid, block, 0, gs, a); } break;
 			switch(G){
 				KWAGE_NARROW_CASE(16) KWAGE_NARROW_CASE(8) KWAGE_NARROW_CASE(4)
 				default: KWAGE_NARROW_CASE(2)

@@ -207,7 +207,6 @@ struct Tuning {
 	int64_t and_wide = 1;           // KWAGE_AND_WIDE: rows beyond the walk form's range, no early exit, a chip-filling launch: vec 4, 8 rows, 8 waves per CU (and_config)
 	int64_t narrow = 1;             // KWAGE_NARROW: several queries per wave for rows <= 512 B
 	int64_t narrow_unroll = 0;      // KWAGE_NARROW_UNROLL: rows in flight per wave of the narrow AND kernel (0 = by the number of waves; 8, 16)
-	int64_t narrow_prefetch = 1;    // KWAGE_NARROW_PREFETCH: the narrow AND kernel requests the next group's row indices while the current group's rows are in flight
 	int64_t force_segs = 0;         // KWAGE_FORCE_SEGS: cut every query's k-mer list into this many segments (tests)
 	int64_t count_walk = 1;         // KWAGE_COUNT_WALK: the persistent count kernel where it applies
 	int64_t count_walk_wpc = 8;     // KWAGE_COUNT_WALK_WPC: its waves per CU (8: 6335 GB/s at C2's shape, 12: 6271, 16: 6250, 20: 5876)

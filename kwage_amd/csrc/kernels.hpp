@@ -840,9 +840,7 @@ __global__ __launch_bounds__(256) void and_band_finish_kernel(SearchArgs a, Band
 // share a wave, 64/G lanes each, so a wave-load still moves up to 1 KiB.  Row indices are per lane group
 // (vector loads, broadcast within the group).  Shorter row lists are padded by re-reading their last row
 // (AND is idempotent), so there is no divergence inside the loop.
-// PFI: the NEXT group's row indices are requested while the current group's rows are in flight -- otherwise every group of
-// UNROLL rows costs two dependent memory round trips (indices, then rows) and the wave's bytes in flight halve.
-template <int G, int UNROLL, bool PFI = true>
+template <int G, int UNROLL>
 __global__ __launch_bounds__(SEARCH_THREADS) void and_narrow_kernel(SearchArgs a)
 {
 	constexpr uint32_t LG = WAVE/G;
@@ -860,21 +858,13 @@ __global__ __launch_bounds__(SEARCH_THREADS) void and_narrow_kernel(SearchArgs a
 
 	u32x4 acc = ~(u32x4)(0u);
 	if(active){
-		uint32_t r[UNROLL];
-		if(PFI){
-#pragma unroll
-			for(int u = 0; u < UNROLL; ++u){ r[u] = rq[min((uint32_t)u, nrows - 1)]; }
-		}
 		for(uint32_t i = 0; __any(i < nrows); i += UNROLL){
 			u32x4 x[UNROLL];
 #pragma unroll
 			for(int u = 0; u < UNROLL; ++u){
-				if(!PFI){ r[u] = rq[min(i + u, nrows - 1)]; }
-				x[u] = load16<true>(reinterpret_cast<const u32x4*>(a.db + (uint64_t)r[u]*a.stride) + unit);
-			}
-			if(PFI){      // (past the list's end: its last row again -- AND is idempotent)
-#pragma unroll
-				for(int u = 0; u < UNROLL; ++u){ r[u] = rq[min(i + UNROLL + u, nrows - 1)]; }
+				const uint32_t idx = min(i + u, nrows - 1);
+				const uint32_t r = rq[idx];
+				x[u] = load16<true>(reinterpret_cast<const u32x4*>(a.db + (uint64_t)r*a.stride) + unit);
 			}
 #pragma unroll
 			for(int u = 0; u < UNROLL; ++u){ acc &= x[u]; }
