@@ -204,6 +204,47 @@ def test_hit_buffer_growth(ka, ctx, oracle, n_queries, monkeypatch):
     g.close()
 
 
+def test_poll_and_exchange_buffers(ka, ctx, oracle):
+    """kwage_search_poll says when collecting would not wait any more (never consumes the search), and the exchange
+    buffers of the persistent kernels read all zero after cut-heavy searches (kwage_ctx_scratch_nonzero): what
+    tools/soak_walk.py checks after tens of thousands of launches, once here."""
+    import ctypes as C
+    import time
+    from kwage_amd.native import lib
+    rng = np.random.default_rng(99)
+    k, nh, L, n_cols = 31, 2, 10, 40000
+    image = _make_random_db(rng, L, n_cols, 0.8)
+    seqs = [rand_seq(rng, int(rng.choice([40, 64, 150, 300]))) for _ in range(400)]
+    g = ka.Group(ctx, k, nh, L, n_cols)
+    g.add_columns(image, n_cols)
+    g.finalize()
+    b = ka.Batch(ctx, seqs)
+    with ctx.tuning(walk=0, count_walk=0):
+        ref = {t: g.search(b, t) for t in (1.0, 0.9)}
+    with ctx.tuning(walk=4, walk_min_rows=1, walk_waves=3001, count_walk_min_rows=1, count_walk_waves=3001, walk_bands=0):
+        for t in (1.0, 0.9, 1.0, 0.9):
+            p = g.submit(b, t)
+            polls = 0
+            while True:
+                state = lib().kwage_search_poll(p._h)
+                assert state in (0, 1)
+                if state == 1:
+                    break
+                polls += 1
+                assert polls < 200000
+                time.sleep(0.0001)
+            assert lib().kwage_search_poll(p._h) == 1          # still there: polling does not consume it
+            r = p.collect()
+            assert r.search_kernel.startswith("and_walk_kernel<" if t == 1.0 else "count_walk_kernel<")
+            assert np.array_equal(r.hits, ref[t].hits)
+        with ctx.tuning(walk_bands=5, walk_bands_min_gib=0):
+            assert np.array_equal(g.search(b, 1.0).hits, ref[1.0].hits)
+        left = ctx.scratch_nonzero()
+    assert set(left) == {"walk_or", "walk_done", "band_or", "band_state", "cwalk_arrived"} and not any(left.values()), left
+    b.close()
+    g.close()
+
+
 @pytest.mark.parametrize("n_cols", [2048, 4000, 5000, 40000, 300000])
 def test_long_lists_come_back_ordered_from_every_kernel_form(ka, ctx, n_cols):
     """Lists above the 8192 records that come back with the counters are ordered on the device WITHOUT a sort: every

@@ -178,6 +178,20 @@ def render_tables():
     return "\n".join(out) + "\n"
 
 
+DESIGN_BEGIN = "<!-- GENERATED:measurements BEGIN (tools/render_tables.py; do not edit) -->"
+DESIGN_END = "<!-- GENERATED:measurements END -->"
+
+
+def design_block():
+    """The newest round's tables as DESIGN.md carries them between its markers."""
+    rnd = rounds()[0]
+    block = ["", "`bench.py` lines of round %s (`profiles/%s_*.json`):" % (rnd[1:].lstrip("0"), rnd), ""] + bench_table(rnd) + ["", "rocprofv3 summaries of the same commands:", ""] + rocprof_table(rnd)
+    for p in sorted(glob.glob(os.path.join(PROF, rnd + "_strong_scaling_proxy.json"))):
+        block += ["", "Strong scaling, one-GPU proxy (`profiles/%s`):" % os.path.basename(p), ""] + proxy_table(p)
+    block += [""]
+    return "\n".join(block)
+
+
 def bootstrap_index():
     """First run: take the hand-written tables of profiles/README.md as the index's descriptions."""
     idx = {}
@@ -224,15 +238,10 @@ def main():
     # the newest round's tables inside DESIGN.md
     dpath = os.path.join(ROOT, "DESIGN.md")
     txt = open(dpath).read()
-    b, e = "<!-- GENERATED:measurements BEGIN (tools/render_tables.py; do not edit) -->", "<!-- GENERATED:measurements END -->"
-    if b in txt and e in txt:
-        rnd = rounds()[0]
-        block = ["", "`bench.py` lines of round %s (`profiles/%s_*.json`):" % (rnd[1:].lstrip("0"), rnd), ""] + bench_table(rnd) + ["", "rocprofv3 summaries of the same commands:", ""] + rocprof_table(rnd)
-        for p in sorted(glob.glob(os.path.join(PROF, rnd + "_strong_scaling_proxy.json"))):
-            block += ["", "Strong scaling, one-GPU proxy (`profiles/%s`):" % os.path.basename(p), ""] + proxy_table(p)
-        block += [""]
-        txt = txt[:txt.index(b) + len(b)] + "\n".join(block) + txt[txt.index(e):]
+    if DESIGN_BEGIN in txt and DESIGN_END in txt:
+        txt = txt[:txt.index(DESIGN_BEGIN) + len(DESIGN_BEGIN)] + design_block() + txt[txt.index(DESIGN_END):]
         open(dpath, "w").write(txt)
+    b = DESIGN_BEGIN
     print("rendered profiles/TABLES.md, profiles/README.md%s" % (", DESIGN.md block" if b in txt else ""))
 
 
