@@ -352,6 +352,22 @@ __device__ __forceinline__ void store_hit(const SearchArgs &a, unsigned long lon
 // hit extraction at threshold == 1 (kwage.cpp:489-499,517-518), restricted to real columns.
 // `on` = this lane holds a real tile position; every lane of the wave must call it.
 // `run`: the number of this reservation in the run table (SearchArgs::runs), wave-uniform (workgroup-uniform with `wg`).
+// The records of a mask that is already restricted to real columns (`m` = 0 in lanes without a tile position).
+__device__ __forceinline__ void emit_masked_hits(const SearchArgs &a, uint32_t q, uint32_t unit, u32x4 m, uint32_t n, uint64_t run, WgHitScratch *wg = nullptr)
+{
+	const uint32_t cnt = __popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w);
+	unsigned long long slot = wg ? reserve_hits_wg(a, cnt, wg, run) : reserve_hits(a, cnt, run);
+#pragma unroll
+	for(int d = 0; d < 4; ++d){
+		uint32_t bits = m[d];
+		while(bits){
+			const uint32_t b = __ffs(bits) - 1;
+			bits &= bits - 1;
+			store_hit(a, slot++, q, unit*128u + d*32u + b, n);       // num_match = num_query_kmer
+		}
+	}
+}
+
 __device__ __forceinline__ void emit_mask_hits(const SearchArgs &a, uint32_t q, uint32_t unit, u32x4 acc, uint32_t n, uint64_t run, bool on = true, WgHitScratch *wg = nullptr)
 {
 	u32x4 m = (u32x4)(0u);
@@ -644,9 +660,19 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void and_walk_kernel(SearchArgs
 #pragma unroll
 				for(int j = 0; j < CH; ++j){ any_left |= ((acc[j].x | acc[j].y | acc[j].z | acc[j].w) != 0); }
 				if(__any(any_left)){
+					// A pair WITH surviving columns: the CH real-column masks are requested together, and a round without a
+					// surviving column in any lane then costs no memory operation at all.  (One emit_mask_hits per round --
+					// a dependent load of the mask, then the scan and the atomic, CH times in a row with nothing else of this
+					// wave in flight -- made every pair with a hit cost ~145 us: with hits in half the queries the walk form
+					// lost 14 % on 150-base reads, profiles/r04_walk_hit_cost.txt.)
 #pragma unroll
 					for(int j = 0; j < CH; ++j){
-						emit_mask_hits(a, q, min(u0 + (uint32_t)j*WAVE, umax), acc[j], n, (uint64_t)q*a.runs_per_query + c*CH + j, u0 + (uint32_t)j*WAVE <= umax);
+						const uint32_t u = u0 + (uint32_t)j*WAVE;
+						acc[j] = (u <= umax) ? (acc[j] & reinterpret_cast<const u32x4*>(a.valid)[u]) : (u32x4)(0u);
+					}
+#pragma unroll
+					for(int j = 0; j < CH; ++j){
+						emit_masked_hits(a, q, min(u0 + (uint32_t)j*WAVE, umax), acc[j], n, (uint64_t)q*a.runs_per_query + c*CH + j);
 					}
 				}
 			}
@@ -830,8 +856,13 @@ __global__ __launch_bounds__(256) void and_band_finish_kernel(SearchArgs a, Band
 		const uint32_t n = nkmer[q];
 		const uint32_t umax = a.units_per_row - 1;
 #pragma unroll
+		for(int j = 0; j < CH; ++j){      // (the real-column masks requested together: and_walk_kernel)
+			const uint32_t u = lane + (uint32_t)j*WAVE;
+			acc[j] = (u <= umax) ? (acc[j] & reinterpret_cast<const u32x4*>(a.valid)[u]) : (u32x4)(0u);
+		}
+#pragma unroll
 		for(int j = 0; j < CH; ++j){
-			emit_mask_hits(a, q, min(lane + (uint32_t)j*WAVE, umax), acc[j], n, (uint64_t)q*a.runs_per_query + j, lane + (uint32_t)j*WAVE <= umax);
+			emit_masked_hits(a, q, min(lane + (uint32_t)j*WAVE, umax), acc[j], n, (uint64_t)q*a.runs_per_query + j);
 		}
 	}
 }
