@@ -68,13 +68,13 @@ WORKLOADS: Dict[str, Workload] = {
 }
 
 
-# tuning tools: KWAGE_WORKLOAD_CUSTOM="samples,log2 filter len,hashes,queries,query length,threshold[,hit fraction]" -> WORKLOADS["custom"]
+# tuning tools: KWAGE_WORKLOAD_CUSTOM="samples,log2 filter len,hashes,queries,query length,threshold[,hit fraction[,columns per planted genome]]" -> WORKLOADS["custom"]
 import os as _os
 if _os.environ.get("KWAGE_WORKLOAD_CUSTOM"):
     _v = _os.environ["KWAGE_WORKLOAD_CUSTOM"].split(",")
     WORKLOADS["custom"] = Workload("custom: %s samples x 2^%s, %s hash(es), %s x %s bp, t=%s" % tuple(_v[:6]), int(_v[0]), int(_v[1]), 31, int(_v[2]), int(_v[3]), int(_v[4]),
                                    float(_v[5]), density_q8=64 if int(_v[2]) == 1 else 194, num_genomes=64, genome_len=max(150_000, 4 * int(_v[4])),
-                                   hit_fraction=float(_v[6]) if len(_v) > 6 else 0.5)
+                                   hit_fraction=float(_v[6]) if len(_v) > 6 else 0.5, columns_per_genome=int(_v[7]) if len(_v) > 7 else 3)
 
 # BASELINE.json configs[4] (C5), the share of ONE GPU: adaptive filter sizes 2^18..2^25, more samples in the
 # small filters (as optimal_bloom_param would assign them), 5 hash functions, threshold 0.8.
