@@ -349,6 +349,67 @@ __device__ __forceinline__ void store_hit(const SearchArgs &a, unsigned long lon
 	}
 }
 
+// ---- hit records of a PERSISTENT wave: collected in LDS, reserved and stored once -------------------------------------
+// A reservation is a returning atomic on the ONE hit counter.  A tiled kernel's wave makes it at the end of its life and
+// nobody waits behind it; a persistent wave streams rows for the whole launch, its later loads return in order behind the
+// atomic, and while that queues at the counter's address the wave streams nothing: with hits in half the queries the walk
+// form lost 14 % on 150-base reads and 3 % on C2 (profiles/r04_walk_hit_cost.txt -- the atomic, not the record stores, not
+// the scans).  So the persistent kernels keep a wave's records in LDS -- one buffer per wave, WBUF_RECS records and
+// WBUF_RUNS runs -- and flush them with ONE reservation when the wave's share is done (or the buffer is full; a single
+// round with more records than the buffer holds goes the direct way).  The list stays dense and every run keeps its entry
+// in the run table, so nothing downstream changes.
+static constexpr uint32_t WBUF_RECS = 256, WBUF_RUNS = 64;
+struct WaveHitBuf {
+	kwage_hit rec[WBUF_RECS];
+	unsigned long long run_id[WBUF_RUNS];
+	uint32_t run_at[WBUF_RUNS], run_n[WBUF_RUNS];
+};
+struct WaveHitState { uint32_t n_rec = 0, n_run = 0; };        // wave-uniform
+
+__device__ __forceinline__ void wave_hits_flush(const SearchArgs &a, WaveHitBuf *buf, WaveHitState &st)
+{
+	if(st.n_rec == 0){ return; }
+	const uint32_t lane = threadIdx.x & (WAVE - 1);
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the lanes' LDS writes before other lanes read them
+	__builtin_amdgcn_wave_barrier();
+	unsigned long long base = 0;
+	if(lane == WAVE - 1){ base = atomicAdd(a.hit_count, (unsigned long long)st.n_rec); }
+	base = __shfl(base, WAVE - 1);
+	for(uint32_t i = lane; i < st.n_rec; i += WAVE){
+		if(base + i < a.cap){ a.hits[base + i] = buf->rec[i]; }
+	}
+	if(a.runs){
+		for(uint32_t k = lane; k < st.n_run; k += WAVE){ a.runs[buf->run_id[k]] = ((base + buf->run_at[k]) << 16) | buf->run_n[k]; }
+	}
+	__builtin_amdgcn_wave_barrier();
+	st.n_rec = 0;
+	st.n_run = 0;
+}
+
+// Room for `total` records of one run in the wave's buffer -> this lane's first place in it (lanes in order, `cnt` each);
+// returns false when the run does not fit the buffer at all (the caller then reserves and stores directly).
+__device__ __forceinline__ bool wave_hits_place(const SearchArgs &a, WaveHitBuf *buf, WaveHitState &st, uint32_t cnt, uint64_t run, uint32_t &at)
+{
+	uint32_t incl = cnt;
+#pragma unroll
+	for(int d = 1; d < WAVE; d <<= 1){
+		const uint32_t up = __shfl_up(incl, d);
+		if((int)(threadIdx.x & (WAVE - 1)) >= d){ incl += up; }
+	}
+	const uint32_t total = __builtin_amdgcn_readfirstlane(__shfl(incl, WAVE - 1));
+	if(total > WBUF_RECS){ wave_hits_flush(a, buf, st); return false; }       // (what is buffered goes first: runs reach the list in the wave's order)
+	if(st.n_rec + total > WBUF_RECS || st.n_run == WBUF_RUNS){ wave_hits_flush(a, buf, st); }
+	at = st.n_rec + (incl - cnt);
+	if((threadIdx.x & (WAVE - 1)) == WAVE - 1){
+		buf->run_id[st.n_run] = run;
+		buf->run_at[st.n_run] = st.n_rec;
+		buf->run_n[st.n_run] = total;
+	}
+	st.n_rec += total;
+	st.n_run += 1;
+	return true;
+}
+
 // hit extraction at threshold == 1 (kwage.cpp:489-499,517-518), restricted to real columns.
 // `on` = this lane holds a real tile position; every lane of the wave must call it.
 // `run`: the number of this reservation in the run table (SearchArgs::runs), wave-uniform (workgroup-uniform with `wg`).
@@ -364,6 +425,25 @@ __device__ __forceinline__ void emit_masked_hits(const SearchArgs &a, uint32_t q
 			const uint32_t b = __ffs(bits) - 1;
 			bits &= bits - 1;
 			store_hit(a, slot++, q, unit*128u + d*32u + b, n);       // num_match = num_query_kmer
+		}
+	}
+}
+
+// The same through the wave's LDS buffer (persistent kernels).
+__device__ __forceinline__ void emit_masked_hits_buffered(const SearchArgs &a, WaveHitBuf *buf, WaveHitState &st, uint32_t q, uint32_t unit, u32x4 m, uint32_t n, uint64_t run)
+{
+	const uint32_t cnt = __popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w);
+	if(!__any(cnt != 0)){ return; }
+	uint32_t at = 0;
+	if(!wave_hits_place(a, buf, st, cnt, run, at)){ emit_masked_hits(a, q, unit, m, n, run); return; }
+#pragma unroll
+	for(int d = 0; d < 4; ++d){
+		uint32_t bits = m[d];
+		while(bits){
+			const uint32_t b = __ffs(bits) - 1;
+			bits &= bits - 1;
+			kwage_hit h; h.query = q; h.column = unit*128u + d*32u + b + a.col_base; h.num_match = n;
+			buf->rec[at++] = h;
 		}
 	}
 }
@@ -527,6 +607,9 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void and_walk_kernel(SearchArgs
 	uint64_t s = (uint64_t)gw*wa.per_wave;
 	const uint64_t s1 = min(wa.total_slots, s + wa.per_wave);
 	if(s >= s1){ return; }
+	__shared__ WaveHitBuf hit_bufs[WALK_WG_WAVES];                // (static: beside the dynamic pad of a chip-filling launch)
+	WaveHitBuf *hbuf = &hit_bufs[threadIdx.x >> 6];
+	WaveHitState hst;
 	const uint32_t ct = wa.coltiles;
 	const uint32_t row_bytes = a.units_per_row*16u;
 	const uint32_t umax = a.units_per_row - 1;
@@ -672,7 +755,7 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void and_walk_kernel(SearchArgs
 					}
 #pragma unroll
 					for(int j = 0; j < CH; ++j){
-						emit_masked_hits(a, q, min(u0 + (uint32_t)j*WAVE, umax), acc[j], n, (uint64_t)q*a.runs_per_query + c*CH + j);
+						emit_masked_hits_buffered(a, hbuf, hst, q, min(u0 + (uint32_t)j*WAVE, umax), acc[j], n, (uint64_t)q*a.runs_per_query + c*CH + j);
 					}
 				}
 			}
@@ -680,6 +763,7 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void and_walk_kernel(SearchArgs
 		s += take;
 		if(j1 == npos && c + 1 == ct){ ++q; }
 	}
+	wave_hits_flush(a, hbuf, hst);          // one reservation for everything the wave found
 }
 
 // ---- the walk form, ADDRESS BAND after ADDRESS BAND ---------------------------------------------------------------
@@ -985,6 +1069,33 @@ __device__ __forceinline__ void emit_count_hits(const SearchArgs &a, uint32_t q,
 	}
 }
 
+// The same through the wave's LDS buffer (the persistent count kernel; see WaveHitBuf).
+template <int PLANES>
+__device__ __forceinline__ void emit_count_hits_buffered(const SearchArgs &a, WaveHitBuf *buf, WaveHitState &st, uint32_t q, uint32_t unit,
+                                                         const u32x4 (&plane)[PLANES], uint32_t thr, uint64_t run, bool on)
+{
+	u32x4 ge = (u32x4)(0u);
+	if(on){ ge = planes_ge<PLANES>(plane, thr) & reinterpret_cast<const u32x4*>(a.valid)[unit]; }
+	const uint32_t nge = __popc(ge.x) + __popc(ge.y) + __popc(ge.z) + __popc(ge.w);
+	if(!__any(nge != 0)){ return; }
+	uint32_t at = 0;
+	const bool buffered = wave_hits_place(a, buf, st, nge, run, at);
+	unsigned long long slot = buffered ? 0ull : reserve_hits(a, nge, run);
+#pragma unroll
+	for(int d = 0; d < 4; ++d){
+		uint32_t bits = ge[d];
+		while(bits){
+			const uint32_t b = __ffs(bits) - 1;
+			bits &= bits - 1;
+			uint32_t cnt = 0;
+#pragma unroll
+			for(int p = 0; p < PLANES; ++p){ cnt |= ((plane[p][d] >> b) & 1u) << p; }
+			if(buffered){ kwage_hit h; h.query = q; h.column = unit*128u + d*32u + b + a.col_base; h.num_match = cnt; buf->rec[at++] = h; }
+			else{ store_hit(a, slot++, q, unit*128u + d*32u + b, cnt); }
+		}
+	}
+}
+
 // Add two bit-sliced counters: acc (PLANES planes) += b (the first nb planes of `b`, the rest zero).
 template <int PLANES, typename LOADB>
 __device__ __forceinline__ void planes_accumulate(u32x4 (&acc)[PLANES], int nb, LOADB loadb)
@@ -1219,6 +1330,9 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void count_walk_kernel(SearchAr
 	uint64_t s = (uint64_t)gw*wa.per_wave;
 	const uint64_t s1 = min(wa.total_slots, s + wa.per_wave);
 	if(s >= s1){ return; }
+	__shared__ WaveHitBuf hit_bufs[WALK_WG_WAVES];
+	WaveHitBuf *hbuf = &hit_bufs[threadIdx.x >> 6];
+	WaveHitState hst;
 	const uint32_t ct = wa.coltiles;
 
 	// the query that holds slot s: the largest q with ct*pos_off[q] <= s
@@ -1287,11 +1401,12 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void count_walk_kernel(SearchAr
 					rep = parent;
 				}
 			}
-			if(emit){ emit_count_hits<PLANES>(a, q, unit, plane, qthr[q], (uint64_t)q*a.runs_per_query + c, live); }
+			if(emit){ emit_count_hits_buffered<PLANES>(a, hbuf, hst, q, unit, plane, qthr[q], (uint64_t)q*a.runs_per_query + c, live); }
 		}
 		s += take;
 		if(j1 == npos && c + 1 == ct){ ++q; }
 	}
+	wave_hits_flush(a, hbuf, hst);          // one reservation for everything the wave found
 }
 
 // Narrow databases, count path: G queries per wave (see and_narrow_kernel).  A shorter k-mer list is padded
