@@ -184,7 +184,7 @@ struct Slot {
 struct Tuning {
 	int64_t walk = 4;               // KWAGE_WALK: and_walk_kernel's rows in flight (4 or 2); 0 = always the tiled kernel
 	int64_t walk_min_rows = -1;     // KWAGE_WALK_MIN_ROWS: batches with fewer rows use the tiled kernel (-1: 64 rows per wave of the chip)
-	int64_t walk_max_kib = 1024;    // KWAGE_WALK_MAX_KIB: widest row the walk form takes, in KiB-steps (rows wider than walk_tile_kib are walked column tile after column tile; round 4: no limit in practice -- with a wave's hit records buffered in LDS the walk form is at least as fast as the tiled kernel's wide shape on C3 / C4 and their column shares)
+	int64_t walk_max_kib = 16;      // KWAGE_WALK_MAX_KIB: widest row the walk form takes, in KiB-steps (wider rows: the tiled kernel's wide shape, which stays 0.5-3 % ahead on C3 / C4 and C3 split in two; the walk form handles them column tile after column tile when the knob is raised)
 	int64_t walk_short_rows = 0;    // KWAGE_WALK_SHORT_ROWS: batches averaging fewer rows per query take the tiled kernel's wide shape instead of the walk form (0: never -- the rule of the middle of round 4, when reservations stalled the walk form's load stream; profiles/r04_walk_hit_cost.txt)
 	int64_t walk_tile_kib = 16;     // KWAGE_WALK_TILE_KIB: widest column tile of the walk form in KiB-steps (rows wider than it are walked tile after tile)
 	int64_t walk_paced = 1;         // KWAGE_WALK_PACED: one KiB-step of the rows in flight at a time (0 with 8 rows in flight and tiles of <= 4: all steps at once)
