@@ -530,8 +530,10 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 			// Band after band (and_band_walk_kernel): matrices large enough to span several regions of the device's memory,
 			// one column tile, a slot of 16 KiB per query affordable.  (With early exit the tiled kernel is the default anyway.)
 			const uint64_t band_items = L->total_pos*a.num_hash;
-			const uint32_t bands = (tn.walk_bands < 0) ? (g->mixes_regions ? 3u : 0u)
-				: (g->alloc_bytes >= ((uint64_t)std::max<int64_t>(tn.walk_bands_min_gib, 0) << 30)) ? (uint32_t)std::min<int64_t>(tn.walk_bands, BAND_MAX) : 0u;
+			// (a matrix of at least walk_bands_min_gib either way: the probe's "mixes regions" on a 14 GB matrix of 1.6 KB rows --
+			// C2's columns split 8 ways -- sent that shape through the band form at 2.8x the walk form's time)
+			const bool big_enough = g->alloc_bytes >= ((uint64_t)std::max<int64_t>(tn.walk_bands_min_gib, 0) << 30);
+			const uint32_t bands = !big_enough ? 0u : (tn.walk_bands < 0) ? (g->mixes_regions ? 3u : 0u) : (uint32_t)std::min<int64_t>(tn.walk_bands, BAND_MAX);
 			if(bands >= 2 && coltiles == 1 &&
 			   (uint64_t)a.n_queries*16*1024 <= (256ull << 20) && band_items < 0x7FFFFFFFull){
 				BandArgs ba;
