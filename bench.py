@@ -507,13 +507,19 @@ def measure(env, args, name, headline):
         """nsteps passes, software-pipelined; -> hits of the last step (as delivered to rank 0)."""
         nhits = 0
         if sharded and pipe is not None:
-            # multi-GPU: step i+1's searches are queued before step i's hits are exchanged (one small all_gather over
-            # RCCL; what does not fit goes to rank 0 alone) and merged on rank 0
+            # multi-GPU: step i+1's searches are queued before step i is finished, and step i+2's right after -- BEFORE step
+            # i's hits are exchanged (one small all_gather over RCCL; what does not fit goes to rank 0 alone) and merged on
+            # rank 0: the collective's kernel waits for wave slots behind the running gather kernel, and the device must
+            # have the next gather kernel queued while the host waits for it (the pipeline's buffers rotate by three)
             pipe.begin(s.batch, threshold)
-            for _ in range(nsteps - 1):
+            if nsteps > 1:
                 pipe.begin(s.batch, threshold)
-                merged = hx.exchange_step(*local_finish())
-            merged = hx.exchange_step(*local_finish())
+            merged = None
+            for i in range(nsteps):
+                buf, n = local_finish()
+                if i + 2 < nsteps:
+                    pipe.begin(s.batch, threshold)
+                merged = hx.exchange_step(buf, n)
             nhits = len(merged) if merged is not None else 0
         elif not sharded:
             # The searches of all steps, group after group, stream through the two search slots of the context: search

@@ -383,14 +383,17 @@ class StepPipeline:
 
     A context runs two searches at a time (two slots): begin() queues a step's searches, finish() completes the
     oldest step, feeding the slots as they come free -- so the next step's first gather kernels are already running
-    while the caller exchanges the finished step's hits.  Two buffers alternate; at most two steps may be open."""
+    while the caller exchanges the finished step's hits.  At most two steps may be open; THREE buffers rotate, so that a
+    caller may begin step i+2 right after finish(i) and only then exchange step i's buffer: the exchange's collective is
+    a small kernel that waits for wave slots behind the running gather kernel, and with a third buffer the device has
+    step i+2's gather kernel queued behind step i+1's while the host waits for it."""
 
     def __init__(self, groups, column_bases, flags: int = 0, device: str = "cuda", initial_capacity: int = 1 << 18):
         import torch
         assert len(groups) == len(column_bases) and len(groups) >= 1
         self.groups, self.bases, self.flags, self.device = list(groups), [int(b) for b in column_bases], flags, device
         # torch.empty, not zeros: a fill kernel would run on torch's stream, unordered with the engine's streams
-        self.bufs = [torch.empty((1 + initial_capacity, 3), dtype=torch.int32, device=device) for _ in range(2)]
+        self.bufs = [torch.empty((1 + initial_capacity, 3), dtype=torch.int32, device=device) for _ in range(3)]
         self.steps = []            # open steps, oldest first: dicts
         self.todo = []             # (step, group index) not yet submitted, in order
         self.inflight = []         # (handle, step, group index), oldest first
@@ -424,7 +427,7 @@ class StepPipeline:
     def begin(self, batch, threshold: float):
         if len(self.steps) >= 2:
             raise RuntimeError("StepPipeline: two steps are open already; finish() one first")
-        step = {"id": self.next_id, "buf": self.next_id & 1, "batch": batch, "threshold": threshold, "done": 0, "n": 0, "ms": 0.0}
+        step = {"id": self.next_id, "buf": self.next_id % 3, "batch": batch, "threshold": threshold, "done": 0, "n": 0, "ms": 0.0}
         self.next_id += 1
         self.steps.append(step)
         self.todo += [(step, gi) for gi in range(len(self.groups))]
