@@ -174,7 +174,9 @@ int print_plan(const vector<string> &db_paths, int n_ranks)
 // (kwage_search_device_append_submit: the first search of a step zeroes the list's counter in stream order, every record
 // carries a GLOBAL column number).  The context runs two searches at a time: begin() queues a step's searches, finish()
 // completes the oldest step, feeding the slots as they come free -- so the next batch's first gather kernels are already
-// running while the finished batch's hits are exchanged over RCCL and filed on rank 0.  Two lists alternate.
+// running while the finished batch's hits are exchanged over RCCL and filed on rank 0.  THREE lists rotate: batch i+2 is
+// queued before batch i is exchanged (the collective's kernel waits for wave slots behind the running gather kernel, and
+// the device must have the next gather kernel queued while the host waits for it).
 struct HitList {
 	uint64_t *d_count = nullptr;         // the list's record counter (what the gather kernels add to)
 	kwage_hit *d_hits = nullptr;
@@ -198,7 +200,7 @@ struct RankPipeline {
 	int rank;
 	float threshold;
 	uint32_t flags;
-	HitList lists[2];
+	HitList lists[3];
 	uint32_t *d_nk = nullptr;            // where a search leaves num_query_kmer for the host (rank 0)
 	uint64_t nk_cap = 0;
 	struct Todo { Step *step; size_t gi; bool first; };
@@ -275,7 +277,7 @@ struct RankPipeline {
 	void begin(Step *st)
 	{
 		st->list = next_list;
-		next_list ^= 1;
+		next_list = (next_list + 1) % 3;
 		check(kwage_batch_create(ctx, st->q.bases.data(), st->q.offsets.data(), (uint32_t)st->q.size(), &st->b));
 		bool first = true;
 		for(size_t gi = 0; gi < groups.size(); ++gi){
@@ -532,10 +534,9 @@ int run_rank(int rank, int n_ranks, Bootstrap *boot, const Cli &cli, const vecto
 		};
 
 		// batches stream through: batch i+1 is parsed (on its own thread) and its searches queued BEFORE batch i is
-		// finished, exchanged and filed
-		unique_ptr<Step> open_step;
-		auto retire = [&](unique_ptr<Step> &st) {
-			pipe.finish(st.get());
+		// finished; batch i is exchanged and filed only AFTER batch i+2 has been queued (three lists rotate)
+		unique_ptr<Step> open_step, done_step;             // begun, not finished yet; finished, not exchanged yet
+		auto hand_over = [&](unique_ptr<Step> &st) {
 			exchange_and_file(st.get());
 			kwage_batch_destroy(st->b);
 			st.reset();
@@ -548,7 +549,8 @@ int run_rank(int rank, int n_ranks, Bootstrap *boot, const Cli &cli, const vecto
 				st->found = &found;
 				if(t_first_begin == 0){ t_first_begin = now_seconds(); }
 				pipe.begin(st.get());
-				if(open_step){ retire(open_step); }
+				if(done_step){ hand_over(done_step); }
+				if(open_step){ pipe.finish(open_step.get()); done_step = std::move(open_step); }
 				open_step = std::move(st);
 				open_step->q.bases = string();                      // resident on the device now
 			}
@@ -562,7 +564,8 @@ int run_rank(int rank, int n_ranks, Bootstrap *boot, const Cli &cli, const vecto
 			FileQueries disk(cli.query_files);
 			run_source(disk, from_files_);
 		}
-		if(open_step){ retire(open_step); }
+		if(done_step){ hand_over(done_step); }
+		if(open_step){ pipe.finish(open_step.get()); hand_over(open_step); }
 		const double t_search = now_seconds() - t_search0;
 		if(stats && rank == 0){
 			const double t_pipe = t_first_begin ? now_seconds() - t_first_begin : 0;
