@@ -124,10 +124,11 @@ int batch_prepare(kwage_batch *b, uint32_t k, const KmerLayout **out)
 	}
 	if(chunk_q.size() > 0x7FFFFFFFull){ return fail(KWAGE_ERR_ARG, "batch too large for one k-mer launch"); }
 	L->n_chunks = chunk_q.size();
-	HIP_TRY(hipMalloc(&L->d_chunk_q, std::max<size_t>(chunk_q.size(), 1)*sizeof(uint32_t)));
-	HIP_TRY(hipMalloc(&L->d_chunk_t0, std::max<size_t>(chunk_q.size(), 1)*sizeof(uint64_t)));
-	HIP_TRY(hipMalloc(&L->d_pos_off, ((size_t)n + 1)*sizeof(uint64_t)));
-	HIP_TRY(hipMalloc(&L->d_tab_off, std::max<size_t>(n, 1)*sizeof(uint64_t)));
+	L->pool = &b->ctx->batch_pool;
+	HIP_TRY(L->pool->take(std::max<size_t>(chunk_q.size(), 1)*sizeof(uint32_t), (void**)&L->d_chunk_q, &L->cap_chunk_q));
+	HIP_TRY(L->pool->take(std::max<size_t>(chunk_q.size(), 1)*sizeof(uint64_t), (void**)&L->d_chunk_t0, &L->cap_chunk_t0));
+	HIP_TRY(L->pool->take(((size_t)n + 1)*sizeof(uint64_t), (void**)&L->d_pos_off, &L->cap_pos_off));
+	HIP_TRY(L->pool->take(std::max<size_t>(n, 1)*sizeof(uint64_t), (void**)&L->d_tab_off, &L->cap_tab_off));
 	// (synchronous copies: the sources are locals, and the layout may be used on either search stream right away)
 	if(L->n_chunks){
 		HIP_TRY(hipMemcpy(L->d_chunk_q, chunk_q.data(), chunk_q.size()*sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1048,6 +1049,7 @@ extern "C" void kwage_shutdown(kwage_ctx *ctx)
 	}
 	if(ctx->gather_stream){ (void)hipStreamDestroy(ctx->gather_stream); }
 	ctx->kmers.release();
+	ctx->batch_pool.close();
 	ctx->result_pool->close();
 	for(int i = 0; i < 2; ++i){
 		ctx->load_pin[i].release(); ctx->load_dev[i].release();
@@ -1108,8 +1110,8 @@ extern "C" int kwage_batch_create(kwage_ctx *ctx, const char *seqs, const uint64
 	b->total_len = total;
 	b->h_seq_off.resize((size_t)n_queries + 1);
 	for(uint32_t i = 0; i <= n_queries; ++i){ b->h_seq_off[i] = offsets[i] - offsets[0]; }
-	hipError_t e = hipMalloc((void**)&b->d_seqs, std::max<uint64_t>(total, 16));
-	if(e == hipSuccess){ e = hipMalloc((void**)&b->d_seq_off, ((size_t)n_queries + 1)*sizeof(uint64_t)); }
+	hipError_t e = ctx->batch_pool.take(std::max<uint64_t>(total, 16), (void**)&b->d_seqs, &b->cap_seqs);
+	if(e == hipSuccess){ e = ctx->batch_pool.take(((size_t)n_queries + 1)*sizeof(uint64_t), (void**)&b->d_seq_off, &b->cap_seq_off); }
 	if(e == hipSuccess && total){ e = hipMemcpyAsync(b->d_seqs, seqs + offsets[0], total, hipMemcpyHostToDevice, ctx->stream); }
 	if(e == hipSuccess){ e = hipMemcpyAsync(b->d_seq_off, b->h_seq_off.data(), ((size_t)n_queries + 1)*sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream); }
 	if(e == hipSuccess){ e = hipStreamSynchronize(ctx->stream); }
@@ -1125,12 +1127,18 @@ extern "C" void kwage_batch_destroy(kwage_batch *b)
 {
 	if(!b){ return; }
 	(void)hipSetDevice(b->ctx->device);
-	(void)hipStreamSynchronize(b->ctx->gather_stream);
-	(void)hipStreamSynchronize(b->ctx->slot[0].stream);
-	(void)hipStreamSynchronize(b->ctx->slot[1].stream);
-	if(b->d_seqs){ (void)hipFree(b->d_seqs); }
-	if(b->d_seq_off){ (void)hipFree(b->d_seq_off); }
-	delete b;      // (its layouts free their device arrays)
+	// A search on this batch that has been collected is done with its device arrays; only one still pending would need
+	// waiting for (a caller's mistake: collect first).  Nothing here waits for the DEVICE: the blocks go back to the
+	// context's pool (hipFree would drain the software pipeline of a host that streams batches through the context).
+	for(int k = 0; k < 2; ++k){
+		if(b->ctx->slot[k].busy && b->ctx->slot[k].b == b){
+			(void)hipStreamSynchronize(b->ctx->gather_stream);
+			(void)hipStreamSynchronize(b->ctx->slot[k].stream);
+		}
+	}
+	b->ctx->batch_pool.give(b->d_seqs, b->cap_seqs);
+	b->ctx->batch_pool.give(b->d_seq_off, b->cap_seq_off);
+	delete b;      // (its layouts give their device arrays back too)
 }
 
 extern "C" uint32_t kwage_batch_num_queries(const kwage_batch *b) { return b ? b->n : 0; }

@@ -54,6 +54,46 @@ struct DevBuf {
 	}
 };
 
+// Device blocks of destroyed query batches, kept for the next ones.  hipFree waits for the whole device: a host that
+// streams batches through a context (the command lines: one batch created and one destroyed per step) would drain its
+// software pipeline at every batch.  Blocks go back here instead and are reused (best fit within 2x); what exceeds
+// KEEP bytes is really freed.
+struct DevPool {
+	struct Block { void *p; uint64_t cap; };
+	std::vector<Block> free_blocks;
+	uint64_t held = 0;
+	static constexpr uint64_t KEEP = 1ull << 30;
+	hipError_t take(uint64_t bytes, void **out, uint64_t *cap)
+	{
+		bytes = std::max<uint64_t>(bytes, 256);
+		size_t best = free_blocks.size();
+		for(size_t i = 0; i < free_blocks.size(); ++i){
+			if(free_blocks[i].cap >= bytes && free_blocks[i].cap <= 2*bytes + (1u << 20) && (best == free_blocks.size() || free_blocks[i].cap < free_blocks[best].cap)){ best = i; }
+		}
+		if(best != free_blocks.size()){
+			*out = free_blocks[best].p; *cap = free_blocks[best].cap;
+			held -= free_blocks[best].cap;
+			free_blocks.erase(free_blocks.begin() + (long)best);
+			return hipSuccess;
+		}
+		*cap = (bytes + 65535)/65536*65536;
+		return hipMalloc(out, *cap);
+	}
+	void give(void *p, uint64_t cap)
+	{
+		if(!p){ return; }
+		if(held + cap > KEEP){ (void)hipFree(p); return; }
+		free_blocks.push_back(Block{p, cap});
+		held += cap;
+	}
+	void close()
+	{
+		for(Block &b : free_blocks){ (void)hipFree(b.p); }
+		free_blocks.clear();
+		held = 0;
+	}
+};
+
 struct PinBuf {
 	void *p = nullptr;
 	uint64_t cap = 0;
@@ -236,6 +276,7 @@ struct kwage_ctx {
 	hipStream_t gather_stream = nullptr;    // the gather kernels of both slots, in submission order (see Slot)
 	kwage::Slot slot[2];
 	kwage::DevBuf kmers;                       // kwage_hash_batch output
+	kwage::DevPool batch_pool;                 // device blocks of destroyed query batches (kwage_batch_destroy never waits for the device)
 	// database loading: two pinned + two device staging buffers, kept across files
 	kwage::PinBuf load_pin[2];
 	kwage::DevBuf load_dev[3];                 // [2] is used by the copy-engine pipeline only (three chunks in flight)
@@ -299,12 +340,15 @@ struct KmerLayout {
 	uint64_t n_chunks = 0;
 	bool multi_chunk = false;          // some query has more than one chunk
 	std::vector<uint64_t> h_pos_off;
+	DevPool *pool = nullptr;           // where the four device arrays came from and go back to (the context's)
+	uint64_t cap_pos_off = 0, cap_tab_off = 0, cap_chunk_q = 0, cap_chunk_t0 = 0;
 	~KmerLayout()
 	{
-		if(d_pos_off){ (void)hipFree(d_pos_off); }
-		if(d_tab_off){ (void)hipFree(d_tab_off); }
-		if(d_chunk_q){ (void)hipFree(d_chunk_q); }
-		if(d_chunk_t0){ (void)hipFree(d_chunk_t0); }
+		if(!pool){ return; }
+		pool->give(d_pos_off, cap_pos_off);
+		pool->give(d_tab_off, cap_tab_off);
+		pool->give(d_chunk_q, cap_chunk_q);
+		pool->give(d_chunk_t0, cap_chunk_t0);
 	}
 };
 
@@ -316,6 +360,7 @@ struct kwage_batch {
 	uint64_t total_len = 0;
 	char *d_seqs = nullptr;
 	uint64_t *d_seq_off = nullptr;
+	uint64_t cap_seqs = 0, cap_seq_off = 0;      // blocks of the context's batch pool
 	std::vector<uint64_t> h_seq_off;
 	// One layout per k-mer length the batch has been searched with (a database directory may hold files of several
 	// k: two or three in practice).  A layout never changes once built, so searches with different k-mer lengths can
