@@ -1,7 +1,7 @@
 // kwage_amd/csrc/builder.hip -- database construction on the device:
 // the bit transpose at the heart of the reference's build_db() (build_db.cpp:24-456, loop
 // :259-315: for every set bit k of filter j, set bit j of slice k -- one get_bit/set_bit pair per
-// bit, single threaded) done as a wave-ballot transpose on the GPU, writing a `.db` file that is
+// bit, single threaded) done as a transpose of 32 x 32 bit blocks in registers on the GPU, writing a `.db` file that is
 // byte-identical to the reference's for the same `.bloom` inputs.
 //
 // `.bloom` file = binary_write<BloomFilter> (binary_io.cpp:182-208): 1 magic byte (0xFF complete),
@@ -30,68 +30,111 @@ using namespace kwage;
 
 namespace {
 
-// One workgroup = 16 waves = 1024 filters x 128 slices.  Lane j of wave w holds 16 bytes (128
-// consecutive bits) of filter f0 + 64w + j; bit b of all 64 lanes is gathered with one ballot into
-// the 8 output bytes that slice (row0 + b) needs for those 64 filters.  The 128 x 128-byte tile is
-// assembled in LDS and written out as full 128-byte row segments.
-static constexpr int TB_WAVES = 16;
-static constexpr int TB_ROWS = 128;
+// One workgroup = 8 waves = a tile of FILTERS filters x ROWS slices (TransposeTile: 64 KB in, 64 KB out).
+//
+// A lane holds a 32 x 32 bit block: one dword (32 consecutive slices) of each of 32 consecutive filters, loaded so
+// that LD consecutive lanes read consecutive dwords of the same filter (64- or 128-byte runs per filter), transposes
+// it in registers (five rounds of masked half-block swaps, ~480 integer operations for 1024 bits -- the ballot form
+// this replaces spent five instructions per 64 bits and was VALU-bound at 0.15 of the HBM rate) and leaves 32 dwords
+// in LDS: slice (32d + b), the four bytes of its 32 filters.  The tile is then written out as whole row segments of
+// FILTERS/8 bytes, 16 bytes per thread.  LDS columns are rotated by 16 bytes per 32 slices so that the lanes of
+// one store spread over the banks (rows are FILTERS/8 = 128 or 64 bytes apart).
+template<int LD, int TB_WAVES> struct TransposeTile {
+	static constexpr int WAVES = TB_WAVES;
+	static constexpr int ROWS = 32*LD;                        // slices per tile
+	static constexpr int GROUPS = TB_WAVES*(64/LD);           // 32-filter groups per tile
+	static constexpr int FILTERS = 32*GROUPS;
+	static constexpr int PITCH = GROUPS;                      // dwords per LDS row
+	static_assert(ROWS*PITCH*4 == TB_WAVES*8*1024, "8 KB per wave");
+};
 
+__device__ inline void transpose_32x32(uint32_t (&a)[32])
+{
+	// a[i] bit b  <->  a[b] bit i (both LSB-first)
+#pragma unroll
+	for(int s = 0; s < 5; ++s){
+		const int j = 16 >> s;
+		const uint32_t m = s == 0 ? 0x0000FFFFu : s == 1 ? 0x00FF00FFu : s == 2 ? 0x0F0F0F0Fu : s == 3 ? 0x33333333u : 0x55555555u;
+#pragma unroll
+		for(int k = 0; k < 32; ++k){
+			if(k & j){ continue; }
+			const uint32_t t = ((a[k] >> j) ^ a[k + j]) & m;
+			a[k + j] ^= t;
+			a[k] ^= t << j;
+		}
+	}
+}
+
+template<int LD, int TB_WAVES>
 __global__ __launch_bounds__(TB_WAVES*64) void transpose_bits_kernel(
 	const uint8_t *__restrict__ in, uint64_t in_stride,   // [n_filters][in_stride bytes]: this chunk's bits
 	uint32_t n_filters, uint64_t chunk_rows,              // rows in this chunk (multiple of 8)
 	uint8_t *__restrict__ out, uint64_t slice_size)       // [chunk_rows][slice_size]
 {
-	__shared__ unsigned long long tile[TB_ROWS][TB_WAVES];
+	using T = TransposeTile<LD, TB_WAVES>;
+	__shared__ uint32_t tile[T::ROWS*T::PITCH];
 
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wave = threadIdx.x >> 6;
-	const uint64_t row0 = (uint64_t)blockIdx.x*TB_ROWS;
-	const uint32_t f0 = blockIdx.y*(TB_WAVES*64);
-	const uint32_t f = f0 + wave*64 + lane;
+	const uint32_t d = lane % LD;                             // dword of the tile's row range
+	const uint32_t g = wave*(64/LD) + lane/LD;                // 32-filter group of the tile
+	const uint64_t row0 = (uint64_t)blockIdx.x*T::ROWS;
+	const uint32_t f0 = blockIdx.y*T::FILTERS;
 
-	uint32_t w[4] = {0, 0, 0, 0};
-	if(f < n_filters){
-		const uint8_t *src = in + (uint64_t)f*in_stride + row0/8;
-		const uint64_t avail = (chunk_rows - row0 + 7)/8;           // bytes of this filter left in the chunk
-		if(avail >= 16 && ((((uintptr_t)src) & 3) == 0)){
-			const uint32_t *s32 = reinterpret_cast<const uint32_t*>(src);
-			w[0] = s32[0]; w[1] = s32[1]; w[2] = s32[2]; w[3] = s32[3];
-		}
-		else{
-			for(uint32_t b = 0; b < 16 && b < avail; ++b){ w[b >> 2] |= (uint32_t)src[b] << (8*(b & 3)); }
-		}
-	}
-
-	// lane (b & 63) keeps the ballot of bit b; two ballots per lane
-	unsigned long long keep0 = 0, keep1 = 0;
+	// bytes of a filter left in the chunk from the tile's first slice on
+	const uint64_t tile_bytes = (chunk_rows - row0 + 7)/8;
+	const uint32_t first = f0 + 32*g;                         // this lane's 32 filters
+	uint32_t a[32];
+	if(tile_bytes >= 4ull*LD && (in_stride & 3) == 0 && (((uintptr_t)in) & 3) == 0){
+		// the whole row range of the tile exists and dwords are aligned (uniform over the workgroup): 32 loads in flight
+		// per lane, no branch between them; filters past the last one read the last one's dword and are zeroed afterwards
+		const uint32_t last = first < n_filters ? std::min<uint32_t>(31u, n_filters - 1 - first) : 0u;
+		const uint8_t *base = in + (uint64_t)(first < n_filters ? first : 0u)*in_stride + row0/8 + 4*d;
 #pragma unroll
-	for(int b = 0; b < 128; ++b){
-		const unsigned long long m = __ballot((w[b >> 5] >> (b & 31)) & 1u);
-		if(b < 64){ if(lane == (uint32_t)b){ keep0 = m; } }
-		else{ if(lane == (uint32_t)(b - 64)){ keep1 = m; } }
+		for(int i = 0; i < 32; ++i){
+			a[i] = *reinterpret_cast<const uint32_t*>(base + (uint64_t)std::min<uint32_t>((uint32_t)i, last)*in_stride);
+		}
+#pragma unroll
+		for(int i = 0; i < 32; ++i){ a[i] = first + i < n_filters ? a[i] : 0u; }
 	}
-	tile[lane][wave] = keep0;
-	tile[64 + lane][wave] = keep1;
+	else{
+		// the last rows of a chunk, or filters shorter than a dword: byte by byte
+		const uint32_t have = tile_bytes > 4ull*d ? (uint32_t)std::min<uint64_t>(4, tile_bytes - 4ull*d) : 0;
+#pragma unroll 1
+		for(int i = 0; i < 32; ++i){
+			const uint32_t f = first + i;
+			uint32_t v = 0;
+			if(f < n_filters){
+				const uint8_t *src = in + (uint64_t)f*in_stride + row0/8 + 4*d;
+				for(uint32_t b = 0; b < have; ++b){ v |= (uint32_t)src[b] << (8*b); }
+			}
+			a[i] = v;
+		}
+	}
+	transpose_32x32(a);
+	{
+		const uint32_t col = (g + 4*d) % T::PITCH;            // rotation: 4 dwords (16 bytes) per 32 slices
+#pragma unroll
+		for(int b = 0; b < 32; ++b){ tile[(32*d + b)*T::PITCH + col] = a[b]; }
+	}
 	__syncthreads();
 
-	// write the tile: 128 rows x up to 128 bytes; thread t moves 16 bytes
-	const uint64_t col0 = f0/8;                                   // first output byte of this filter block
-	const uint8_t *t8 = reinterpret_cast<const uint8_t*>(&tile[0][0]);
-	for(uint32_t i = threadIdx.x; i < TB_ROWS*8; i += blockDim.x){
-		const uint32_t r = i >> 3, seg = i & 7;                   // 8 segments of 16 bytes per row
+	// write the tile: ROWS rows x FILTERS/8 bytes; a thread moves 16 bytes
+	constexpr uint32_t SEGS = T::PITCH/4;                     // 16-byte segments per row
+	const uint64_t col0 = f0/8;                               // first output byte of this filter block
+	for(uint32_t i = threadIdx.x; i < T::ROWS*SEGS; i += TB_WAVES*64){
+		const uint32_t r = i / SEGS, seg = i % SEGS;
 		const uint64_t row = row0 + r;
 		if(row >= chunk_rows){ continue; }
 		const uint64_t cb = col0 + seg*16;
 		if(cb >= slice_size){ continue; }
 		const uint64_t nb = std::min<uint64_t>(16, slice_size - cb);
 		uint8_t *dst = out + row*slice_size + cb;
-		const uint8_t *srcb = t8 + r*(TB_WAVES*8) + seg*16;
-		if(nb == 16 && ((((uintptr_t)dst) & 15) == 0)){
-			*reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(srcb);
-		}
+		const uint4 v = *reinterpret_cast<const uint4*>(&tile[r*T::PITCH + 4*((seg + r/32) % SEGS)]);
+		if(nb == 16 && ((((uintptr_t)dst) & 15) == 0)){ *reinterpret_cast<uint4*>(dst) = v; }
 		else{
-			for(uint64_t b = 0; b < nb; ++b){ dst[b] = srcb[b]; }
+			const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+			for(uint64_t b = 0; b < nb; ++b){ dst[b] = (uint8_t)(w[b >> 2] >> (8*(b & 3))); }
 		}
 	}
 }
@@ -255,6 +298,9 @@ extern "C" int kwage_build_db(kwage_ctx *ctx, const char *out_path, const kwage_
 	if(e == hipSuccess){ e = hipHostMalloc(&h_out, chunk_rows*slice_size, hipHostMallocDefault); }
 	uint32_t db_crc = 0;            // output_header.crc32 starts at 0 (build_db.cpp:192,307)
 	double t_kernel_ms = 0;
+	// tile shape, KWAGE_BUILD_TILE: 0 = 1024 filters x 512 slices (64-byte reads per filter, 128-byte row segments out),
+	// 1 = 512 x 1024 (128-byte reads, 64-byte segments), 2 = 512 x 512 and 3 = 256 x 1024 with four waves (32 KB of LDS)
+	const int tile_shape = []() { const char *v = getenv("KWAGE_BUILD_TILE"); return v ? atoi(v) : 0; }();
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	if(e == hipSuccess){ e = hipEventCreate(&ev0); }
 	if(e == hipSuccess){ e = hipEventCreate(&ev1); }
@@ -266,10 +312,19 @@ extern "C" int kwage_build_db(kwage_ctx *ctx, const char *out_path, const kwage_
 		}
 		e = hipMemcpyAsync(d_in, h_in, in_stride*n, hipMemcpyHostToDevice, stream);
 		if(e != hipSuccess){ break; }
-		const dim3 grid((uint32_t)((nr + TB_ROWS - 1)/TB_ROWS), (n + TB_WAVES*64 - 1)/(TB_WAVES*64));
 		(void)hipEventRecord(ev0, stream);
-		hipLaunchKernelGGL(transpose_bits_kernel, grid, dim3(TB_WAVES*64), 0, stream,
-		                   (const uint8_t*)d_in, in_stride, n, nr, (uint8_t*)d_out, slice_size);
+		auto launch = [&](auto tile_tag) {
+			using T = decltype(tile_tag);
+			const dim3 grid((uint32_t)((nr + T::ROWS - 1)/T::ROWS), (n + T::FILTERS - 1)/T::FILTERS);
+			hipLaunchKernelGGL((transpose_bits_kernel<T::ROWS/32, T::WAVES>), grid, dim3(T::WAVES*64), 0, stream,
+			                   (const uint8_t*)d_in, in_stride, n, nr, (uint8_t*)d_out, slice_size);
+		};
+		switch(tile_shape){
+		case 1: launch(TransposeTile<32, 8>()); break;
+		case 2: launch(TransposeTile<16, 4>()); break;
+		case 3: launch(TransposeTile<32, 4>()); break;
+		default: launch(TransposeTile<16, 8>()); break;
+		}
 		(void)hipEventRecord(ev1, stream);
 		e = hipGetLastError();
 		if(e == hipSuccess){ e = hipMemcpyAsync(h_out, d_out, nr*slice_size, hipMemcpyDeviceToHost, stream); }

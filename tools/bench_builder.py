@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Device bit-transpose database builder vs the reference's build_db() (oracle/_ref/ref_tool build)
-on the same `.bloom` files.   python tools/bench_builder.py [n_filters] [log2_len]"""
+on the same `.bloom` files.   python tools/bench_builder.py [n_filters] [log2_len] [noref]"""
 import ctypes as C
 import os
 import shutil
@@ -46,7 +46,7 @@ try:
     print("device builder: %d filters x 2^%d bits: wall %.3f s (file I/O + CRC32 + transpose), transpose kernel %.3f ms "
           "= %.1f G bits/s, %.1f GB/s in+out" % (n, L, best, st.transpose_kernel_ms, bits_total / st.transpose_kernel_ms / 1e6,
                                                   2 * bits_total / 8 / st.transpose_kernel_ms / 1e6))
-    if os.access(oracle.REF_TOOL, os.X_OK):
+    if os.access(oracle.REF_TOOL, os.X_OK) and "noref" not in sys.argv[3:]:
         ref = os.path.join(tmp, "ref.db")
         t0 = time.perf_counter()
         subprocess.check_call([oracle.REF_TOOL, "build", ref, "31", str(L), "1", lst])
