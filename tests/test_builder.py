@@ -182,6 +182,27 @@ def test_repack_is_the_column_concatenation(oracle, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [1, 2, 3])
+def test_every_transpose_tile_shape_builds_the_same_file(oracle, tmp_path, shape):
+    """KWAGE_BUILD_TILE (read once per process) selects the transpose kernel's tile: 1300 filters x 2^12 bits cover partial
+    filter tiles, row tiles and an output row that is not a multiple of 16 bytes, for the three shapes that are not the default."""
+    import subprocess
+    from kwage_amd import native
+    tool = os.path.join(os.path.dirname(native.KWAGE_BIN), "kwage_dbtool")
+    rng = np.random.default_rng(77)
+    paths = []
+    for j in range(1300):
+        p = str(tmp_path / ("f%04d.bloom" % j))
+        oracle.write_bloom(p, 21, 12, 1, oracle.FilterInfo(run_accession=oracle.str_to_accession("SRR%d" % (j + 1))),
+                           rng.integers(0, 256, size=512, dtype=np.uint8))
+        paths.append(p)
+    out = str(tmp_path / "out.db")
+    r = subprocess.run([tool, "build", out, "21", "12", "1"] + paths, capture_output=True, text=True, env=dict(os.environ, KWAGE_BUILD_TILE=str(shape)))
+    assert r.returncode == 0, r.stderr
+    assert open(out, "rb").read() == oracle.build_db_bytes(paths)
+
+
+@pytest.mark.gpu
 def test_dbtool_front_end(tmp_path):
     """kwage_dbtool drives the same C-ABI entry points from the shell."""
     import subprocess
