@@ -65,37 +65,23 @@ __device__ inline void transpose_32x32(uint32_t (&a)[32])
 	}
 }
 
-template<int LD, int TB_WAVES>
-__global__ __launch_bounds__(TB_WAVES*64) void transpose_bits_kernel(
-	const uint8_t *__restrict__ in, uint64_t in_stride,   // [n_filters][in_stride bytes]: this chunk's bits
-	uint32_t n_filters, uint64_t chunk_rows,              // rows in this chunk (multiple of 8)
-	uint8_t *__restrict__ out, uint64_t slice_size)       // [chunk_rows][slice_size]
+// A lane's 32 dwords of tile (row0, f0): the loads are ISSUED here and nothing else touches the values on the fast path
+// (filters past the last one read the last one's dword; tile_zero_past_end() clears them before the transpose), so the
+// caller can leave them in flight behind other work.
+template<int LD>
+__device__ __forceinline__ void tile_request(uint32_t (&a)[32], const uint8_t *__restrict__ in, uint64_t in_stride, uint32_t n_filters,
+                                             uint64_t chunk_rows, uint64_t row0, uint32_t first, uint32_t d)
 {
-	using T = TransposeTile<LD, TB_WAVES>;
-	__shared__ uint32_t tile[T::ROWS*T::PITCH];
-
-	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t wave = threadIdx.x >> 6;
-	const uint32_t d = lane % LD;                             // dword of the tile's row range
-	const uint32_t g = wave*(64/LD) + lane/LD;                // 32-filter group of the tile
-	const uint64_t row0 = (uint64_t)blockIdx.x*T::ROWS;
-	const uint32_t f0 = blockIdx.y*T::FILTERS;
-
-	// bytes of a filter left in the chunk from the tile's first slice on
-	const uint64_t tile_bytes = (chunk_rows - row0 + 7)/8;
-	const uint32_t first = f0 + 32*g;                         // this lane's 32 filters
-	uint32_t a[32];
+	const uint64_t tile_bytes = (chunk_rows - row0 + 7)/8;    // bytes of a filter left in the chunk from the tile's first slice on
 	if(tile_bytes >= 4ull*LD && (in_stride & 3) == 0 && (((uintptr_t)in) & 3) == 0){
 		// the whole row range of the tile exists and dwords are aligned (uniform over the workgroup): 32 loads in flight
-		// per lane, no branch between them; filters past the last one read the last one's dword and are zeroed afterwards
+		// per lane, no branch between them
 		const uint32_t last = first < n_filters ? std::min<uint32_t>(31u, n_filters - 1 - first) : 0u;
 		const uint8_t *base = in + (uint64_t)(first < n_filters ? first : 0u)*in_stride + row0/8 + 4*d;
 #pragma unroll
 		for(int i = 0; i < 32; ++i){
 			a[i] = *reinterpret_cast<const uint32_t*>(base + (uint64_t)std::min<uint32_t>((uint32_t)i, last)*in_stride);
 		}
-#pragma unroll
-		for(int i = 0; i < 32; ++i){ a[i] = first + i < n_filters ? a[i] : 0u; }
 	}
 	else{
 		// the last rows of a chunk, or filters shorter than a dword: byte by byte
@@ -111,31 +97,75 @@ __global__ __launch_bounds__(TB_WAVES*64) void transpose_bits_kernel(
 			a[i] = v;
 		}
 	}
-	transpose_32x32(a);
-	{
-		const uint32_t col = (g + 4*d) % T::PITCH;            // rotation: 4 dwords (16 bytes) per 32 slices
-#pragma unroll
-		for(int b = 0; b < 32; ++b){ tile[(32*d + b)*T::PITCH + col] = a[b]; }
-	}
-	__syncthreads();
+}
 
-	// write the tile: ROWS rows x FILTERS/8 bytes; a thread moves 16 bytes
-	constexpr uint32_t SEGS = T::PITCH/4;                     // 16-byte segments per row
-	const uint64_t col0 = f0/8;                               // first output byte of this filter block
-	for(uint32_t i = threadIdx.x; i < T::ROWS*SEGS; i += TB_WAVES*64){
-		const uint32_t r = i / SEGS, seg = i % SEGS;
-		const uint64_t row = row0 + r;
-		if(row >= chunk_rows){ continue; }
-		const uint64_t cb = col0 + seg*16;
-		if(cb >= slice_size){ continue; }
-		const uint64_t nb = std::min<uint64_t>(16, slice_size - cb);
-		uint8_t *dst = out + row*slice_size + cb;
-		const uint4 v = *reinterpret_cast<const uint4*>(&tile[r*T::PITCH + 4*((seg + r/32) % SEGS)]);
-		if(nb == 16 && ((((uintptr_t)dst) & 15) == 0)){ *reinterpret_cast<uint4*>(dst) = v; }
-		else{
-			const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-			for(uint64_t b = 0; b < nb; ++b){ dst[b] = (uint8_t)(w[b >> 2] >> (8*(b & 3))); }
+__device__ __forceinline__ void tile_zero_past_end(uint32_t (&a)[32], uint32_t first, uint32_t n_filters)
+{
+#pragma unroll
+	for(int i = 0; i < 32; ++i){ a[i] = first + i < n_filters ? a[i] : 0u; }
+}
+
+// PERSISTENT: a workgroup takes tiles t = blockIdx.x, + gridDim.x, ... (slice tiles fastest); the next tile's 32 loads per
+// lane are requested before the current tile is written out of LDS, so reads and writes of a CU overlap although the
+// 64 KB tile leaves room for only two workgroups per CU (one tile per workgroup, no overlap: 3.8 TB/s in + out; a
+// device-to-device copy on the same box 5.3).
+template<int LD, int TB_WAVES>
+__global__ __launch_bounds__(TB_WAVES*64) void transpose_bits_kernel(
+	const uint8_t *__restrict__ in, uint64_t in_stride,   // [n_filters][in_stride bytes]: this chunk's bits
+	uint32_t n_filters, uint64_t chunk_rows,              // rows in this chunk (multiple of 8)
+	uint8_t *__restrict__ out, uint64_t slice_size,       // [chunk_rows][slice_size]
+	uint32_t tiles_x, uint32_t n_tiles)                   // slice tiles per filter tile, tiles in all
+{
+	using T = TransposeTile<LD, TB_WAVES>;
+	__shared__ uint32_t tile[T::ROWS*T::PITCH];
+
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = threadIdx.x >> 6;
+	const uint32_t d = lane % LD;                             // dword of the tile's row range
+	const uint32_t g = wave*(64/LD) + lane/LD;                // 32-filter group of the tile
+	constexpr uint32_t SEGS = T::PITCH/4;                     // 16-byte segments per row of the tile
+
+	uint32_t t = blockIdx.x;
+	if(t >= n_tiles){ return; }
+	uint32_t a[32];
+	tile_request<LD>(a, in, in_stride, n_filters, chunk_rows, (uint64_t)(t % tiles_x)*T::ROWS, (t / tiles_x)*T::FILTERS + 32*g, d);
+	for(;;){
+		const uint64_t row0 = (uint64_t)(t % tiles_x)*T::ROWS;
+		const uint32_t f0 = (t / tiles_x)*T::FILTERS;
+		tile_zero_past_end(a, f0 + 32*g, n_filters);
+		transpose_32x32(a);
+		{
+			const uint32_t col = (g + 4*d) % T::PITCH;        // rotation: 4 dwords (16 bytes) per 32 slices
+#pragma unroll
+			for(int b = 0; b < 32; ++b){ tile[(32*d + b)*T::PITCH + col] = a[b]; }
 		}
+		__syncthreads();
+
+		const uint32_t tn = t + gridDim.x;
+		if(tn < n_tiles){
+			tile_request<LD>(a, in, in_stride, n_filters, chunk_rows, (uint64_t)(tn % tiles_x)*T::ROWS, (tn / tiles_x)*T::FILTERS + 32*g, d);
+		}
+
+		// write the tile: ROWS rows x FILTERS/8 bytes; a thread moves 16 bytes
+		const uint64_t col0 = f0/8;                           // first output byte of this filter block
+		for(uint32_t i = threadIdx.x; i < T::ROWS*SEGS; i += TB_WAVES*64){
+			const uint32_t r = i / SEGS, seg = i % SEGS;
+			const uint64_t row = row0 + r;
+			if(row >= chunk_rows){ continue; }
+			const uint64_t cb = col0 + seg*16;
+			if(cb >= slice_size){ continue; }
+			const uint64_t nb = std::min<uint64_t>(16, slice_size - cb);
+			uint8_t *dst = out + row*slice_size + cb;
+			const uint4 v = *reinterpret_cast<const uint4*>(&tile[r*T::PITCH + 4*((seg + r/32) % SEGS)]);
+			if(nb == 16 && ((((uintptr_t)dst) & 15) == 0)){ *reinterpret_cast<uint4*>(dst) = v; }
+			else{
+				const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+				for(uint64_t b = 0; b < nb; ++b){ dst[b] = (uint8_t)(w[b >> 2] >> (8*(b & 3))); }
+			}
+		}
+		__syncthreads();                                      // the tile is free again
+		if(tn >= n_tiles){ break; }
+		t = tn;
 	}
 }
 
@@ -290,7 +320,13 @@ extern "C" int kwage_build_db(kwage_ctx *ctx, const char *out_path, const kwage_
 	// chunk rows: bounded so that the input (n x rows/8) and the output (rows x slice) both stay <= 512 MiB
 	uint64_t chunk_rows = filter_len;
 	while(chunk_rows > 1024 && (chunk_rows/8*n > (512ull << 20) || chunk_rows*slice_size > (512ull << 20))){ chunk_rows /= 2; }
-	const uint64_t in_stride = (chunk_rows + 7)/8;
+	// Filters lie `in_stride` apart in the device's input block, and a lane's 32 loads go to 32 consecutive filters at the
+	// same offset: with a power-of-two stride they all fall on the same few memory channels (3.87 TB/s in + out; a stride of
+	// an ODD number of 256-byte units: 4.43-4.50, profiles/r04_builder_transpose.txt).  KWAGE_BUILD_PAD = bytes added instead.
+	const uint64_t chunk_bytes = (chunk_rows + 7)/8;
+	uint64_t in_stride = (chunk_bytes + 255)/256*256;
+	if((in_stride/256) % 2 == 0){ in_stride += 256; }
+	if(const char *v = getenv("KWAGE_BUILD_PAD")){ in_stride = chunk_bytes + (uint64_t)atoll(v)/4*4; }
 	void *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
 	hipError_t e = hipMalloc(&d_in, in_stride*n);
 	if(e == hipSuccess){ e = hipMalloc(&d_out, chunk_rows*slice_size); }
@@ -301,6 +337,11 @@ extern "C" int kwage_build_db(kwage_ctx *ctx, const char *out_path, const kwage_
 	// tile shape, KWAGE_BUILD_TILE: 0 = 1024 filters x 512 slices (64-byte reads per filter, 128-byte row segments out),
 	// 1 = 512 x 1024 (128-byte reads, 64-byte segments), 2 = 512 x 512 and 3 = 256 x 1024 with four waves (32 KB of LDS)
 	const int tile_shape = []() { const char *v = getenv("KWAGE_BUILD_TILE"); return v ? atoi(v) : 0; }();
+	// KWAGE_BUILD_PERSISTENT=1: a resident grid walking the tiles, the next tile requested before the current one is written
+	// out, instead of one workgroup per tile (measured 10 % SLOWER: profiles/r04_builder_transpose.txt)
+	const bool persistent = []() { const char *v = getenv("KWAGE_BUILD_PERSISTENT"); return v && atoi(v) != 0; }();
+	int n_cus = 256;
+	(void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, ctx_device(ctx));
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	if(e == hipSuccess){ e = hipEventCreate(&ev0); }
 	if(e == hipSuccess){ e = hipEventCreate(&ev1); }
@@ -315,9 +356,11 @@ extern "C" int kwage_build_db(kwage_ctx *ctx, const char *out_path, const kwage_
 		(void)hipEventRecord(ev0, stream);
 		auto launch = [&](auto tile_tag) {
 			using T = decltype(tile_tag);
-			const dim3 grid((uint32_t)((nr + T::ROWS - 1)/T::ROWS), (n + T::FILTERS - 1)/T::FILTERS);
-			hipLaunchKernelGGL((transpose_bits_kernel<T::ROWS/32, T::WAVES>), grid, dim3(T::WAVES*64), 0, stream,
-			                   (const uint8_t*)d_in, in_stride, n, nr, (uint8_t*)d_out, slice_size);
+			const uint64_t tiles_x = (nr + T::ROWS - 1)/T::ROWS, tiles = tiles_x*((n + T::FILTERS - 1)/T::FILTERS);
+			const uint64_t resident = (uint64_t)n_cus*(128/(T::WAVES*8));      // workgroups the device holds at once (LDS: 8 KB per wave)
+			const uint32_t wgs = (uint32_t)std::min<uint64_t>(tiles, persistent ? resident : tiles);
+			hipLaunchKernelGGL((transpose_bits_kernel<T::ROWS/32, T::WAVES>), dim3(wgs), dim3(T::WAVES*64), 0, stream,
+			                   (const uint8_t*)d_in, in_stride, n, nr, (uint8_t*)d_out, slice_size, (uint32_t)tiles_x, (uint32_t)tiles);
 		};
 		switch(tile_shape){
 		case 1: launch(TransposeTile<32, 8>()); break;

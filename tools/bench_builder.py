@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Device bit-transpose database builder vs the reference's build_db() (oracle/_ref/ref_tool build)
-on the same `.bloom` files.   python tools/bench_builder.py [n_filters] [log2_len] [noref]"""
+on the same `.bloom` files.   python tools/bench_builder.py [n_filters] [log2_len] [noref] [copyref]"""
 import ctypes as C
 import os
 import shutil
@@ -46,6 +46,19 @@ try:
     print("device builder: %d filters x 2^%d bits: wall %.3f s (file I/O + CRC32 + transpose), transpose kernel %.3f ms "
           "= %.1f G bits/s, %.1f GB/s in+out" % (n, L, best, st.transpose_kernel_ms, bits_total / st.transpose_kernel_ms / 1e6,
                                                   2 * bits_total / 8 / st.transpose_kernel_ms / 1e6))
+    if "copyref" in sys.argv[3:]:
+        # what a kernel that writes as much as it reads can reach on this box: a device-to-device copy of one chunk's size
+        import torch
+        nbytes = min(bits_total // 8, 512 << 20)
+        a = torch.empty(nbytes, dtype=torch.uint8, device="cuda"); b = torch.empty_like(a)
+        a.fill_(3); b.copy_(a); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            b.copy_(a)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        print("device-to-device copy of %d MB: %.3f ms = %.1f GB/s in+out" % (nbytes >> 20, ms, 2 * nbytes / ms / 1e6))
     if os.access(oracle.REF_TOOL, os.X_OK) and "noref" not in sys.argv[3:]:
         ref = os.path.join(tmp, "ref.db")
         t0 = time.perf_counter()
