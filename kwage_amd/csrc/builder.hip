@@ -105,10 +105,10 @@ __device__ __forceinline__ void tile_zero_past_end(uint32_t (&a)[32], uint32_t f
 	for(int i = 0; i < 32; ++i){ a[i] = first + i < n_filters ? a[i] : 0u; }
 }
 
-// PERSISTENT: a workgroup takes tiles t = blockIdx.x, + gridDim.x, ... (slice tiles fastest); the next tile's 32 loads per
-// lane are requested before the current tile is written out of LDS, so reads and writes of a CU overlap although the
-// 64 KB tile leaves room for only two workgroups per CU (one tile per workgroup, no overlap: 3.8 TB/s in + out; a
-// device-to-device copy on the same box 5.3).
+// A workgroup takes tiles t = blockIdx.x, + gridDim.x, ... (slice tiles fastest).  The launch has one workgroup per tile.
+// (KWAGE_BUILD_PERSISTENT=1: a resident grid instead -- the next tile's 32 loads per lane are then requested before the
+// current tile is written out of LDS, so that reads and writes of a CU overlap although the 64 KB tile leaves room for
+// only two workgroups per CU; measured 8-10 % slower than leaving the order of the tiles to the dispatcher.)
 template<int LD, int TB_WAVES>
 __global__ __launch_bounds__(TB_WAVES*64) void transpose_bits_kernel(
 	const uint8_t *__restrict__ in, uint64_t in_stride,   // [n_filters][in_stride bytes]: this chunk's bits
