@@ -317,9 +317,10 @@ extern "C" int kwage_build_db(kwage_ctx *ctx, const char *out_path, const kwage_
 	bool ok = fwrite(hdr, 1, sizeof(hdr), fout) == sizeof(hdr);
 
 	// ---- transpose, chunk by chunk --------------------------------------------------------------
-	// chunk rows: bounded so that the input (n x rows/8) and the output (rows x slice) both stay <= 512 MiB
+	// chunk rows: bounded so that the input (n x rows/8) and the output (rows x slice) both stay <= 256 MiB (the output is
+	// double-buffered: a chunk's CRC32 and file write run on a host thread beside the next chunk's gather, copies and kernel)
 	uint64_t chunk_rows = filter_len;
-	while(chunk_rows > 1024 && (chunk_rows/8*n > (512ull << 20) || chunk_rows*slice_size > (512ull << 20))){ chunk_rows /= 2; }
+	while(chunk_rows > 1024 && (chunk_rows/8*n > (256ull << 20) || chunk_rows*slice_size > (256ull << 20))){ chunk_rows /= 2; }
 	// Filters lie `in_stride` apart in the device's input block, and a lane's 32 loads go to 32 consecutive filters at the
 	// same offset: with a power-of-two stride they all fall on the same few memory channels (3.87 TB/s in + out; a stride of
 	// an ODD number of 256-byte units: 4.43-4.50, profiles/r04_builder_transpose.txt).  KWAGE_BUILD_PAD = bytes added instead.
@@ -327,11 +328,14 @@ extern "C" int kwage_build_db(kwage_ctx *ctx, const char *out_path, const kwage_
 	uint64_t in_stride = (chunk_bytes + 255)/256*256;
 	if((in_stride/256) % 2 == 0){ in_stride += 256; }
 	if(const char *v = getenv("KWAGE_BUILD_PAD")){ in_stride = chunk_bytes + (uint64_t)atoll(v)/4*4; }
-	void *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
+	void *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out[2] = {nullptr, nullptr};
 	hipError_t e = hipMalloc(&d_in, in_stride*n);
 	if(e == hipSuccess){ e = hipMalloc(&d_out, chunk_rows*slice_size); }
 	if(e == hipSuccess){ e = hipHostMalloc(&h_in, in_stride*n, hipHostMallocDefault); }
-	if(e == hipSuccess){ e = hipHostMalloc(&h_out, chunk_rows*slice_size, hipHostMallocDefault); }
+	for(int k = 0; k < 2; ++k){ if(e == hipSuccess){ e = hipHostMalloc(&h_out[k], chunk_rows*slice_size, hipHostMallocDefault); } }
+	std::thread writer;                 // CRC32 + fwrite of the previous chunk
+	bool writer_ok = true;
+	uint32_t n_chunk = 0;
 	uint32_t db_crc = 0;            // output_header.crc32 starts at 0 (build_db.cpp:192,307)
 	double t_kernel_ms = 0;
 	// tile shape, KWAGE_BUILD_TILE: 0 = 1024 filters x 512 slices (64-byte reads per filter, 128-byte row segments out),
@@ -348,8 +352,15 @@ extern "C" int kwage_build_db(kwage_ctx *ctx, const char *out_path, const kwage_
 	for(uint64_t r0 = 0; r0 < filter_len && ok && e == hipSuccess; r0 += chunk_rows){
 		const uint64_t nr = std::min(chunk_rows, filter_len - r0);
 		const uint64_t nb = (nr + 7)/8;
-		for(uint32_t i = 0; i < n; ++i){
-			memcpy((char*)h_in + (uint64_t)i*in_stride, files[i].map + files[i].bits_off + r0/8, nb);
+		{	// this chunk of every filter into the pinned block (host threads: one memcpy per filter, 2048 of up to 256 KB)
+			const unsigned nthread = (uint64_t)n*nb < (8u << 20) ? 1u : std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+			auto gather = [&](unsigned t) {
+				for(uint32_t i = t; i < n; i += nthread){ memcpy((char*)h_in + (uint64_t)i*in_stride, files[i].map + files[i].bits_off + r0/8, nb); }
+			};
+			std::vector<std::thread> pool;
+			for(unsigned t = 1; t < nthread; ++t){ pool.emplace_back(gather, t); }
+			gather(0);
+			for(auto &th : pool){ th.join(); }
 		}
 		e = hipMemcpyAsync(d_in, h_in, in_stride*n, hipMemcpyHostToDevice, stream);
 		if(e != hipSuccess){ break; }
@@ -370,19 +381,27 @@ extern "C" int kwage_build_db(kwage_ctx *ctx, const char *out_path, const kwage_
 		}
 		(void)hipEventRecord(ev1, stream);
 		e = hipGetLastError();
-		if(e == hipSuccess){ e = hipMemcpyAsync(h_out, d_out, nr*slice_size, hipMemcpyDeviceToHost, stream); }
+		unsigned char *hb = (unsigned char*)h_out[n_chunk++ & 1];      // (its previous user, two chunks ago, was joined below)
+		if(e == hipSuccess){ e = hipMemcpyAsync(hb, d_out, nr*slice_size, hipMemcpyDeviceToHost, stream); }
 		if(e == hipSuccess){ e = hipStreamSynchronize(stream); }
 		if(e != hipSuccess){ break; }
 		float ms = 0;
 		(void)hipEventElapsedTime(&ms, ev0, ev1);
 		t_kernel_ms += ms;
-		db_crc = crc32_parallel(db_crc, (const unsigned char*)h_out, nr*slice_size);
-		ok = fwrite(h_out, 1, nr*slice_size, fout) == nr*slice_size;
+		if(writer.joinable()){ writer.join(); }
+		ok = writer_ok;
+		if(!ok){ break; }
+		writer = std::thread([&db_crc, &writer_ok, fout, hb, bytes = nr*slice_size]() {        // (chunks are written in order: one writer at a time)
+			db_crc = crc32_parallel(db_crc, hb, bytes);
+			writer_ok = fwrite(hb, 1, bytes, fout) == bytes;
+		});
 	}
+	if(writer.joinable()){ writer.join(); }
+	ok = ok && writer_ok;
 	if(d_in){ (void)hipFree(d_in); }
 	if(d_out){ (void)hipFree(d_out); }
 	if(h_in){ (void)hipHostFree(h_in); }
-	if(h_out){ (void)hipHostFree(h_out); }
+	for(int k = 0; k < 2; ++k){ if(h_out[k]){ (void)hipHostFree(h_out[k]); } }
 	if(ev0){ (void)hipEventDestroy(ev0); }
 	if(ev1){ (void)hipEventDestroy(ev1); }
 	if(e != hipSuccess){ fclose(fout); cleanup(); return fail(KWAGE_ERR_DEVICE, "kwage_build_db: %s", hipGetErrorString(e)); }
