@@ -76,7 +76,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-result-check", action="store_true", help="skip the post-timing check of the hit lists against the oracle")
     ap.add_argument("--no-sustained", action="store_true", help="skip the %.0f s sustained block after the timed steps" % SUSTAINED_SECONDS)
-    ap.add_argument("--early-exit", action="store_true", help="enable the reference's early exit (not the nominal figure)")
+    ap.add_argument("--early-exit", action="store_true", help="enable the reference's early exit for the WHOLE run (not the nominal figure; the PMC passes behind the `early_exit` blocks use it)")
+    ap.add_argument("--no-early-exit-block", action="store_true", help="skip the `early_exit` block (the same batch searched with the reference's early exit, after the timed region)")
     ap.add_argument("--cpu-files", type=int, default=0, help="number of 2048-column .db files of the CPU sample (default: host cores, max 16)")
     return ap.parse_args(argv)
 
@@ -218,20 +219,19 @@ def measured_traffic(workload, kernel, early_exit):
     command (counters cannot be collected from inside the run), kept in profiles/pmc_traffic.json with the kernel
     (name + template shape) and the HASH OF THE CODE they were taken on.  The number is reported only when this run
     used that kernel AND the kernel sources + engine are byte for byte what the pass profiled; otherwise null, with
-    the reason in traffic_source.  tools/pmc_refresh.py regenerates every entry in one GPU session."""
+    the reason in traffic_source.  tools/pmc_refresh.py regenerates every entry in one GPU session.
+    Searches with early exit have entries of their own ("c2@ee": the pass ran `bench.py --workload c2 --early-exit`);
+    what they fetch depends on the data, which is seeded, not on the box."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         # (a workload whose kernel depends on where its matrix lies -- and_walk_kernel or, band after band,
         # and_band_walk_kernel -- has one pass per kernel: "c2" and "c2@and_band_walk_kernel<13,4>")
-        t = rec.get("%s@%s" % (workload, kernel)) or rec.get(workload)
+        t = rec.get("%s@ee" % workload) if early_exit else (rec.get("%s@%s" % (workload, kernel)) or rec.get(workload))
     except Exception as exc:
         return None, {"file": "profiles/pmc_traffic.json", "status": "unreadable: %r" % (exc,)}
     if not t:
-        return None, {"file": "profiles/pmc_traffic.json", "status": "no PMC pass recorded for workload %r" % workload}
+        return None, {"file": "profiles/pmc_traffic.json", "status": "no PMC pass recorded for workload %r%s" % (workload, " with early exit" if early_exit else "")}
     src = {"file": "profiles/pmc_traffic.json", "pmc_pass": t.get("source"), "kernel": t.get("kernel"), "code_hash": t.get("code_hash")}
-    if early_exit:
-        src["status"] = "not applicable with --early-exit"
-        return None, src
     if t.get("kernel") != kernel:
         src["status"] = "stale: the PMC pass profiled %s, this run used %s" % (t.get("kernel"), kernel)
         return None, src
@@ -347,6 +347,66 @@ def result_check(members, results, threshold, n_hit=2, n_miss=1):
     out["groups"] = len(members)
     out["oracle"] = "oracle/kwage_oracle.c (kwo_search_rows) on rows read back with kwage_group_read_rows"
     out["seconds"] = round(time.perf_counter() - t0, 2)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------
+# early_exit: the default path of the command-line programs, measured on the resident matrix
+# ------------------------------------------------------------------------------------------------------
+def early_exit_block(args, name, members, s, threshold, flags, nominal):
+    """The batch that was just timed, searched again with KWAGE_SEARCH_EARLY_EXIT: warm-up, then args.steps steps through
+    the two search slots exactly like the timed region.  -> {ms_per_step, kernel, kernel_ms, nominal_rate (the
+    ALGORITHMIC bytes of the batch over the time -- bytes the early exit mostly does not read, labelled as such),
+    fetched_bytes (PMC pass of `bench.py --workload X --early-exit`, profiles/pmc_traffic.json "X@ee") and
+    frac_of_fetched = fetched bytes / kernel time / 8 TB/s, identical_to_nominal (the hit lists equal the timed
+    kernel's, record for record), result_check}."""
+    import numpy as np
+    import kwage_amd as ka
+    from collections import deque
+    fl = flags | ka.SEARCH_EARLY_EXIT
+    n_groups = len(members)
+    for _ in range(max(args.warmup, 1)):
+        for m in members:
+            m.group.search(s.batch, threshold, fl)
+    pend, acc, last, kernel_ms = deque(), [], [], []
+    nsteps = args.steps
+
+    def collect_one():
+        acc.append(pend.popleft().collect())
+        if len(acc) == n_groups:
+            kernel_ms.append(sum(r.search_kernel_ms for r in acc))
+            last[:] = acc
+            acc.clear()
+    t0 = time.perf_counter()
+    for j in range(nsteps * n_groups):
+        pend.append(members[j % n_groups].group.submit(s.batch, threshold, fl))
+        if len(pend) == 2:
+            collect_one()
+    while pend:
+        collect_one()
+    dt = time.perf_counter() - t0
+    k_ms = float(np.mean(kernel_ms))
+    alg = int(sum(r.algorithmic_bytes for r in last))
+    kernel = getattr(last[0], "search_kernel", "")
+    fetched, fsrc = measured_traffic(name, kernel, True)
+    same = all(np.array_equal(a.hits, b.hits) and np.array_equal(a.num_query_kmer, b.num_query_kmer) for a, b in zip(last, nominal))
+    out = {"ms_per_step": round(dt / nsteps * 1e3, 4), "steps": nsteps, "kernel": kernel, "kernel_ms": round(k_ms, 4),
+           "kernel_ms_min": round(float(np.min(kernel_ms)), 4), "kernel_ms_max": round(float(np.max(kernel_ms)), 4),
+           "kernel_ms_scope": "gather stage (all its launches)",
+           "hits_per_step": int(sum(len(r.hits) for r in last)),
+           "nominal_rate": {"algorithmic_bytes": alg, "gbps": round(alg / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
+                            "note": "the batch's ALGORITHMIC bytes (no early exit) over the early-exit kernel time: bytes mostly NOT read, not an HBM rate"},
+           "speedup_vs_nominal_kernel": round(float(np.mean([r.search_kernel_ms for r in nominal])) * n_groups / k_ms, 2) if k_ms > 0 else None,
+           "fetched_bytes": fetched, "fetched_source": fsrc,
+           "frac_of_fetched": round(fetched / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if (fetched and k_ms > 0) else None,
+           "identical_to_nominal": bool(same)}
+    if not args.no_result_check:
+        rc = result_check(members, last, threshold)
+        out["result_check"] = {k: rc[k] for k in ("ok", "planted_queries", "planted_columns_found", "planted_columns_expected", "sampled_queries",
+                                                   "sampled_hits_compared", "mismatches", "seconds") if k in rc}
+        out["ok"] = bool(same and rc.get("ok"))
+    else:
+        out["ok"] = bool(same)
     return out
 
 
@@ -606,6 +666,15 @@ def measure(env, args, name, headline):
             rcheck = result_check(members, probe, threshold)
         except Exception as exc:          # a checker that cannot run is a failed check, not a skipped one
             rcheck = {"ok": False, "error": repr(exc)}
+    # ---- early_exit: the SAME batch against the SAME resident matrix with the reference's early exit (kwage.cpp:437-483)
+    # on -- what `kwage` and `kwage_node` run by default.  After the timed region (never part of `value`); rank-local.
+    ee = None
+    if not args.no_early_exit_block and not args.early_exit:
+        try:
+            ee = early_exit_block(args, name, members, s, threshold, flags, probe)
+        except Exception as exc:
+            ee = {"ok": False, "error": repr(exc)}
+    ee_ok = 1.0 if (ee is None or ee.get("ok", True)) else 0.0
     probe = probe[0]
 
     def stats(xs):
@@ -615,7 +684,7 @@ def measure(env, args, name, headline):
     # every rank's kernel time (timed region: mean/min/max; sustained block: mean/min/max), its work per step and the
     # verdict of its result check, gathered on all ranks
     mine = stats(timed_kernel_ms) + (stats(sus_kernel_ms) if sustained else [0.0, 0.0, 0.0]) \
-        + [float(bit_tests_rank), float(alg_bytes_rank), 1.0 if (rcheck is None or rcheck.get("ok")) else 0.0]
+        + [float(bit_tests_rank), float(alg_bytes_rank), (1.0 if (rcheck is None or rcheck.get("ok")) else 0.0) * ee_ok]
     per_rank = [mine]
     if dist is not None:
         t = torch.tensor(mine, dtype=torch.float64, device=cdev)
@@ -703,6 +772,8 @@ def measure(env, args, name, headline):
                            "searches_per_step": n_groups}
             if exchange_check is not None:
                 out["exchange_check"] = exchange_check
+        if ee is not None:
+            out["early_exit"] = ee
         if rcheck is not None:
             rcheck["ranks_ok"] = [bool(r[8] == 1.0) for r in per_rank]
             rcheck["checked"] = "rank-local hit lists of the kernel that was timed (%s), after the timed region" % kernel
@@ -729,7 +800,7 @@ def measure(env, args, name, headline):
 
 
 ALSO_KEYS = ("value", "unit", "ms_per_step", "steps", "warmup", "scaling", "config", "hbm_gbps_algorithmic_whole_step", "roofline",
-             "aggregate", "rccl", "exchange_check", "result_check")
+             "aggregate", "rccl", "exchange_check", "result_check", "early_exit")
 
 
 def rank_main(args):

@@ -31,10 +31,11 @@ static_assert(TUNING_DEFAULT_BLOCK_WAVES == SEARCH_THREADS/WAVE, "the tiled AND 
 struct TuningName { const char *name; int64_t Tuning::*field; };
 static const TuningName TUNING_NAMES[] = {
 	{"walk", &Tuning::walk}, {"walk_min_rows", &Tuning::walk_min_rows}, {"walk_max_kib", &Tuning::walk_max_kib}, {"walk_min_kib", &Tuning::walk_min_kib}, {"walk_short_rows", &Tuning::walk_short_rows}, {"walk_tile_kib", &Tuning::walk_tile_kib}, {"walk_paced", &Tuning::walk_paced},
-	{"walk_early_exit", &Tuning::walk_early_exit}, {"walk_waves", &Tuning::walk_waves}, {"walk_fences", &Tuning::walk_fences}, {"walk_one_wg_per_cu", &Tuning::walk_one_wg_per_cu},
+	{"walk_waves", &Tuning::walk_waves}, {"walk_fences", &Tuning::walk_fences}, {"walk_one_wg_per_cu", &Tuning::walk_one_wg_per_cu},
 	{"walk_bands", &Tuning::walk_bands}, {"walk_bands_min_gib", &Tuning::walk_bands_min_gib},
 	{"and_vec", &Tuning::and_vec}, {"and_unroll", &Tuning::and_unroll}, {"and_nt", &Tuning::and_nt}, {"and_lds_kb", &Tuning::and_lds_kb},
 	{"and_block_waves", &Tuning::and_block_waves}, {"and_wide", &Tuning::and_wide}, {"and_wide_min_kib", &Tuning::and_wide_min_kib}, {"narrow", &Tuning::narrow}, {"narrow_unroll", &Tuning::narrow_unroll}, {"force_segs", &Tuning::force_segs},
+	{"ee_refine", &Tuning::ee_refine}, {"refine_seg_rows", &Tuning::refine_seg_rows}, {"refine_min_rows", &Tuning::refine_min_rows}, {"refine_max_groups", &Tuning::refine_max_groups}, {"refine_unroll", &Tuning::refine_unroll}, {"refine_list_cap", &Tuning::refine_list_cap}, {"screen_wpc", &Tuning::screen_wpc},
 	{"count_walk", &Tuning::count_walk}, {"count_walk_wpc", &Tuning::count_walk_wpc}, {"count_walk_waves", &Tuning::count_walk_waves},
 	{"count_walk_min_rows", &Tuning::count_walk_min_rows}, {"count_walk_prefetch", &Tuning::count_walk_prefetch}, {"count_walk_kps", &Tuning::count_walk_kps},
 	{"count_narrow_kps", &Tuning::count_narrow_kps},
@@ -436,6 +437,58 @@ int reserve_zeroed(DevBuf &buf, uint64_t bytes, hipStream_t s)
 	return KWAGE_OK;
 }
 
+// The lists of the early-exit form "screen, then refine" (kernels.hpp and_screen_kernel), sized from the batch: room for
+// eight handed-over 128-byte groups per query (three planted columns per query is what the synthetic workloads hold; a
+// tile that finds the lists full walks on by itself) and for the units of as many items of average length.  Half of
+// every list is static -- its places dealt out to the `screen_waves` waves of the screen launch beforehand, taken without an
+// atomic --, the rest is reserved in chunks through three counters, zeroed on the gather stream before every stage.
+// `item_bytes`: mask (t = 1: 128) or counters (t < 1: planes x 128) per item; `unit_bytes`: partial counters per unit
+// (t < 1 only).
+struct RefineSetup { RefineArgs ra; uint32_t refine_wgs, emit_wgs; };
+
+int refine_setup(Slot *sl, const Tuning &tn, const SearchArgs &a, uint64_t total_rows, uint64_t max_rows, uint32_t max_seg, uint64_t item_bytes, uint64_t unit_bytes,
+                 uint64_t tiles, uint64_t screen_waves, uint64_t ncu, hipStream_t gs, RefineSetup *out)
+{
+	int rc;
+	RefineArgs &ra = out->ra;
+	ra.seg_rows = (uint32_t)std::min<int64_t>(std::max<int64_t>(tn.refine_seg_rows, 8), max_seg);
+	ra.seg_rows = (uint32_t)std::max<uint64_t>(ra.seg_rows, (max_rows + 65535)/65536);              // (at most 2^16 units per item)
+	ra.min_rows = (uint32_t)std::max<int64_t>(tn.refine_min_rows, 1);
+	ra.max_groups = (uint32_t)std::min<int64_t>(std::max<int64_t>(tn.refine_max_groups, 0), 16);      // (0: nothing is ever handed over)
+	uint64_t items = std::min<uint64_t>(std::max<uint64_t>(8ull*a.n_queries, 1u << 16), 1u << 20);
+	items = std::max<uint64_t>(std::min<uint64_t>(items, (256ull << 20)/item_bytes), 1024);
+	uint64_t units = std::min<uint64_t>(std::max<uint64_t>(8*total_rows/ra.seg_rows, 1u << 18), 1u << 24);
+	if(unit_bytes){ units = std::max<uint64_t>(std::min<uint64_t>(units, (512ull << 20)/unit_bytes), 4096); }
+	if(tn.refine_list_cap > 0){ items = units = (uint64_t)std::min<int64_t>(tn.refine_list_cap, 1 << 20); }
+	// dynamic chunks: what a wave is likely to need for a few of its tiles (a wave with one or two tiles takes exactly what it needs)
+	const uint64_t tiles_per_wave = (tiles + screen_waves - 1)/std::max<uint64_t>(screen_waves, 1);
+	auto list = [&](uint64_t cap, uint64_t stat_max, uint64_t chunk_max) {
+		RefineList ls;
+		ls.cap = (uint32_t)cap;
+		ls.stat = (uint32_t)std::min<uint64_t>(stat_max, cap/2/std::max<uint64_t>(screen_waves, 1));
+		ls.base = (uint32_t)(ls.stat*screen_waves);
+		ls.chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(chunk_max, tiles_per_wave/4));
+		return ls;
+	};
+	ra.lc = list(items, 32, 32);
+	ra.li = list(items, 64, 64);
+	ra.lu = list(units, 256, 256);
+	if((rc = sl->ref_counters.reserve(4*sizeof(uint32_t)))){ return rc; }
+	if((rc = sl->ref_clusters.reserve(items*sizeof(RefineCluster)))){ return rc; }
+	if((rc = sl->ref_masks.reserve(items*item_bytes))){ return rc; }
+	if((rc = sl->ref_units.reserve(units*sizeof(RefineUnit)))){ return rc; }
+	if(unit_bytes && (rc = sl->ref_slab.reserve(units*unit_bytes))){ return rc; }
+	ra.counters = (uint32_t*)sl->ref_counters.p;
+	ra.clusters = (RefineCluster*)sl->ref_clusters.p;
+	ra.masks = (uint32_t*)sl->ref_masks.p;
+	ra.units = (RefineUnit*)sl->ref_units.p;
+	ra.slab = (uint32_t*)sl->ref_slab.p;
+	HIP_TRY(hipMemsetAsync(ra.counters, 0, 4*sizeof(uint32_t), gs));
+	out->refine_wgs = (uint32_t)(ncu*8);          // 32 waves per CU, eight units each
+	out->emit_wgs = (uint32_t)(ncu*4);            // 16 waves per CU, four clusters at a time each
+	return KWAGE_OK;
+}
+
 // Launch the gather+reduce kernel(s) for the current batch.
 int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayout *L, float threshold, uint32_t flags,
                         kwage_hit *d_hits, uint64_t cap, unsigned long long *hit_count, hipStream_t gs, const StageEvents &ge)
@@ -497,6 +550,27 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 			HIP_TRY(hipGetLastError());
 			return KWAGE_OK;
 		}
+		// early exit on rows of a KiB and more: screen, then refine (kernels.hpp and_screen_kernel)
+		if(a.early_exit && tn.ee_refine && a.units_per_row >= WAVE && tn.force_segs <= 0){
+			RefineSetup rs;
+			const int vec = (a.units_per_row >= 4*WAVE) ? 2 : 1;
+			a.segs = 1;
+			a.chunks = (a.units_per_row + WAVE*vec - 1)/(WAVE*vec);
+			const uint64_t tiles = (uint64_t)a.n_queries*a.chunks;
+			// (a persistent grid: tile t goes to wave t mod waves; 20 waves per CU is what the kernel's registers allow)
+			const uint64_t screen_waves = (std::min<uint64_t>(tiles, ncu*(uint64_t)std::max<int64_t>(tn.screen_wpc, 1)) + 3)/4*4;
+			if((rc = refine_setup(sl, tn, a, L->total_pos*a.num_hash, L->max_pos*a.num_hash, 1u << 20, 128, 0, tiles, screen_waves, ncu, gs, &rs))){ return rc; }
+			const int unroll = (tn.refine_unroll == 16) ? 16 : 8;
+			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_screen_kernel<%d,8>+refine<%d>", vec, unroll);
+			const dim3 grid((uint32_t)(screen_waves/4)), block(SEARCH_THREADS);
+			if(vec == 2){ KW_GATHER_LAUNCH(ge, true, false, (and_screen_kernel<2, 8>), grid, block, 0, gs, a, rs.ra); }
+			else{ KW_GATHER_LAUNCH(ge, true, false, (and_screen_kernel<1, 8>), grid, block, 0, gs, a, rs.ra); }
+			if(unroll == 16){ KW_GATHER_LAUNCH(ge, false, false, (and_refine_kernel<16>), dim3(rs.refine_wgs), block, 0, gs, a, rs.ra); }
+			else{ KW_GATHER_LAUNCH(ge, false, false, (and_refine_kernel<8>), dim3(rs.refine_wgs), block, 0, gs, a, rs.ra); }
+			KW_GATHER_LAUNCH(ge, false, true, and_refine_emit_kernel, dim3(rs.emit_wgs), block, 0, gs, a, rs.ra);
+			HIP_TRY(hipGetLastError());
+			return KWAGE_OK;
+		}
 		// rows of 3..16 KiB: the walk form (a persistent grid, every wave walks an equal share of the batch's row
 		// list over the whole width of a column tile; kernels.hpp and_walk_kernel).  Worth it once every wave of
 		// the chip gets a few dozen rows; smaller batches stay with the tiled kernel and its row-list segments.
@@ -510,10 +584,10 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 		// of eight rows at once: the tiled kernel's wide shape on the balanced persistent grid)
 		const uint32_t walk_tile = (uint32_t)std::min<int64_t>(std::max<int64_t>(tn.walk_tile_kib, 1), 16);
 		const uint32_t coltiles = (kib + walk_tile - 1)/walk_tile, walk_ch = (kib + coltiles - 1)/coltiles;     // balanced tiles of <= walk_tile KiB
-		// With early exit the tiled kernel wins: a tile that holds no candidate column stops after a few rows even
-		// when another tile of the same query holds a hit, whereas a walking wave covers the hit column's whole row
-		// width and never stops (C2 with early exit: 0.64 ms tiled, 1.29 ms walk).
-		const bool walk_ee_ok = !a.early_exit || tn.walk_early_exit;
+		// (early exit never comes here: a walking wave covers a column tile's whole width and has nothing to give up --
+		// C2 with early exit measured 1.29 ms through the walk form against 0.64 ms tiled; the screen + refine form above
+		// takes rows of a KiB and more, the tiled kernel below the rest)
+		const bool walk_ee_ok = !a.early_exit;
 		const uint64_t walk_slots = (uint64_t)coltiles*L->total_pos;
 		const uint32_t walk_min_kib = (uint32_t)std::max<int64_t>(tn.walk_min_kib, 1);
 		// rows in flight per wave: 4; 8 for rows of one or two KiB-steps (a group of four such rows is only 4-8 loads: C2's
@@ -1042,6 +1116,7 @@ extern "C" void kwage_shutdown(kwage_ctx *ctx)
 		sl->partial.release(); sl->h_stage.release(); sl->sort_scratch.release(); sl->runs.release();
 		sl->walk_or.release(); sl->walk_done.release();
 		sl->band_rows.release(); sl->band_loc.release(); sl->band_or.release(); sl->band_state.release(); sl->cwalk_slab.release(); sl->cwalk_arrived.release();
+		sl->ref_counters.release(); sl->ref_clusters.release(); sl->ref_masks.release(); sl->ref_units.release(); sl->ref_slab.release();
 		for(int i = 0; i < 4; ++i){ if(sl->ev[i]){ (void)hipEventDestroy(sl->ev[i]); } }
 		if(sl->kmer_done){ (void)hipEventDestroy(sl->kmer_done); }
 		if(sl->gather_done){ (void)hipEventDestroy(sl->gather_done); }

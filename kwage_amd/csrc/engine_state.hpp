@@ -209,6 +209,8 @@ struct Slot {
 	DevBuf band_rows, band_loc, band_or, band_state;
 	// count_walk_kernel's: partial counters of cut pairs (overwritten before they are read) and the arrival counters of their trees (zero between searches)
 	DevBuf cwalk_slab, cwalk_arrived;
+	// early exit, screen + refine (kernels.hpp and_screen_kernel): the three counters and the lists of the tiles handed over
+	DevBuf ref_counters, ref_clusters, ref_masks, ref_units, ref_slab;
 	uint64_t staged_hits = 0;
 	kwage_hit *ext_hits = nullptr;      // caller-owned device buffer (kwage_search_device) or null
 	uint64_t ext_cap = 0;
@@ -230,7 +232,6 @@ struct Tuning {
 	int64_t walk_paced = 1;         // KWAGE_WALK_PACED: one KiB-step of the rows in flight at a time (0 with 8 rows in flight and tiles of <= 4: all steps at once)
 	int64_t walk_min_kib = 2;       // KWAGE_WALK_MIN_KIB: narrowest row (in KiB-steps) the walk form takes (round 4: 2 -- rows of 1-2 KiB no
 	                                //   longer need the tiled kernel's segments + combine pass: 0.263 vs 0.284 ms at C2's columns split 8 ways)
-	int64_t walk_early_exit = 0;    // KWAGE_WALK_EARLY_EXIT: use the walk form with early exit too (the tiled kernel stops sooner)
 	int64_t walk_waves = 0;         // KWAGE_WALK_WAVES: exactly this many waves (tests: shares of every size); 0 = from the CU count
 	int64_t walk_fences = 0;        // KWAGE_WALK_FENCES: agent-scope fences around the cut-pair count (measurement only)
 	int64_t walk_one_wg_per_cu = 1; // KWAGE_WALK_ONE_WG_PER_CU: chip-filling launches of the persistent kernels use one workgroup of 8 waves per CU (0: workgroups of 4 waves, placed by the dispatcher)
@@ -248,6 +249,14 @@ struct Tuning {
 	int64_t narrow = 1;             // KWAGE_NARROW: several queries per wave for rows <= 512 B
 	int64_t narrow_unroll = 0;      // KWAGE_NARROW_UNROLL: rows in flight per wave of the narrow AND kernel (0 = by the number of waves; 8, 16)
 	int64_t force_segs = 0;         // KWAGE_FORCE_SEGS: cut every query's k-mer list into this many segments (tests)
+	int64_t ee_refine = 1;          // KWAGE_EE_REFINE: with early exit, tiles that still hold a candidate column after the first rows are handed over to the
+	                                //   refine launch, which reads 128-byte groups on a balanced grid (0: the tile's own wave walks on 1-2 KiB wide)
+	int64_t refine_seg_rows = 64;   // KWAGE_REFINE_SEG_ROWS: rows (k-mers at t < 1) per unit of the refine launch (t < 1: at most 127)
+	int64_t refine_min_rows = 32;   // KWAGE_REFINE_MIN_ROWS: a tile with fewer rows (k-mers) left finishes by itself
+	int64_t refine_max_groups = 4;  // KWAGE_REFINE_MAX_GROUPS: a tile is handed over once at most this many of its 128-byte groups hold a candidate column
+	int64_t refine_unroll = 8;      // KWAGE_REFINE_UNROLL: rows in flight per 128-byte group in the refine launch (8 or 16)
+	int64_t screen_wpc = 20;        // KWAGE_SCREEN_WPC: waves per CU of the persistent screen launch
+	int64_t refine_list_cap = 0;    // KWAGE_REFINE_LIST_CAP: capacity of each of the three lists of handed-over tiles (0 = from the batch; tests: full lists)
 	int64_t count_walk = 1;         // KWAGE_COUNT_WALK: the persistent count kernel where it applies
 	int64_t count_walk_wpc = 8;     // KWAGE_COUNT_WALK_WPC: its waves per CU (8: 6335 GB/s at C2's shape, 12: 6271, 16: 6250, 20: 5876)
 	int64_t count_walk_waves = 0;   // KWAGE_COUNT_WALK_WAVES: exactly this many waves (tests)

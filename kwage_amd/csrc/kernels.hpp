@@ -560,6 +560,343 @@ __global__ __launch_bounds__(SEARCH_THREADS) void and_kernel(SearchArgs a)
 	}
 }
 
+// ---- early exit at threshold == 1: SCREEN, then REFINE -------------------------------------------------------------
+// kwage.cpp:466-470 stops a query once no column can match any more.  Per (query, 2 KiB tile) that rule kills a tile
+// without a matching column after 8-16 random rows -- but a tile that HOLDS a matching column never dies: in and_kernel
+// its wave walks all of the query's rows 2 KiB wide, alone, long after its sibling tiles stopped (C2's shape: ~1500 such
+// walks of 970 rows on 256 CUs were the whole launch, and 15/16 of the bytes they fetched belonged to columns that had
+// been ruled out after 16 rows).  So the work is cut in two:
+//   and_screen_kernel   and_kernel's tile loop (accumulator preset with the real-column mask).  After every group of rows:
+//                       no column left -> the tile is done (the reference's exit); columns left in at most `max_groups`
+//                       128-byte groups of the tile and at least `min_rows` rows to go -> the tile is HANDED OVER: per
+//                       KiB-step with survivors one CLUSTER (the unit of hit reservation: one run of the run table), per
+//                       128-byte group with survivors one ITEM (its 128 bytes of mask so far), and per item and segment of
+//                       `seg_rows` remaining rows one UNIT, all appended to lists in memory; otherwise it goes on.
+//                       A tile that reaches the end of its row list reports its hits itself, as and_kernel does.
+//   and_refine_kernel   a persistent grid over the unit list, EIGHT units per wave (8 lanes x 16 B = one 128-byte line of
+//                       each row): ANDs the unit's rows of that line only, and folds the result into the item's mask with
+//                       atomic ANDs -- skipped where the mask would not change (the rule for a true positive), and the
+//                       whole unit is skipped when an earlier one has already emptied the mask.
+//   and_refine_emit_kernel  one wave per cluster: the surviving columns of its items, one reservation.
+// Lists that are full: the tile simply goes on by itself (reserved places are filled with REFINE_NONE entries).
+// A unit carries everything the refine launch needs (no dependent loads of item or query records before its rows).
+struct RefineUnit { uint32_t item, r0, r1, unit0, rq_lo, rq_hi, q, pad; };      // rows [r0, r1) of the row list at a.rows + rq; unit0: first 16-byte unit of the 128-byte group; item: whose mask
+struct RefineCluster { uint32_t q, kstep_groups, first_item, n; };       // kstep << 8 | bitmap of the KiB-step's 128-byte groups that are items (ascending: first_item, +1, ...); n = num_query_kmer
+static constexpr uint32_t REFINE_NONE = 0xFFFFFFFFu;
+static constexpr uint32_t REFINE_PLANES = 7;                              // counters of a count unit: seg_rows k-mers <= 127
+
+// Three lists: clusters and units are SCANNED by the launches that follow (places nobody filled hold REFINE_NONE), items
+// are only places for masks.  Every list has a static part -- `stat` places per wave of the screen launch, taken without
+// any atomic -- and, behind it (from `base` = waves x stat), a dynamic part reserved `chunk` places at a time through
+// counters[]: hand-overs come in bursts (all tiles reach their eighth row together), and returning atomics on one cache
+// line serialise at the memory side at ~25 ns each -- three per hand-over were 0.2 ms of C2's launch and 27 ms of a
+// launch of 100 k short reads (300 k hand-overs).
+struct RefineList { uint32_t cap, stat, base, chunk; };
+struct RefineArgs {
+	uint32_t *counters;             // [0] clusters, [1] items, [2] units reserved in the dynamic parts (zeroed before the stage; may run past the capacities)
+	RefineCluster *clusters;
+	uint32_t *masks;                // AND: u32x4 [item][8 lanes], the item's 128 bytes of mask; count: u32x4 [item][PLANES][8 lanes], its counters so far
+	RefineUnit *units;
+	uint32_t *slab;                 // count only: [unit][REFINE_PLANES][8] u32x4 counters of the unit's k-mers
+	RefineList lc, li, lu;          // clusters, items, units
+	uint32_t seg_rows;              // rows (count: k-mers) per unit
+	uint32_t min_rows;              // hand a tile over only when at least this many rows (k-mers) are left
+	uint32_t max_groups;            // ... and at most this many of its 128-byte groups hold a surviving column
+};
+
+// one bit per 8 lanes of a ballot: the 128-byte groups of a KiB-step with a lane set
+__device__ __forceinline__ uint32_t group_bits(uint64_t lanes)
+{
+	uint32_t g = 0;
+#pragma unroll
+	for(int k = 0; k < 8; ++k){ g |= ((lanes >> (8*k)) & 0xFFull) ? (1u << k) : 0u; }
+	return g;
+}
+
+// position of the j-th set bit of `bits` (j < popcount)
+__device__ __forceinline__ uint32_t nth_set_bit(uint32_t bits, uint32_t j)
+{
+	for(uint32_t k = 0; k < j; ++k){ bits &= bits - 1; }
+	return __ffs(bits) - 1;
+}
+
+struct RefineChunk { uint32_t next = 0, end = 0; };            // a wave's private stretch of a list (wave-uniform)
+
+__device__ __forceinline__ void refine_none_clusters(const RefineArgs &ra, uint32_t from, uint32_t to)
+{
+	to = min(to, ra.lc.cap);
+	for(uint32_t i = from + (threadIdx.x & (WAVE - 1)); i < to; i += WAVE){ ra.clusters[i].q = REFINE_NONE; }
+}
+__device__ __forceinline__ void refine_none_units(const RefineArgs &ra, uint32_t from, uint32_t to)
+{
+	to = min(to, ra.lu.cap);
+	for(uint32_t i = from + (threadIdx.x & (WAVE - 1)); i < to; i += WAVE){ ra.units[i].item = REFINE_NONE; }
+}
+
+// `need` consecutive places of list `which` (0 clusters, 1 items, 2 units) from the wave's chunk -> first place, or
+// REFINE_NONE when the list is full.  A chunk that is too short is closed (NONE entries where the list is scanned) and a
+// new one reserved in the list's dynamic part: `chunk` places, or `need` if that is more (the units of one long query).
+// Wave-uniform; every lane calls.
+__device__ __forceinline__ uint32_t refine_take(const RefineArgs &ra, int which, RefineChunk &ch, uint32_t need)
+{
+	const RefineList &ls = (which == 0) ? ra.lc : (which == 1) ? ra.li : ra.lu;
+	if(ch.end - ch.next < need){
+		if(which == 0){ refine_none_clusters(ra, ch.next, ch.end); } else if(which == 2){ refine_none_units(ra, ch.next, ch.end); }
+		ch.next = ch.end = 0;
+		if((uint64_t)ls.base + __hip_atomic_load(ra.counters + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ls.cap){ return REFINE_NONE; }      // (full: no more atomics on it)
+		const uint32_t want = max(need, ls.chunk);
+		uint32_t r = 0;
+		if((threadIdx.x & (WAVE - 1)) == 0){ r = atomicAdd(ra.counters + which, want); }
+		const uint64_t at = (uint64_t)ls.base + __builtin_amdgcn_readfirstlane(r);
+		if(at + want > ls.cap){                 // the tail of the list: too short for this wave; close it
+			if(at < ls.cap){
+				if(which == 0){ refine_none_clusters(ra, (uint32_t)at, ls.cap); } else if(which == 2){ refine_none_units(ra, (uint32_t)at, ls.cap); }
+			}
+			return REFINE_NONE;
+		}
+		ch.next = (uint32_t)at;
+		ch.end = (uint32_t)at + want;
+	}
+	const uint32_t at = ch.next;
+	ch.next += need;
+	return at;
+}
+
+// how far the launches that follow have to scan a list
+__device__ __forceinline__ uint32_t refine_list_end(const RefineArgs &ra, int which)
+{
+	const RefineList &ls = (which == 0) ? ra.lc : (which == 1) ? ra.li : ra.lu;
+	return (uint32_t)min((uint64_t)ls.base + ra.counters[which], (uint64_t)ls.cap);
+}
+
+// (a PERSISTENT grid: tile t of the batch -- (query, 64*VEC*16 bytes of every row), query-major -- goes to wave t mod waves,
+// so the waves of a workgroup screen adjacent tiles of the same rows at the same time)
+template <int VEC, int UNROLL>
+__global__ __launch_bounds__(SEARCH_THREADS) void and_screen_kernel(SearchArgs a, RefineArgs ra)
+{
+	const uint32_t lane = threadIdx.x & (WAVE - 1);
+	const uint64_t n_tiles = (uint64_t)a.n_queries*a.chunks;
+	const uint32_t n_waves = gridDim.x*(blockDim.x/WAVE);
+	const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x*(blockDim.x/WAVE) + (threadIdx.x >> 6));
+	__shared__ WaveHitBuf hit_bufs[SEARCH_THREADS/WAVE];           // (a persistent wave reserves its hit records once: WaveHitBuf)
+	WaveHitBuf *hbuf = &hit_bufs[threadIdx.x >> 6];
+	WaveHitState hst;
+	RefineChunk cc, ci, cu;               // the wave's static places first
+	cc.next = gw*ra.lc.stat; cc.end = cc.next + ra.lc.stat;
+	ci.next = gw*ra.li.stat; ci.end = ci.next + ra.li.stat;
+	cu.next = gw*ra.lu.stat; cu.end = cu.next + ra.lu.stat;
+	bool lists_full = false;
+	for(uint64_t tile = gw; tile < n_tiles; tile += n_waves){
+		const uint32_t q = __builtin_amdgcn_readfirstlane((uint32_t)(tile / a.chunks));
+		const uint32_t c = __builtin_amdgcn_readfirstlane((uint32_t)(tile % a.chunks));
+		const uint32_t n = a.nkmer[q];
+		if(n == 0){ continue; }
+		const uint32_t nrows = n*a.num_hash;
+		const uint64_t rq_off = a.pos_off[q]*a.num_hash;
+		const uint32_t *rq = a.rows + rq_off;
+
+		uint32_t unit[VEC];
+		u32x4 acc[VEC];
+#pragma unroll
+		for(int v = 0; v < VEC; ++v){
+			const uint32_t u = c*(WAVE*VEC) + v*WAVE + lane;
+			const bool live = (u < a.units_per_row);
+			unit[v] = live ? u : (a.units_per_row - 1);
+			// only real columns can survive: pad bits between file blocks (whatever they hold) never keep a tile alive
+			acc[v] = live ? reinterpret_cast<const u32x4*>(a.valid)[u] : (u32x4)(0u);
+		}
+
+		bool may_hand_over = !lists_full, gone = false;
+		uint32_t i = 0;
+		for(; i + UNROLL <= nrows; i += UNROLL){
+			u32x4 x[UNROLL][VEC];
+#pragma unroll
+			for(int u = 0; u < UNROLL; ++u){
+				const uint32_t r = rq[i + u];
+				const u32x4 *p = reinterpret_cast<const u32x4*>(a.db + (uint64_t)r*a.stride);
+#pragma unroll
+				for(int v = 0; v < VEC; ++v){ x[u][v] = load16<true>(p + unit[v]); }
+			}
+#pragma unroll
+			for(int u = 0; u < UNROLL; ++u){
+#pragma unroll
+				for(int v = 0; v < VEC; ++v){ acc[v] &= x[u][v]; }
+			}
+			uint32_t gb[VEC], ngroups = 0;
+#pragma unroll
+			for(int v = 0; v < VEC; ++v){
+				gb[v] = group_bits(__ballot((acc[v].x | acc[v].y | acc[v].z | acc[v].w) != 0));
+				ngroups += __popc(gb[v]);
+			}
+			if(ngroups == 0){ gone = true; break; }       // kwage.cpp:466-470 per tile: nothing left that could match
+			const uint32_t done = i + UNROLL;
+			if(may_hand_over && ngroups <= ra.max_groups && nrows - done >= ra.min_rows){
+				may_hand_over = false;                    // (one attempt per tile)
+				const uint32_t nseg = (nrows - done + ra.seg_rows - 1)/ra.seg_rows;
+				uint32_t nc = 0;
+#pragma unroll
+				for(int v = 0; v < VEC; ++v){ nc += gb[v] ? 1u : 0u; }
+				const uint32_t nu = ngroups*nseg;             // (ngroups <= 16; the host keeps nseg <= 2^16)
+				const uint32_t c0 = refine_take(ra, 0, cc, nc);
+				const uint32_t i0 = (c0 != REFINE_NONE) ? refine_take(ra, 1, ci, ngroups) : REFINE_NONE;
+				const uint32_t u0 = (i0 != REFINE_NONE) ? refine_take(ra, 2, cu, nu) : REFINE_NONE;
+				if(u0 == REFINE_NONE){
+					// some list is full: the cluster places taken stay empty, and the tile walks on by itself
+					if(c0 != REFINE_NONE){ refine_none_clusters(ra, c0, c0 + nc); }
+					lists_full = true;
+					continue;
+				}
+				uint32_t cidx = c0, ii = i0, all_groups = 0;
+#pragma unroll
+				for(int v = 0; v < VEC; ++v){
+					all_groups |= gb[v] << (8*v);
+					if(!gb[v]){ continue; }
+					if(lane == 0){
+						RefineCluster cl; cl.q = q; cl.kstep_groups = ((c*VEC + v) << 8) | gb[v]; cl.first_item = ii; cl.n = n;
+						ra.clusters[cidx] = cl;
+					}
+					const uint32_t k = lane >> 3;                                  // this lane's 128-byte group of the KiB-step
+					if((gb[v] >> k) & 1u){
+						const uint32_t it = ii + __popc(gb[v] & ((1u << k) - 1u));
+						reinterpret_cast<u32x4*>(ra.masks)[(uint64_t)it*8 + (lane & 7u)] = acc[v];
+					}
+					++cidx;
+					ii += __popc(gb[v]);
+				}
+				for(uint32_t e = lane; e < nu; e += WAVE){
+					const uint32_t j = e / nseg, sg = e % nseg;                     // item j of the tile (ascending by column), segment sg
+					const uint32_t gpos = nth_set_bit(all_groups, j);               // bit v*8 + k
+					RefineUnit un;
+					un.item = i0 + j;
+					un.r0 = done + sg*ra.seg_rows;
+					un.r1 = min(nrows, un.r0 + ra.seg_rows);
+					un.unit0 = c*(WAVE*VEC) + gpos*8u;                             // (= v*64 + k*8 within the tile)
+					un.rq_lo = (uint32_t)rq_off; un.rq_hi = (uint32_t)(rq_off >> 32);
+					un.q = q; un.pad = 0;
+					ra.units[u0 + e] = un;
+				}
+				gone = true;                              // the refine launch takes it from here
+				break;
+			}
+		}
+		if(gone){ continue; }
+		for(; i < nrows; ++i){
+			const uint32_t r = rq[i];
+			const u32x4 *p = reinterpret_cast<const u32x4*>(a.db + (uint64_t)r*a.stride);
+#pragma unroll
+			for(int v = 0; v < VEC; ++v){ acc[v] &= load16<true>(p + unit[v]); }
+		}
+#pragma unroll
+		for(int v = 0; v < VEC; ++v){
+			emit_masked_hits_buffered(a, hbuf, hst, q, unit[v], acc[v], n, (uint64_t)q*a.runs_per_query + c*VEC + v);      // (acc is 0 in lanes past the row end)
+		}
+	}
+	wave_hits_flush(a, hbuf, hst);
+	// what the wave did not use of its places
+	refine_none_clusters(ra, cc.next, cc.end);
+	refine_none_units(ra, cu.next, cu.end);
+}
+
+// Eight units per wave: lane group g (8 lanes x 16 B = the unit's 128-byte line of every row) walks unit base + g.  The
+// unit's row numbers are fetched 64 at a time, eight per lane, before the rows (a row number per lane and row would put
+// a second dependent load in front of every group of rows); a lane's neighbours hand them round (ds_bpermute).
+template <int UNROLL>
+__global__ __launch_bounds__(SEARCH_THREADS) void and_refine_kernel(SearchArgs a, RefineArgs ra)
+{
+	static_assert(UNROLL == 8 || UNROLL == 16, "eight or sixteen rows in flight");
+	const uint32_t lane = threadIdx.x & (WAVE - 1), l = lane & 7u, sh = lane & ~7u;
+	const uint32_t n_units = refine_list_end(ra, 2);
+	const uint64_t gw = (uint64_t)blockIdx.x*(blockDim.x/WAVE) + (threadIdx.x >> 6);
+	const uint64_t step = (uint64_t)gridDim.x*(blockDim.x/WAVE)*8;
+	for(uint64_t base = gw*8; base < n_units; base += step){
+		const uint64_t u = base + (lane >> 3);
+		RefineUnit un;
+		un.item = REFINE_NONE;
+		if(u < n_units){ un = ra.units[u]; }
+		bool on = (un.item != REFINE_NONE);
+		uint32_t *M = ra.masks;
+		u32x4 m = (u32x4)(0u);
+		if(on){
+			M = ra.masks + ((uint64_t)un.item*8 + l)*4;
+#pragma unroll
+			for(int d = 0; d < 4; ++d){ m[d] = __hip_atomic_load(M + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+		}
+		// an earlier unit of the item has emptied the mask: nothing this one finds can matter
+		on = on && (((uint32_t)(__ballot((m.x | m.y | m.z | m.w) != 0) >> sh) & 0xFFu) != 0);
+		if(on){
+			const uint32_t *rq = a.rows + (((uint64_t)un.rq_hi << 32) | un.rq_lo);
+			const u32x4 *col = reinterpret_cast<const u32x4*>(a.db) + (un.unit0 + l);
+			u32x4 acc = ~(u32x4)(0u);
+			bool alive = true;
+			for(uint32_t b = un.r0; alive && b < un.r1; b += 64){
+				uint32_t idx[8];           // lane l: rows b + l, b + 8 + l, ... (past the end: the last row again -- AND is idempotent)
+#pragma unroll
+				for(int k = 0; k < 8; ++k){ idx[k] = rq[min(b + 8u*k + l, un.r1 - 1)]; }
+#pragma unroll
+				for(int k = 0; k < 8; k += UNROLL/8){
+					if(b + 8u*k >= un.r1){ break; }
+					u32x4 x[UNROLL];
+#pragma unroll
+					for(int j = 0; j < UNROLL; ++j){
+						const uint32_t r = __shfl(idx[k + j/8], sh + (j & 7));
+						x[j] = load16<true>(reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(col) + (uint64_t)r*a.stride));
+					}
+#pragma unroll
+					for(int j = 0; j < UNROLL; ++j){ acc &= x[j]; }
+					if((((uint32_t)(__ballot((acc.x | acc.y | acc.z | acc.w) != 0) >> sh)) & 0xFFu) == 0){ alive = false; break; }      // the group's 128 bytes are empty
+				}
+			}
+			// fold into the item's mask; where it would not change (m is a subset of acc: the rule for a column that
+			// really matches, and masks only ever lose bits) there is nothing to do
+#pragma unroll
+			for(int d = 0; d < 4; ++d){
+				if(m[d] & ~acc[d]){ __hip_atomic_fetch_and(M + d, acc[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+			}
+		}
+	}
+}
+
+// (a wave takes every nw-th cluster, four at a time: the four records, then the four sets of masks are requested together;
+// the records found go through the wave's LDS buffer and are reserved ONCE per wave -- 150 k clusters with a hit each,
+// reserved one by one, were 1.8 ms of returning atomics on the one hit counter)
+__global__ __launch_bounds__(SEARCH_THREADS) void and_refine_emit_kernel(SearchArgs a, RefineArgs ra)
+{
+	constexpr int B = 4;
+	__shared__ WaveHitBuf hit_bufs[SEARCH_THREADS/WAVE];
+	WaveHitBuf *hbuf = &hit_bufs[threadIdx.x >> 6];
+	WaveHitState hst;
+	const uint32_t lane = threadIdx.x & (WAVE - 1), l = lane & 7u, g = lane >> 3;
+	const uint32_t n_clusters = refine_list_end(ra, 0);
+	const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x*(blockDim.x/WAVE) + (threadIdx.x >> 6));
+	const uint32_t nw = gridDim.x*(blockDim.x/WAVE);
+	for(uint64_t c0 = gw; c0 < n_clusters; c0 += (uint64_t)B*nw){
+		RefineCluster cl[B];
+		u32x4 m[B];
+#pragma unroll
+		for(int k = 0; k < B; ++k){
+			const uint64_t ci = c0 + (uint64_t)k*nw;
+			cl[k].q = REFINE_NONE;
+			if(ci < n_clusters){ cl[k] = ra.clusters[ci]; }
+		}
+#pragma unroll
+		for(int k = 0; k < B; ++k){
+			const uint32_t groups = cl[k].kstep_groups & 0xFFu;
+			m[k] = (u32x4)(0u);
+			if(cl[k].q != REFINE_NONE && ((groups >> g) & 1u)){          // this lane's 128-byte group of the KiB-step is an item
+				const uint32_t it = cl[k].first_item + __popc(groups & ((1u << g) - 1u));
+				m[k] = reinterpret_cast<const u32x4*>(ra.masks)[(uint64_t)it*8 + l];
+			}
+		}
+#pragma unroll
+		for(int k = 0; k < B; ++k){
+			if(cl[k].q == REFINE_NONE){ continue; }
+			const uint32_t kstep = cl[k].kstep_groups >> 8;
+			emit_masked_hits_buffered(a, hbuf, hst, cl[k].q, kstep*WAVE + lane, m[k], cl[k].n, (uint64_t)cl[k].q*a.runs_per_query + kstep);
+		}
+	}
+	wave_hits_flush(a, hbuf, hst);
+}
+
 // threshold == 1.0f, "walk" form of the gather + AND for rows of 3..16 KiB: a wave walks each of its rows over
 // the WHOLE width of a column tile (CH KiB, CH accumulators per lane), UNROLL rows at a time, so a row's
 // consecutive KiB are requested back to back by one wave instead of by different waves at different times as in
@@ -669,12 +1006,6 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void and_walk_kernel(SearchArgs
 					// (PACED = false, narrow column tiles: all CH steps of the UNROLL rows are requested together -- the
 					// tiled kernel's "wide" access pattern, 4 KiB of a row at once, on the balanced persistent grid)
 					if(PACED){ __builtin_amdgcn_sched_barrier(0); }
-				}
-				if(a.early_exit){     // kwage.cpp:466-470: this part alone already rules every column of the tile out
-					bool nz = false;
-#pragma unroll
-					for(int j = 0; j < CH; ++j){ nz |= ((acc[j].x | acc[j].y | acc[j].z | acc[j].w) != 0); }
-					if(!__any(nz)){ break; }
 				}
 			}
 
@@ -882,12 +1213,6 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void and_band_walk_kernel(Searc
 #pragma unroll
 						for(int u = 0; u < UNROLL; ++u){ acc[j] &= (x[u] | fill[u]); }
 						__builtin_amdgcn_sched_barrier(0);               // one KiB-step of UNROLL rows at a time (and_walk_kernel)
-					}
-					if(a.early_exit){     // kwage.cpp:466-470: this part alone already rules every column out
-						bool nz = false;
-#pragma unroll
-						for(int j = 0; j < CH; ++j){ nz |= ((acc[j].x | acc[j].y | acc[j].z | acc[j].w) != 0); }
-						if(!__any(nz)){ break; }
 					}
 				}
 				bool nz = false;

@@ -88,8 +88,14 @@ def test_traffic_is_reported_only_for_the_kernel_and_code_that_were_profiled(mon
     assert bench.measured_traffic("no-such-workload", "k", False)[0] is None
     # a workload whose kernel depends on where its matrix lies has one pass per kernel ("c2" and "c2@<the band form>"):
     # the run's kernel picks the pass
-    keyed = [k for k in rec if "@" in k]
+    keyed = [k for k in rec if "@" in k and not k.endswith("@ee")]
     assert keyed
+    # searches with early exit have passes of their own ("c2@ee": `bench.py --workload c2 --early-exit`), reported by the
+    # line's `early_exit` block only
+    for key in [k for k in rec if k.endswith("@ee")]:
+        monkeypatch.setattr(bench, "kernel_code_hash", lambda e=rec[key]: e["code_hash"])
+        assert bench.measured_traffic(key[:-3], rec[key]["kernel"], True)[0] == rec[key]["hbm_read_bytes_per_launch"]
+        assert bench.measured_traffic(key[:-3], rec[key]["kernel"], False)[0] != rec[key]["hbm_read_bytes_per_launch"]
     for key in keyed:
         workload, kern = key.split("@", 1)
         monkeypatch.setattr(bench, "kernel_code_hash", lambda e=rec[key]: e["code_hash"])

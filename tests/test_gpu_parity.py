@@ -299,6 +299,12 @@ def test_long_lists_come_back_ordered_from_every_kernel_form(ka, ctx, n_cols):
         check(g.search(b, 0.5), "count_kernel<")
     with ctx.tuning(**off):
         check(g.search(b, 0.5), "count_kernel<")
+    if units >= 64:
+        # early exit, every tile handed over to the refine launch after its first eight rows: one reservation per cluster
+        # (= per query and KiB-step), by the emit launch; and with lists of three places: most tiles walk on by themselves
+        for knobs in (dict(refine_max_groups=16, refine_min_rows=1, refine_seg_rows=8), dict(refine_max_groups=16, refine_min_rows=1, refine_list_cap=3)):
+            with ctx.tuning(**dict(off, **knobs)):
+                check(g.search(b, 1.0, ka.SEARCH_EARLY_EXIT), "and_screen_kernel<")
     for waves in (0, 37):
         with ctx.tuning(**dict(off, count_walk=1, count_walk_min_rows=1, count_walk_waves=waves)):
             check(g.search(b, 0.5), "count_walk_kernel<")
@@ -308,6 +314,54 @@ def test_long_lists_come_back_ordered_from_every_kernel_form(ka, ctx, n_cols):
             if units <= 16 * 64:
                 with ctx.tuning(**dict(off, walk=4, walk_min_rows=1, walk_waves=waves, walk_bands=3, walk_bands_min_gib=0)):
                     check(g.search(b, 1.0), "and_band_walk_kernel<")
+    b.close()
+    g.close()
+
+
+@pytest.mark.parametrize("n_cols,num_hash,density", [(8192, 1, 0.25), (20000, 2, 0.5), (100000, 1, 0.25), (131073, 3, 0.7)])
+def test_early_exit_screen_then_refine(ka, ctx, oracle, n_cols, num_hash, density):
+    """Early exit at threshold 1 on rows of a KiB and more: and_screen_kernel hands every tile that still holds a candidate
+    column after its first rows over to and_refine_kernel (128-byte groups, segments of the remaining rows, masks meeting
+    by atomic AND) and and_refine_emit_kernel (one reservation per query and KiB-step).  Planted columns in the first,
+    middle and last 128-byte groups, two of them in ONE group and two in one KiB-step, ragged query lengths (shorter than
+    one segment ... dozens of segments), queries without a k-mer in between; swept over segment lengths, the hand-over
+    rule, both unrolls and list capacities so small that most tiles find the lists full and walk on by themselves.  Every
+    variant must return the list of the search without early exit, which is checked against the oracle."""
+    rng = np.random.default_rng(n_cols + num_hash)
+    k, L = 31, 10
+    image = _make_random_db(rng, L, n_cols, density)
+    genome = rand_seq(rng, 3000)
+    cols = sorted({0, 5, 1030, n_cols // 2, n_cols - 1000, n_cols - 2, n_cols - 1})
+    for col in cols:
+        for r in oracle.row_indices(oracle.unique_kmers(genome, k), k, num_hash, L).reshape(-1):
+            image[r, col // 8] |= np.uint8(1 << (col % 8))
+    seqs = []
+    for i in range(300):
+        n = int(rng.choice([0, 30, 31, 33, 40, 64, 100, 150, 300, 1000, 2500]))
+        if i % 2 == 0 and n >= 31:
+            a = int(rng.integers(0, len(genome) - n + 1)); seqs.append(genome[a:a + n])
+        elif i % 11 == 0:
+            seqs.append("N" * n)
+        else:
+            seqs.append(rand_seq(rng, n))
+    g = ka.Group(ctx, k, num_hash, L, n_cols)
+    g.add_columns(image, n_cols)
+    g.finalize()
+    b = ka.Batch(ctx, seqs)
+    ref = g.search(b, 1.0, 0)
+    exp = [oracle.search_image(image, image.shape[1], k, num_hash, L, n_cols, oracle.unique_kmers(s, k), 1.0)[0] for s in seqs]
+    assert ref.per_query() == exp
+    planted = [e for s, e in zip(seqs, exp) if len(s) >= 31 and s in genome]
+    assert planted and all({c for c, _ in e} >= set(cols) for e in planted)
+    variants = [dict(), dict(refine_seg_rows=8, refine_min_rows=1), dict(refine_seg_rows=1000000, refine_unroll=16), dict(refine_max_groups=16, refine_min_rows=1, refine_seg_rows=17),
+                dict(refine_max_groups=1), dict(refine_max_groups=0), dict(refine_list_cap=1, refine_min_rows=1), dict(refine_list_cap=7, refine_max_groups=16),
+                dict(refine_list_cap=40, refine_seg_rows=8), dict(ee_refine=0)]
+    for knobs in variants:
+        with ctx.tuning(**knobs):
+            for rep in range(2):
+                r = g.search(b, 1.0, ka.SEARCH_EARLY_EXIT)
+                assert r.search_kernel.startswith("and_kernel<" if knobs.get("ee_refine") == 0 else "and_screen_kernel<"), r.search_kernel
+                assert np.array_equal(r.hits, ref.hits) and np.array_equal(r.num_query_kmer, ref.num_query_kmer), (n_cols, knobs, rep)
     b.close()
     g.close()
 
@@ -859,7 +913,7 @@ def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, request):
     column tiles whose last chunk lies wholly past the row end, 300000 columns three tiles (by default rows wider
     than 16 KiB and batches below 256k rows stay with the tiled kernel: both limits are moved here).  Every case
     with the natural number of waves and with shares of a handful of positions."""
-    scope = ctx.tuning(walk_max_kib=64, walk_min_rows=1, walk_waves=0, walk_early_exit=0, walk=4)      # (knobs of the module's shared context)
+    scope = ctx.tuning(walk_max_kib=64, walk_min_rows=1, walk_waves=0, walk=4)      # (knobs of the module's shared context)
     scope.__enter__()
     request.addfinalizer(lambda: scope.__exit__(None, None, None))
     rng = np.random.default_rng(n_cols)
@@ -887,10 +941,10 @@ def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, request):
     first = None
     for waves in ((0, 5, 3001, 16384) if n_cols < 100000 or n_cols == 131073 else (0, 3001)):       # (wide matrices return millions of records per search)
         ctx.set_tuning("walk_waves", waves)
-        for flags, ee in ((0, 0), (ka.SEARCH_EARLY_EXIT, 1), (ka.SEARCH_EARLY_EXIT, 0)):
-            ctx.set_tuning("walk_early_exit", ee)      # with early exit the host prefers the tiled kernel unless told otherwise
+        for flags, refine in ((0, 1), (ka.SEARCH_EARLY_EXIT, 1), (ka.SEARCH_EARLY_EXIT, 0)):
+            ctx.set_tuning("ee_refine", refine)      # early exit never takes the walk form: screen + refine, or (knob) the tiled kernel alone
             r = g.search(b, 1.0, flags)
-            assert r.search_kernel.startswith("and_kernel<" if (flags and ee == 0) else "and_walk_kernel<"), r.search_kernel
+            assert r.search_kernel.startswith(("and_screen_kernel<" if refine else "and_kernel<") if flags else "and_walk_kernel<"), r.search_kernel
             if first is None:
                 first = r
                 assert r.per_query() == exp, (n_cols, flags, waves)           # against the oracle once ...
@@ -898,19 +952,20 @@ def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, request):
                 assert np.array_equal(r.hits, first.hits) and np.array_equal(r.num_query_kmer, first.num_query_kmer), (n_cols, flags, waves)
     # band after band of the matrix (and_band_walk_kernel: rows regrouped by band, parts meet in per-query slots, a finish
     # kernel reports): 2, 5 and 64 bands, the natural number of waves and shares of a handful of rows, twice each (the
-    # slots must be left zero), with and without early exit inside a part
+    # slots must be left zero)
     if n_cols <= 131072:
-        with ctx.tuning(walk_bands_min_gib=0, walk_early_exit=1):
+        with ctx.tuning(walk_bands_min_gib=0):
             for bands in (2, 5, 64):
                 for waves in (0, 3001):
                     ctx.set_tuning("walk_bands", bands)
                     ctx.set_tuning("walk_waves", waves)
-                    for flags in (0, 0, ka.SEARCH_EARLY_EXIT):
+                    for flags in (0, 0):
                         r = g.search(b, 1.0, flags)
                         assert r.search_kernel.startswith("and_band_walk_kernel<"), r.search_kernel
                         assert np.array_equal(r.hits, first.hits) and np.array_equal(r.num_query_kmer, first.num_query_kmer), (n_cols, bands, waves, flags)
             ctx.set_tuning("walk_bands", 0)
     ctx.set_tuning("walk_waves", 0)
+    ctx.set_tuning("ee_refine", 1)
     ctx.set_tuning("walk", 0)
     r = g.search(b, 1.0, 0)
     assert r.search_kernel.startswith("and_kernel<") and np.array_equal(r.hits, first.hits)

@@ -133,7 +133,7 @@ def main():
             say("%-58s launches %6d  mismatches %d  exchange buffers non-zero words %s  %.1f s"
                 % (label, done, mism, dirty or "none", time.perf_counter() - t0))
 
-        base = dict(walk=4, walk_min_rows=1, walk_max_kib=64, walk_early_exit=0, walk_bands=0, count_walk=1, count_walk_min_rows=1)
+        base = dict(walk=4, walk_min_rows=1, walk_max_kib=64, walk_bands=0, count_walk=1, count_walk_min_rows=1)
         for waves in WAVES:
             soak("and_walk_kernel       walk_waves=%-6d" % waves, 1.0, ref_and, dict(base, walk_waves=waves), "and_walk_kernel<", launches)
         for waves in WAVES:

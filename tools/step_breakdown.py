@@ -24,7 +24,7 @@ for name, nq, qlen in shapes:
         continue
     w = replace(base, num_queries=nq, query_len=qlen)
     s = synth.build(ctx, w)
-    for thr_v, ee in ((1.0, 0), (1.0, ka.SEARCH_EARLY_EXIT), (0.8, 0), (0.0001, 0)):
+    for thr_v, ee in ((1.0, 0), (1.0, ka.SEARCH_EARLY_EXIT), (0.8, 0), (0.8, ka.SEARCH_EARLY_EXIT), (0.0001, 0)):
         if thr_v == 0.0001 and nq * 100_000 > 200_000_000:
             continue                  # every column matches every query: keep the hit list below 200 M records
         thr = C.c_float(thr_v)
