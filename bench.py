@@ -18,9 +18,17 @@ BASELINE.json quotes the metric on, unchanged from round to round -- and carries
     a planted genome reports the genome's columns, and three sampled queries are bit-exact against the CPU oracle on the
     rows they address, read back from HBM.  The oracle is used here as the checker only, never inside a timed region;
     a mismatch ends the run with a non-zero status on every rank.
+  * `early_exit`: the SAME batch against the SAME resident matrix searched with the reference's early exit
+    (kwage.cpp:437-483) -- what `kwage` and `kwage_node` run by default -- after the timed region: `ms_per_step`,
+    `kernel`, `kernel_ms`, the nominal rate (the batch's algorithmic bytes over that time, labelled as bytes mostly NOT
+    read), `fetched_bytes` from the PMC pass of `bench.py --workload X --early-exit` (profiles/pmc_traffic.json "X@ee")
+    with `frac_of_fetched` = fetched bytes / kernel time / 8 TB/s, `identical_to_nominal` (the hit lists equal the timed
+    kernel's record for record) and its own `result_check`.  Never part of `value`.
   * `also`: the other BASELINE.json configurations this launch can hold, each measured like the headline (own
-    `ms_per_step`, `roofline`, `result_check`, at N > 1 `exchange_check`) after the headline's matrix was freed:
-    at N = 1 **C3** (the largest 1-GPU configuration), at N > 1 the per-GPU shares of **C4** and **C5**.
+    `ms_per_step`, `roofline`, `early_exit`, `result_check`, at N > 1 `exchange_check`) after the headline's matrix was
+    freed: at N = 1 **C3** (the largest 1-GPU configuration), at N > 1 the per-GPU shares of **C4** and **C5** and
+    **`c3_strong`** -- C3's 1 M columns SPLIT over the N ranks: the fixed-total-work curve (its N = 1 point is the
+    N = 1 line's `also.c3`), next to the weak-scaling headline.
 
 N > 1: one process per GPU.  Either the caller starts the ranks (`python -m torch.distributed.run
 --nproc-per-node N ... bench.py --gpus N`: RANK / LOCAL_RANK / WORLD_SIZE come from the environment), or
@@ -281,8 +289,11 @@ def also_workloads(args, world):
     if sel == "auto":
         if args.workload != "c2" or args.scaling != "weak" or args.share_of or args.early_exit:
             return []
-        return ["c3"] if world == 1 else ["c4", "c5"]
-    return [x for x in (s.strip() for s in sel.split(",")) if x and x != args.workload]
+        # N > 1: the per-GPU shares of the two 8-GPU configurations (weak: every rank a full share) AND the fixed-total-work
+        # curve: C3's 1 M columns SPLIT over the N ranks (131 GB / N per GPU) -- what "scaling from 1 to 8 GPUs" means
+        # when the work does not grow with N (the N = 1 point of that curve is this same block of the N = 1 line: also.c3)
+        return ["c3"] if world == 1 else ["c4", "c5", "c3_strong"]
+    return [x for x in (s.strip() for s in sel.split(",")) if x and x != args.workload]      # ("c3_strong": c3 split over the ranks)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -418,7 +429,7 @@ class Env:
     pass
 
 
-def measure(env, args, name, headline):
+def measure(env, args, name, headline, force_scaling=None):
     """Build workload `name` on this rank, run warm-up + EXACTLY args.steps timed steps (+ the sustained block for the
     headline), check the results, free everything.  -> the JSON block on rank 0, None elsewhere.  Raises SystemExit(3/4)
     on every rank when the exchange or the results fail their check."""
@@ -432,7 +443,7 @@ def measure(env, args, name, headline):
 
     split = args.share_of if args.share_of > 1 else world
     part = (args.share_rank if args.share_of > 1 else rank)
-    scaling = "strong" if (args.scaling == "strong" or args.share_of > 1) else "weak"
+    scaling = force_scaling or ("strong" if (args.scaling == "strong" or args.share_of > 1) else "weak")
     w, groups, total_samples = rank_share(name, scaling, split, part)
     t_build = time.perf_counter()
     multi = None
@@ -730,6 +741,8 @@ def measure(env, args, name, headline):
                        "step_pipeline": pipeline_note,
                        "total_kmers_per_step": int(probe.total_kmers) if not multi else None, "hits_per_step": int(nhits),
                        "db_build_s": round(t_build, 2),
+                       # which box this is (kwage_device_fingerprint) and what its HBM streams: boxes of the pool differ by several per cent
+                       "box": dict(ctx.fingerprint(), measured_stream_read_gbps=round(stream_gbps, 1), host=socket.gethostname()),
                        # how the loader chose each matrix's device block (rank 0): candidates compared, gather-probe GB/s on the kept / released one
                        "matrix_placement": [m.group.placement for m in multi] if multi else s.group.placement,
                        "seeds": {"queries_and_planted_genomes": 1, "columns": "rank (splitmix64 keyed by seed, row, word; kwage_amd/synth.py)"}},
@@ -862,15 +875,17 @@ def rank_main(args):
         also = {}
         for name in names:
             t0 = time.perf_counter()
+            wl, _, how = name.partition("_")          # "c3_strong": workload c3, its columns split over the ranks
+            force = "strong" if how == "strong" else None
             if world == 1:
                 try:
-                    blk = measure(env, args, name, False)
+                    blk = measure(env, args, wl, False, force)
                 except SystemExit:
                     raise
                 except Exception as exc:          # e.g. the matrix does not fit beside another tenant of the device
                     blk = {"error": repr(exc)}
             else:
-                blk = measure(env, args, name, False)       # ranks stay in step: an exception ends the job (the headline is on stderr)
+                blk = measure(env, args, wl, False, force)       # ranks stay in step: an exception ends the job (the headline is on stderr)
             if rank == 0:
                 also[name] = {k: blk[k] for k in ALSO_KEYS if k in blk} if "error" not in blk else blk
                 also[name]["wall_s"] = round(time.perf_counter() - t0, 2)

@@ -65,6 +65,11 @@ int kwage_init(int device, kwage_ctx **out);
 void kwage_shutdown(kwage_ctx *ctx);
 /* Free / total device memory in bytes. */
 int kwage_mem_info(kwage_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
+/* Identity of the device behind a context, as one line of `key=value` pairs separated by `;` -- `uuid` (hipDeviceGetUuid,
+ * hex), `name`, `arch`, `cus`, `sclk_mhz`, `mclk_mhz`, `hbm_bus_bits`, `pci` (domain:bus:device) -- written NUL-terminated
+ * into `buf` (at most `len` bytes; 256 is enough).  The boxes of a pool differ by several per cent in what their HBM
+ * delivers: every measurement this repo files carries the line, so two of them can be paired or told apart. */
+int kwage_device_fingerprint(kwage_ctx *ctx, char *buf, uint64_t len);
 /* Block until everything queued on the context's stream has finished. */
 int kwage_sync(kwage_ctx *ctx);
 
@@ -80,6 +85,11 @@ int kwage_ctx_get_tuning(kwage_ctx *ctx, const char *name, int64_t *value);
  * out[0] cut-pair masks, out[1] cut-pair counts + flags (and_walk), out[2] per-query masks, out[3] per-query flags
  * (and_band_walk), out[4] tree arrival counters (count_walk).  Waits for the context's streams first.  tools/soak_walk.py. */
 int kwage_ctx_scratch_nonzero(kwage_ctx *ctx, uint64_t out[5]);
+/* Diagnostic: what the LAST early-exit search of each slot handed over from its screen launch to its refine launch
+ * (kernels.hpp and_screen_kernel / count_screen_kernel): per slot k, out[4k + 0] cluster places, [1] item places and
+ * [2] unit places taken (static parts included, i.e. what the refine / emit launches scanned), [3] the capacity of the
+ * unit list.  Waits for the context's streams first.  tools/step_breakdown.py, tests. */
+int kwage_ctx_refine_stats(kwage_ctx *ctx, uint64_t out[8]);
 
 /* ------------------------------------------------------------------------------------
  * Database group: all columns (samples) that share (kmer_len, num_hash, log_2_filter_len,

@@ -26,19 +26,16 @@
 
 using namespace kwage;
 
-static_assert(TUNING_DEFAULT_BLOCK_WAVES == SEARCH_THREADS/WAVE, "the tiled AND kernel's default workgroup");
 
 struct TuningName { const char *name; int64_t Tuning::*field; };
 static const TuningName TUNING_NAMES[] = {
-	{"walk", &Tuning::walk}, {"walk_min_rows", &Tuning::walk_min_rows}, {"walk_max_kib", &Tuning::walk_max_kib}, {"walk_min_kib", &Tuning::walk_min_kib}, {"walk_short_rows", &Tuning::walk_short_rows}, {"walk_tile_kib", &Tuning::walk_tile_kib}, {"walk_paced", &Tuning::walk_paced},
-	{"walk_waves", &Tuning::walk_waves}, {"walk_fences", &Tuning::walk_fences}, {"walk_one_wg_per_cu", &Tuning::walk_one_wg_per_cu},
+	{"walk", &Tuning::walk}, {"walk_min_rows", &Tuning::walk_min_rows}, {"walk_max_kib", &Tuning::walk_max_kib}, {"walk_min_kib", &Tuning::walk_min_kib}, {"walk_tile_kib", &Tuning::walk_tile_kib},
+	 {"walk_waves", &Tuning::walk_waves}, {"walk_one_wg_per_cu", &Tuning::walk_one_wg_per_cu},
 	{"walk_bands", &Tuning::walk_bands}, {"walk_bands_min_gib", &Tuning::walk_bands_min_gib},
-	{"and_vec", &Tuning::and_vec}, {"and_unroll", &Tuning::and_unroll}, {"and_nt", &Tuning::and_nt}, {"and_lds_kb", &Tuning::and_lds_kb},
-	{"and_block_waves", &Tuning::and_block_waves}, {"and_wide", &Tuning::and_wide}, {"and_wide_min_kib", &Tuning::and_wide_min_kib}, {"narrow", &Tuning::narrow}, {"narrow_unroll", &Tuning::narrow_unroll}, {"force_segs", &Tuning::force_segs},
-	{"ee_refine", &Tuning::ee_refine}, {"refine_seg_rows", &Tuning::refine_seg_rows}, {"refine_min_rows", &Tuning::refine_min_rows}, {"refine_max_groups", &Tuning::refine_max_groups}, {"refine_unroll", &Tuning::refine_unroll}, {"refine_list_cap", &Tuning::refine_list_cap}, {"screen_wpc", &Tuning::screen_wpc},
+	{"and_vec", &Tuning::and_vec}, {"and_wide", &Tuning::and_wide}, {"and_wide_min_kib", &Tuning::and_wide_min_kib}, {"narrow", &Tuning::narrow}, {"force_segs", &Tuning::force_segs},
+	{"ee_refine", &Tuning::ee_refine}, {"refine_seg_rows", &Tuning::refine_seg_rows}, {"refine_min_rows", &Tuning::refine_min_rows}, {"refine_max_groups", &Tuning::refine_max_groups}, {"refine_unroll", &Tuning::refine_unroll}, {"refine_list_cap", &Tuning::refine_list_cap}, {"refine_static", &Tuning::refine_static}, {"screen_wpc", &Tuning::screen_wpc}, {"count_screen_wpc", &Tuning::count_screen_wpc}, {"count_screen_min_tiles", &Tuning::count_screen_min_tiles},
 	{"count_walk", &Tuning::count_walk}, {"count_walk_wpc", &Tuning::count_walk_wpc}, {"count_walk_waves", &Tuning::count_walk_waves},
-	{"count_walk_min_rows", &Tuning::count_walk_min_rows}, {"count_walk_prefetch", &Tuning::count_walk_prefetch}, {"count_walk_kps", &Tuning::count_walk_kps},
-	{"count_narrow_kps", &Tuning::count_narrow_kps},
+	{"count_walk_min_rows", &Tuning::count_walk_min_rows},
 	{"hit_sort_host", &Tuning::hit_sort_host}, {"hit_copy_piece_kb", &Tuning::hit_copy_piece_kb}, {"shared_table_log2", &Tuning::shared_table_log2},
 	{"ext_launch_events", &Tuning::ext_launch_events}, {"group_contiguous", &Tuning::group_contiguous}, {"group_placement_probe", &Tuning::group_placement_probe},
 };
@@ -231,9 +228,9 @@ WalkShape walk_shape(const Tuning &tn, uint64_t want_waves, uint64_t ncu)
 	return w;
 }
 
-// Shape of the tiled AND kernel: VEC 16-byte vectors per lane, UNROLL rows in flight, nontemporal loads, and (tuning
-// only) dynamic LDS per workgroup and waves per workgroup.  Defaults come from measurements on MI355X.
-struct AndCfg { int vec, unroll, nt, lds_bytes, block_waves; };
+// Shape of the tiled AND kernel: VEC 16-byte vectors per lane (by row width; knob and_vec), and -- the WIDE shape only -- a
+// dynamic-LDS pad that caps the waves per CU.  Eight rows in flight and nontemporal loads always.
+struct AndCfg { int vec, lds_bytes; };
 
 // `wide`: rows beyond the walk form's range searched without early exit by a launch that fills the chip (C3, C4 and their
 // column shares): four vectors per lane, eight rows in flight, and a dynamic-LDS pad that keeps 8 waves per CU resident
@@ -243,52 +240,34 @@ struct AndCfg { int vec, unroll, nt, lds_bytes, block_waves; };
 AndCfg and_config(const Tuning &t, uint32_t units_per_row, bool wide = false)
 {
 	AndCfg c;
-	if(wide && t.and_vec == 0 && t.and_lds_kb == 0 && t.and_unroll == 8 && t.and_block_waves == TUNING_DEFAULT_BLOCK_WAVES){
-		c.vec = 4; c.unroll = 8; c.nt = t.and_nt ? 1 : 0; c.lds_bytes = 80*1024; c.block_waves = SEARCH_THREADS/WAVE;
-		return c;
-	}
+	if(wide && t.and_vec == 0){ c.vec = 4; c.lds_bytes = 80*1024; return c; }
 	c.vec = (t.and_vec == 1 || t.and_vec == 2 || t.and_vec == 4) ? (int)t.and_vec : ((units_per_row >= 4*WAVE) ? 2 : 1);
-	c.unroll = (t.and_unroll == 4 || t.and_unroll == 16 || t.and_unroll == 32) ? (int)t.and_unroll : 8;
-	if((c.unroll == 16 && c.vec == 4) || (c.unroll == 32 && c.vec != 1)){ c.unroll = 8; }       // shapes that are not instantiated
-	c.nt = t.and_nt ? 1 : 0;      // +4-10 % on MI355X: each row byte is consumed once per (query, tile)
-	c.lds_bytes = (t.and_lds_kb > 0 && t.and_lds_kb <= 160) ? (int)t.and_lds_kb*1024 : 0;
-	c.block_waves = (t.and_block_waves == 1 || t.and_block_waves == 2) ? (int)t.and_block_waves : SEARCH_THREADS/WAVE;
+	c.lds_bytes = 0;
 	return c;
 }
 
-template <int VEC, int UNROLL, bool NT>
+template <int VEC>
 void launch_and(const SearchArgs &a, hipStream_t s, const AndCfg &c, const StageEvents &ge)
 {
 	const uint64_t tiles = (uint64_t)a.n_queries*a.segs*a.chunks;
-	const uint32_t bw = (uint32_t)c.block_waves;
-	const dim3 grid((uint32_t)((tiles + bw - 1)/bw)), block(bw*WAVE);
+	const uint32_t bw = SEARCH_THREADS/WAVE;
+	const dim3 grid((uint32_t)((tiles + bw - 1)/bw)), block(SEARCH_THREADS);
 	if(c.lds_bytes > 48*1024){
-		(void)hipFuncSetAttribute((const void*)and_kernel<VEC, UNROLL, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds_bytes);
-		(void)hipFuncSetAttribute((const void*)and_kernel<VEC, UNROLL, NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds_bytes);
+		(void)hipFuncSetAttribute((const void*)and_kernel<VEC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds_bytes);
 	}
 	if(a.segs > 1){
-		KW_GATHER_LAUNCH(ge, true, false, (and_kernel<VEC, UNROLL, NT, true>), grid, block, c.lds_bytes, s, a);      // (and_combine_kernel ends the stage)
+		KW_GATHER_LAUNCH(ge, true, false, (and_kernel<VEC, true>), grid, block, 0, s, a);      // (and_combine_kernel ends the stage)
 	}
 	else{
-		KW_GATHER_LAUNCH(ge, true, true, (and_kernel<VEC, UNROLL, NT, false>), grid, block, c.lds_bytes, s, a);
+		KW_GATHER_LAUNCH(ge, true, true, (and_kernel<VEC, false>), grid, block, c.lds_bytes, s, a);
 	}
 }
 
-template <int VEC, bool NT>
-void launch_and_u(const SearchArgs &a, hipStream_t s, const AndCfg &c, const StageEvents &ge)
-{
-	if(c.unroll == 4){ launch_and<VEC, 4, NT>(a, s, c, ge); }
-	else if(c.unroll == 16 && VEC < 4){ launch_and<VEC, 16, NT>(a, s, c, ge); }
-	else if(c.unroll == 32 && VEC == 1){ launch_and<VEC, 32, NT>(a, s, c, ge); }
-	else{ launch_and<VEC, 8, NT>(a, s, c, ge); }
-}
-
-template <bool NT>
 void launch_and_v(const SearchArgs &a, hipStream_t s, const AndCfg &c, const StageEvents &ge)
 {
-	if(c.vec == 1){ launch_and_u<1, NT>(a, s, c, ge); }
-	else if(c.vec == 2){ launch_and_u<2, NT>(a, s, c, ge); }
-	else{ launch_and_u<4, NT>(a, s, c, ge); }
+	if(c.vec == 1){ launch_and<1>(a, s, c, ge); }
+	else if(c.vec == 2){ launch_and<2>(a, s, c, ge); }
+	else{ launch_and<4>(a, s, c, ge); }
 }
 
 template <int PLANES, int NH>
@@ -302,25 +281,18 @@ void launch_count(const SearchArgs &a, hipStream_t s, const StageEvents &ge)
 	}
 }
 
-template <int PLANES, int G, int KPS>
+template <int PLANES, int G>
 void launch_count_narrow(const SearchArgs &a, hipStream_t s, const StageEvents &ge)
 {
 	const uint64_t waves = ((uint64_t)a.n_queries + G - 1)/G;
 	const dim3 grid((uint32_t)((waves + 3)/4)), block(SEARCH_THREADS);
 	switch(a.num_hash){
-		case 1: KW_GATHER_LAUNCH(ge, true, true, (count_narrow_kernel<PLANES, 1, G, KPS>), grid, block, 0, s, a); break;
-		case 2: KW_GATHER_LAUNCH(ge, true, true, (count_narrow_kernel<PLANES, 2, G, KPS>), grid, block, 0, s, a); break;
-		case 3: KW_GATHER_LAUNCH(ge, true, true, (count_narrow_kernel<PLANES, 3, G, KPS>), grid, block, 0, s, a); break;
-		case 4: KW_GATHER_LAUNCH(ge, true, true, (count_narrow_kernel<PLANES, 4, G, KPS>), grid, block, 0, s, a); break;
-		default: KW_GATHER_LAUNCH(ge, true, true, (count_narrow_kernel<PLANES, 5, G, KPS>), grid, block, 0, s, a); break;
+		case 1: KW_GATHER_LAUNCH(ge, true, true, (count_narrow_kernel<PLANES, 1, G>), grid, block, 0, s, a); break;
+		case 2: KW_GATHER_LAUNCH(ge, true, true, (count_narrow_kernel<PLANES, 2, G>), grid, block, 0, s, a); break;
+		case 3: KW_GATHER_LAUNCH(ge, true, true, (count_narrow_kernel<PLANES, 3, G>), grid, block, 0, s, a); break;
+		case 4: KW_GATHER_LAUNCH(ge, true, true, (count_narrow_kernel<PLANES, 4, G>), grid, block, 0, s, a); break;
+		default: KW_GATHER_LAUNCH(ge, true, true, (count_narrow_kernel<PLANES, 5, G>), grid, block, 0, s, a); break;
 	}
-}
-
-template <int PLANES, int G>
-void launch_count_narrow_k(const SearchArgs &a, hipStream_t s, int kps, const StageEvents &ge)
-{
-	if(kps == 4){ launch_count_narrow<PLANES, G, 4>(a, s, ge); }
-	else{ launch_count_narrow<PLANES, G, 8>(a, s, ge); }
 }
 
 template <int PLANES>
@@ -354,42 +326,33 @@ void launch_count_planes(uint32_t planes, const SearchArgs &a, hipStream_t s, co
 	}
 }
 
-template <int PLANES, int NH, bool PF>
-void launch_count_walk(const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s, const StageEvents &ge, int kps)
+template <int PLANES, int NH>
+void launch_count_walk(const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s, const StageEvents &ge)
 {
-	// (eight k-mers per step exist for the prefetching loop with 14 planes and more: where the ripple adders dominate)
-	if constexpr(PF && PLANES >= 14){
-		if(kps == 8){
-			if(w.lds > 48*1024){ (void)hipFuncSetAttribute((const void*)count_walk_kernel<PLANES, NH, PF, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds); }
-			KW_GATHER_LAUNCH(ge, true, true, (count_walk_kernel<PLANES, NH, PF, 8>), dim3(w.wgs), dim3(w.wg_waves*WAVE), w.lds, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr);
-			return;
-		}
-	}
-	if(w.lds > 48*1024){ (void)hipFuncSetAttribute((const void*)count_walk_kernel<PLANES, NH, PF, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds); }
-	KW_GATHER_LAUNCH(ge, true, true, (count_walk_kernel<PLANES, NH, PF, 4>), dim3(w.wgs), dim3(w.wg_waves*WAVE), w.lds, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr);
+	if(w.lds > 48*1024){ (void)hipFuncSetAttribute((const void*)count_walk_kernel<PLANES, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds); }
+	KW_GATHER_LAUNCH(ge, true, true, (count_walk_kernel<PLANES, NH>), dim3(w.wgs), dim3(w.wg_waves*WAVE), w.lds, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr);
 }
 
-template <int PLANES, bool PF>
-void launch_count_walk_nh(const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s, const StageEvents &ge, int kps)
+template <int PLANES>
+void launch_count_walk_nh(const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s, const StageEvents &ge)
 {
 	switch(a.num_hash){
-		case 1: launch_count_walk<PLANES, 1, PF>(a, wa, w, s, ge, kps); break;
-		case 2: launch_count_walk<PLANES, 2, PF>(a, wa, w, s, ge, kps); break;
-		case 3: launch_count_walk<PLANES, 3, PF>(a, wa, w, s, ge, kps); break;
-		case 4: launch_count_walk<PLANES, 4, PF>(a, wa, w, s, ge, kps); break;
-		default: launch_count_walk<PLANES, 5, PF>(a, wa, w, s, ge, kps); break;
+		case 1: launch_count_walk<PLANES, 1>(a, wa, w, s, ge); break;
+		case 2: launch_count_walk<PLANES, 2>(a, wa, w, s, ge); break;
+		case 3: launch_count_walk<PLANES, 3>(a, wa, w, s, ge); break;
+		case 4: launch_count_walk<PLANES, 4>(a, wa, w, s, ge); break;
+		default: launch_count_walk<PLANES, 5>(a, wa, w, s, ge); break;
 	}
 }
 
-template <bool PF>
-void launch_count_walk_planes(uint32_t planes, const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s, const StageEvents &ge, int kps)
+void launch_count_walk_planes(uint32_t planes, const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s, const StageEvents &ge)
 {
 	switch(planes){
-		case 7: launch_count_walk_nh<7, PF>(a, wa, w, s, ge, kps); break;
-		case 10: launch_count_walk_nh<10, PF>(a, wa, w, s, ge, kps); break;
-		case 14: launch_count_walk_nh<14, PF>(a, wa, w, s, ge, kps); break;
-		case 20: launch_count_walk_nh<20, PF>(a, wa, w, s, ge, kps); break;
-		default: launch_count_walk_nh<32, PF>(a, wa, w, s, ge, kps); break;
+		case 7: launch_count_walk_nh<7>(a, wa, w, s, ge); break;
+		case 10: launch_count_walk_nh<10>(a, wa, w, s, ge); break;
+		case 14: launch_count_walk_nh<14>(a, wa, w, s, ge); break;
+		case 20: launch_count_walk_nh<20>(a, wa, w, s, ge); break;
+		default: launch_count_walk_nh<32>(a, wa, w, s, ge); break;
 	}
 }
 
@@ -452,7 +415,7 @@ int refine_setup(Slot *sl, const Tuning &tn, const SearchArgs &a, uint64_t total
 	int rc;
 	RefineArgs &ra = out->ra;
 	ra.seg_rows = (uint32_t)std::min<int64_t>(std::max<int64_t>(tn.refine_seg_rows, 8), max_seg);
-	ra.seg_rows = (uint32_t)std::max<uint64_t>(ra.seg_rows, (max_rows + 65535)/65536);              // (at most 2^16 units per item)
+	ra.seg_rows = (uint32_t)std::max<uint64_t>(ra.seg_rows, (max_rows + 65535)/65536);              // (at most 2^16 units per item; the count path passes its own segment length)
 	ra.min_rows = (uint32_t)std::max<int64_t>(tn.refine_min_rows, 1);
 	ra.max_groups = (uint32_t)std::min<int64_t>(std::max<int64_t>(tn.refine_max_groups, 0), 16);      // (0: nothing is ever handed over)
 	uint64_t items = std::min<uint64_t>(std::max<uint64_t>(8ull*a.n_queries, 1u << 16), 1u << 20);
@@ -465,7 +428,7 @@ int refine_setup(Slot *sl, const Tuning &tn, const SearchArgs &a, uint64_t total
 	auto list = [&](uint64_t cap, uint64_t stat_max, uint64_t chunk_max) {
 		RefineList ls;
 		ls.cap = (uint32_t)cap;
-		ls.stat = (uint32_t)std::min<uint64_t>(stat_max, cap/2/std::max<uint64_t>(screen_waves, 1));
+		ls.stat = tn.refine_static ? (uint32_t)std::min<uint64_t>(stat_max, cap/2/std::max<uint64_t>(screen_waves, 1)) : 0u;
 		ls.base = (uint32_t)(ls.stat*screen_waves);
 		ls.chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(chunk_max, tiles_per_wave/4));
 		return ls;
@@ -473,7 +436,7 @@ int refine_setup(Slot *sl, const Tuning &tn, const SearchArgs &a, uint64_t total
 	ra.lc = list(items, 32, 32);
 	ra.li = list(items, 64, 64);
 	ra.lu = list(units, 256, 256);
-	if((rc = sl->ref_counters.reserve(4*sizeof(uint32_t)))){ return rc; }
+	if((rc = sl->ref_counters.reserve(8*sizeof(uint32_t)))){ return rc; }
 	if((rc = sl->ref_clusters.reserve(items*sizeof(RefineCluster)))){ return rc; }
 	if((rc = sl->ref_masks.reserve(items*item_bytes))){ return rc; }
 	if((rc = sl->ref_units.reserve(units*sizeof(RefineUnit)))){ return rc; }
@@ -483,10 +446,32 @@ int refine_setup(Slot *sl, const Tuning &tn, const SearchArgs &a, uint64_t total
 	ra.masks = (uint32_t*)sl->ref_masks.p;
 	ra.units = (RefineUnit*)sl->ref_units.p;
 	ra.slab = (uint32_t*)sl->ref_slab.p;
-	HIP_TRY(hipMemsetAsync(ra.counters, 0, 4*sizeof(uint32_t), gs));
+	HIP_TRY(hipMemsetAsync(ra.counters, 0, 8*sizeof(uint32_t), gs));
+	sl->ref_base[0] = ra.lc.base; sl->ref_base[1] = ra.li.base; sl->ref_base[2] = ra.lu.base;
+	sl->ref_cap[0] = ra.lc.cap; sl->ref_cap[1] = ra.li.cap; sl->ref_cap[2] = ra.lu.cap;
+	ra.queue_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16, tiles/(8*std::max<uint64_t>(screen_waves, 1))));
 	out->refine_wgs = (uint32_t)(ncu*8);          // 32 waves per CU, eight units each
 	out->emit_wgs = (uint32_t)(ncu*4);            // 16 waves per CU, four clusters at a time each
 	return KWAGE_OK;
+}
+
+// Workgroups of count_screen_kernel<planes, nh> a CU holds at once (registers; asked of the runtime once per shape).
+uint32_t count_screen_blocks_per_cu(uint32_t planes, uint32_t nh)
+{
+	static int cache[5][5] = {};
+	const int pi = (planes <= 7) ? 0 : (planes <= 10) ? 1 : (planes <= 14) ? 2 : (planes <= 20) ? 3 : 4, ni = (int)std::min(std::max(nh, 1u), 5u) - 1;
+	if(cache[pi][ni] == 0){
+		int nb = 0;
+		hipError_t e = hipErrorUnknown;
+#define KWAGE_OCC_NH(P, N) case N: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, count_screen_kernel<P, N>, SEARCH_THREADS, 0); break;
+#define KWAGE_OCC_P(I, P) case I: switch(ni + 1){ KWAGE_OCC_NH(P, 1) KWAGE_OCC_NH(P, 2) KWAGE_OCC_NH(P, 3) KWAGE_OCC_NH(P, 4) default: KWAGE_OCC_NH(P, 5) } break;
+		switch(pi){ KWAGE_OCC_P(0, 7) KWAGE_OCC_P(1, 10) KWAGE_OCC_P(2, 14) KWAGE_OCC_P(3, 20) default: KWAGE_OCC_P(4, 32) }
+#undef KWAGE_OCC_P
+#undef KWAGE_OCC_NH
+		if(e != hipSuccess || nb <= 0){ (void)hipGetLastError(); nb = 2; }
+		cache[pi][ni] = nb;
+	}
+	return (uint32_t)cache[pi][ni];
 }
 
 // Launch the gather+reduce kernel(s) for the current batch.
@@ -517,16 +502,13 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 	int rc;
 
 	if(threshold == 1.0f){
-		// The wide shape of the tiled kernel (and_config) where a launch without early exit fills the chip with 4 KiB tiles:
-		// for rows beyond the walk form's range, and -- within that range -- for batches of SHORT row lists: with 120 rows
-		// per query (150-base reads) the tiled wide shape reads 4-9 % faster than the walk form at 6-16 KB rows, with 220
-		// rows and more the walk form wins by 2-8 % (profiles/r04_walk_vs_tiled_wide_grid.txt; crossover ~170 rows).
-		const uint32_t kib_rows = (a.units_per_row + WAVE - 1)/WAVE;
+		// The wide shape of the tiled kernel (and_config) where a launch without early exit fills the chip with 4 KiB tiles: for
+		// rows beyond the walk form's range.  (Within that range the walk form is ahead for every row-list length since its
+		// waves buffer their hit records: a rule that sent batches of short row lists to the wide shape was dropped in round 4,
+		// its knob in round 5; profiles/r04_walk_vs_tiled_wide_grid.txt, r04_walk_hit_cost.txt.)
 		const uint64_t wide_tiles = (uint64_t)a.n_queries*((a.units_per_row + 4*WAVE - 1)/(4*WAVE));
 		const bool wide_ok = tn.and_wide && !(flags & KWAGE_SEARCH_EARLY_EXIT) && wide_tiles >= 8*ncu;
-		const bool short_lists = wide_ok && kib_rows >= 5 && wide_tiles >= 128*ncu
-		                         && L->total_pos*a.num_hash < (uint64_t)std::max<int64_t>(tn.walk_short_rows, 0)*a.n_queries;
-		const bool wide_rows = wide_ok && (a.units_per_row > (uint32_t)std::max<int64_t>(tn.and_wide_min_kib, 1)*WAVE || short_lists);
+		const bool wide_rows = wide_ok && a.units_per_row > (uint32_t)std::max<int64_t>(tn.and_wide_min_kib, 1)*WAVE;
 		const AndCfg cfg = and_config(tn, a.units_per_row, wide_rows);
 		a.chunks = (a.units_per_row + WAVE*cfg.vec - 1)/(WAVE*cfg.vec);
 		choose_segments(a, L->max_pos, 4096, tn.force_segs);
@@ -537,7 +519,7 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 			const uint64_t waves = ((uint64_t)a.n_queries + G - 1)/G;
 			const dim3 grid((uint32_t)((waves + 3)/4)), block(SEARCH_THREADS);
 			// few waves (10 k queries of 1 kb: ten per CU): sixteen rows in flight per wave instead of eight
-			const int unroll = (tn.narrow_unroll == 8 || tn.narrow_unroll == 16) ? (int)tn.narrow_unroll : ((waves < ncu*16) ? 16 : 8);
+			const int unroll = (waves < ncu*16) ? 16 : 8;
 			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_narrow_kernel<%u,%d>", G, unroll);
 #define KWAGE_NARROW_CASE(GG) case GG: \
 				if(unroll == 16){ KW_GATHER_LAUNCH(ge, true, true, (and_narrow_kernel<GG, 16>), grid, block, 0, gs, a); } \
@@ -591,9 +573,9 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 		const uint64_t walk_slots = (uint64_t)coltiles*L->total_pos;
 		const uint32_t walk_min_kib = (uint32_t)std::max<int64_t>(tn.walk_min_kib, 1);
 		// rows in flight per wave: 4; 8 for rows of one or two KiB-steps (a group of four such rows is only 4-8 loads: C2's
-		// columns split 8 ways, 1664-byte rows, 0.2626 vs 0.2667 ms) and, by knob, up to four; 2 by knob
-		const int walk_unroll = (walk_knob == 2) ? 2 : ((walk_knob == 8 && walk_ch <= 4) || walk_ch <= 2) ? 8 : 4;
-		if(walk_knob && walk_ee_ok && !short_lists && kib >= walk_min_kib && kib <= walk_max_kib && walk_slots*a.num_hash >= walk_min_rows && walk_slots > 0){
+		// columns split 8 ways, 1664-byte rows, 0.2626 vs 0.2667 ms)
+		const int walk_unroll = (walk_ch <= 2) ? 8 : 4;
+		if(walk_knob && walk_ee_ok && kib >= walk_min_kib && kib <= walk_max_kib && walk_slots*a.num_hash >= walk_min_rows && walk_slots > 0){
 			// WALK_WAVES_PER_CU waves per CU, all resident at once (__launch_bounds__(256, 4) allows twice as many),
 			// fewer when the batch is small: a wave should have WALK_MIN_ROWS_PER_WAVE rows to walk
 			const uint64_t chip_waves = ncu*WALK_WAVES_PER_CU;
@@ -627,17 +609,17 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 				wb.total_slots = walk_slots;                         // (one column tile: slots = positions)
 				wb.per_wave = (walk_slots + waves - 1)/waves;
 				wb.coltiles = 1;
-				wb.orbuf = nullptr; wb.done = nullptr; wb.full_fences = 0;
+				wb.orbuf = nullptr; wb.done = nullptr;
 				a.segs = 1;
 				a.chunks = 1;
-				snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_band_walk_kernel<%u,%d>", walk_ch, walk_unroll == 2 ? 2 : 4);
+				snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_band_walk_kernel<%u,4>", walk_ch);
 				const dim3 grid(wgs), block(shape.wg_waves*WAVE), fgrid((a.n_queries + 3)/4);
 #define KWAGE_BAND_LAUNCH(CH, U) do { \
 					if(shape.lds > 48*1024){ (void)hipFuncSetAttribute((const void*)and_band_walk_kernel<CH, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shape.lds); } \
 					KW_GATHER_LAUNCH(ge, false, false, (and_band_walk_kernel<CH, U>), grid, block, shape.lds, gs, a, ba, wb, (const uint32_t*)rows2, (const uint32_t*)loc, a.pos_off, a.nkmer); \
 					KW_GATHER_LAUNCH(ge, false, true, (and_band_finish_kernel<CH>), fgrid, dim3(256), 0, gs, a, ba, a.nkmer); } while(0)
 #define KWAGE_BAND_CASE(CH) case CH: \
-					if(walk_unroll == 2){ KWAGE_BAND_LAUNCH(CH, 2); } else{ KWAGE_BAND_LAUNCH(CH, 4); } break;
+					KWAGE_BAND_LAUNCH(CH, 4); break;
 				switch(walk_ch){
 					KWAGE_BAND_CASE(3) KWAGE_BAND_CASE(4) KWAGE_BAND_CASE(5) KWAGE_BAND_CASE(6) KWAGE_BAND_CASE(7)
 					KWAGE_BAND_CASE(8) KWAGE_BAND_CASE(9) KWAGE_BAND_CASE(10) KWAGE_BAND_CASE(11) KWAGE_BAND_CASE(12)
@@ -658,21 +640,17 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 			if((rc = reserve_zeroed(sl->walk_done, waves*2*sizeof(uint32_t), gs))){ return rc; }
 			wa.orbuf = (uint32_t*)sl->walk_or.p;
 			wa.done = (uint32_t*)sl->walk_done.p;
-			wa.full_fences = tn.walk_fences ? 1 : 0;
 			a.segs = 1;
 			a.chunks = coltiles;
-			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_walk_kernel<%u,%d%s>", walk_ch, walk_unroll, (walk_unroll == 8 && walk_ch <= 4 && !tn.walk_paced) ? ",unpaced" : "");
+			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_walk_kernel<%u,%d>", walk_ch, walk_unroll);
 			const dim3 grid(wgs), block(shape.wg_waves*WAVE);
 #define KWAGE_WALK_LAUNCH(...) do { \
 				if(shape.lds > 48*1024){ (void)hipFuncSetAttribute((const void*)and_walk_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shape.lds); } \
 				KW_GATHER_LAUNCH(ge, true, true, (and_walk_kernel<__VA_ARGS__>), grid, block, shape.lds, gs, a, wa, a.rows, a.pos_off, a.nkmer); } while(0)
-#define KWAGE_WALK_CASE(CH) case CH: \
-				if(walk_unroll == 2){ KWAGE_WALK_LAUNCH(CH, 2); } else{ KWAGE_WALK_LAUNCH(CH, 4); } break;
-#define KWAGE_WALK_CASE8(CH) case CH: \
-				if(walk_unroll == 2){ KWAGE_WALK_LAUNCH(CH, 2); } else if(walk_unroll == 8 && !tn.walk_paced){ KWAGE_WALK_LAUNCH(CH, 8, false); } \
-				else if(walk_unroll == 8){ KWAGE_WALK_LAUNCH(CH, 8); } else{ KWAGE_WALK_LAUNCH(CH, 4); } break;
+#define KWAGE_WALK_CASE(CH) case CH: KWAGE_WALK_LAUNCH(CH, 4); break;
+#define KWAGE_WALK_CASE8(CH) case CH: KWAGE_WALK_LAUNCH(CH, 8); break;
 			switch(walk_ch){
-				KWAGE_WALK_CASE8(1) KWAGE_WALK_CASE8(2) KWAGE_WALK_CASE8(3) KWAGE_WALK_CASE8(4) KWAGE_WALK_CASE(5) KWAGE_WALK_CASE(6) KWAGE_WALK_CASE(7)
+				KWAGE_WALK_CASE8(1) KWAGE_WALK_CASE8(2) KWAGE_WALK_CASE(3) KWAGE_WALK_CASE(4) KWAGE_WALK_CASE(5) KWAGE_WALK_CASE(6) KWAGE_WALK_CASE(7)
 				KWAGE_WALK_CASE(8) KWAGE_WALK_CASE(9) KWAGE_WALK_CASE(10) KWAGE_WALK_CASE(11) KWAGE_WALK_CASE(12)
 				KWAGE_WALK_CASE(13) KWAGE_WALK_CASE(14) KWAGE_WALK_CASE(15)
 				default: KWAGE_WALK_CASE(16)
@@ -689,9 +667,8 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 			HIP_TRY(hipMemsetAsync(sl->partial.p, 0xFF, bytes, gs));
 			a.partial = (uint32_t*)sl->partial.p;
 		}
-		snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_kernel<%d,%d,%s>%s", cfg.vec, cfg.unroll, cfg.nt ? "nt" : "t", a.segs > 1 ? "+segments" : "");
-		if(cfg.nt){ launch_and_v<true>(a, gs, cfg, ge); }
-		else{ launch_and_v<false>(a, gs, cfg, ge); }
+		snprintf(sl->kernel_name, sizeof(sl->kernel_name), "and_kernel<%d,8,nt>%s", cfg.vec, a.segs > 1 ? "+segments" : "");      // (shape: vectors per lane, rows in flight, nontemporal)
+		launch_and_v(a, gs, cfg, ge);
 		if(a.segs > 1){
 			KW_GATHER_LAUNCH(ge, false, true, and_combine_kernel, dim3((a.units_per_row + 255)/256, a.n_queries), dim3(256), 0, gs, a);
 		}
@@ -710,6 +687,41 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 		// inside bench.py: 1.988 vs 2.077 ms, profiles/r03_c2t_bench_ab.txt).  (Alone on the chip, batches whose tiles
 		// all fit in one round are 2-3 % faster through the tiled kernel -- 300 queries 0.582 vs 0.598 ms --: not worth
 		// a rule of their own.)  Early exit, tiny batches and forced segment counts go on below.
+		// early exit on rows of a KiB and more, enough (query, KiB tile) pairs to keep a persistent grid busy: screen, then refine
+		// (kernels.hpp count_screen_kernel).  Few long queries stay with the segments below: every tile has to read the first
+		// (1 - t) n k-mers before the bound can prune anything, and a handful of tiles that long would be the whole launch.
+		if(a.early_exit && tn.ee_refine && !narrow && tn.force_segs <= 0 && a.units_per_row >= WAVE
+		   && (uint64_t)a.n_queries*a.chunks >= (uint64_t)std::max<int64_t>(tn.count_screen_min_tiles, 1) && L->max_pos <= (1u << 21)){
+			const uint64_t tiles = (uint64_t)a.n_queries*a.chunks;
+			// k-mers per unit: 64 (7 counter planes per unit); queries above 8192 positions: 1/128 of the longest (14 planes)
+			uint32_t seg = (uint32_t)std::min<int64_t>(std::max<int64_t>(tn.refine_seg_rows, 8), 120)/8*8;
+			int up = 7;
+			if(L->max_pos > 8192){ seg = (uint32_t)((L->max_pos + 127)/128 + 7)/8*8; up = 14; }
+			// (as many waves as the kernel's registers let a CU hold -- knob count_screen_wpc caps it; they draw their tiles from a queue)
+			const uint64_t wpc = std::min<uint64_t>((uint64_t)std::max<int64_t>(tn.count_screen_wpc, 1), 4ull*count_screen_blocks_per_cu(planes, std::min(a.num_hash, 5u)));
+			const uint64_t screen_waves = (std::min<uint64_t>(tiles, ncu*wpc) + 3)/4*4;
+			RefineSetup rs;
+			if((rc = refine_setup(sl, tn, a, L->total_pos, 0, seg, (uint64_t)planes*128, (uint64_t)up*128, tiles, screen_waves, ncu, gs, &rs))){ return rc; }
+			rs.ra.seg_rows = seg;
+			a.segs = 1;
+			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_screen_kernel<%u,%u>+refine<%d>", planes, std::min(a.num_hash, 5u), up);
+			const dim3 grid((uint32_t)(screen_waves/4)), block(SEARCH_THREADS);
+#define KWAGE_CS_NH(P, N) case N: KW_GATHER_LAUNCH(ge, true, false, (count_screen_kernel<P, N>), grid, block, 0, gs, a, rs.ra); break;
+#define KWAGE_CS_P(P) case P: switch(std::min(a.num_hash, 5u)){ KWAGE_CS_NH(P, 1) KWAGE_CS_NH(P, 2) KWAGE_CS_NH(P, 3) KWAGE_CS_NH(P, 4) default: KWAGE_CS_NH(P, 5) } break;
+			switch(planes){ KWAGE_CS_P(7) KWAGE_CS_P(10) KWAGE_CS_P(14) KWAGE_CS_P(20) default: KWAGE_CS_P(32) }
+#undef KWAGE_CS_P
+#undef KWAGE_CS_NH
+#define KWAGE_CR_NH(N) case N: if(up == 7){ KW_GATHER_LAUNCH(ge, false, false, (count_refine_kernel<N, 7>), dim3(rs.refine_wgs), block, 0, gs, a, rs.ra); } \
+				else{ KW_GATHER_LAUNCH(ge, false, false, (count_refine_kernel<N, 14>), dim3(rs.refine_wgs), block, 0, gs, a, rs.ra); } break;
+			switch(std::min(a.num_hash, 5u)){ KWAGE_CR_NH(1) KWAGE_CR_NH(2) KWAGE_CR_NH(3) KWAGE_CR_NH(4) default: KWAGE_CR_NH(5) }
+#undef KWAGE_CR_NH
+#define KWAGE_CE_P(P) case P: if(up == 7){ KW_GATHER_LAUNCH(ge, false, true, (count_refine_emit_kernel<P, 7>), dim3(rs.emit_wgs), block, 0, gs, a, rs.ra); } \
+				else{ KW_GATHER_LAUNCH(ge, false, true, (count_refine_emit_kernel<P, (P >= 14 ? 14 : 7)>), dim3(rs.emit_wgs), block, 0, gs, a, rs.ra); } break;
+			switch(planes){ KWAGE_CE_P(7) KWAGE_CE_P(10) KWAGE_CE_P(14) KWAGE_CE_P(20) default: KWAGE_CE_P(32) }
+#undef KWAGE_CE_P
+			HIP_TRY(hipGetLastError());
+			return KWAGE_OK;
+		}
 		if(tn.count_walk && !a.early_exit && !narrow && tn.force_segs <= 0 && L->total_pos > 0){
 			const uint64_t slots = (uint64_t)a.chunks*L->total_pos;
 			const uint64_t chip_waves = ncu*(uint64_t)std::max<int64_t>(tn.count_walk_wpc, 1);
@@ -728,11 +740,9 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 				wa.slab = (uint32_t*)sl->cwalk_slab.p;
 				wa.arrived = (uint32_t*)sl->cwalk_arrived.p;
 				a.segs = 1;
-				// k-mers per step: 8 with 14 planes and more (knob count_walk_kps: 0 = this rule, 4, 8)
-				const int kps = (tn.count_walk_prefetch && planes >= 14 && (tn.count_walk_kps == 8 || tn.count_walk_kps == 0)) ? 8 : 4;
-				snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_walk_kernel<%u,%u%s%s>", planes, std::min(a.num_hash, 5u), tn.count_walk_prefetch ? ",pf" : "", kps == 8 ? ",8" : "");
-				if(tn.count_walk_prefetch){ launch_count_walk_planes<true>(planes, a, wa, shape, gs, ge, kps); }
-				else{ launch_count_walk_planes<false>(planes, a, wa, shape, gs, ge, kps); }
+				// (shape: planes, hashes, the next step's rows prefetched, eight k-mers per step with 14 planes and more)
+				snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_walk_kernel<%u,%u,pf%s>", planes, std::min(a.num_hash, 5u), planes >= 14 ? ",8" : "");
+				launch_count_walk_planes(planes, a, wa, shape, gs, ge);
 				HIP_TRY(hipGetLastError());
 				return KWAGE_OK;
 			}
@@ -756,17 +766,17 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 		}
 		if(narrow && a.segs == 1){
 			// one reference file (<= 2048 columns = 16 units) or two: 4 resp. 2 queries per wave
-			const int kps = (tn.count_narrow_kps == 4) ? 4 : 8;
+			const int kps = 8;
 			snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_narrow_kernel<%u,%u,%d,%d>", planes, a.num_hash, a.units_per_row <= 16 ? 4 : 2, kps);
 			if(a.units_per_row <= 16){
-				if(planes == 7){ launch_count_narrow_k<7, 4>(a, gs, kps, ge); }
-				else if(planes == 10){ launch_count_narrow_k<10, 4>(a, gs, kps, ge); }
-				else{ launch_count_narrow_k<14, 4>(a, gs, kps, ge); }
+				if(planes == 7){ launch_count_narrow<7, 4>(a, gs, ge); }
+				else if(planes == 10){ launch_count_narrow<10, 4>(a, gs, ge); }
+				else{ launch_count_narrow<14, 4>(a, gs, ge); }
 			}
 			else{
-				if(planes == 7){ launch_count_narrow_k<7, 2>(a, gs, kps, ge); }
-				else if(planes == 10){ launch_count_narrow_k<10, 2>(a, gs, kps, ge); }
-				else{ launch_count_narrow_k<14, 2>(a, gs, kps, ge); }
+				if(planes == 7){ launch_count_narrow<7, 2>(a, gs, ge); }
+				else if(planes == 10){ launch_count_narrow<10, 2>(a, gs, ge); }
+				else{ launch_count_narrow<14, 2>(a, gs, ge); }
 			}
 			HIP_TRY(hipGetLastError());
 			return KWAGE_OK;
@@ -963,8 +973,8 @@ Slot *free_slot(kwage_ctx *ctx)
 
 namespace {
 
-// The knobs' values at context creation: KWAGE_<NAME> for every name of TUNING_NAMES, plus the two historic spellings
-// KWAGE_AND_CFG="vec,unroll,nt[,ldsKB[,block waves]]" and KWAGE_HIT_SORT=host.
+// The knobs' values at context creation: KWAGE_<NAME> for every name of TUNING_NAMES, plus the historic spelling
+// KWAGE_HIT_SORT=host.
 void tuning_from_environment(Tuning *t)
 {
 	for(const TuningName &tn : TUNING_NAMES){
@@ -972,15 +982,6 @@ void tuning_from_environment(Tuning *t)
 		for(const char *c = tn.name; *c; ++c){ env += (char)toupper((unsigned char)*c); }
 		const char *e = getenv(env.c_str());
 		if(e && *e){ t->*(tn.field) = strtoll(e, nullptr, 10); }
-	}
-	if(const char *e = getenv("KWAGE_AND_CFG")){
-		int v = 0, u = 0, n = 0, l = 0, w = 0;
-		const int got = sscanf(e, "%d,%d,%d,%d,%d", &v, &u, &n, &l, &w);
-		if(got >= 3){
-			t->and_vec = v; t->and_unroll = u; t->and_nt = n;
-			t->and_lds_kb = (got >= 4) ? l : 0;
-			t->and_block_waves = (got >= 5) ? w : SEARCH_THREADS/WAVE;
-		}
 	}
 	if(const char *e = getenv("KWAGE_HIT_SORT")){ t->hit_sort_host = !strcmp(e, "host") ? 1 : 0; }
 }
@@ -1044,6 +1045,23 @@ extern "C" int kwage_ctx_scratch_nonzero(kwage_ctx *ctx, uint64_t out[5])
 	(void)hipFree(d);
 	if(e != hipSuccess){ return fail(KWAGE_ERR_DEVICE, "kwage_ctx_scratch_nonzero: %s", hipGetErrorString(e)); }
 	for(int j = 0; j < 5; ++j){ out[j] = h[j]; }
+	return KWAGE_OK;
+}
+
+extern "C" int kwage_ctx_refine_stats(kwage_ctx *ctx, uint64_t out[8])
+{
+	if(!ctx || !out){ return fail(KWAGE_ERR_ARG, "kwage_ctx_refine_stats: NULL argument"); }
+	for(int i = 0; i < 2; ++i){ if(ctx->slot[i].busy){ return fail(KWAGE_ERR_STATE, "kwage_ctx_refine_stats: a search is pending on this context"); } }
+	int rc = set_device(ctx);
+	if(rc){ return rc; }
+	HIP_TRY(hipStreamSynchronize(ctx->gather_stream));
+	for(int k = 0; k < 2; ++k){
+		Slot *sl = &ctx->slot[k];
+		uint32_t h[4] = {0, 0, 0, 0};
+		if(sl->ref_counters.p){ HIP_TRY(hipMemcpy(h, sl->ref_counters.p, sizeof(h), hipMemcpyDeviceToHost)); }
+		for(int j = 0; j < 3; ++j){ out[4*k + j] = std::min<uint64_t>((uint64_t)sl->ref_base[j] + h[j], sl->ref_cap[j]); }
+		out[4*k + 3] = sl->ref_cap[2];
+	}
 	return KWAGE_OK;
 }
 
@@ -1148,6 +1166,24 @@ extern "C" int kwage_mem_info(kwage_ctx *ctx, uint64_t *free_bytes, uint64_t *to
 	HIP_TRY(hipMemGetInfo(&f, &t));
 	if(free_bytes){ *free_bytes = f; }
 	if(total_bytes){ *total_bytes = t; }
+	return KWAGE_OK;
+}
+
+extern "C" int kwage_device_fingerprint(kwage_ctx *ctx, char *buf, uint64_t len)
+{
+	if(!ctx || !buf || len == 0){ return fail(KWAGE_ERR_ARG, "kwage_device_fingerprint: NULL argument"); }
+	int rc = set_device(ctx);
+	if(rc){ return rc; }
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+	hipUUID id;
+	memset(&id, 0, sizeof(id));
+	(void)hipDeviceGetUuid(&id, ctx->device);
+	char hex[2*sizeof(id.bytes) + 1];
+	for(size_t i = 0; i < sizeof(id.bytes); ++i){ snprintf(hex + 2*i, 3, "%02x", (unsigned)(unsigned char)id.bytes[i]); }
+	snprintf(buf, (size_t)len, "uuid=%s;name=%s;arch=%s;cus=%d;sclk_mhz=%d;mclk_mhz=%d;hbm_bus_bits=%d;pci=%04x:%02x:%02x",
+	         hex, prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate/1000, prop.memoryClockRate/1000, prop.memoryBusWidth,
+	         (unsigned)prop.pciDomainID, (unsigned)prop.pciBusID, (unsigned)prop.pciDeviceID);
 	return KWAGE_OK;
 }
 

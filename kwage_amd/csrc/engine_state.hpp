@@ -164,8 +164,6 @@ struct PinnedPool {
 	}
 };
 
-// (SEARCH_THREADS / WAVE of kernels.hpp, which this header does not need otherwise; engine.hip asserts they agree)
-static const int64_t TUNING_DEFAULT_BLOCK_WAVES = 4;
 
 // Everything one in-flight search owns.  A context has two slots so that a second search can be
 // submitted (and its k-mer stage run) while the first one's results are still being collected.
@@ -211,6 +209,7 @@ struct Slot {
 	DevBuf cwalk_slab, cwalk_arrived;
 	// early exit, screen + refine (kernels.hpp and_screen_kernel): the three counters and the lists of the tiles handed over
 	DevBuf ref_counters, ref_clusters, ref_masks, ref_units, ref_slab;
+	uint32_t ref_base[3] = {0, 0, 0}, ref_cap[3] = {0, 0, 0};      // of the last such search (kwage_ctx_refine_stats)
 	uint64_t staged_hits = 0;
 	kwage_hit *ext_hits = nullptr;      // caller-owned device buffer (kwage_search_device) or null
 	uint64_t ext_cap = 0;
@@ -224,30 +223,22 @@ struct Slot {
 // Kernel-selection knobs.  They are parsed ONCE, from the environment, when a context is created, and changed afterwards
 // only through kwage_ctx_set_tuning (tests and tuning tools): nothing on the search path reads the environment.
 struct Tuning {
-	int64_t walk = 4;               // KWAGE_WALK: and_walk_kernel's rows in flight (4 or 2); 0 = always the tiled kernel
+	int64_t walk = 4;               // KWAGE_WALK: 0 = never the walk form (always the tiled kernel)
 	int64_t walk_min_rows = -1;     // KWAGE_WALK_MIN_ROWS: batches with fewer rows use the tiled kernel (-1: 64 rows per wave of the chip)
 	int64_t walk_max_kib = 16;      // KWAGE_WALK_MAX_KIB: widest row the walk form takes, in KiB-steps (wider rows: the tiled kernel's wide shape, which stays 0.5-3 % ahead on C3 / C4 and C3 split in two; the walk form handles them column tile after column tile when the knob is raised)
-	int64_t walk_short_rows = 0;    // KWAGE_WALK_SHORT_ROWS: batches averaging fewer rows per query take the tiled kernel's wide shape instead of the walk form (0: never -- the rule of the middle of round 4, when reservations stalled the walk form's load stream; profiles/r04_walk_hit_cost.txt)
 	int64_t walk_tile_kib = 16;     // KWAGE_WALK_TILE_KIB: widest column tile of the walk form in KiB-steps (rows wider than it are walked tile after tile)
-	int64_t walk_paced = 1;         // KWAGE_WALK_PACED: one KiB-step of the rows in flight at a time (0 with 8 rows in flight and tiles of <= 4: all steps at once)
 	int64_t walk_min_kib = 2;       // KWAGE_WALK_MIN_KIB: narrowest row (in KiB-steps) the walk form takes (round 4: 2 -- rows of 1-2 KiB no
 	                                //   longer need the tiled kernel's segments + combine pass: 0.263 vs 0.284 ms at C2's columns split 8 ways)
 	int64_t walk_waves = 0;         // KWAGE_WALK_WAVES: exactly this many waves (tests: shares of every size); 0 = from the CU count
-	int64_t walk_fences = 0;        // KWAGE_WALK_FENCES: agent-scope fences around the cut-pair count (measurement only)
 	int64_t walk_one_wg_per_cu = 1; // KWAGE_WALK_ONE_WG_PER_CU: chip-filling launches of the persistent kernels use one workgroup of 8 waves per CU (0: workgroups of 4 waves, placed by the dispatcher)
 	int64_t walk_bands = -1;        // KWAGE_WALK_BANDS: the walk form takes the rows band after band of the matrix, all waves together (and_band_walk_kernel):
 	                                //   -1 = three bands where the loader's probe found that the matrix's block mixes regions of the device's memory
 	                                //   (the windowed probe > 3 % faster than the plain one), 0 = never, 2..64 = always, that many
 	int64_t walk_bands_min_gib = 48;    // KWAGE_WALK_BANDS_MIN_GIB: a forced band count applies to matrices of at least this size
-	int64_t and_vec = 0;            // KWAGE_AND_CFG="vec,unroll,nt[,ldsKB[,block waves]]": shape of the tiled AND kernel (0 = by row width)
-	int64_t and_unroll = 8;
-	int64_t and_nt = 1;
-	int64_t and_lds_kb = 0;         //   dynamic LDS per workgroup caps the waves per CU (tuning only)
-	int64_t and_block_waves = TUNING_DEFAULT_BLOCK_WAVES;
+	int64_t and_vec = 0;            // KWAGE_AND_VEC: 16-byte vectors per lane of the tiled AND kernel (1, 2, 4; 0 = by row width)
 	int64_t and_wide_min_kib = 16;  // KWAGE_AND_WIDE_MIN_KIB: ... for rows above this many KiB-steps (the walk form takes rows up to walk_max_kib first)
 	int64_t and_wide = 1;           // KWAGE_AND_WIDE: rows beyond the walk form's range, no early exit, a chip-filling launch: vec 4, 8 rows, 8 waves per CU (and_config)
 	int64_t narrow = 1;             // KWAGE_NARROW: several queries per wave for rows <= 512 B
-	int64_t narrow_unroll = 0;      // KWAGE_NARROW_UNROLL: rows in flight per wave of the narrow AND kernel (0 = by the number of waves; 8, 16)
 	int64_t force_segs = 0;         // KWAGE_FORCE_SEGS: cut every query's k-mer list into this many segments (tests)
 	int64_t ee_refine = 1;          // KWAGE_EE_REFINE: with early exit, tiles that still hold a candidate column after the first rows are handed over to the
 	                                //   refine launch, which reads 128-byte groups on a balanced grid (0: the tile's own wave walks on 1-2 KiB wide)
@@ -256,14 +247,14 @@ struct Tuning {
 	int64_t refine_max_groups = 4;  // KWAGE_REFINE_MAX_GROUPS: a tile is handed over once at most this many of its 128-byte groups hold a candidate column
 	int64_t refine_unroll = 8;      // KWAGE_REFINE_UNROLL: rows in flight per 128-byte group in the refine launch (8 or 16)
 	int64_t screen_wpc = 20;        // KWAGE_SCREEN_WPC: waves per CU of the persistent screen launch
+	int64_t count_screen_wpc = 32;  // KWAGE_COUNT_SCREEN_WPC: at most this many waves per CU in the count path's screen launch (fewer where the kernel's registers hold fewer)
+	int64_t count_screen_min_tiles = 8192;  // KWAGE_COUNT_SCREEN_MIN_TILES: at t < 1, batches with fewer (query, KiB tile) pairs keep the tiled kernel and its segments
+	int64_t refine_static = 1;      // KWAGE_REFINE_STATIC: half of every list is dealt out to the screen launch's waves beforehand (0: every place is reserved through the counters -- diagnostics: kwage_ctx_refine_stats then counts the hand-overs exactly)
 	int64_t refine_list_cap = 0;    // KWAGE_REFINE_LIST_CAP: capacity of each of the three lists of handed-over tiles (0 = from the batch; tests: full lists)
 	int64_t count_walk = 1;         // KWAGE_COUNT_WALK: the persistent count kernel where it applies
 	int64_t count_walk_wpc = 8;     // KWAGE_COUNT_WALK_WPC: its waves per CU (8: 6335 GB/s at C2's shape, 12: 6271, 16: 6250, 20: 5876)
 	int64_t count_walk_waves = 0;   // KWAGE_COUNT_WALK_WAVES: exactly this many waves (tests)
 	int64_t count_walk_min_rows = -1;   // KWAGE_COUNT_WALK_MIN_ROWS: smaller batches use the tiled kernel (-1: 64 rows for each of its waves)
-	int64_t count_walk_prefetch = 1;    // KWAGE_COUNT_WALK_PREFETCH: request the next four k-mers' rows before adding the current four (+1.3 % at C2's shape)
-	int64_t count_walk_kps = 0;     // KWAGE_COUNT_WALK_KPS: k-mers per step of the persistent count kernel (0 = 8 with 14 counter planes and more, else 4; 4; 8)
-	int64_t count_narrow_kps = 8;   // KWAGE_COUNT_NARROW_KPS: k-mers per step of the narrow count kernel (8 or 4)
 	int64_t hit_sort_host = 0;      // KWAGE_HIT_SORT=host: order long hit lists on the host (A/B runs, the fallback)
 	int64_t hit_copy_piece_kb = 0;  // KWAGE_HIT_COPY_PIECE_KB: piece size of the copy-back of a long hit list (0 = default)
 	int64_t ext_launch_events = 1;  // KWAGE_EXT_LAUNCH_EVENTS: a gather stage's start / end events ride on its kernel launches (hipExtLaunchKernelGGL: no

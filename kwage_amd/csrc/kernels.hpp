@@ -477,12 +477,14 @@ __device__ __forceinline__ void tile_coords(const SearchArgs &a, uint64_t tile, 
 
 // threshold == 1.0f: AND of every addressed row (kwage.cpp:404-470).
 //   VEC    16-byte vectors per lane per row (tile = 64*VEC*16 bytes of each row per wave)
-//   UNROLL rows in flight per wave
-//   NT     nontemporal loads: every row byte is used exactly once per (query, tile)
 //   SEG    the query's row list is split over several waves (see SearchArgs::segs)
-template <int VEC, int UNROLL, bool NT, bool SEG>
+// Eight rows in flight per wave, nontemporal loads (every row byte is used exactly once per (query, tile): +4-10 %): 4, 16
+// and 32 rows and plain loads were template axes until round 5 -- no selection rule ever reached them.
+template <int VEC, bool SEG>
 __global__ __launch_bounds__(SEARCH_THREADS) void and_kernel(SearchArgs a)
 {
+	constexpr int UNROLL = 8;
+	constexpr bool NT = true;
 	const uint32_t lane = threadIdx.x & (WAVE - 1);
 	const uint64_t tile = (uint64_t)blockIdx.x*(blockDim.x/WAVE) + (threadIdx.x >> 6);
 	if(tile >= (uint64_t)a.n_queries*a.segs*a.chunks){ return; }
@@ -581,9 +583,11 @@ __global__ __launch_bounds__(SEARCH_THREADS) void and_kernel(SearchArgs a)
 // Lists that are full: the tile simply goes on by itself (reserved places are filled with REFINE_NONE entries).
 // A unit carries everything the refine launch needs (no dependent loads of item or query records before its rows).
 struct RefineUnit { uint32_t item, r0, r1, unit0, rq_lo, rq_hi, q, pad; };      // rows [r0, r1) of the row list at a.rows + rq; unit0: first 16-byte unit of the 128-byte group; item: whose mask
-struct RefineCluster { uint32_t q, kstep_groups, first_item, n; };       // kstep << 8 | bitmap of the KiB-step's 128-byte groups that are items (ascending: first_item, +1, ...); n = num_query_kmer
+struct RefineCluster {
+	uint32_t q, kstep_groups, first_item, n;      // kstep << 8 | bitmap of the KiB-step's 128-byte groups that are items (ascending: first_item, +1, ...); n = num_query_kmer
+	uint32_t first_unit, nseg, pad0, pad1;        // count path: item j's units are first_unit + j*nseg ... (their partial counters: RefineArgs::slab)
+};
 static constexpr uint32_t REFINE_NONE = 0xFFFFFFFFu;
-static constexpr uint32_t REFINE_PLANES = 7;                              // counters of a count unit: seg_rows k-mers <= 127
 
 // Three lists: clusters and units are SCANNED by the launches that follow (places nobody filled hold REFINE_NONE), items
 // are only places for masks.  Every list has a static part -- `stat` places per wave of the screen launch, taken without
@@ -593,15 +597,16 @@ static constexpr uint32_t REFINE_PLANES = 7;                              // cou
 // launch of 100 k short reads (300 k hand-overs).
 struct RefineList { uint32_t cap, stat, base, chunk; };
 struct RefineArgs {
-	uint32_t *counters;             // [0] clusters, [1] items, [2] units reserved in the dynamic parts (zeroed before the stage; may run past the capacities)
+	uint32_t *counters;             // [0] clusters, [1] items, [2] units reserved in the dynamic parts (zeroed before the stage; may run past the capacities); [4..5]: the tile queue of count_screen_kernel (u64)
 	RefineCluster *clusters;
 	uint32_t *masks;                // AND: u32x4 [item][8 lanes], the item's 128 bytes of mask; count: u32x4 [item][PLANES][8 lanes], its counters so far
 	RefineUnit *units;
-	uint32_t *slab;                 // count only: [unit][REFINE_PLANES][8] u32x4 counters of the unit's k-mers
+	uint32_t *slab;                 // count only: u32x4 [unit][UP planes][8 lanes], the counters of the unit's k-mers
 	RefineList lc, li, lu;          // clusters, items, units
 	uint32_t seg_rows;              // rows (count: k-mers) per unit
 	uint32_t min_rows;              // hand a tile over only when at least this many rows (k-mers) are left
 	uint32_t max_groups;            // ... and at most this many of its 128-byte groups hold a surviving column
+	uint32_t queue_batch;           // count_screen_kernel: tiles a wave draws from the queue at a time
 };
 
 // one bit per 8 lanes of a ballot: the 128-byte groups of a KiB-step with a lane set
@@ -753,6 +758,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void and_screen_kernel(SearchArgs a
 					if(!gb[v]){ continue; }
 					if(lane == 0){
 						RefineCluster cl; cl.q = q; cl.kstep_groups = ((c*VEC + v) << 8) | gb[v]; cl.first_item = ii; cl.n = n;
+						cl.first_unit = 0; cl.nseg = 0; cl.pad0 = 0; cl.pad1 = 0;
 						ra.clusters[cidx] = cl;
 					}
 					const uint32_t k = lane >> 3;                                  // this lane's 128-byte group of the KiB-step
@@ -925,7 +931,6 @@ struct WalkArgs {
 	uint32_t coltiles;              // column tiles per row (balanced, each <= 16 KiB)
 	uint32_t *orbuf;                // [waves][CH][4][64] complemented partial masks of the cut pairs
 	uint32_t *done;                 // [waves][2]: k-mers folded into the slot so far, and its WALK_DEAD / WALK_DIRTY flags
-	int full_fences;                // measurement only: agent-scope release/acquire fences around the count (see the kernel)
 };
 
 // (rows, pos_off and nkmer are passed as __restrict__ parameters of their own besides SearchArgs: the kernel stores
@@ -935,7 +940,7 @@ struct WalkArgs {
 // fills the chip: ONE workgroup per CU, so every CU runs exactly the same number of waves -- with workgroups of four
 // waves the dispatcher's placement left some CUs with three workgroups and others with one: +0.8-0.9 % at C2's shape,
 // profiles/r03_walk_cu_shapes.txt)
-template <int CH, int UNROLL, bool PACED = true>
+template <int CH, int UNROLL>
 __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void and_walk_kernel(SearchArgs a, WalkArgs wa, const uint32_t *__restrict__ rows,
                                                                       const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ nkmer)
 {
@@ -1003,9 +1008,9 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void and_walk_kernel(SearchArgs
 					// memory system likes is ~8192 sequential row streams chip-wide (8 waves per CU x 4 rows), each a KiB
 					// deep; left alone the scheduler keeps 8-9 KiB per wave in flight, which measures 1 % slower, and more
 					// streams (16 waves per CU, or 8 rows) 2-3 % slower (profiles/r02_walk_sizes_schedules.txt).
-					// (PACED = false, narrow column tiles: all CH steps of the UNROLL rows are requested together -- the
-					// tiled kernel's "wide" access pattern, 4 KiB of a row at once, on the balanced persistent grid)
-					if(PACED){ __builtin_amdgcn_sched_barrier(0); }
+					// (all CH steps of eight rows of narrow column tiles requested together -- the tiled kernel's "wide" access pattern on
+					// the balanced persistent grid -- measured no better in round 4 and was removed in round 5)
+					__builtin_amdgcn_sched_barrier(0);
 				}
 			}
 
@@ -1038,16 +1043,14 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void and_walk_kernel(SearchArgs
 				// goes through device-scope atomics, which are performed at the device's point of coherence and
 				// acknowledged from there, so waiting for the acknowledgements (vmcnt) orders them.  A C++ release fence
 				// would do it too but also writes the L2 back (buffer_wbl2 sc1) once per cut pair, and the waves all
-				// reach this point together at the end of the kernel: +0.14 ms per launch, measured (tools/walk_sizes.py,
-				// KWAGE_WALK_FENCES=1).
-				if(wa.full_fences){ __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
-				else{ asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+				// reach this point together at the end of the kernel: +0.14 ms per launch, measured in round 2
+				// (profiles/r02_walk_sizes_fences.txt; 62 000 soaked launches without a mismatch: profiles/r05_soak.txt).
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 				uint32_t old = 0;
 				if(lane == 0){ old = __hip_atomic_fetch_add(state, jv1 - j0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 				old = __builtin_amdgcn_readfirstlane(old);
 				emit = false;
 				if(old + (jv1 - j0) == n){                                       // this part completes the pair
-					if(wa.full_fences){ __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }       // (the reads below are device-scope loads)
 					const uint32_t fl = __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					if(fl & WALK_DIRTY){
 						emit = !(fl & WALK_DEAD);
@@ -1566,6 +1569,241 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 	}
 }
 
+// ---- early exit at threshold < 1: SCREEN, then REFINE (and_screen_kernel's idea for the count path) ---------------------
+// kwage.cpp:478-481 gives a query up once max count + remaining k-mers < threshold.  Per column that bound cannot prune
+// before n - threshold k-mers are in, and then needs a margin the random matches stay below: every tile reads the first
+// ~30 % of a query's rows at t = 0.8 whatever else happens -- the launch's floor.  What the tiled count_kernel adds to that
+// floor is the tail: a tile that HOLDS a column above the threshold is counted to the end, 1 KiB wide, by one wave.
+//   count_screen_kernel  count_kernel's tile loop on a persistent grid; every 16 k-mers (once the bound can bite): no column
+//                        can reach the threshold any more -> done; such columns in at most `max_groups` 128-byte groups and
+//                        `min_rows` k-mers to go -> the tile is handed over (cluster, items with their counters so far,
+//                        units of `seg_rows` k-mers); otherwise it goes on, and reports itself at the end of the list.
+//   count_refine_kernel  eight units per wave, 8 lanes x 16 B each: the unit's k-mers counted in UP planes -> slab.
+//   count_refine_emit_kernel  per cluster: item counters + the units' counters, threshold, one reservation per wave.
+template <int PLANES, int NH>
+__global__ __launch_bounds__(SEARCH_THREADS) void count_screen_kernel(SearchArgs a, RefineArgs ra)
+{
+	constexpr uint32_t CHECK = 16;            // k-mers between two looks at the bound
+	constexpr int KPS = (NH <= 2) ? 8 : 4;    // k-mers per step: 8 or 4*NH rows in flight
+	__shared__ WaveHitBuf hit_bufs[SEARCH_THREADS/WAVE];
+	WaveHitBuf *hbuf = &hit_bufs[threadIdx.x >> 6];
+	WaveHitState hst;
+	const uint32_t lane = threadIdx.x & (WAVE - 1);
+	const uint64_t n_tiles = (uint64_t)a.n_queries*a.chunks;
+	const uint32_t n_waves = gridDim.x*(blockDim.x/WAVE);
+	const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x*(blockDim.x/WAVE) + (threadIdx.x >> 6));
+	RefineChunk cc, ci, cu;
+	cc.next = gw*ra.lc.stat; cc.end = cc.next + ra.lc.stat;
+	ci.next = gw*ra.li.stat; ci.end = ci.next + ra.li.stat;
+	cu.next = gw*ra.lu.stat; cu.end = cu.next + ra.lu.stat;
+	bool lists_full = false;
+	// Tiles are HEAVY here (hundreds of k-mers before the bound can bite) and a wave gets only a few: dealt out beforehand,
+	// 13 000 tiles over 4096 waves are 3 for most waves and 4 for some -- a quarter of the launch spent waiting for those.
+	// So the waves draw their tiles, `queue_batch` at a time, from a counter (ra.counters[4..5], zeroed with the others).
+	unsigned long long *queue = reinterpret_cast<unsigned long long*>(ra.counters + 4);
+	// (every wave's FIRST tile is its own number -- thousands of waves asking the one counter at the same moment would
+	// start one after the other, ~25 ns apart -- and the queue holds the tiles from n_waves on)
+	uint64_t tile = gw, tile_end = (gw < n_tiles) ? (uint64_t)gw + 1 : (uint64_t)gw;      // (the last workgroup may have a wave too many)
+	for(;;){
+		if(tile == tile_end){
+			unsigned long long t0 = 0;
+			if(lane == 0){ t0 = atomicAdd(queue, (unsigned long long)ra.queue_batch); }
+			tile = n_waves + (((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(t0 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)t0));
+			if(tile >= n_tiles){ break; }
+			tile_end = min(n_tiles, tile + ra.queue_batch);
+		}
+		const uint32_t q = __builtin_amdgcn_readfirstlane((uint32_t)(tile / a.chunks));
+		const uint32_t c = __builtin_amdgcn_readfirstlane((uint32_t)(tile % a.chunks));
+		++tile;
+		const uint32_t nk = a.nkmer[q];
+		if(nk == 0){ continue; }
+		const uint32_t thr = a.qthr[q];
+		const uint64_t rq_off = a.pos_off[q]*NH;
+		const uint32_t *rq = a.rows + rq_off;
+		const uint32_t u0 = c*WAVE + lane;
+		const bool live = (u0 < a.units_per_row);
+		const uint32_t unit = live ? u0 : (a.units_per_row - 1);
+		const u32x4 real = live ? reinterpret_cast<const u32x4*>(a.valid)[unit] : (u32x4)(0u);     // only real columns keep a tile alive
+
+		u32x4 plane[PLANES];
+#pragma unroll
+		for(int p = 0; p < PLANES; ++p){ plane[p] = (u32x4)(0u); }
+		bool may_hand_over = !lists_full, gone = false;
+		uint32_t i = 0;
+		for(; i + KPS <= nk; ){
+			u32x4 m[KPS];
+#pragma unroll
+			for(int u = 0; u < KPS; ++u){
+				u32x4 x[NH];
+#pragma unroll
+				for(int h = 0; h < NH; ++h){
+					const uint32_t r = rq[(i + u)*NH + h];
+					x[h] = load16<true>(reinterpret_cast<const u32x4*>(a.db + (uint64_t)r*a.stride) + unit);
+				}
+				m[u] = x[0];
+#pragma unroll
+				for(int h = 1; h < NH; ++h){ m[u] &= x[h]; }    // kmer_match &= slice
+			}
+			if constexpr(KPS == 8){ planes_add8<PLANES>(plane, m); }
+			else{ planes_add4<PLANES>(plane, m[0], m[1], m[2], m[3]); }
+			i += KPS;
+			const uint32_t remaining = nk - i;
+			if((i & (CHECK - 1)) != 0 || thr <= remaining){ continue; }
+			// kwage.cpp:478-481 per column: the columns that can still reach the threshold if every remaining k-mer matches
+			const u32x4 can = planes_ge<PLANES>(plane, thr - remaining) & real;
+			const uint32_t gb = group_bits(__ballot((can.x | can.y | can.z | can.w) != 0));
+			const uint32_t ngroups = __popc(gb);
+			if(ngroups == 0){ gone = true; break; }
+			if(may_hand_over && ngroups <= ra.max_groups && remaining >= ra.min_rows){
+				// Only columns that are ON TRACK -- matching at the threshold's rate so far: count >= threshold x i / n -- are worth
+				// the refine launch, which counts every handed-over group to the END of the list.  A column that can still reach the
+				// threshold but matches at a lower rate (a related genome: 40 % of the k-mers) is ruled out by the bound a few dozen
+				// k-mers later; while one is left, the tile goes on as it is.
+				const uint32_t on_track = (uint32_t)(((uint64_t)thr*i + nk - 1)/nk);
+				const u32x4 off = can & ~planes_ge<PLANES>(plane, on_track);
+				if(__any((off.x | off.y | off.z | off.w) != 0)){ continue; }
+				may_hand_over = false;                    // (one attempt per tile)
+				const uint32_t nseg = (remaining + ra.seg_rows - 1)/ra.seg_rows;
+				const uint32_t nu = ngroups*nseg;
+				const uint32_t c0 = refine_take(ra, 0, cc, 1);
+				const uint32_t i0 = (c0 != REFINE_NONE) ? refine_take(ra, 1, ci, ngroups) : REFINE_NONE;
+				const uint32_t un0 = (i0 != REFINE_NONE) ? refine_take(ra, 2, cu, nu) : REFINE_NONE;
+				if(un0 == REFINE_NONE){
+					if(c0 != REFINE_NONE){ refine_none_clusters(ra, c0, c0 + 1); }
+					lists_full = true;
+					continue;
+				}
+				if(lane == 0){
+					RefineCluster cl; cl.q = q; cl.kstep_groups = (c << 8) | gb; cl.first_item = i0; cl.n = nk;
+					cl.first_unit = un0; cl.nseg = nseg; cl.pad0 = 0; cl.pad1 = 0;
+					ra.clusters[c0] = cl;
+				}
+				const uint32_t k = lane >> 3;
+				if((gb >> k) & 1u){
+					const uint32_t it = i0 + __popc(gb & ((1u << k) - 1u));
+					u32x4 *dst = reinterpret_cast<u32x4*>(ra.masks) + (uint64_t)it*PLANES*8 + (lane & 7u);
+#pragma unroll
+					for(int p = 0; p < PLANES; ++p){ dst[p*8] = plane[p]; }
+				}
+				for(uint32_t e = lane; e < nu; e += WAVE){
+					const uint32_t j = e / nseg, sg = e % nseg;
+					RefineUnit un;
+					un.item = i0 + j;
+					un.r0 = i + sg*ra.seg_rows;                                    // (k-mers, not rows)
+					un.r1 = min(nk, un.r0 + ra.seg_rows);
+					un.unit0 = c*WAVE + nth_set_bit(gb, j)*8u;
+					un.rq_lo = (uint32_t)rq_off; un.rq_hi = (uint32_t)(rq_off >> 32);
+					un.q = q; un.pad = 0;
+					ra.units[un0 + e] = un;
+				}
+				gone = true;
+				break;
+			}
+		}
+		if(gone){ continue; }
+		for(; i < nk; ++i){
+			u32x4 mm = ~(u32x4)(0u);
+#pragma unroll
+			for(int h = 0; h < NH; ++h){
+				const uint32_t r = rq[i*NH + h];
+				mm &= load16<true>(reinterpret_cast<const u32x4*>(a.db + (uint64_t)r*a.stride) + unit);
+			}
+			planes_add<PLANES>(plane, mm, 0);
+		}
+		emit_count_hits_buffered<PLANES>(a, hbuf, hst, q, unit, plane, thr, (uint64_t)q*a.runs_per_query + c, live);
+	}
+	wave_hits_flush(a, hbuf, hst);
+	refine_none_clusters(ra, cc.next, cc.end);
+	refine_none_units(ra, cu.next, cu.end);
+}
+
+// UP counter planes per unit (seg_rows k-mers < 2^UP).  A lane holds the NH row numbers of ONE k-mer of a block of eight
+// (fetched together, handed round by ds_bpermute); KPS k-mers' rows are in flight at a time.
+template <int NH, int UP>
+__global__ __launch_bounds__(SEARCH_THREADS) void count_refine_kernel(SearchArgs a, RefineArgs ra)
+{
+	constexpr int KPS = (NH <= 2) ? 8 : 4;
+	const uint32_t lane = threadIdx.x & (WAVE - 1), l = lane & 7u, sh = lane & ~7u;
+	const uint32_t n_units = refine_list_end(ra, 2);
+	const uint64_t gw = (uint64_t)blockIdx.x*(blockDim.x/WAVE) + (threadIdx.x >> 6);
+	const uint64_t step = (uint64_t)gridDim.x*(blockDim.x/WAVE)*8;
+	for(uint64_t base = gw*8; base < n_units; base += step){
+		const uint64_t u = base + (lane >> 3);
+		RefineUnit un;
+		un.item = REFINE_NONE;
+		if(u < n_units){ un = ra.units[u]; }
+		if(un.item == REFINE_NONE){ continue; }                    // (lanes of a group agree)
+		const uint32_t *rq = a.rows + (((uint64_t)un.rq_hi << 32) | un.rq_lo);
+		const uint8_t *col = a.db + (uint64_t)(un.unit0 + l)*16;
+		u32x4 plane[UP];
+#pragma unroll
+		for(int p = 0; p < UP; ++p){ plane[p] = (u32x4)(0u); }
+		for(uint32_t b = un.r0; b < un.r1; b += 8){
+			uint32_t idx[NH];          // the rows of k-mer b + l (past the end: the last k-mer's -- its match is dropped below)
+#pragma unroll
+			for(int h = 0; h < NH; ++h){ idx[h] = rq[(uint64_t)min(b + l, un.r1 - 1)*NH + h]; }
+			u32x4 m[8];
+#pragma unroll
+			for(int k0 = 0; k0 < 8; k0 += KPS){
+				u32x4 x[KPS][NH];
+#pragma unroll
+				for(int j = 0; j < KPS; ++j){
+#pragma unroll
+					for(int h = 0; h < NH; ++h){
+						const uint32_t r = __shfl(idx[h], sh + k0 + j);
+						x[j][h] = load16<true>(reinterpret_cast<const u32x4*>(col + (uint64_t)r*a.stride));
+					}
+				}
+#pragma unroll
+				for(int j = 0; j < KPS; ++j){
+					u32x4 mm = x[j][0];
+#pragma unroll
+					for(int h = 1; h < NH; ++h){ mm &= x[j][h]; }
+					m[k0 + j] = (b + k0 + j < un.r1) ? mm : (u32x4)(0u);
+				}
+			}
+			planes_add8<UP>(plane, m);
+		}
+		u32x4 *dst = reinterpret_cast<u32x4*>(ra.slab) + u*UP*8 + l;
+#pragma unroll
+		for(int p = 0; p < UP; ++p){ dst[p*8] = plane[p]; }
+	}
+}
+
+template <int PLANES, int UP>
+__global__ __launch_bounds__(SEARCH_THREADS) void count_refine_emit_kernel(SearchArgs a, RefineArgs ra)
+{
+	__shared__ WaveHitBuf hit_bufs[SEARCH_THREADS/WAVE];
+	WaveHitBuf *hbuf = &hit_bufs[threadIdx.x >> 6];
+	WaveHitState hst;
+	const uint32_t lane = threadIdx.x & (WAVE - 1), l = lane & 7u, g = lane >> 3;
+	const uint32_t n_clusters = refine_list_end(ra, 0);
+	const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x*(blockDim.x/WAVE) + (threadIdx.x >> 6));
+	const uint32_t nw = gridDim.x*(blockDim.x/WAVE);
+	for(uint32_t ci = gw; ci < n_clusters; ci += nw){
+		const RefineCluster cl = ra.clusters[ci];
+		if(cl.q == REFINE_NONE){ continue; }
+		const uint32_t groups = cl.kstep_groups & 0xFFu, kstep = cl.kstep_groups >> 8;
+		const bool on = ((groups >> g) & 1u) != 0;               // this lane's 128-byte group of the KiB-step is an item
+		u32x4 plane[PLANES];
+#pragma unroll
+		for(int p = 0; p < PLANES; ++p){ plane[p] = (u32x4)(0u); }
+		if(on){
+			const uint32_t j = __popc(groups & ((1u << g) - 1u));
+			const u32x4 *src = reinterpret_cast<const u32x4*>(ra.masks) + (uint64_t)(cl.first_item + j)*PLANES*8 + l;
+#pragma unroll
+			for(int p = 0; p < PLANES; ++p){ plane[p] = src[p*8]; }
+			const u32x4 *sl = reinterpret_cast<const u32x4*>(ra.slab) + ((uint64_t)cl.first_unit + (uint64_t)j*cl.nseg)*UP*8 + l;
+			for(uint32_t sg = 0; sg < cl.nseg; ++sg){
+				const u32x4 *s2 = sl + (uint64_t)sg*UP*8;
+				planes_accumulate<PLANES>(plane, UP < PLANES ? UP : PLANES, [&](int p){ return s2[p*8]; });
+			}
+		}
+		emit_count_hits_buffered<PLANES>(a, hbuf, hst, cl.q, min(kstep*WAVE + lane, a.units_per_row - 1), plane, a.qthr[cl.q], (uint64_t)cl.q*a.runs_per_query + kstep, on);
+	}
+	wave_hits_flush(a, hbuf, hst);
+}
+
 // The same loop with the NEXT four k-mers' rows requested before the current four are added up (16 more VGPRs): for the
 // persistent kernel below, whose few waves per CU leave nothing else to cover the adders' time.
 // KPS k-mers per step: 4, or 8 (seven carry-save adders, then ONE ripple through the upper planes per eight k-mers): with
@@ -1645,7 +1883,7 @@ struct CountWalkArgs {
 	uint32_t *arrived;              // [waves][CWALK_LEVELS] arrivals at the tree node (first wave of the node's subtree, level); zero between searches
 };
 
-template <int PLANES, int NH, bool PF, int KPS = 4>
+template <int PLANES, int NH>
 __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void count_walk_kernel(SearchArgs a, CountWalkArgs wa, const uint32_t *__restrict__ rows,
                                                                     const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ nkmer,
                                                                     const uint32_t *__restrict__ qthr)
@@ -1688,8 +1926,9 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void count_walk_kernel(SearchAr
 			u32x4 plane[PLANES];
 #pragma unroll
 			for(int p = 0; p < PLANES; ++p){ plane[p] = (u32x4)(0u); }
-			if(PF){ count_kmers_prefetch<PLANES, NH, KPS>(a.db, a.stride, rows + (p0 + j0)*NH, jv1 - j0, unit, plane); }
-			else{ count_kmers<PLANES, NH>(a.db, a.stride, rows + (p0 + j0)*NH, jv1 - j0, unit, plane, [](uint32_t) -> bool { return false; }); }
+			// (eight k-mers per step with 14 counter planes and more, where the ripple through the upper planes is most of the
+			// kernel's instructions; the form without the prefetch and four per step at every width were knobs until round 5)
+			count_kmers_prefetch<PLANES, NH, (PLANES >= 14) ? 8 : 4>(a.db, a.stride, rows + (p0 + j0)*NH, jv1 - j0, unit, plane);
 
 			bool emit = true;
 			if(j0 != 0 || jv1 != n){
@@ -1736,9 +1975,10 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void count_walk_kernel(SearchAr
 
 // Narrow databases, count path: G queries per wave (see and_narrow_kernel).  A shorter k-mer list is padded
 // with all-zero matches (counting is not idempotent, so padded steps must add nothing).
-template <int PLANES, int NH, int G, int KPS>
+template <int PLANES, int NH, int G>
 __global__ __launch_bounds__(SEARCH_THREADS) void count_narrow_kernel(SearchArgs a)
 {
+	constexpr int KPS = 8;
 	constexpr uint32_t LG = WAVE/G;
 	const uint32_t lane = threadIdx.x & (WAVE - 1);
 	const uint32_t l = lane % LG;
@@ -1777,13 +2017,11 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_narrow_kernel(SearchArgs
 		fetch(0, cur);
 		for(uint32_t i = KPS; __any(i < nk); i += KPS){
 			fetch(i, nxt);
-			if(KPS == 8){ planes_add8<PLANES>(plane, reinterpret_cast<const u32x4 (&)[8]>(cur)); }
-			else{ planes_add4<PLANES>(plane, cur[0], cur[1], cur[2], cur[3]); }
+			planes_add8<PLANES>(plane, cur);
 #pragma unroll
 			for(int u = 0; u < KPS; ++u){ cur[u] = nxt[u]; }
 		}
-		if(KPS == 8){ planes_add8<PLANES>(plane, reinterpret_cast<const u32x4 (&)[8]>(cur)); }
-		else{ planes_add4<PLANES>(plane, cur[0], cur[1], cur[2], cur[3]); }
+		planes_add8<PLANES>(plane, cur);
 	}
 	__shared__ WgHitScratch wg_scratch;
 	emit_count_hits<PLANES>(a, q, unit, plane, a.qthr[q], blockIdx.x, active, &wg_scratch);      // every wave of the workgroup gets here, exactly once

@@ -47,6 +47,16 @@ class Context:
         check(lib().kwage_mem_info(self._h, C.byref(f), C.byref(t)))
         return f.value, t.value
 
+    def fingerprint(self) -> dict:
+        """Identity of the device (kwage_device_fingerprint): uuid, name, arch, cus, clocks, pci -- filed with every measurement."""
+        buf = C.create_string_buffer(512)
+        check(lib().kwage_device_fingerprint(self._h, buf, 512))
+        out = {}
+        for kv in buf.value.decode("latin-1").split(";"):
+            k, _, v = kv.partition("=")
+            out[k] = int(v) if v.isdigit() else v
+        return out
+
     def sync(self) -> None:
         check(lib().kwage_sync(self._h))
 
@@ -65,6 +75,13 @@ class Context:
         out = (C.c_uint64 * 5)()
         check(lib().kwage_ctx_scratch_nonzero(self._h, out))
         return dict(zip(("walk_or", "walk_done", "band_or", "band_state", "cwalk_arrived"), (int(x) for x in out)))
+
+    def refine_stats(self) -> list:
+        """Per search slot: places of the cluster / item / unit lists the last early-exit search took, and the unit list's
+        capacity (kwage_ctx_refine_stats)."""
+        out = (C.c_uint64 * 8)()
+        check(lib().kwage_ctx_refine_stats(self._h, out))
+        return [dict(zip(("clusters", "items", "units", "units_cap"), (int(x) for x in out[4 * k:4 * k + 4]))) for k in range(2)]
 
     def tuning(self, **knobs):
         """`with ctx.tuning(walk_waves=17, walk_min_rows=1): ...` -- the knobs are set inside the block and put back

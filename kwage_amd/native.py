@@ -101,12 +101,14 @@ _SIGNATURES = [
     ("kwage_init", C.c_int, [C.c_int, C.POINTER(_P)]),
     ("kwage_shutdown", None, [_P]),
     ("kwage_mem_info", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("kwage_device_fingerprint", C.c_int, [_P, C.c_char_p, C.c_uint64]),
     ("kwage_set_load_progress", None, [_P, C.POINTER(C.c_uint64)]),
     ("kwage_sort_hits", None, [C.c_void_p, C.c_uint64]),
     ("kwage_sync", C.c_int, [_P]),
     ("kwage_ctx_set_tuning", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("kwage_ctx_get_tuning", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
     ("kwage_ctx_scratch_nonzero", C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    ("kwage_ctx_refine_stats", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("kwage_group_create", C.c_int, [_P, C.POINTER(Params), C.c_uint64, C.POINTER(_P)]),
     ("kwage_group_destroy", None, [_P]),
     ("kwage_group_create_sparse", C.c_int, [_P, C.POINTER(Params), C.c_uint64, _P, C.c_uint64, C.POINTER(_P)]),

@@ -43,6 +43,9 @@ WORKLOADS: Dict[str, Workload] = {
     # C2 through the count path (threshold < 1, one hash): fewest loads in flight per wave
     "c2t": Workload("C2 at t=0.8 (count path, 1 hash): 100k samples x 2^23-bit filters, 1k x 1 kb queries", 100_000, 23, 31, 1,
                     1000, 1000, 0.8, num_genomes=32, genome_len=50_000),
+    # few LONG queries against C2's matrix (the early-exit path's other extreme: 200 x 5 kb)
+    "c2q5k": Workload("200 x 5 kb queries against 100k samples x 2^23-bit filters, 1 hash, t=1.0", 100_000, 23, 31, 1, 200, 5000, 1.0,
+                      num_genomes=32, genome_len=50_000),
     # BASELINE.json configs[2]
     "c3": Workload("C3: 1M samples x 2^20-bit filters, 100k x 150 bp queries, 1 hash, t=1.0", 1_000_000, 20, 31, 1,
                    100_000, 150, 1.0, num_genomes=64, genome_len=150_000),
@@ -53,8 +56,8 @@ WORKLOADS: Dict[str, Workload] = {
     "c5s": Workload("C5-single-group: 200k samples x 2^22-bit filters, 5 hashes, 1k x 1 kb queries, t=0.8", 200_000, 22,
                     31, 5, 1000, 1000, 0.8, density_q8=194, num_genomes=32, genome_len=50_000),
     # BASELINE.json configs[4], per-GPU share; the groups are C5_GROUPS (bench.py --workload c5)
-    "c5": Workload("C5: adaptive 2^18-2^25-bit filter groups (1.09M samples/GPU), 5 hashes, 1k x 1 kb queries, t=0.8", 0, 0, 31, 5,
-                   1000, 1000, 0.8, density_q8=194, num_genomes=32, genome_len=50_000),
+    "c5": Workload("C5: adaptive 2^18-2^25-bit filter groups (1.09M samples/GPU), 5 hashes, 10k x 1 kb queries, t=0.8", 0, 0, 31, 5,
+                   10_000, 1000, 0.8, density_q8=194, num_genomes=64, genome_len=100_000),
     # the C5 code path (several groups searched back to back) on toy groups: C5_TEST_GROUPS (tests of bench.py)
     "c5tiny": Workload("C5 code path on toy groups 2^10-2^13", 0, 0, 31, 5, 64, 300, 0.8, density_q8=194, num_genomes=4, genome_len=1000),
     # one reference file (2048 columns, 256-byte rows): the several-queries-per-wave kernels (tools/tune_knob.py)

@@ -202,7 +202,9 @@ def test_strong_split_is_the_sharded_hosts_partition():
 def test_also_blocks_follow_the_default_headline_only():
     import bench
     a = bench.parse_args([])
-    assert bench.also_workloads(a, 1) == ["c3"] and bench.also_workloads(a, 8) == ["c4", "c5"] and bench.also_workloads(a, 2) == ["c4", "c5"]
+    # N = 1: C3.  N > 1: the C4 and C5 per-GPU shares (weak) and C3 split over the ranks (the fixed-total-work curve)
+    assert bench.also_workloads(a, 1) == ["c3"] and bench.also_workloads(a, 8) == ["c4", "c5", "c3_strong"] and bench.also_workloads(a, 2) == ["c4", "c5", "c3_strong"]
+    assert bench.also_workloads(bench.parse_args(["--also", "c3_strong"]), 2) == ["c3_strong"]
     for argv in (["--workload", "c3"], ["--scaling", "strong"], ["--share-of", "4"], ["--early-exit"], ["--also", "none"]):
         assert bench.also_workloads(bench.parse_args(argv), 1) == [], argv
     assert bench.also_workloads(bench.parse_args(["--also", "c5s,c2t,c2"]), 1) == ["c5s", "c2t"]      # never the headline twice

@@ -159,7 +159,7 @@ def test_c4_per_gpu_share_full_size_properties(ka, oracle):
 @pytest.mark.timeout(1200)
 def test_c5_per_gpu_share_full_size_properties(ka, oracle):
     """BASELINE.json configs[4], what ONE of its 8 GPUs holds: the eight adaptive filter-size groups 2^18 .. 2^25
-    (1.09 M samples, 189 GB resident together), 5 hash functions, threshold 0.8 (count path), 1 k x 1 kb queries
+    (1.09 M samples, 189 GB resident together), 5 hash functions, threshold 0.8 (count path), 10 k x 1 kb queries
     searched against every group."""
     from kwage_amd import synth
     w = synth.WORKLOADS["c5"]
@@ -172,8 +172,8 @@ def test_c5_per_gpu_share_full_size_properties(ka, oracle):
         assert [m.workload.log_2_filter_len for m in multi] == list(range(18, 26))
         for m in multi:
             r1 = m.group.search(multi[0].batch, 0.8)
-            assert r1.total_kmers == 970 * 1000
-            assert r1.algorithmic_bytes == 970 * 1000 * 5 * ((m.workload.num_samples + 7) // 8)
+            assert r1.total_kmers == 970 * 10000
+            assert r1.algorithmic_bytes == 970 * 10000 * 5 * ((m.workload.num_samples + 7) // 8)
             assert (r1.query_threshold == 776).all()                      # (unsigned)(0.8f * 970), kwage.cpp:388
             _check_planted(m, r1, complete_match=False)
             _check_sampled(ka, oracle, m, r1, _sample_queries(m, 1, 1), 0.8)

@@ -303,8 +303,9 @@ def test_long_lists_come_back_ordered_from_every_kernel_form(ka, ctx, n_cols):
         # early exit, every tile handed over to the refine launch after its first eight rows: one reservation per cluster
         # (= per query and KiB-step), by the emit launch; and with lists of three places: most tiles walk on by themselves
         for knobs in (dict(refine_max_groups=16, refine_min_rows=1, refine_seg_rows=8), dict(refine_max_groups=16, refine_min_rows=1, refine_list_cap=3)):
-            with ctx.tuning(**dict(off, **knobs)):
+            with ctx.tuning(**dict(off, count_screen_min_tiles=1, **knobs)):
                 check(g.search(b, 1.0, ka.SEARCH_EARLY_EXIT), "and_screen_kernel<")
+                check(g.search(b, 0.5, ka.SEARCH_EARLY_EXIT), "count_screen_kernel<")
     for waves in (0, 37):
         with ctx.tuning(**dict(off, count_walk=1, count_walk_min_rows=1, count_walk_waves=waves)):
             check(g.search(b, 0.5), "count_walk_kernel<")
@@ -320,13 +321,16 @@ def test_long_lists_come_back_ordered_from_every_kernel_form(ka, ctx, n_cols):
 
 @pytest.mark.parametrize("n_cols,num_hash,density", [(8192, 1, 0.25), (20000, 2, 0.5), (100000, 1, 0.25), (131073, 3, 0.7)])
 def test_early_exit_screen_then_refine(ka, ctx, oracle, n_cols, num_hash, density):
-    """Early exit at threshold 1 on rows of a KiB and more: and_screen_kernel hands every tile that still holds a candidate
+    """Early exit on rows of a KiB and more.  Threshold 1: and_screen_kernel hands every tile that still holds a candidate
     column after its first rows over to and_refine_kernel (128-byte groups, segments of the remaining rows, masks meeting
-    by atomic AND) and and_refine_emit_kernel (one reservation per query and KiB-step).  Planted columns in the first,
-    middle and last 128-byte groups, two of them in ONE group and two in one KiB-step, ragged query lengths (shorter than
-    one segment ... dozens of segments), queries without a k-mer in between; swept over segment lengths, the hand-over
-    rule, both unrolls and list capacities so small that most tiles find the lists full and walk on by themselves.  Every
-    variant must return the list of the search without early exit, which is checked against the oracle."""
+    by atomic AND) and and_refine_emit_kernel (one reservation per query and KiB-step).  Threshold < 1: count_screen_kernel
+    hands over the tiles in which few columns can still reach the threshold (kwage.cpp:478-481 per column), with their
+    counters so far; count_refine_kernel counts segments of the remaining k-mers, count_refine_emit_kernel adds up.
+    Planted columns in the first, middle and last 128-byte groups, two of them in ONE group and two in one KiB-step, ragged
+    query lengths (shorter than one segment ... dozens of segments), exact and mutated copies of the planted genome
+    (counts between the threshold and num_query_kmer), queries without a k-mer in between; swept over segment lengths, the
+    hand-over rule, both unrolls and list capacities so small that most tiles find the lists full and walk on by
+    themselves.  Every variant must return the list of the search without early exit, which is checked against the oracle."""
     rng = np.random.default_rng(n_cols + num_hash)
     k, L = 31, 10
     image = _make_random_db(rng, L, n_cols, density)
@@ -339,7 +343,12 @@ def test_early_exit_screen_then_refine(ka, ctx, oracle, n_cols, num_hash, densit
     for i in range(300):
         n = int(rng.choice([0, 30, 31, 33, 40, 64, 100, 150, 300, 1000, 2500]))
         if i % 2 == 0 and n >= 31:
-            a = int(rng.integers(0, len(genome) - n + 1)); seqs.append(genome[a:a + n])
+            a = int(rng.integers(0, len(genome) - n + 1))
+            q = list(genome[a:a + n])
+            if i % 4 == 0:                      # a copy with a substitution every ~150 bases: most k-mers still match
+                for pos in range(int(rng.integers(0, 150)), n, 150):
+                    q[pos] = "ACGT"[("ACGT".index(q[pos]) + 1) % 4]
+            seqs.append("".join(q))
         elif i % 11 == 0:
             seqs.append("N" * n)
         else:
@@ -348,20 +357,34 @@ def test_early_exit_screen_then_refine(ka, ctx, oracle, n_cols, num_hash, densit
     g.add_columns(image, n_cols)
     g.finalize()
     b = ka.Batch(ctx, seqs)
-    ref = g.search(b, 1.0, 0)
-    exp = [oracle.search_image(image, image.shape[1], k, num_hash, L, n_cols, oracle.unique_kmers(s, k), 1.0)[0] for s in seqs]
-    assert ref.per_query() == exp
-    planted = [e for s, e in zip(seqs, exp) if len(s) >= 31 and s in genome]
-    assert planted and all({c for c, _ in e} >= set(cols) for e in planted)
     variants = [dict(), dict(refine_seg_rows=8, refine_min_rows=1), dict(refine_seg_rows=1000000, refine_unroll=16), dict(refine_max_groups=16, refine_min_rows=1, refine_seg_rows=17),
                 dict(refine_max_groups=1), dict(refine_max_groups=0), dict(refine_list_cap=1, refine_min_rows=1), dict(refine_list_cap=7, refine_max_groups=16),
                 dict(refine_list_cap=40, refine_seg_rows=8), dict(ee_refine=0)]
-    for knobs in variants:
-        with ctx.tuning(**knobs):
-            for rep in range(2):
-                r = g.search(b, 1.0, ka.SEARCH_EARLY_EXIT)
-                assert r.search_kernel.startswith("and_kernel<" if knobs.get("ee_refine") == 0 else "and_screen_kernel<"), r.search_kernel
-                assert np.array_equal(r.hits, ref.hits) and np.array_equal(r.num_query_kmer, ref.num_query_kmer), (n_cols, knobs, rep)
+    for thr in (1.0, 0.8, 0.5):
+        ref = g.search(b, thr, 0)
+        thr32 = float(np.float32(thr))
+        if thr == 1.0 or n_cols <= 20000:       # (the oracle's per-bit counting loop over 100 k columns is slow)
+            exp = [oracle.search_image(image, image.shape[1], k, num_hash, L, n_cols, oracle.unique_kmers(s, k), thr32)[0] for s in seqs]
+            assert ref.per_query() == exp
+            planted = [e for s, e in zip(seqs, exp) if len(s) >= 31 and s in genome]
+            assert planted and all({c for c, _ in e} >= set(cols) for e in planted)
+        want = "and_screen_kernel<" if thr == 1.0 else "count_screen_kernel<"
+        for knobs in variants:
+            with ctx.tuning(count_screen_min_tiles=1, **knobs):
+                for rep in range(2):
+                    r = g.search(b, thr, ka.SEARCH_EARLY_EXIT)
+                    assert r.search_kernel.startswith(want) != (knobs.get("ee_refine") == 0), (r.search_kernel, knobs)
+                    assert np.array_equal(r.hits, ref.hits) and np.array_equal(r.num_query_kmer, ref.num_query_kmer), (n_cols, thr, knobs, rep)
+    # one query of 20 k positions among the others: units of 1/128 of it, 14 counter planes per unit
+    seqs2 = seqs[:40] + [(genome * 7)[:20500], rand_seq(rng, 9000)]
+    b2 = ka.Batch(ctx, seqs2)
+    for thr in (1.0, 0.7):
+        ref = g.search(b2, thr, 0)
+        with ctx.tuning(count_screen_min_tiles=1, refine_min_rows=1):
+            r = g.search(b2, thr, ka.SEARCH_EARLY_EXIT)
+        assert r.search_kernel.startswith("and_screen_kernel<" if thr == 1.0 else "count_screen_kernel<") and (thr == 1.0 or r.search_kernel.endswith("+refine<14>")), r.search_kernel
+        assert np.array_equal(r.hits, ref.hits) and np.array_equal(r.num_query_kmer, ref.num_query_kmer), (n_cols, thr)
+    b2.close()
     b.close()
     g.close()
 
@@ -561,16 +584,16 @@ def test_long_queries_are_segmented(ka, ctx, oracle, num_hash, monkeypatch):
     b = ka.Batch(ctx, seqs)
     # (0 = the natural choice: few tiles -> segments; "cw" = the persistent count kernel with a pair spread over
     # up to 40 waves instead of the segment slab)
-    # (the persistent kernel takes eight k-mers per step with 14 counter planes and more -- here 20 --; "cw4": four)
-    for force in (0, 1, 7, 64, "cw", "cw4"):
-        knobs = dict(force_segs=0, count_walk_min_rows=1, count_walk_waves=1500, count_walk_kps=4 if force == "cw4" else 0) if force in ("cw", "cw4") else dict(force_segs=force)
+    # (the persistent kernel takes eight k-mers per step with 14 counter planes and more -- here 20)
+    for force in (0, 1, 7, 64, "cw"):
+        knobs = dict(force_segs=0, count_walk_min_rows=1, count_walk_waves=1500) if force == "cw" else dict(force_segs=force)
         with ctx.tuning(**knobs):
             for threshold in (1.0, 0.97, 0.5):
                 thr32 = float(np.float32(threshold))
                 for flags in (0, ka.SEARCH_EARLY_EXIT):
                     r = g.search(b, threshold, flags)
-                    if force in ("cw", "cw4") and threshold < 1.0 and not flags:
-                        assert r.search_kernel.startswith("count_walk_kernel<") and r.search_kernel.endswith(",8>") == (force == "cw"), r.search_kernel
+                    if force == "cw" and threshold < 1.0 and not flags:
+                        assert r.search_kernel.startswith("count_walk_kernel<") and r.search_kernel.endswith(",8>"), r.search_kernel
                     per_q = r.per_query()
                     for i, s in enumerate(seqs):
                         kmers = oracle.unique_kmers(s, k)
@@ -606,7 +629,7 @@ def test_queries_above_2_pow_20_positions_use_32_plane_counters(ka, ctx, oracle)
     assert {5, 199} <= {c for c, _ in exp[0]} and max(m for _, m in exp[0]) > 1 << 20
     seen = set()
     for knobs, flags in ((dict(count_walk=0), 0), (dict(count_walk=0), ka.SEARCH_EARLY_EXIT), (dict(count_walk=1, count_walk_min_rows=1), 0),
-                         (dict(count_walk=1, count_walk_min_rows=1, count_walk_waves=333, count_walk_prefetch=0), 0)):
+                         (dict(count_walk=1, count_walk_min_rows=1, count_walk_waves=333), 0)):
         with ctx.tuning(narrow=0, **knobs):
             r = g.search(b, thr, flags)
         seen.add(r.search_kernel)
@@ -990,8 +1013,8 @@ def test_walk_rows_many_queries(ka, ctx, oracle, n_cols, request):
             else:
                 h = ref.hits[ref.hits["query"] == i]
                 assert [(int(c), int(m)) for c, m in zip(h["column"], h["num_match"])] == e, (n_cols, thr, i)
-        for waves, pf in (((0, 1), (7, 0), (3001, 1), (30000, 0)) if small else ((0, 1), (3001, 0))):
-            with ctx.tuning(count_walk_waves=waves, count_walk_min_rows=1, count_walk_prefetch=pf):
+        for waves in ((0, 7, 3001, 30000) if small else (0, 3001)):
+            with ctx.tuning(count_walk_waves=waves, count_walk_min_rows=1):
                 for rep in range(2):
                     r = g.search(b, thr, 0)
                     assert r.search_kernel.startswith("count_walk_kernel<"), r.search_kernel

@@ -70,32 +70,32 @@ def test_random_configuration(oracle, seed, monkeypatch):
                     assert r.num_query_kmer[i] == nk, (seed, thr, i)
                     assert per_q[i] == e, (seed, k, nh, L, n_cols, thr, flags, force, i, len(per_q[i]), len(e))
             ctx.set_tuning("force_segs", 0)
-            if thr == 1.0 and n_cols >= 8192:
+            if n_cols >= 8192:
                 # early exit on rows of a KiB and more: screen + refine, with short segments, every tile handed over, full lists
                 for knobs in (dict(refine_seg_rows=8, refine_min_rows=1, refine_max_groups=16), dict(refine_list_cap=3, refine_min_rows=1), dict(refine_unroll=16, refine_max_groups=1)):
-                    with ctx.tuning(**knobs):
+                    with ctx.tuning(count_screen_min_tiles=1, **knobs):
                         r = g.search(b, thr, ka.SEARCH_EARLY_EXIT)
-                        assert r.search_kernel.startswith("and_screen_kernel<"), r.search_kernel
+                        assert r.search_kernel.startswith("and_screen_kernel<" if thr == 1.0 else "count_screen_kernel<"), r.search_kernel
                         assert [(int(n), e) for n, e in zip(r.num_query_kmer, r.per_query())] == exp, (seed, n_cols, knobs)
             if thr < 1.0 and n_cols > 256:
                 # the persistent form of the count path (normally for batches that give every wave of the chip a few dozen
                 # rows): shares of a few positions / hundreds / more waves than the chip holds, long queries spread over
                 # dozens of waves each; twice per case (the kernel must leave its pair counters zero)
                 for waves in (0, int(rng.choice([3, 11, 64])), int(rng.choice([700, 2048, 9000]))):
-                    with ctx.tuning(count_walk_min_rows=1, count_walk_waves=waves, narrow=0, count_walk_prefetch=int(waves % 2)):
+                    with ctx.tuning(count_walk_min_rows=1, count_walk_waves=waves, narrow=0):
                         for _ in range(2):
                             r = g.search(b, thr, 0)
                             assert r.search_kernel.startswith("count_walk_kernel<"), r.search_kernel
                             assert [(int(n), e) for n, e in zip(r.num_query_kmer, r.per_query())] == exp, (seed, n_cols, thr, waves)
             if thr == 1.0 and n_cols > 16384:
-                # the walk form of the AND kernel (normally for batches of >= 256k rows and rows of 3..16 KiB), both
-                # unrolls, with the batch's positions cut into few / many / very many wave shares: the long queries
-                # are then finished through the cut-pair slots by dozens of waves each
-                for unroll, flags, waves in ((4, 0, 0), (2, 0, 7), (4, 0, 1000), (2, 0, 4096)):
-                    with ctx.tuning(walk_min_rows=1, walk_max_kib=64, walk=unroll, walk_waves=waves):
+                # the walk form of the AND kernel (normally for batches of >= 256k rows and rows of 3..16 KiB), with the
+                # batch's positions cut into few / many / very many wave shares: the long queries are then finished
+                # through the cut-pair slots by dozens of waves each
+                for flags, waves in ((0, 0), (0, 7), (0, 1000), (0, 4096)):
+                    with ctx.tuning(walk_min_rows=1, walk_max_kib=64, walk=4, walk_waves=waves):
                         for _ in range(2):         # twice: the kernel must leave its cut-pair slots clean
                             r = g.search(b, thr, flags)
                             assert r.search_kernel.startswith("and_walk_kernel<")
-                            assert [(int(n), e) for n, e in zip(r.num_query_kmer, r.per_query())] == exp, (seed, n_cols, unroll, waves)
+                            assert [(int(n), e) for n, e in zip(r.num_query_kmer, r.per_query())] == exp, (seed, n_cols, waves)
         b.close()
         g.close()

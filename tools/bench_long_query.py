@@ -16,12 +16,11 @@ for name, w in (("1 x 100 kb vs 100k samples", synth.Workload("long1", 100_000, 
                 ("4 x 1 Mb vs 100k samples", synth.Workload("long4", 100_000, 20, 31, 1, 4, 1_000_000, 1.0, num_genomes=4, genome_len=1_000_000, hit_fraction=1.0))):
     s = synth.build(ctx, w)
     for thr in (1.0, 0.9):
-        for force in ("1", None, "cw", "cw-nopf"):       # one wave per (query, tile) / segments / persistent count kernel with long part chains
-            if force in ("cw", "cw-nopf") and thr == 1.0:
+        for force in ("1", None, "cw"):       # one wave per (query, tile) / segments / persistent count kernel with long part chains
+            if force == "cw" and thr == 1.0:
                 continue
             ctx.set_tuning("force_segs", int(force) if force == "1" else 0)
-            ctx.set_tuning("count_walk", 1 if force in ("cw", "cw-nopf") else 0)
-            ctx.set_tuning("count_walk_prefetch", 0 if force == "cw-nopf" else 1)
+            ctx.set_tuning("count_walk", 1 if force == "cw" else 0)
             best = None
             for _ in range(3):
                 r = s.group.search(s.batch, thr, ka.SEARCH_TIMING | ka.SEARCH_TIMING_KMER)

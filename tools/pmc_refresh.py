@@ -22,7 +22,8 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (pure Python at import time: no torch, no HIP)
 
 N_GROUPS = {"c5": 8}
-GATHER = ("and_kernel", "and_walk_kernel", "and_band_walk_kernel", "and_narrow_kernel", "count_kernel", "count_walk_kernel", "count_narrow_kernel")
+GATHER = ("and_kernel", "and_walk_kernel", "and_band_walk_kernel", "and_narrow_kernel", "count_kernel", "count_walk_kernel", "count_narrow_kernel",
+          "and_screen_kernel", "and_refine_kernel", "and_refine_emit_kernel", "count_screen_kernel", "count_refine_kernel", "count_refine_emit_kernel")
 
 
 def short(kernel_name):
@@ -33,22 +34,24 @@ def short(kernel_name):
 
 def main():
     args = sys.argv[1:]
-    rnd = "r04"
+    rnd = "r05"
     if args[:1] == ["--round"]:
         rnd, args = args[1], args[2:]
     # "c2+bands": the same workload with the walk kernel forced band after band (its entry is keyed "c2@<kernel>")
+    # "c2+ee": the same workload searched with the reference's early exit (`bench.py --early-exit`; entry "c2@ee", read by
+    # the `early_exit` block of the driver's line): the bytes of ALL the stage's launches (screen + refine + emit) per step
     workloads = args or ["c2", "c2+bands", "c2t", "c3", "c4", "c5s", "c5"]
     out_root = os.path.join(ROOT, "gpurun_out", "pmc_" + rnd)
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     rec = json.load(open(path))
     code = bench.kernel_code_hash()
     for spec in workloads:
-        wl, banded = spec.split("+")[0], spec.endswith("+bands")
+        wl, banded, ee = spec.split("+")[0], spec.endswith("+bands"), spec.endswith("+ee")
         knobs = {"KWAGE_WALK_BANDS": "3", "KWAGE_WALK_BANDS_MIN_GIB": "0"} if banded else {"KWAGE_WALK_BANDS": "0"}
         d = os.path.join(out_root, spec.replace("+", "_"))
         os.makedirs(d, exist_ok=True)
         cmd = ["rocprofv3", "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", d, "--",
-               sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--no-cpu-baseline", "--no-sustained", "--no-result-check", "--also", "none", "--steps", "5", "--warmup", "1"]
+               sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--no-cpu-baseline", "--no-sustained", "--no-result-check", "--no-early-exit-block", "--also", "none", "--steps", "5", "--warmup", "1"] + (["--early-exit"] if ee else [])
         t0 = time.time()
         r = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", **knobs))
         print("[pmc_refresh] %s: rc %d in %.0f s" % (wl, r.returncode, time.time() - t0), flush=True)
@@ -76,10 +79,11 @@ def main():
             print("[pmc_refresh] %s: no gather kernel in the counter file" % wl)
             continue
         ng = N_GROUPS.get(wl, 1)
-        launches = sum(len(v) for v in gather.values())
-        steps = launches / float(ng)
-        per_step = sum(sum(v) for v in gather.values()) * 1024.0 * factor / steps
         dominant = max(gather, key=lambda k: sum(gather[k]))
+        # (a stage of several launches -- screen + refine + emit -- counts once per step: the dispatches of its first kernel)
+        first = [k for k in gather if "_screen_kernel" in k]
+        steps = (len(gather[first[0]]) if first else sum(len(v) for v in gather.values())) / float(ng)
+        per_step = sum(sum(v) for v in gather.values()) * 1024.0 * factor / steps
         summary = {"workload": wl, "bench_line": line, "calibration": {"stream_read_dispatches": len(cal), "known_bytes": known, "factor": factor},
                    "kernels": {short(k): {"dispatches": len(v), "FETCH_SIZE_avg_KiB": sum(v) / len(v)} for k, v in agg.items()}}
         sfile = os.path.join(ROOT, "profiles", "%s_%s_pmc_fetch_size.json" % (rnd, spec.replace("+", "_")))
@@ -90,7 +94,9 @@ def main():
                  "source": os.path.relpath(sfile, ROOT), "code_hash": code, "round": rnd}
         if ng > 1:
             entry["note"] = "per STEP = the %d groups' launches together, as bench.py sums kernel time and algorithmic bytes over the groups" % ng
-        rec["%s@%s" % (wl, entry["kernel"]) if banded else wl] = entry
+        if ee:
+            entry["per_kernel_bytes_per_step"] = {short(k): int(sum(v) * 1024.0 * factor / steps) for k, v in gather.items()}
+        rec[("%s@%s" % (wl, entry["kernel"])) if banded else ("%s@ee" % wl if ee else wl)] = entry
         print("[pmc_refresh] %s: %s  %.3f GB per step for %.3f GB algorithmic = %.4fx (factor %.4f)" %
               (wl, short(dominant), per_step / 1e9, entry["algorithmic_bytes_per_launch"] / 1e9, entry["ratio"], factor), flush=True)
         json.dump(rec, open(path, "w"), indent=1)

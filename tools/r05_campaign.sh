@@ -29,6 +29,27 @@ ee_prof)
   done
   cd $R
   ;;
+ee_stats)
+  KWAGE_REFINE_STATIC=0 python tools/step_breakdown.py "1000 x 1 kb" 2>&1 | grep -E " ee "
+  KWAGE_REFINE_STATIC=0 python tools/step_breakdown.py "100k x 150" 2>&1 | grep -E " ee "
+  ;;
+count_ab)
+  for w in c2t c5s; do for r in 0 1; do
+    KWAGE_EE_REFINE=$r python bench.py --workload $w --early-exit --no-cpu-baseline --no-sustained --also none --steps 10 --warmup 3 2>/dev/null | python -c "
+import json,sys
+l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$w ee_refine=$r', l['ms_per_step'], l['roofline']['kernel'], l['roofline']['kernel_ms'], l['config']['hits_per_step'], l['result_check']['ok'])"
+  done; done
+  ;;
+suite)
+  python -m pytest tests -m gpu -x -q --durations=10 > $O/r05_gpu_suite_durations.txt 2>&1 || { tail -60 $O/r05_gpu_suite_durations.txt; exit 1; }
+  tail -14 $O/r05_gpu_suite_durations.txt
+  ;;
+probe)
+  df -h /tmp /dev/shm $R 2>&1; free -g; nproc; echo TMPDIR=$TMPDIR; cat /proc/cpuinfo | grep "model name" | sort | uniq -c
+  ;;
+identical)
+  python tools/e2e_c2_identical.py --out $O/r05_c2_identical_db
+  ;;
 line)
   python bench.py --steps 20 --warmup 5 > $O/r05_c2_bench.json 2> $O/r05_c2_bench.err || { tail -30 $O/r05_c2_bench.err; exit 1; }
   python - <<PY

@@ -10,10 +10,10 @@ test_walk_rows_many_queries: query lengths 0 ... 300, planted windows so that pa
 too-short queries), software-pipelined through the context's two slots so that the NEXT search's k-mer stage runs beside
 the gather kernel, every hit list compared with the first one (which is compared with the tiled kernel's, itself checked
 against the CPU oracle once), and at the end of every setting the kernels' exchange buffers read back: all zero, or a
-pair was left unfinished (kwage_ctx_scratch_nonzero).  A last block repeats and_walk_kernel with walk_fences=1 (the
-C++ release / acquire form) for contrast.
+pair was left unfinished (kwage_ctx_scratch_nonzero).  (The C++ release / acquire form that round 4 soaked for contrast was a
+knob, `walk_fences`, and went with it in round 5.)
 
-    python tools/soak_walk.py [--launches 5000] [--out gpurun_out/soak/r04_soak.txt]
+    python tools/soak_walk.py [--launches 5000] [--out gpurun_out/soak/r05_soak.txt]
 
 Not part of pytest (suite time).  Exit status 1 on any mismatch."""
 import os
@@ -36,7 +36,7 @@ def rand_seq(rng, n):
 
 def main():
     args = sys.argv[1:]
-    launches, out_path = 5000, os.path.join(ROOT, "gpurun_out", "soak", "r04_soak.txt")
+    launches, out_path = 5000, os.path.join(ROOT, "gpurun_out", "soak", "r05_soak.txt")
     while args:
         if args[0] == "--launches":
             launches, args = int(args[1]), args[2:]
@@ -142,9 +142,6 @@ def main():
                      dict(base, walk_waves=waves, walk_bands=bands, walk_bands_min_gib=0), "and_band_walk_kernel<", launches // 2)
         for waves in WAVES:
             soak("count_walk_kernel     count_walk_waves=%-6d" % waves, 0.95, ref_cnt, dict(base, count_walk_waves=waves), "count_walk_kernel<", launches)
-        for waves in (3001, 30000):
-            soak("and_walk_kernel       walk_waves=%-6d walk_fences=1" % waves, 1.0, ref_and, dict(base, walk_waves=waves, walk_fences=1),
-                 "and_walk_kernel<", max(launches // 5, 1))
         b.close()
         other.close()
         g.close()

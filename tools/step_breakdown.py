@@ -38,6 +38,6 @@ for name, nq, qlen in shapes:
             nh = res.contents.n_hits; kern = (res.contents.search_kernel or b"").decode()
             L.kwage_result_free(res)
         wl, k, km = np.median(walls[2:]), np.median(ks[2:]), np.median(kms[2:])
-        print("%-18s t=%-6g %s call %9.3f ms | gather %9.3f (%s) | k-mer stage %7.3f | rest %8.3f | hits %d"
-              % (name, thr_v, "ee" if ee else "  ", wl, k, kern, km, wl - k - km, nh), flush=True)
+        print("%-18s t=%-6g %s call %9.3f ms | gather %9.3f (%s) | k-mer stage %7.3f | rest %8.3f | hits %d%s"
+              % (name, thr_v, "ee" if ee else "  ", wl, k, kern, km, wl - k - km, nh, (" | lists " + str(ctx.refine_stats()[0])) if "screen" in kern else ""), flush=True)
     s.batch.close(); s.group.close()

@@ -17,8 +17,7 @@ sizes = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else []
 ctx = ka.Context(0)
 s = synth.build(ctx, synth.WORKLOADS[wl])
 thr = s.workload.threshold
-variants = [("tiled", dict(count_walk=0))] + [("walk %d waves/CU%s" % (w, " pf" if pf else ""), dict(count_walk=1, count_walk_wpc=w, count_walk_min_rows=1, count_walk_prefetch=pf))
-                                               for w, pf in ((6, 0), (8, 0), (8, 1), (12, 0), (12, 1))]
+variants = [("tiled", dict(count_walk=0))] + [("walk %d waves/CU" % w, dict(count_walk=1, count_walk_wpc=w, count_walk_min_rows=1)) for w in (6, 8, 12)]
 
 
 def run(batch, label):

@@ -16,19 +16,14 @@ acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
 extra = [acgt[rng.integers(0, 4, size=1000)].tobytes().decode() for _ in range(4000)]
 variants = [("tiled", {"walk": 0}), ("walk", {"walk": 4, "walk_min_rows": 1})]
 for wv in sys.argv[1:]:
-    if wv.startswith("cfg:"):        # cfg:<rows in flight>:<waves>
-        _, u, wvs = wv.split(":")
-        variants.append(("walk u%s %s waves" % (u, wvs), {"walk": int(u), "walk_min_rows": 1, "walk_waves": int(wvs)}))
-    elif wv == "fences":
-        variants.append(("walk/full fences", {"walk": 4, "walk_min_rows": 1, "walk_fences": 1}))
-    else:
+    if True:
         variants.append(("walk/%s waves" % wv, {"walk": 4, "walk_min_rows": 1, "walk_waves": int(wv)}))
 for nq in [int(x) for x in os.environ.get("WALK_SIZES", "50,100,200,300,500,700,900,1000,1024,1030,1100,1300,1500,2048,2100,3000,5000").split(",")]:
     qs = (s.queries + extra)[:nq]
     b = ka.Batch(ctx, qs)
     out = []
     for name, knobs in variants:
-        with ctx.tuning(**dict({"walk": 4, "walk_min_rows": -1, "walk_waves": 0, "walk_fences": 0}, **knobs)):
+        with ctx.tuning(**dict({"walk": 4, "walk_min_rows": -1, "walk_waves": 0}, **knobs)):
             ms = [s.group.search(b, 1.0, ka.SEARCH_TIMING).search_kernel_ms for _ in range(6)]
             r = s.group.search(b, 1.0, ka.SEARCH_TIMING)
         out.append("%s %s %.3f ms (%.0f GB/s)" % (name, r.search_kernel, float(np.median(ms[1:])), r.algorithmic_bytes / float(np.median(ms[1:])) / 1e6))
