@@ -82,6 +82,8 @@ def parse_args(argv=None):
     ap.add_argument("--also", default=os.environ.get("KWAGE_BENCH_ALSO", "auto"),
                     help="other configurations measured after the headline: auto (N=1: c3; N>1: c4,c5 -- only when the headline is c2), none, or a comma list")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=("auto", "sample"), default="auto",
+                    help="auto: the reference on the IDENTICAL database (the resident matrix written as .db files) where the host has room, plus the bounded sample; sample: the bounded sample only")
     ap.add_argument("--no-result-check", action="store_true", help="skip the post-timing check of the hit lists against the oracle")
     ap.add_argument("--no-sustained", action="store_true", help="skip the %.0f s sustained block after the timed steps" % SUSTAINED_SECONDS)
     ap.add_argument("--early-exit", action="store_true", help="enable the reference's early exit for the WHOLE run (not the nominal figure; the PMC passes behind the `early_exit` blocks use it)")
@@ -133,6 +135,150 @@ def launch_ranks(n_ranks, argv):
 # ------------------------------------------------------------------------------------------------------
 # CPU baseline
 # ------------------------------------------------------------------------------------------------------
+def find_room(nbytes, prefer=""):
+    """A directory with room for `nbytes` of files (+ slack): `prefer`, $TMPDIR, /tmp, /dev/shm, gpurun_out/.  tmpfs
+    lives in memory: there the files must fit beside this process.  -> (dir or None, {dir: free bytes})"""
+    cands = [d for d in (prefer, os.environ.get("TMPDIR", ""), "/tmp", "/dev/shm", os.path.join(ROOT, "gpurun_out")) if d and os.path.isdir(d)]
+    free = {d: shutil.disk_usage(d).free for d in cands}
+    avail = 0
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                avail = int(ln.split()[1]) * 1024
+    except OSError:
+        pass
+    for d in cands:
+        room = free[d] - (8 << 30)
+        if d.startswith("/dev/shm"):
+            room = min(room, avail - (24 << 30))
+        if nbytes + (64 << 20) <= room:
+            return d, free
+    return None, free
+
+
+def export_group_as_db_files(group, w, dbdir, ncol_file=2048, progress=False):
+    """The RESIDENT matrix of a synthetic workload, read back from HBM band by band (kwage_group_read_rows) and written as
+    reference-format `.db` files of <= ncol_file columns (what `maestro` would produce, options.h:137; layout
+    build_db.cpp:189-427), sample j named SRR%07d.  -> {files, bytes, d2h_seconds, seconds}"""
+    import concurrent.futures
+    import struct
+    import zlib
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import kwage_oracle as oracle
+    L, k, nh = w.log_2_filter_len, w.kmer_len, w.num_hash
+    nrows = 1 << L
+    n_files = (w.num_samples + ncol_file - 1) // ncol_file
+    files = []
+    for f in range(n_files):
+        ncol = min(ncol_file, w.num_samples - f * ncol_file)
+        path = os.path.join(dbdir, "part%03d.db" % f)
+        files.append({"path": path, "fd": os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644), "ncol": ncol,
+                      "b0": f * ncol_file // 8, "nb": (ncol + 7) // 8, "crc": 0})
+    band = max(1, min(nrows, (2 << 30) // group.row_bytes))
+    t0 = time.perf_counter()
+    t_read = 0.0
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(os.cpu_count() or 1, 16)) as pool:
+        for r0 in range(0, nrows, band):
+            n = min(band, nrows - r0)
+            ta = time.perf_counter()
+            block = group.read_rows(np.arange(r0, r0 + n, dtype=np.uint32))
+            t_read += time.perf_counter() - ta
+
+            def put(fi):
+                part = np.ascontiguousarray(block[:, fi["b0"]:fi["b0"] + fi["nb"]])
+                fi["crc"] = zlib.crc32(part, fi["crc"])
+                os.pwrite(fi["fd"], part, oracle.HEADER_SIZE + r0 * fi["nb"])
+            list(pool.map(put, files))
+            if progress and (r0 // band) % 8 == 0:
+                print("  [export] rows %d / %d written (%.0f s)" % (r0 + n, nrows, time.perf_counter() - t0), file=sys.stderr, flush=True)
+    for f, fi in enumerate(files):
+        ncol = fi["ncol"]
+        hdr = oracle.DBHeader(kmer_len=k, num_hash=nh, log_2_filter_len=L, num_filter=ncol, hash_func=0, compression=0)
+        hdr.crc32 = fi["crc"] & 0xFFFFFFFF            # build_db.cpp:307
+        hdr.info_start = oracle.HEADER_SIZE + nrows * fi["nb"]
+        recs = [oracle.pack_filter_info(oracle.FilterInfo(run_accession=oracle.str_to_accession("SRR%07d" % (f * ncol_file + j)))) for j in range(ncol)]
+        loc, locs = hdr.info_start + 8 * ncol, []
+        for rr in recs:
+            locs.append(loc)
+            loc += len(rr)
+        os.pwrite(fi["fd"], hdr.pack(), 0)
+        os.pwrite(fi["fd"], struct.pack("<%dQ" % ncol, *locs) + b"".join(recs), hdr.info_start)
+        os.close(fi["fd"])
+    return {"files": n_files, "bytes": int(sum(os.path.getsize(fi["path"]) for fi in files)), "d2h_seconds": round(t_read, 2),
+            "seconds": round(time.perf_counter() - t0, 2), "band_rows": band}
+
+
+def cpu_baseline_identical(s, w, nominal, max_seconds=90.0):
+    """BASELINE.md section 4 as planned: the reference `kwage` (oracle/_ref/kwage: the reference's own sources, OpenMP over
+    files, host threads = min(CPUs, files), page cache warm, best of 2) on the IDENTICAL database -- the resident matrix
+    read back from HBM and written as <= 2048-column `.db` files -- and the identical queries, and its report compared
+    with the timed kernel's hit list: the WHOLE list, per query, as sets of (run accession, k-mers found).
+    -> the cpu_baseline block, or None when the reference binary or the room for the files is missing (the caller then
+    times the bounded sample).  The reference has no switch for its early exit (kwage.cpp:437-483): the figure is its
+    default behaviour on these bits, the counterpart of the line's `early_exit` block; the bounded sample beside it
+    (`no_early_exit_sample`) keeps every addressed row read, the counterpart of `value`."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import kwage_oracle as oracle
+    if not os.access(oracle.REF_KWAGE, os.X_OK) or not w.log_2_filter_len:
+        return None
+    nbytes = (1 << w.log_2_filter_len) * ((w.num_samples + 7) // 8)
+    if nbytes / 4e9 > max_seconds:             # (measured: 5 GB/s read back + written on the pool's boxes)
+        return None
+    where, free = find_room(nbytes)
+    if where is None:
+        return None
+    work = tempfile.mkdtemp(prefix="kwage_cpu_identical_", dir=where)
+    try:
+        dbdir = os.path.join(work, "db")
+        os.makedirs(dbdir)
+        exp = export_group_as_db_files(s.group, w, dbdir)
+        qfile = os.path.join(work, "q.fa")
+        with open(qfile, "w") as fh:
+            for i, q in enumerate(s.queries):
+                fh.write(">query_%d\n%s\n" % (i, q))
+        cores = os.cpu_count() or 1
+        threads = min(cores, exp["files"])
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads))
+        best, text = None, None
+        for _ in range(2):
+            o = os.path.join(work, "ref.csv")
+            t0 = time.perf_counter()
+            r = subprocess.run([oracle.REF_KWAGE, "-d", dbdir, "-i", qfile, "-t", repr(float(w.threshold)), "--o.csv", "-o", o], env=env, capture_output=True)
+            dt = time.perf_counter() - t0
+            if r.returncode != 0:
+                raise RuntimeError("reference kwage failed: " + r.stderr.decode()[-1000:])
+            if best is None or dt < best:
+                best, text = dt, open(o).read()
+        ref = oracle.parse_csv(text)
+        # the timed kernel's list in the report's terms: query name -> {(run accession, k-mers found)}
+        hits = nominal.hits
+        order = np.argsort(hits["query"], kind="stable")
+        hq = hits["query"][order]
+        starts = np.searchsorted(hq, np.arange(len(s.queries) + 1))
+        same, n_ref = True, 0
+        for qi in range(len(s.queries)):
+            sl = order[starts[qi]:starts[qi + 1]]
+            mine = sorted(("SRR%07d" % int(c), int(n)) for c, n in zip(hits["column"][sl], hits["num_match"][sl]))
+            theirs = sorted((acc, found) for acc, _, found, _ in ref.get("query_%d" % qi, []))
+            n_ref += len(theirs)
+            if mine != theirs:
+                same = False
+        bit_tests = int(nominal.bit_tests)
+        return {"value": round(bit_tests / best / 1e9, 3), "unit": "G bit-tests/s", "cores": threads, "kind": "reference", "extrapolated": False,
+                "identical_db": {"files": exp["files"], "db_bytes": exp["bytes"], "log_2_rows": int(w.log_2_filter_len), "columns": int(w.num_samples), "directory": where,
+                                 "export_seconds": exp["seconds"], "d2h_seconds": exp["d2h_seconds"], "reference_wall_s": round(best, 3), "threads": threads, "cpus": cores,
+                                 "threshold": float(w.threshold), "reference_hits": n_ref, "device_hits": int(len(hits)),
+                                 "whole_list_identical": bool(same)},
+                "sample": "reference kwage (OpenMP over files, %d threads of %d CPUs) on the IDENTICAL database: the resident matrix read back from HBM and written as %d reference-format "
+                          ".db files (%.1f GB, %s) + the identical %d queries, page cache warm, best of 2, wall %.2f s; its early exit (kwage.cpp:437-483) cannot be switched off: "
+                          "this is its default behaviour on these bits -- the counterpart of the line's `early_exit` block; whole hit list identical to the timed kernel's: %s"
+                          % (threads, cores, exp["files"], exp["bytes"] / 1e9, where, len(s.queries), best, same)}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def cpu_baseline(w, queries, n_files):
     """Time the reference CPU `kwage` (or the oracle port) on a bounded sample of workload w:
     n_files .db files x 2048 columns, 2^min(L,20) rows, SAME k / hashes / threshold / queries.
@@ -794,11 +940,28 @@ def measure(env, args, name, headline, force_scaling=None):
         if force_sharded:
             out["config"]["note"] = "KWAGE_BENCH_FORCE_SHARDED: multi-GPU code path on one rank"
         if headline and world == 1 and not args.no_cpu_baseline:
+            # the planned baseline first -- the reference on the IDENTICAL database, whole-list parity included --, where the
+            # host has the room (105 GB of files for C2) and the reference binary travelled; the bounded sample always (it is
+            # the one that reads every addressed row, like `value`)
+            ident = None
+            if not multi and args.cpu_baseline != "sample":
+                try:
+                    ident = cpu_baseline_identical(s, w, probe)
+                except Exception as e:
+                    ident = {"error": repr(e)}
             try:
-                out["cpu_baseline"] = cpu_baseline(w, s.queries, args.cpu_files)
+                sample = cpu_baseline(w, s.queries, args.cpu_files)
             except Exception as e:   # the baseline is informative; never lose the GPU number over it
-                out["cpu_baseline"] = {"value": None, "unit": "G bit-tests/s", "cores": 0, "kind": "port",
-                                       "sample": "failed: %r" % (e,)}
+                sample = {"value": None, "unit": "G bit-tests/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+            if ident and "error" not in ident:
+                ident["no_early_exit_sample"] = sample
+                out["cpu_baseline"] = ident
+                if not ident["identical_db"]["whole_list_identical"]:
+                    checks_ok = False
+            else:
+                if ident:
+                    sample["identical_db"] = ident
+                out["cpu_baseline"] = sample
 
     for m in members:
         m.batch.close()

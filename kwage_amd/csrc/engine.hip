@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cctype>
 #include <cstring>
 #include <new>
 #include <string>
@@ -1180,7 +1181,10 @@ extern "C" int kwage_device_fingerprint(kwage_ctx *ctx, char *buf, uint64_t len)
 	memset(&id, 0, sizeof(id));
 	(void)hipDeviceGetUuid(&id, ctx->device);
 	char hex[2*sizeof(id.bytes) + 1];
-	for(size_t i = 0; i < sizeof(id.bytes); ++i){ snprintf(hex + 2*i, 3, "%02x", (unsigned)(unsigned char)id.bytes[i]); }
+	bool text = true;                  // (the runtime hands out sixteen hex DIGITS as characters: kept as they are)
+	for(size_t i = 0; i < sizeof(id.bytes); ++i){ text = text && isalnum((unsigned char)id.bytes[i]); }
+	if(text){ memcpy(hex, id.bytes, sizeof(id.bytes)); hex[sizeof(id.bytes)] = 0; }
+	else{ for(size_t i = 0; i < sizeof(id.bytes); ++i){ snprintf(hex + 2*i, 3, "%02x", (unsigned)(unsigned char)id.bytes[i]); } }
 	snprintf(buf, (size_t)len, "uuid=%s;name=%s;arch=%s;cus=%d;sclk_mhz=%d;mclk_mhz=%d;hbm_bus_bits=%d;pci=%04x:%02x:%02x",
 	         hex, prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate/1000, prop.memoryClockRate/1000, prop.memoryBusWidth,
 	         (unsigned)prop.pciDomainID, (unsigned)prop.pciBusID, (unsigned)prop.pciDeviceID);

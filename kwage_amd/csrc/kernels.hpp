@@ -1815,8 +1815,34 @@ __device__ __forceinline__ void count_kmers_prefetch(const uint8_t *db, uint64_t
                                                      u32x4 (&plane)[PLANES])
 {
 	static_assert(KPS == 4 || KPS == 8, "four or eight k-mers per step");
+	// With 14 counter planes and more the matches are counted in a BLOCK counter of seven planes first (120 k-mers at most)
+	// and the block is added to the PLANES-plane total once per block: the upper planes are touched once per 120 k-mers
+	// instead of once per eight -- the ripple through them was most of the 20-plane form's instructions (a wave spent 42 % of
+	// its time issuing them, profiles/r04_long1t_pmc_occupancy.json).
+	constexpr bool BLOCKS = (KPS == 8 && PLANES >= 14);
+	constexpr int BP = 7;
+	u32x4 blk[BP];
+	uint32_t in_blk = 0;
+	if constexpr(BLOCKS){
+#pragma unroll
+		for(int p = 0; p < BP; ++p){ blk[p] = (u32x4)(0u); }
+	}
+	auto fold = [&]() {
+		if constexpr(BLOCKS){
+			if(in_blk == 0){ return; }
+			planes_accumulate<PLANES>(plane, BP, [&](int p) -> u32x4 { return blk[p < BP ? p : 0]; });
+#pragma unroll
+			for(int p = 0; p < BP; ++p){ blk[p] = (u32x4)(0u); }
+			in_blk = 0;
+		}
+	};
 	auto add = [&](const u32x4 (&m)[KPS]) {
-		if constexpr(KPS == 8){ planes_add8<PLANES>(plane, m); }
+		if constexpr(BLOCKS){
+			planes_add8<BP>(blk, m);
+			in_blk += 8;
+			if(in_blk > 127 - 8){ fold(); }
+		}
+		else if constexpr(KPS == 8){ planes_add8<PLANES>(plane, m); }
 		else{ planes_add4<PLANES>(plane, m[0], m[1], m[2], m[3]); }
 	};
 	auto fetch = [&](uint32_t i, u32x4 (&m)[KPS]) {
@@ -1852,8 +1878,13 @@ __device__ __forceinline__ void count_kmers_prefetch(const uint8_t *db, uint64_t
 			const uint32_t r = rq[i*NH + h];
 			mm &= load16<true>(reinterpret_cast<const u32x4*>(db + (uint64_t)r*stride) + unit);
 		}
-		planes_add<PLANES>(plane, mm, 0);
+		if constexpr(BLOCKS){
+			planes_add<BP>(blk, mm, 0);
+			if(++in_blk == 127){ fold(); }
+		}
+		else{ planes_add<PLANES>(plane, mm, 0); }
 	}
+	fold();
 }
 
 // The same counts from a PERSISTENT, statically balanced grid (and_walk_kernel's idea for the threshold < 1 path).  The

@@ -27,8 +27,13 @@
 //                       travel through a shared host segment instead of RCCL (which refuses two ranks on one device).
 //                       The searches still run on the GPU; sharding, global numbering, gather and report are the same
 //                       code.  For tests on one-GPU boxes, not for production.
-//   KWAGE_EARLY_EXIT, KWAGE_BATCH_BASES   as for kwage
-// Every parameter group must fit its ranks' HBM in one pass (kwage itself also handles databases that do not).
+//   KWAGE_EARLY_EXIT, KWAGE_BATCH_BASES, KWAGE_MAX_GROUP_BYTES   as for kwage
+//   KWAGE_NODE_COMM_TIMEOUT_S   how long a rank waits for the communicator to come up (default 120 s): a rank whose peers never
+//                       arrive exits non-zero instead of waiting forever, and the parent ends the others
+// A database that does not fit its ranks' HBM is searched in PASSES, as kwage does it (kwage_main.cpp: units of whole files
+// packed into what is free; the query sources are read once per pass; results are additive): every rank plans every
+// rank's passes from the file headers and the ranks' budgets (one all-gather), so all of them make the same number of
+// exchanges -- a rank whose files are done contributes empty lists.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <pthread.h>
@@ -78,6 +83,19 @@ Share share_of(const vector<uint32_t> &group_files, const vector<DbFileEntry> &f
 	return s;
 }
 
+// What one rank holds resident in one pass: a span of whole files of one group, one matrix.  The records it produces carry
+// base + column-in-matrix, which is the file's place in the GLOBAL numbering whatever the pass (a unit starts at a file,
+// and files follow each other in a unit exactly as in the rank's whole share: blocks at 16-byte boundaries).
+struct Unit {
+	size_t gi = 0;                       // index into the groups
+	vector<uint32_t> files;              // indices into the list of database files
+	vector<uint64_t> first_column;       // of each file's block within the unit's matrix
+	uint64_t span_columns = 0;
+	uint64_t base = 0;                   // global number of the unit's column 0
+	uint32_t kmer_len = 0;
+	kwage_group *mine = nullptr;
+};
+
 // A file's columns in the global numbering of the hit records.
 struct ColumnBlock { uint64_t first_global_column; uint32_t file_index, kmer_len; };
 
@@ -86,7 +104,6 @@ struct NodeGroup {
 	kwage_params params;
 	vector<Share> share;                 // per rank
 	vector<uint64_t> base;               // per rank: global number of the rank's column 0 of this group
-	kwage_group *mine = nullptr;         // this rank's matrix (null: no file of the group here)
 };
 
 // How rank 0 hands the communicator's unique id to the other ranks: anonymous shared memory mapped before the fork.
@@ -130,6 +147,45 @@ vector<NodeGroup> plan_groups(const vector<DbFileEntry> &files, int n_ranks)
 	}
 	if(next_base > (1ull << 32)){ throw "main: more than 2^32 columns in the database"; }
 	return groups;
+}
+
+// The passes of one rank (kwage_main.cpp's packing): its files of every group, in order, cut into units that fit what is
+// left of `budget` bytes in the current pass; a file that does not fit goes to the next pass -- unless the pass is still
+// empty: then it is tried alone (and the allocation reports it if it really is too large).
+vector<vector<Unit> > plan_passes(const vector<NodeGroup> &groups, const vector<DbFileEntry> &files, size_t rank, uint64_t budget)
+{
+	vector<vector<Unit> > passes(1);
+	uint64_t pass_left = budget;
+	for(size_t gi = 0; gi < groups.size(); ++gi){
+		const Share &sh = groups[gi].share[rank];
+		const uint64_t nrows = 1ull << groups[gi].params.log_2_filter_len;
+		for(size_t m0 = 0; m0 < sh.files.size(); ){
+			uint64_t span_bytes = 0;
+			size_t m1 = m0;
+			Unit u;
+			while(m1 < sh.files.size()){
+				const uint64_t at = (span_bytes + 15)/16*16;
+				const uint64_t next = at + ((uint64_t)files[sh.files[m1]].header.num_filter + 7)/8;
+				if(((next + 127)/128*128)*nrows > pass_left && (m1 > m0 || !passes.back().empty())){ break; }
+				u.files.push_back(sh.files[m1]);
+				u.first_column.push_back(at*8);
+				span_bytes = next;
+				++m1;
+			}
+			if(m1 > m0){
+				u.gi = gi;
+				u.span_columns = span_bytes*8;
+				u.base = groups[gi].base[rank] + sh.first_column[m0];
+				u.kmer_len = groups[gi].params.kmer_len;
+				pass_left -= min(pass_left, ((span_bytes + 127)/128*128)*nrows);
+				passes.back().push_back(std::move(u));
+				m0 = m1;
+			}
+			if(m0 < sh.files.size()){ passes.emplace_back(); pass_left = budget; }
+		}
+	}
+	if(passes.back().empty() && passes.size() > 1){ passes.pop_back(); }
+	return passes;
 }
 
 // KWAGE_NODE_PLAN=1: print the plan for n_ranks ranks and stop -- no device is touched (tests; a dry run before a long job)
@@ -196,7 +252,7 @@ struct Step {
 
 struct RankPipeline {
 	kwage_ctx *ctx;
-	vector<NodeGroup> &groups;
+	vector<Unit> *units = nullptr;       // what is resident in the current pass
 	int rank;
 	float threshold;
 	uint32_t flags;
@@ -209,7 +265,7 @@ struct RankPipeline {
 	deque<Flying> flying;
 	int next_list = 0;
 
-	RankPipeline(kwage_ctx *c, vector<NodeGroup> &g, int r, float t, uint32_t f) : ctx(c), groups(g), rank(r), threshold(t), flags(f)
+	RankPipeline(kwage_ctx *c, int r, float t, uint32_t f) : ctx(c), rank(r), threshold(t), flags(f)
 	{
 		for(HitList &l : lists){
 			l.cap = 1u << 18;
@@ -226,11 +282,11 @@ struct RankPipeline {
 	}
 	void submit(const Todo &t)
 	{
-		NodeGroup &g = groups[t.gi];
+		Unit &u = (*units)[t.gi];
 		HitList &l = lists[t.step->list];
 		kwage_pending *p = nullptr;
-		check(kwage_search_device_append_submit(g.mine, t.step->b, threshold, flags | KWAGE_SEARCH_TIMING, l.d_hits, l.cap, l.d_count,
-		                                        (uint32_t)g.base[(size_t)rank], t.first ? 1 : 0, &p));
+		check(kwage_search_device_append_submit(u.mine, t.step->b, threshold, flags | KWAGE_SEARCH_TIMING, l.d_hits, l.cap, l.d_count,
+		                                        (uint32_t)u.base, t.first ? 1 : 0, &p));
 		flying.push_back(Flying{p, t.step, t.gi});
 	}
 	void pump() { while(!todo.empty() && flying.size() < 2){ submit(todo.front()); todo.pop_front(); } }
@@ -239,7 +295,7 @@ struct RankPipeline {
 		Flying f = flying.front();
 		flying.pop_front();
 		Step *st = f.step;
-		const uint32_t k = groups[f.gi].params.kmer_len;
+		const uint32_t k = (*units)[f.gi].kmer_len;
 		// rank 0 files the hits and needs num_query_kmer of every query: it comes with the search (one device-to-host copy
 		// per distinct k-mer length and batch), not from a k-mer stage of its own
 		const bool want_nk = (rank == 0) && st->q.size() && !st->nk.count(k);
@@ -263,6 +319,9 @@ struct RankPipeline {
 	// Wait for `stream` (the exchange's) WITHOUT leaving the device unfed: a collective queued behind a running gather
 	// kernel can take as long as that kernel, and only two searches are queued at a time -- so while the exchange is
 	// pending, searches that have finished are collected and the step's next ones submitted.
+	// (No sleeping poll: the host always BLOCKS on something that has to complete anyway -- the oldest search in flight while
+	// there is one (its collection frees a slot for the step's next search), the exchange's stream itself otherwise.  Filing
+	// a batch a kernel's length later costs nothing: it happens beside the following batches' searches.)
 	void wait_feeding(hipStream_t stream)
 	{
 		for(;;){
@@ -270,8 +329,9 @@ struct RankPipeline {
 			if(e == hipSuccess){ return; }
 			(void)hipGetLastError();
 			if(e != hipErrorNotReady){ throw string("hipStreamQuery failed: ") + hipGetErrorString(e); }
-			if(!flying.empty() && kwage_search_poll(flying.front().p) == 1){ collect_oldest(); pump(); }
-			else{ usleep(20); }
+			if(flying.empty()){ NODE_HIP(hipStreamSynchronize(stream)); return; }
+			collect_oldest();
+			pump();
 		}
 	}
 	void begin(Step *st)
@@ -280,12 +340,13 @@ struct RankPipeline {
 		next_list = (next_list + 1) % 3;
 		check(kwage_batch_create(ctx, st->q.bases.data(), st->q.offsets.data(), (uint32_t)st->q.size(), &st->b));
 		bool first = true;
-		for(size_t gi = 0; gi < groups.size(); ++gi){
-			if(!groups[gi].mine){ continue; }
-			todo.push_back(Todo{st, gi, first});
+		for(size_t ui = 0; ui < units->size(); ++ui){
+			todo.push_back(Todo{st, ui, first});
 			first = false;
 			++st->searches;
 		}
+		// (a rank with nothing resident in this pass still takes part in the exchange: an empty list)
+		if(st->searches == 0){ NODE_HIP(hipMemset(lists[st->list].d_count, 0, sizeof(uint64_t))); }
 		pump();
 	}
 	// Complete every search of `st` (the oldest open step).  A list that outgrew its buffer is redone after growing it.
@@ -302,9 +363,8 @@ struct RankPipeline {
 				st->done = 0;
 				st->kernel_ms = 0;
 				bool first = true;
-				for(size_t gi = 0; gi < groups.size(); ++gi){
-					if(!groups[gi].mine){ continue; }
-					submit(Todo{st, gi, first});
+				for(size_t ui = 0; ui < units->size(); ++ui){
+					submit(Todo{st, ui, first});
 					first = false;
 					collect_oldest();
 				}
@@ -383,23 +443,36 @@ int run_rank(int rank, int n_ranks, Bootstrap *boot, const Cli &cli, const vecto
 				__sync_synchronize();
 				memcpy(&id, &boot->id, sizeof(id));
 			}
-			const ncclResult_t comm_up = ncclCommInitRank(&comm, n_ranks, id, rank);
+			// ncclCommInitRank has no timeout of its own: a rank whose peers never arrive (one of them failed before this point)
+			// would wait forever.  It runs on a thread; if it is not back in time the process exits non-zero without
+			// returning into RCCL, and the parent ends the other ranks.
+			ncclResult_t comm_up = ncclInternalError;
+			{
+				struct Up { mutex mu; condition_variable cv; bool done = false; ncclResult_t rc = ncclInternalError; ncclComm_t comm = nullptr; };
+				shared_ptr<Up> up = make_shared<Up>();
+				const int device = rank;
+				thread([up, n_ranks, id, rank, device]() {
+					(void)hipSetDevice(device);
+					ncclComm_t c = nullptr;
+					const ncclResult_t rc = ncclCommInitRank(&c, n_ranks, id, rank);
+					lock_guard<mutex> lk(up->mu);
+					up->rc = rc; up->comm = c; up->done = true;
+					up->cv.notify_all();
+				}).detach();
+				unique_lock<mutex> lk(up->mu);
+				const uint64_t limit_s = env_u64("KWAGE_NODE_COMM_TIMEOUT_S", 120);
+				if(!up->cv.wait_for(lk, chrono::seconds(limit_s), [&]{ return up->done; })){
+					cerr << "Caught the error rank " << rank << ": the RCCL communicator did not come up within " << limit_s << " s (a peer is missing)" << endl;
+					fflush(nullptr);
+					_exit(EXIT_FAILURE);
+				}
+				comm_up = up->rc;
+				comm = up->comm;
+			}
 			fflush(stdout);
 			dup2(report_fd, STDOUT_FILENO);
 			close(report_fd);
 			if(comm_up != ncclSuccess){ throw string("ncclCommInitRank failed: ") + ncclGetErrorString(comm_up); }
-		}
-
-		for(NodeGroup &g : groups){
-			const Share &s = g.share[(size_t)rank];
-			if(s.files.empty()){ continue; }
-			check(kwage_group_create(ctx, &g.params, s.span_columns, &g.mine));
-			vector<const char*> paths;
-			for(uint32_t fi : s.files){ paths.push_back(files[fi].path.c_str()); }
-			vector<uint64_t> first(paths.size());
-			check(kwage_group_add_db_files(g.mine, paths.data(), (uint32_t)paths.size(), first.data(), nullptr));
-			if(first != s.first_column){ throw "main: the loaded layout differs from the planned one"; }
-			check(kwage_group_finalize(g.mine));
 		}
 
 		// ---- the exchange's buffers: every rank's count, rank 0's gathered list (device + pinned host) ------------------
@@ -416,8 +489,50 @@ int run_rank(int rank, int n_ranks, Bootstrap *boot, const Cli &cli, const vecto
 		const double t_search0 = now_seconds();
 		double t_first_begin = 0;
 
+		// ---- the passes: every rank's budget to everyone, then every rank plans every rank's passes ---------------------------
+		vector<vector<Unit> > my_passes;
+		size_t n_passes = 1;
 		{
-		RankPipeline pipe(ctx, groups, rank, cli.threshold, flags);
+			uint64_t budget = env_u64("KWAGE_MAX_GROUP_BYTES", 0);
+			if(budget == 0){
+				uint64_t free_b = 0, total_b = 0;
+				check(kwage_mem_info(ctx, &free_b, &total_b));
+				budget = free_b - free_b/8;              // leave room for staging buffers, row indices, hits
+				if(rehearsal){ budget /= (uint64_t)n_ranks; }      // (the rehearsed ranks share one device)
+			}
+			vector<uint64_t> budgets((size_t)n_ranks, budget);
+			if(rehearsal){
+				rehearsal->counts[rank] = budget;
+				pthread_barrier_wait(&rehearsal->barrier);
+				for(int r = 0; r < n_ranks; ++r){ budgets[(size_t)r] = rehearsal->counts[r]; }
+				pthread_barrier_wait(&rehearsal->barrier);
+			}
+			else if(n_ranks > 1){
+				uint64_t *d_mine = nullptr;
+				NODE_HIP(hipMalloc((void**)&d_mine, sizeof(uint64_t)));
+				NODE_HIP(hipMemcpy(d_mine, &budget, sizeof(uint64_t), hipMemcpyHostToDevice));
+				NODE_NCCL(ncclAllGather(d_mine, d_counts, 1, ncclUint64, comm, stream));
+				NODE_HIP(hipMemcpyAsync(h_counts, d_counts, (size_t)n_ranks*sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+				NODE_HIP(hipStreamSynchronize(stream));
+				for(int r = 0; r < n_ranks; ++r){ budgets[(size_t)r] = h_counts[r]; }
+				(void)hipFree(d_mine);
+			}
+			for(int r = 0; r < n_ranks; ++r){
+				vector<vector<Unit> > pr = plan_passes(groups, files, (size_t)r, budgets[(size_t)r]);
+				n_passes = max(n_passes, pr.size());
+				if(r == rank){ my_passes = std::move(pr); }
+			}
+			my_passes.resize(n_passes);
+			if(env_u64("KWAGE_VERBOSE", 0) || stats){
+				size_t nu = 0;
+				for(const auto &ps : my_passes){ nu += ps.size(); }
+				cerr << "[kwage_node] rank " << rank << ": budget " << budget << " bytes per pass, " << n_passes << " pass(es), " << nu << " unit(s) of its own" << endl;
+			}
+		}
+		double t_parse_wait = 0;
+
+		{
+		RankPipeline pipe(ctx, rank, cli.threshold, flags);
 
 		// The gatherv of one finished step: counts to everyone (one ncclAllGather straight from the lists' counter words),
 		// records in exact sizes to rank 0 (one grouped ncclSend / ncclRecv; RCCL has no gatherv); rank 0 files them.
@@ -501,7 +616,7 @@ int run_rank(int rank, int n_ranks, Bootstrap *boot, const Cli &cli, const vecto
 				// of them) are the one case that still needs a k-mer stage of its own
 				for(const NodeGroup &g : groups){
 					if(st->nk.count(g.params.kmer_len)){ continue; }
-					while(!pipe.flying.empty()){ pipe.collect_oldest(); }      // (kwage_hash_batch wants the context's slots idle)
+					while(!pipe.flying.empty()){ pipe.collect_oldest(); pipe.pump(); }      // (kwage_hash_batch wants the context's slots idle)
 					vector<uint64_t> off(q.size() + 1);
 					vector<uint32_t> nk(q.size());
 					check(kwage_hash_batch(ctx, &g.params, st->b, off.data(), nk.data(), nullptr, nullptr));
@@ -545,7 +660,10 @@ int run_rank(int rank, int n_ranks, Bootstrap *boot, const Cli &cli, const vecto
 			PrefetchedQueries ahead(source, max_batch_bases);
 			for(;;){
 				unique_ptr<Step> st(new Step());
-				if(!ahead.fill(st->q, max_batch_bases)){ break; }
+				const double t_fill = now_seconds();
+				const bool more = ahead.fill(st->q, max_batch_bases);
+				t_parse_wait += now_seconds() - t_fill;        // (every rank parses the query files, on a thread of its own: what the searches waited for it)
+				if(!more){ break; }
 				st->found = &found;
 				if(t_first_begin == 0){ t_first_begin = now_seconds(); }
 				pipe.begin(st.get());
@@ -556,16 +674,36 @@ int run_rank(int rank, int n_ranks, Bootstrap *boot, const Cli &cli, const vecto
 			}
 		};
 		Findings from_command_line_, from_files_;
-		{
-			CommandLineQueries typed(cli.query_seqs);
-			run_source(typed, from_command_line_);
+		double t_load = 0;
+		for(size_t pass = 0; pass < n_passes; ++pass){
+			// ---- this pass's matrices (none: the rank's files are done -- it still takes part in every exchange) ------------
+			vector<Unit> &units = my_passes[pass];
+			const double t_l0 = now_seconds();
+			for(Unit &u : units){
+				NodeGroup &g = groups[u.gi];
+				check(kwage_group_create(ctx, &g.params, u.span_columns, &u.mine));
+				vector<const char*> paths;
+				for(uint32_t fi : u.files){ paths.push_back(files[fi].path.c_str()); }
+				vector<uint64_t> first(paths.size());
+				check(kwage_group_add_db_files(u.mine, paths.data(), (uint32_t)paths.size(), first.data(), nullptr));
+				if(first != u.first_column){ throw "main: the loaded layout differs from the planned one"; }
+				check(kwage_group_finalize(u.mine));
+			}
+			t_load += now_seconds() - t_l0;
+			pipe.units = &units;
+			// the query sources are read once per pass (results are additive: a query's matches of this pass join those of the others)
+			{
+				CommandLineQueries typed(cli.query_seqs);
+				run_source(typed, from_command_line_);
+			}
+			if(!cli.query_files.empty()){
+				FileQueries disk(cli.query_files);
+				run_source(disk, from_files_);
+			}
+			if(done_step){ hand_over(done_step); }
+			if(open_step){ pipe.finish(open_step.get()); hand_over(open_step); }
+			for(Unit &u : units){ if(u.mine){ kwage_group_destroy(u.mine); u.mine = nullptr; } }
 		}
-		if(!cli.query_files.empty()){
-			FileQueries disk(cli.query_files);
-			run_source(disk, from_files_);
-		}
-		if(done_step){ hand_over(done_step); }
-		if(open_step){ pipe.finish(open_step.get()); hand_over(open_step); }
 		const double t_search = now_seconds() - t_search0;
 		if(stats && rank == 0){
 			const double t_pipe = t_first_begin ? now_seconds() - t_first_begin : 0;
@@ -573,6 +711,8 @@ int run_rank(int rank, int n_ranks, Bootstrap *boot, const Cli &cli, const vecto
 			                "sum of gather-kernel time (rank 0) %.3f ms = %.1f %% of it; exchange %.3f ms, filing %.3f ms (both beside the next batch's searches)\n",
 			        (unsigned long long)n_batches, (unsigned long long)n_records, t_pipe*1e3, t_search*1e3,
 			        sum_kernel_ms, t_pipe > 0 ? 100.0*sum_kernel_ms/(t_pipe*1e3) : 0.0, t_exchange*1e3, t_file*1e3);
+			fprintf(stderr, "[kwage_node] %zu pass(es), loading %.3f s; waited %.3f ms for this rank's own query parser (every rank parses the query files on a prefetch thread)\n",
+			        n_passes, t_load, t_parse_wait*1e3);
 		}
 
 		// (pipe is destroyed before the context)
@@ -602,7 +742,6 @@ int run_rank(int rank, int n_ranks, Bootstrap *boot, const Cli &cli, const vecto
 			cerr << "Search complete in " << (time(nullptr) - started) << " sec" << endl;
 		}
 		}
-		for(NodeGroup &g : groups){ if(g.mine){ kwage_group_destroy(g.mine); } }
 		kwage_shutdown(ctx);
 	}
 	catch(const char *error){

@@ -54,7 +54,7 @@ class Context:
         out = {}
         for kv in buf.value.decode("latin-1").split(";"):
             k, _, v = kv.partition("=")
-            out[k] = int(v) if v.isdigit() else v
+            out[k] = int(v) if (v.isdigit() and k not in ("uuid", "pci")) else v
         return out
 
     def sync(self) -> None:

@@ -98,6 +98,28 @@ def test_node_cli_several_ranks_rehearsed(ranks, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [1, 2, 3])
+def test_node_cli_database_larger_than_hbm_takes_passes(ranks):
+    """A database that does not fit its ranks' HBM in one pass (KWAGE_MAX_GROUP_BYTES stands in for the free memory: here
+    less than two files' matrices): every rank plans every rank's passes from the headers and the budgets, loads one span
+    of whole files per pass, reads the query sources once per pass, and takes part in every exchange -- with an empty list
+    once its own files are done.  The report must be kwage's, byte for byte (one rank: over RCCL; more: rehearsed)."""
+    cdir = os.path.join(GOLDEN, "multi")
+    for args in (["-d", "dbs", "-i", "reads.fastq", "-i", "contigs.fa.gz", "-t", "0.7", "--o.json", "TTACAGCCGATGTTAGCGCGCGCTGGAATTACAAAGCTCACTGCCAAGTTAAACCATGGGGCGCGGGTAT"],
+                 ["-d", "dbs", "-i", "reads.fastq", "-t", "1", "--o.csv"]):
+        want = subprocess.run([KWAGE] + args, cwd=cdir, capture_output=True, timeout=300)
+        assert want.returncode == 0 and want.stdout
+        for env in ({"KWAGE_MAX_GROUP_BYTES": "200000"}, {"KWAGE_MAX_GROUP_BYTES": "300000", "KWAGE_BATCH_BASES": "300", "KWAGE_EARLY_EXIT": "0"}):
+            extra = {"KWAGE_NODE_REHEARSE": "1"} if ranks > 1 else {}
+            r = subprocess.run([NODE] + args, cwd=cdir, capture_output=True, timeout=300,
+                               env=_env(KWAGE_NODE_RANKS=str(ranks), KWAGE_NODE_STATS="1", **extra, **env))
+            assert r.returncode == 0, r.stderr.decode()
+            assert r.stdout == want.stdout, (ranks, args, env)
+            passes = [int(x) for x in re.findall(rb"bytes per pass, (\d+) pass\(es\)", r.stderr)]
+            assert len(passes) == ranks and len(set(passes)) == 1 and passes[0] >= 2, r.stderr.decode()      # every rank knows the same number of passes
+
+
+@pytest.mark.gpu
 def test_node_cli_a_failing_rank_ends_the_run(tmp_path):
     """A rank that cannot continue (here: a rehearsal segment too small for the hit list) must not leave the others waiting."""
     cdir = os.path.join(GOLDEN, "multi")

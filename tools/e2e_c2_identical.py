@@ -14,17 +14,14 @@ compared as sets per query -- the WHOLE hit list, not sampled queries.
 Free space is probed first (--dir, $TMPDIR, /tmp, /dev/shm, the repo): when 2^23 rows do not fit anywhere the largest
 log2 row count that does is taken instead and the report says so (the same samples, queries and densities; fewer rows)."""
 import argparse
-import concurrent.futures
 import hashlib
 import json
 import os
 import shutil
 import socket
-import struct
 import subprocess
 import sys
 import time
-import zlib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -102,48 +99,10 @@ def main():
             r = s.group.search(s.batch, t, 0)
             nominal[t] = (len(r.hits), int(r.total_kmers))
         total_kmers = nominal[list(nominal)[0]][1]
-        k, nh = w.kmer_len, w.num_hash
-        nrows = 1 << L
-        files = []
-        for f in range(n_files):
-            ncol = min(ncol_file, w.num_samples - f * ncol_file)
-            path = os.path.join(dbdir, "part%03d.db" % f)
-            fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
-            files.append({"path": path, "fd": fd, "ncol": ncol, "b0": f * ncol_file // 8, "nb": (ncol + 7) // 8, "crc": 0})
-        band = max(1, min(nrows, (2 << 30) // s.group.row_bytes))
-        pool = concurrent.futures.ThreadPoolExecutor(max_workers=min(os.cpu_count() or 1, 16))
-        t0 = time.perf_counter()
-        t_read = 0.0
-        for r0 in range(0, nrows, band):
-            n = min(band, nrows - r0)
-            ta = time.perf_counter()
-            block = s.group.read_rows(np.arange(r0, r0 + n, dtype=np.uint32))
-            t_read += time.perf_counter() - ta
-
-            def put(fi):
-                part = np.ascontiguousarray(block[:, fi["b0"]:fi["b0"] + fi["nb"]])
-                fi["crc"] = zlib.crc32(part, fi["crc"])
-                os.pwrite(fi["fd"], part, oracle.HEADER_SIZE + r0 * fi["nb"])
-            list(pool.map(put, files))
-            if (r0 // band) % 8 == 0:
-                print("  rows %d / %d written (%.0f s)" % (r0 + n, nrows, time.perf_counter() - t0), flush=True)
-        for f, fi in enumerate(files):
-            ncol = fi["ncol"]
-            hdr = oracle.DBHeader(kmer_len=k, num_hash=nh, log_2_filter_len=L, num_filter=ncol, hash_func=0, compression=0)
-            hdr.crc32 = fi["crc"] & 0xFFFFFFFF
-            hdr.info_start = oracle.HEADER_SIZE + nrows * fi["nb"]
-            recs = [oracle.pack_filter_info(oracle.FilterInfo(run_accession=oracle.str_to_accession("SRR%07d" % (f * ncol_file + j)))) for j in range(ncol)]
-            loc, locs = hdr.info_start + 8 * ncol, []
-            for rr in recs:
-                locs.append(loc)
-                loc += len(rr)
-            os.pwrite(fi["fd"], hdr.pack(), 0)
-            os.pwrite(fi["fd"], struct.pack("<%dQ" % ncol, *locs) + b"".join(recs), hdr.info_start)
-            os.close(fi["fd"])
-        t_write = time.perf_counter() - t0
-        total_bytes = sum(os.path.getsize(fi["path"]) for fi in files)
+        exp = bench.export_group_as_db_files(s.group, w, dbdir, ncol_file, progress=True)
+        total_bytes, nrows, nh = exp["bytes"], 1 << L, w.num_hash
         say("read back %d rows x %d bytes in bands of %d rows (D2H %.1f s) and wrote %d reference-format .db files, %.1f GB, in %.1f s -> %s"
-            % (nrows, s.group.row_bytes, band, t_read, n_files, total_bytes / 1e9, t_write, dbdir))
+            % (nrows, s.group.row_bytes, exp["band_rows"], exp["d2h_seconds"], n_files, total_bytes / 1e9, exp["seconds"], dbdir))
         qfile = os.path.join(work, "q.fa")
         with open(qfile, "w") as fh:
             for i, q in enumerate(s.queries):
@@ -203,6 +162,16 @@ def main():
             for ln in split:
                 say("      " + ln)
             result["runs"]["%g" % thr] = rec
+        # the same command with the WHOLE database loaded (KWAGE_SPARSE=0): what a host that keeps the database resident pays once
+        thr0 = float(args.thresholds.split(",")[0])
+        t_full, out_full, err_full = run(native.KWAGE_BIN, thr0, dict(os.environ, KWAGE_VERBOSE="1", KWAGE_SPARSE="0"), 1)
+        same_full = oracle.parse_csv(out_full) == oracle.parse_csv(run(native.KWAGE_BIN, thr0, dict(os.environ), 1)[1])
+        say("t = %g with KWAGE_SPARSE=0 (every row of every file loaded, not only the rows the batch addresses): wall %.2f s; same report: %s" % (thr0, t_full, same_full))
+        for ln in [ln.strip() for ln in err_full.splitlines() if ("loaded" in ln and "GB/s" in ln) or "from the start of main" in ln]:
+            say("      " + ln)
+        result["whole_database_load"] = {"threshold": thr0, "wall_s": round(t_full, 3), "same_report": bool(same_full),
+                                         "verbose": [ln.strip() for ln in err_full.splitlines() if "loaded" in ln and "GB/s" in ln]}
+        ok_all = ok_all and same_full
         result["reports_identical"] = bool(ok_all)
         say("reports identical: %s" % ok_all)
         os.makedirs(os.path.dirname(args.out), exist_ok=True)
