@@ -211,6 +211,22 @@ struct BloomFile {
 	}
 };
 
+// f(0) ... f(nparts - 1), on threads of their own where they can be had.  A thread that cannot be created
+// (std::system_error -- which must never cross the C ABI this file exports) leaves its part to the caller.
+template <typename F>
+void run_parts(unsigned nparts, F f)
+{
+	std::vector<std::thread> pool;
+	std::vector<unsigned> mine;
+	for(unsigned t = 1; t < nparts; ++t){
+		try{ pool.emplace_back(f, t); }
+		catch(...){ mine.push_back(t); }
+	}
+	if(nparts){ f(0u); }
+	for(unsigned t : mine){ f(t); }
+	for(auto &th : pool){ th.join(); }
+}
+
 // crc32 of a large buffer continued from `crc`: parts in parallel, stitched with crc32_combine
 // (the result is identical to one sequential crc32_z call).
 uint32_t crc32_parallel(uint32_t crc, const unsigned char *buf, uint64_t len)
@@ -220,14 +236,8 @@ uint32_t crc32_parallel(uint32_t crc, const unsigned char *buf, uint64_t len)
 	const uint64_t part = (len + nthread - 1)/nthread;
 	std::vector<uint32_t> pc(nthread, 0);
 	std::vector<uint64_t> pl(nthread, 0);
-	std::vector<std::thread> pool;
-	for(unsigned t = 0; t < nthread; ++t){
-		const uint64_t b = (uint64_t)t*part;
-		if(b >= len){ break; }
-		pl[t] = std::min(part, len - b);
-		pool.emplace_back([&, t, b]() { pc[t] = (uint32_t)crc32_z(crc32_z(0L, Z_NULL, 0), buf + b, pl[t]); });
-	}
-	for(auto &th : pool){ th.join(); }
+	for(unsigned t = 0; t < nthread; ++t){ pl[t] = ((uint64_t)t*part < len) ? std::min(part, len - (uint64_t)t*part) : 0; }
+	run_parts(nthread, [&](unsigned t) { if(pl[t]){ pc[t] = (uint32_t)crc32_z(crc32_z(0L, Z_NULL, 0), buf + (uint64_t)t*part, pl[t]); } });
 	uint64_t out = crc;
 	for(unsigned t = 0; t < nthread && pl[t]; ++t){ out = crc32_combine(out, pc[t], (z_off_t)pl[t]); }
 	return (uint32_t)out;
@@ -285,17 +295,13 @@ extern "C" int kwage_build_db(kwage_ctx *ctx, const char *out_path, const kwage_
 	{
 		const unsigned nthread = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
 		std::atomic<uint32_t> next(0), bad(0xFFFFFFFFu);
-		std::vector<std::thread> pool;
-		for(unsigned t = 0; t < nthread; ++t){
-			pool.emplace_back([&]() {
-				for(uint32_t i = next++; i < n; i = next++){
-					uint64_t crc = crc32_z(0L, Z_NULL, 0);
-					crc = crc32_z(crc, files[i].map + files[i].bits_off, filter_bytes);
-					if((uint32_t)crc != files[i].crc){ bad = i; }
-				}
-			});
-		}
-		for(auto &t : pool){ t.join(); }
+		run_parts(nthread, [&](unsigned) {
+			for(uint32_t i = next++; i < n; i = next++){
+				uint64_t crc = crc32_z(0L, Z_NULL, 0);
+				crc = crc32_z(crc, files[i].map + files[i].bits_off, filter_bytes);
+				if((uint32_t)crc != files[i].crc){ bad = i; }
+			}
+		});
 		if(bad != 0xFFFFFFFFu){
 			const uint32_t i = bad;
 			cleanup();
@@ -327,7 +333,7 @@ extern "C" int kwage_build_db(kwage_ctx *ctx, const char *out_path, const kwage_
 	const uint64_t chunk_bytes = (chunk_rows + 7)/8;
 	uint64_t in_stride = (chunk_bytes + 255)/256*256;
 	if((in_stride/256) % 2 == 0){ in_stride += 256; }
-	if(const char *v = getenv("KWAGE_BUILD_PAD")){ in_stride = chunk_bytes + (uint64_t)atoll(v)/4*4; }
+	if(const char *v = getenv("KWAGE_BUILD_PAD")){ in_stride = (chunk_bytes + 3)/4*4 + (uint64_t)std::max<long long>(atoll(v), 0)/4*4; }      // (never below the chunk itself)
 	void *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out[2] = {nullptr, nullptr};
 	hipError_t e = hipMalloc(&d_in, in_stride*n);
 	if(e == hipSuccess){ e = hipMalloc(&d_out, chunk_rows*slice_size); }
@@ -341,11 +347,8 @@ extern "C" int kwage_build_db(kwage_ctx *ctx, const char *out_path, const kwage_
 	// tile shape, KWAGE_BUILD_TILE: 0 = 1024 filters x 512 slices (64-byte reads per filter, 128-byte row segments out),
 	// 1 = 512 x 1024 (128-byte reads, 64-byte segments), 2 = 512 x 512 and 3 = 256 x 1024 with four waves (32 KB of LDS)
 	const int tile_shape = []() { const char *v = getenv("KWAGE_BUILD_TILE"); return v ? atoi(v) : 0; }();
-	// KWAGE_BUILD_PERSISTENT=1: a resident grid walking the tiles, the next tile requested before the current one is written
-	// out, instead of one workgroup per tile (measured 10 % SLOWER: profiles/r04_builder_transpose.txt)
-	const bool persistent = []() { const char *v = getenv("KWAGE_BUILD_PERSISTENT"); return v && atoi(v) != 0; }();
-	int n_cus = 256;
-	(void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, ctx_device(ctx));
+	// (a resident grid walking the tiles with the next tile requested before the current one is written out measured 10 %
+	// SLOWER than one workgroup per tile -- profiles/r04_builder_transpose.txt -- and went in round 5)
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	if(e == hipSuccess){ e = hipEventCreate(&ev0); }
 	if(e == hipSuccess){ e = hipEventCreate(&ev1); }
@@ -354,13 +357,9 @@ extern "C" int kwage_build_db(kwage_ctx *ctx, const char *out_path, const kwage_
 		const uint64_t nb = (nr + 7)/8;
 		{	// this chunk of every filter into the pinned block (host threads: one memcpy per filter, 2048 of up to 256 KB)
 			const unsigned nthread = (uint64_t)n*nb < (8u << 20) ? 1u : std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
-			auto gather = [&](unsigned t) {
+			run_parts(nthread, [&](unsigned t) {
 				for(uint32_t i = t; i < n; i += nthread){ memcpy((char*)h_in + (uint64_t)i*in_stride, files[i].map + files[i].bits_off + r0/8, nb); }
-			};
-			std::vector<std::thread> pool;
-			for(unsigned t = 1; t < nthread; ++t){ pool.emplace_back(gather, t); }
-			gather(0);
-			for(auto &th : pool){ th.join(); }
+			});
 		}
 		e = hipMemcpyAsync(d_in, h_in, in_stride*n, hipMemcpyHostToDevice, stream);
 		if(e != hipSuccess){ break; }
@@ -368,8 +367,7 @@ extern "C" int kwage_build_db(kwage_ctx *ctx, const char *out_path, const kwage_
 		auto launch = [&](auto tile_tag) {
 			using T = decltype(tile_tag);
 			const uint64_t tiles_x = (nr + T::ROWS - 1)/T::ROWS, tiles = tiles_x*((n + T::FILTERS - 1)/T::FILTERS);
-			const uint64_t resident = (uint64_t)n_cus*(128/(T::WAVES*8));      // workgroups the device holds at once (LDS: 8 KB per wave)
-			const uint32_t wgs = (uint32_t)std::min<uint64_t>(tiles, persistent ? resident : tiles);
+			const uint32_t wgs = (uint32_t)tiles;
 			hipLaunchKernelGGL((transpose_bits_kernel<T::ROWS/32, T::WAVES>), dim3(wgs), dim3(T::WAVES*64), 0, stream,
 			                   (const uint8_t*)d_in, in_stride, n, nr, (uint8_t*)d_out, slice_size, (uint32_t)tiles_x, (uint32_t)tiles);
 		};
@@ -391,10 +389,12 @@ extern "C" int kwage_build_db(kwage_ctx *ctx, const char *out_path, const kwage_
 		if(writer.joinable()){ writer.join(); }
 		ok = writer_ok;
 		if(!ok){ break; }
-		writer = std::thread([&db_crc, &writer_ok, fout, hb, bytes = nr*slice_size]() {        // (chunks are written in order: one writer at a time)
+		auto write_chunk = [&db_crc, &writer_ok, fout, hb, bytes = nr*slice_size]() {        // (chunks are written in order: one writer at a time)
 			db_crc = crc32_parallel(db_crc, hb, bytes);
 			writer_ok = fwrite(hb, 1, bytes, fout) == bytes;
-		});
+		};
+		try{ writer = std::thread(write_chunk); }
+		catch(...){ write_chunk(); }          // no thread to be had: this chunk is written here (no exception leaves this function)
 	}
 	if(writer.joinable()){ writer.join(); }
 	ok = ok && writer_ok;

@@ -128,13 +128,16 @@ int batch_prepare(kwage_batch *b, uint32_t k, const KmerLayout **out)
 	HIP_TRY(L->pool->take(std::max<size_t>(chunk_q.size(), 1)*sizeof(uint64_t), (void**)&L->d_chunk_t0, &L->cap_chunk_t0));
 	HIP_TRY(L->pool->take(((size_t)n + 1)*sizeof(uint64_t), (void**)&L->d_pos_off, &L->cap_pos_off));
 	HIP_TRY(L->pool->take(std::max<size_t>(n, 1)*sizeof(uint64_t), (void**)&L->d_tab_off, &L->cap_tab_off));
-	// (synchronous copies: the sources are locals, and the layout may be used on either search stream right away)
+	// (on the context's upload stream, waited for here: the sources are locals, the layout may be used on either search
+	// stream right away -- and nothing of this waits for a search that is pending on a slot)
+	hipStream_t us = b->ctx->upload_stream;
 	if(L->n_chunks){
-		HIP_TRY(hipMemcpy(L->d_chunk_q, chunk_q.data(), chunk_q.size()*sizeof(uint32_t), hipMemcpyHostToDevice));
-		HIP_TRY(hipMemcpy(L->d_chunk_t0, chunk_t0.data(), chunk_t0.size()*sizeof(uint64_t), hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpyAsync(L->d_chunk_q, chunk_q.data(), chunk_q.size()*sizeof(uint32_t), hipMemcpyHostToDevice, us));
+		HIP_TRY(hipMemcpyAsync(L->d_chunk_t0, chunk_t0.data(), chunk_t0.size()*sizeof(uint64_t), hipMemcpyHostToDevice, us));
 	}
-	HIP_TRY(hipMemcpy(L->d_pos_off, L->h_pos_off.data(), ((size_t)n + 1)*sizeof(uint64_t), hipMemcpyHostToDevice));
-	if(n){ HIP_TRY(hipMemcpy(L->d_tab_off, tab_off.data(), (size_t)n*sizeof(uint64_t), hipMemcpyHostToDevice)); }
+	HIP_TRY(hipMemcpyAsync(L->d_pos_off, L->h_pos_off.data(), ((size_t)n + 1)*sizeof(uint64_t), hipMemcpyHostToDevice, us));
+	if(n){ HIP_TRY(hipMemcpyAsync(L->d_tab_off, tab_off.data(), (size_t)n*sizeof(uint64_t), hipMemcpyHostToDevice, us)); }
+	HIP_TRY(hipStreamSynchronize(us));
 	L->total_pos = L->h_pos_off[n];
 	L->max_pos = maxp;
 	L->table_slots = slots;
@@ -903,8 +906,12 @@ int submit_search(Slot *sl, kwage_group *g, kwage_batch *b, float threshold, uin
 	sl->n_runs = 0;
 	sl->runs_per_query = 0;
 	if(ext_hits == nullptr && ext_cap == 0 && b->n && g->num_columns){
+		// (KiB-steps of a row, plus what the tilings round up: and_kernel's 1 / 2 / 4 vectors per lane pad to a multiple of four,
+		// the walk form's balanced column tiles to tiles x steps < kib + tiles.  The narrow kernels number their WORKGROUPS,
+		// fewer than queries.)
 		const uint64_t kib = (g->stride/16 + WAVE - 1)/WAVE;
-		sl->runs_per_query = (uint32_t)(2*kib + 4);           // (column tiles of any width: tiles x steps < kib + tiles)
+		const uint64_t walk_tile = (uint64_t)std::min<int64_t>(std::max<int64_t>(ctx->tune.walk_tile_kib, 1), 16);
+		sl->runs_per_query = (uint32_t)(kib + (kib + walk_tile - 1)/walk_tile + 4);
 		sl->n_runs = (uint64_t)b->n*sl->runs_per_query;
 		if((rc = sl->runs.reserve(sl->n_runs*sizeof(unsigned long long)))){ return rc; }
 	}
@@ -926,9 +933,28 @@ int submit_search(Slot *sl, kwage_group *g, kwage_batch *b, float threshold, uin
 	return KWAGE_OK;
 }
 
+int collect_search_steps(Slot *sl, SearchOutcome *out);
+
 // Second half: wait for the slot's stream, grow the hit buffer and re-run the search kernel if it
 // overflowed (own buffer only), report counts and timings. Frees the slot.
+// A collection that FAILS half-way may leave kernels of this search queued (the k-mer stage or the gather kernels of a
+// re-run): the slot is released all the same, so both of its streams are drained first -- the batch's device blocks go
+// back to the context's pool the moment the caller destroys it (kwage_batch_destroy no longer waits for the device), and
+// nothing may still be reading them then.
 int collect_search(Slot *sl, SearchOutcome *out)
+{
+	if(!sl->busy){ return fail(KWAGE_ERR_STATE, "no pending search in this slot"); }
+	kwage_ctx *ctx = sl->g->ctx;
+	const int rc = collect_search_steps(sl, out);
+	if(rc){
+		(void)hipStreamSynchronize(ctx->gather_stream);
+		(void)hipStreamSynchronize(sl->stream);
+		(void)hipGetLastError();
+	}
+	return rc;
+}
+
+int collect_search_steps(Slot *sl, SearchOutcome *out)
 {
 	if(!sl->busy){ return fail(KWAGE_ERR_STATE, "no pending search in this slot"); }
 	kwage_ctx *ctx = sl->g->ctx;
@@ -1115,6 +1141,7 @@ extern "C" int kwage_init(int device, kwage_ctx **out)
 		HIP_TRY(hipEventCreate(&sl->gather_done));           // (carries the gather stage's end time too)
 	}
 	HIP_TRY(hipStreamCreateWithFlags(&ctx->gather_stream, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
 	ctx->stream = ctx->slot[0].stream;
 	*out = ctx;
 	return KWAGE_OK;
@@ -1142,6 +1169,7 @@ extern "C" void kwage_shutdown(kwage_ctx *ctx)
 		if(sl->stream){ (void)hipStreamDestroy(sl->stream); }
 	}
 	if(ctx->gather_stream){ (void)hipStreamDestroy(ctx->gather_stream); }
+	if(ctx->upload_stream){ (void)hipStreamSynchronize(ctx->upload_stream); (void)hipStreamDestroy(ctx->upload_stream); }
 	ctx->kmers.release();
 	ctx->batch_pool.close();
 	ctx->result_pool->close();
@@ -1227,9 +1255,10 @@ extern "C" int kwage_batch_create(kwage_ctx *ctx, const char *seqs, const uint64
 	for(uint32_t i = 0; i <= n_queries; ++i){ b->h_seq_off[i] = offsets[i] - offsets[0]; }
 	hipError_t e = ctx->batch_pool.take(std::max<uint64_t>(total, 16), (void**)&b->d_seqs, &b->cap_seqs);
 	if(e == hipSuccess){ e = ctx->batch_pool.take(((size_t)n_queries + 1)*sizeof(uint64_t), (void**)&b->d_seq_off, &b->cap_seq_off); }
-	if(e == hipSuccess && total){ e = hipMemcpyAsync(b->d_seqs, seqs + offsets[0], total, hipMemcpyHostToDevice, ctx->stream); }
-	if(e == hipSuccess){ e = hipMemcpyAsync(b->d_seq_off, b->h_seq_off.data(), ((size_t)n_queries + 1)*sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream); }
-	if(e == hipSuccess){ e = hipStreamSynchronize(ctx->stream); }
+	// (the context's upload stream: a host that streams batches creates the next one while slot 0 holds a pending search)
+	if(e == hipSuccess && total){ e = hipMemcpyAsync(b->d_seqs, seqs + offsets[0], total, hipMemcpyHostToDevice, ctx->upload_stream); }
+	if(e == hipSuccess){ e = hipMemcpyAsync(b->d_seq_off, b->h_seq_off.data(), ((size_t)n_queries + 1)*sizeof(uint64_t), hipMemcpyHostToDevice, ctx->upload_stream); }
+	if(e == hipSuccess){ e = hipStreamSynchronize(ctx->upload_stream); }
 	if(e != hipSuccess){
 		kwage_batch_destroy(b);
 		return fail(KWAGE_ERR_DEVICE, "kwage_batch_create: %s", hipGetErrorString(e));

@@ -34,6 +34,29 @@ namespace kwage {
 
 struct KmerLayout;
 
+// Device memory that is only PARKED -- the blocks of destroyed query batches a context keeps for the next ones (DevPool
+// below) -- must never be the reason an allocation fails: every pool is listed here, and an allocation that runs out of
+// memory empties them all and tries once more.
+struct DevPool;
+struct DevPoolRegistry {
+	std::mutex mu;
+	std::vector<DevPool*> pools;
+	static DevPoolRegistry &get() { static DevPoolRegistry r; return r; }
+	void drain_all();
+};
+
+// hipMalloc; out of memory: the parked blocks of every context's pool are released, then once more.
+inline hipError_t device_malloc(void **out, uint64_t bytes)
+{
+	hipError_t e = hipMalloc(out, bytes);
+	if(e == hipErrorOutOfMemory){
+		(void)hipGetLastError();
+		DevPoolRegistry::get().drain_all();
+		e = hipMalloc(out, bytes);
+	}
+	return e;
+}
+
 // A device buffer that only ever grows (scratch reused across searches).
 struct DevBuf {
 	void *p = nullptr;
@@ -43,7 +66,7 @@ struct DevBuf {
 		if(bytes <= cap){ return KWAGE_OK; }
 		if(p){ (void)hipFree(p); p = nullptr; cap = 0; }
 		const uint64_t want = std::max<uint64_t>(bytes + bytes/4, 4096);
-		HIP_TRY(hipMalloc(&p, want));
+		HIP_TRY(device_malloc(&p, want));
 		cap = want;
 		return KWAGE_OK;
 	}
@@ -60,9 +83,18 @@ struct DevBuf {
 // KEEP bytes is really freed.
 struct DevPool {
 	struct Block { void *p; uint64_t cap; };
-	std::vector<Block> free_blocks;
+	std::vector<Block> free_blocks;        // oldest first
 	uint64_t held = 0;
 	static constexpr uint64_t KEEP = 1ull << 30;
+	DevPool() { std::lock_guard<std::mutex> lk(DevPoolRegistry::get().mu); DevPoolRegistry::get().pools.push_back(this); }
+	~DevPool()
+	{
+		std::lock_guard<std::mutex> lk(DevPoolRegistry::get().mu);
+		std::vector<DevPool*> &v = DevPoolRegistry::get().pools;
+		v.erase(std::remove(v.begin(), v.end(), this), v.end());
+	}
+	DevPool(const DevPool&) = delete;
+	DevPool &operator=(const DevPool&) = delete;
 	hipError_t take(uint64_t bytes, void **out, uint64_t *cap)
 	{
 		bytes = std::max<uint64_t>(bytes, 256);
@@ -77,12 +109,25 @@ struct DevPool {
 			return hipSuccess;
 		}
 		*cap = (bytes + 65535)/65536*65536;
-		return hipMalloc(out, *cap);
+		hipError_t e = hipMalloc(out, *cap);
+		if(e == hipErrorOutOfMemory){          // what is parked here (and in the other contexts' pools) goes first
+			(void)hipGetLastError();
+			close();
+			DevPoolRegistry::get().drain_all();
+			e = hipMalloc(out, *cap);
+		}
+		return e;
 	}
+	// (over KEEP the OLDEST parked blocks go, not the incoming one: what a streaming host hands back is what it asks for next)
 	void give(void *p, uint64_t cap)
 	{
 		if(!p){ return; }
-		if(held + cap > KEEP){ (void)hipFree(p); return; }
+		if(cap > KEEP){ (void)hipFree(p); return; }
+		while(held + cap > KEEP && !free_blocks.empty()){
+			(void)hipFree(free_blocks.front().p);
+			held -= free_blocks.front().cap;
+			free_blocks.erase(free_blocks.begin());
+		}
 		free_blocks.push_back(Block{p, cap});
 		held += cap;
 	}
@@ -93,6 +138,14 @@ struct DevPool {
 		held = 0;
 	}
 };
+
+inline void DevPoolRegistry::drain_all()
+{
+	// (a context is used by one host thread at a time; the registry only guards the LIST: pools are drained by the thread
+	// whose allocation failed, which is the thread that owns the pool in every host this library has)
+	std::lock_guard<std::mutex> lk(mu);
+	for(DevPool *p : pools){ p->close(); }
+}
 
 struct PinBuf {
 	void *p = nullptr;
@@ -274,6 +327,7 @@ struct kwage_ctx {
 	kwage::Tuning tune;
 	hipStream_t stream = nullptr;       // == slot[0].stream; loading, building and the synchronous calls use it
 	hipStream_t gather_stream = nullptr;    // the gather kernels of both slots, in submission order (see Slot)
+	hipStream_t upload_stream = nullptr;    // query batches and their layouts go to the device here: creating a batch never waits for a pending search
 	kwage::Slot slot[2];
 	kwage::DevBuf kmers;                       // kwage_hash_batch output
 	kwage::DevPool batch_pool;                 // device blocks of destroyed query batches (kwage_batch_destroy never waits for the device)

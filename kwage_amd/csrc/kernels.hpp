@@ -359,6 +359,11 @@ __device__ __forceinline__ void store_hit(const SearchArgs &a, unsigned long lon
 // round with more records than the buffer holds goes the direct way).  The list stays dense and every run keeps its entry
 // in the run table, so nothing downstream changes.
 static constexpr uint32_t WBUF_RECS = 256, WBUF_RUNS = 64;
+// (a run table entry is `first slot << 16 | records`: what ONE reservation can hold must fit 16 bits -- a wave's 64 lanes x
+// 128 columns, a narrow kernel's workgroup of SEARCH_THREADS lanes x 128 columns, a wave's LDS buffer)
+static_assert(SEARCH_THREADS*128 <= 0xFFFF, "a workgroup's reservation must fit the run table's 16-bit record field");
+static_assert(WAVE*128 <= 0xFFFF, "a wave's reservation must fit the run table's 16-bit record field");
+static_assert(WBUF_RECS <= 0xFFFF, "a wave's buffered records must fit the run table's 16-bit record field");
 struct WaveHitBuf {
 	kwage_hit rec[WBUF_RECS];
 	unsigned long long run_id[WBUF_RUNS];

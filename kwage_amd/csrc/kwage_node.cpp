@@ -526,7 +526,8 @@ int run_rank(int rank, int n_ranks, Bootstrap *boot, const Cli &cli, const vecto
 			if(env_u64("KWAGE_VERBOSE", 0) || stats){
 				size_t nu = 0;
 				for(const auto &ps : my_passes){ nu += ps.size(); }
-				cerr << "[kwage_node] rank " << rank << ": budget " << budget << " bytes per pass, " << n_passes << " pass(es), " << nu << " unit(s) of its own" << endl;
+				// (one write: the ranks share stderr)
+				fprintf(stderr, "[kwage_node] rank %d: budget %llu bytes per pass, %zu pass(es), %zu unit(s) of its own\n", rank, (unsigned long long)budget, n_passes, nu);
 			}
 		}
 		double t_parse_wait = 0;

@@ -208,7 +208,7 @@ hipError_t allocate_block(uint64_t bytes, bool contiguous, void **out)
 		e = hipExtMallocWithFlags(out, bytes, hipDeviceMallocContiguous);
 		if(e != hipSuccess){ (void)hipGetLastError(); *out = nullptr; }
 	}
-	if(e != hipSuccess){ e = hipMalloc(out, bytes); }
+	if(e != hipSuccess){ e = device_malloc(out, bytes); }      // (out of memory: what the contexts' batch pools hold is released first)
 	if(e != hipSuccess){ (void)hipGetLastError(); *out = nullptr; }
 	return e;
 }

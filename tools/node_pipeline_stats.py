@@ -79,7 +79,10 @@ try:
     runs = [("kwage, one process", [native.KWAGE_BIN], {}),
             ("kwage_node, 1 rank over RCCL", [NODE_BIN], {"KWAGE_NODE_RANKS": "1"}),
             ("kwage_node, 2 rehearsed ranks on device 0", [NODE_BIN], {"KWAGE_NODE_RANKS": "2", "KWAGE_NODE_REHEARSE": "1"}),
-            ("kwage_node, 3 rehearsed ranks on device 0", [NODE_BIN], {"KWAGE_NODE_RANKS": "3", "KWAGE_NODE_REHEARSE": "1"})]
+            ("kwage_node, 3 rehearsed ranks on device 0", [NODE_BIN], {"KWAGE_NODE_RANKS": "3", "KWAGE_NODE_REHEARSE": "1"}),
+            # a database twice what a rank may hold at once (KWAGE_MAX_GROUP_BYTES stands in for the free HBM): passes
+            ("kwage_node, 1 rank over RCCL, budget = half the database", [NODE_BIN], {"KWAGE_NODE_RANKS": "1", "KWAGE_MAX_GROUP_BYTES": str(total // 2)}),
+            ("kwage_node, 2 rehearsed ranks, budget = a quarter of the database each", [NODE_BIN], {"KWAGE_NODE_RANKS": "2", "KWAGE_NODE_REHEARSE": "1", "KWAGE_MAX_GROUP_BYTES": str(total // 4)})]
     outs = []
     for label, prog, extra in runs:
         for rep in range(2):          # (the second run has the files in the page cache and the pinned pools warm)

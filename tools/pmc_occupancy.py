@@ -2,7 +2,7 @@
 """What caps a gather kernel that sits below the others: occupancy / waiting, from one `rocprofv3 --pmc` pass of SQ and
 GRBM counters per workload (separate from the FETCH_SIZE pass of tools/pmc_refresh.py: counters in their own run).
 
-    python tools/pmc_occupancy.py [--round r04] [workload ...]        (default: c2 narrow narrowt long1t)
+    python tools/pmc_occupancy.py [--round r05] [workload ...]        (default: c2 narrow narrowt long1t)
 
 Per gather kernel: waves launched, mean waves resident per CU (SQ_WAVE_CYCLES is in quad-cycles, summed over waves;
 GRBM_GUI_ACTIVE is summed over the 8 XCDs), the share of wave time spent parked in s_waitcnt (SQ_WAIT_ANY), issuing
@@ -23,12 +23,13 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 COUNTERS = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"]
-GATHER = ("and_kernel", "and_walk_kernel", "and_band_walk_kernel", "and_narrow_kernel", "count_kernel", "count_walk_kernel", "count_narrow_kernel")
+GATHER = ("and_kernel", "and_walk_kernel", "and_band_walk_kernel", "and_narrow_kernel", "count_kernel", "count_walk_kernel", "count_narrow_kernel",
+          "and_screen_kernel", "and_refine_kernel", "and_refine_emit_kernel", "count_screen_kernel", "count_refine_kernel", "count_refine_emit_kernel")
 
 
 def main():
     args = sys.argv[1:]
-    rnd = "r04"
+    rnd = "r05"
     if args[:1] == ["--round"]:
         rnd, args = args[1], args[2:]
     workloads = args or ["c2", "narrow", "narrowt", "long1t"]

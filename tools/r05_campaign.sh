@@ -50,6 +50,68 @@ probe)
 identical)
   python tools/e2e_c2_identical.py --out $O/r05_c2_identical_db
   ;;
+long1t)
+  python -m pytest tests/test_gpu_parity.py tests/test_gpu_node_cli.py tests/test_gpu_random_configs.py -m gpu -x -q -k "2_pow_20 or long_quer or segments or node_cli or random_config or walk_rows_many" > $O/long_tests.txt 2>&1 || { tail -40 $O/long_tests.txt; exit 1; }
+  tail -3 $O/long_tests.txt
+  python bench.py --workload long1t --no-cpu-baseline --also none --no-early-exit-block --steps 10 --warmup 3 2>/dev/null > $O/r05_long1t_bench.json
+  python -c "
+import json; l=json.loads(open('$O/r05_long1t_bench.json').read().strip().splitlines()[-1]); print('long1t', l['roofline']['kernel'], l['roofline']['kernel_ms'], l['roofline']['frac'], l['roofline']['frac_of_measured_stream'])"
+  python tools/bench_long_query.py 2>&1 | tee $O/r05_long_query_segments.txt
+  ;;
+lines)
+  python bench.py --steps 20 --warmup 5 > $O/r05_c2_bench.json 2> $O/r05_c2_bench.err
+  for w in c2t c4 c5s c5 c3; do python bench.py --workload $w --no-cpu-baseline --steps 10 --warmup 3 > $O/r05_${w}_bench.json 2>/dev/null; echo "line $w done"; done
+  for w in c2 c2t c2q5k c3; do python bench.py --workload $w --early-exit --no-cpu-baseline --also none --steps 10 --warmup 3 > $O/r05_ee_${w}_bench.json 2>/dev/null; echo "ee line $w done"; done
+  ;;
+rocprof)
+  cd /tmp; export TMPDIR=/tmp
+  for w in c2 c2t c4 c5; do
+    rm -rf $O/prof_$w
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -- python3 $R/bench.py --workload $w --no-cpu-baseline --steps 20 --warmup 5 > $O/r05_${w}_bench_under_rocprof.json 2>/dev/null
+    cp $(ls $O/prof_$w/*/*kernel_stats.csv | tail -1) $O/r05_${w}_kernel_stats.csv
+    rm -rf $O/prof_$w; echo "rocprof $w done"
+  done
+  for w in c2 c2t c2q5k c3; do
+    rm -rf $O/prof_ee_$w
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ee_$w -- python3 $R/bench.py --workload $w --early-exit --no-cpu-baseline --also none --steps 20 --warmup 5 > $O/r05_ee_${w}_bench_under_rocprof.json 2>/dev/null
+    cp $(ls $O/prof_ee_$w/*/*kernel_stats.csv | tail -1) $O/r05_ee_${w}_kernel_stats.csv
+    rm -rf $O/prof_ee_$w; echo "rocprof ee $w done"
+  done
+  cd $R
+  ;;
+pmc)
+  python tools/pmc_refresh.py --round r05 c2 c2+bands c2t c3 c4 c5s c5 narrow narrowt long1t c2+ee c3+ee c2q5k+ee c2t+ee > $O/pmc_refresh.txt 2>&1 || true
+  cp gpurun_out/pmc_r05/pmc_traffic.json gpurun_out/pmc_r05/r05_*_pmc_fetch_size.json $O/
+  tail -20 $O/pmc_refresh.txt
+  ;;
+occupancy)
+  python tools/pmc_occupancy.py --round r05 long1t c2 > $O/pmc_occupancy.txt 2>&1 || true
+  cp gpurun_out/pmc_r05/r05_*_pmc_occupancy.json $O/ 2>/dev/null || true
+  tail -12 $O/pmc_occupancy.txt
+  ;;
+sharded)
+  for w in c2 c3 c5; do KWAGE_BENCH_FORCE_SHARDED=1 python bench.py --workload $w --no-cpu-baseline --also none --steps 10 --warmup 3 > $O/r05_${w}_bench_sharded_world1.json 2>/dev/null; echo "sharded $w done"; done
+  KWAGE_BENCH_BACKEND=gloo KWAGE_BENCH_ONE_DEVICE=1 python bench.py --gpus 2 --also c3_strong --no-cpu-baseline --steps 10 --warmup 3 > $O/r05_c2_bench_two_ranks_one_gpu_gloo_also_c3_strong.json 2>$O/two_ranks.err || tail -20 $O/two_ranks.err
+  python - <<PY
+import json
+l = json.loads(open("$O/r05_c2_bench_two_ranks_one_gpu_gloo_also_c3_strong.json").read().strip().splitlines()[-1])
+b = l["also"]["c3_strong"]
+print("2 ranks: c2", l["ms_per_step"], "c3_strong", b["ms_per_step"], b["scaling"], b["config"]["samples_per_gpu"], b["roofline"]["kernel"], b.get("exchange_check", {}).get("ok"), b["result_check"]["ok"])
+PY
+  ;;
+proxy)
+  python tools/strong_scaling_proxy.py --round r05 > $O/proxy.txt 2>&1
+  cp gpurun_out/proxy_r05/r05_* $O/
+  tail -12 $O/proxy.txt
+  ;;
+soak)
+  python tools/soak_walk.py --launches 5000 --out $O/r05_soak.txt > /dev/null
+  tail -5 $O/r05_soak.txt
+  ;;
+node)
+  python tools/node_pipeline_stats.py > $O/r05_node_pipeline_stats.txt 2>&1
+  tail -30 $O/r05_node_pipeline_stats.txt
+  ;;
 line)
   python bench.py --steps 20 --warmup 5 > $O/r05_c2_bench.json 2> $O/r05_c2_bench.err || { tail -30 $O/r05_c2_bench.err; exit 1; }
   python - <<PY

@@ -20,7 +20,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
-GATHER = ("and_kernel", "and_walk_kernel", "and_band_walk_kernel", "and_narrow_kernel", "count_kernel", "count_walk_kernel", "count_narrow_kernel")
+GATHER = ("and_kernel", "and_walk_kernel", "and_band_walk_kernel", "and_narrow_kernel", "count_kernel", "count_walk_kernel", "count_narrow_kernel",
+          "and_screen_kernel", "and_refine_kernel", "and_refine_emit_kernel", "count_screen_kernel", "count_refine_kernel", "count_refine_emit_kernel")
 
 
 def load_line(path):

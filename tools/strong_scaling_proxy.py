@@ -12,7 +12,7 @@ roofline fraction from the HIP events AND rocprofv3's own average for it, the st
 Rank 0's share is the widest one of the split (partition_columns gives the first ranks the extra 1024-column unit), so
 it is the rank the job waits for.
 
-    python tools/strong_scaling_proxy.py [--round r04] [--steps 20] [--no-rocprof] [c3 c2 ...]
+    python tools/strong_scaling_proxy.py [--round r05] [--steps 20] [--no-rocprof] [c3 c2 ...]
 
 Writes profiles/<round>_strong_scaling_proxy.json and profiles/<round>_proxy_<workload>_of<K>_kernel_stats.csv.
 This script never touches the GPU itself: every measurement is a child process."""
