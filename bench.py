@@ -557,6 +557,12 @@ def early_exit_block(args, name, members, s, threshold, flags, nominal):
            "fetched_bytes": fetched, "fetched_source": fsrc,
            "frac_of_fetched": round(fetched / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if (fetched and k_ms > 0) else None,
            "identical_to_nominal": bool(same)}
+    try:        # what the screen launch of the last search handed over (places taken of the three lists; a full unit list means tiles walked on by themselves)
+        st = [x for x in members[0].group.ctx.refine_stats() if x["units_cap"]]
+        if st:
+            out["handed_over"] = dict(st[-1], lists_full=bool(st[-1]["units"] >= st[-1]["units_cap"]))
+    except Exception:
+        pass
     if not args.no_result_check:
         rc = result_check(members, last, threshold)
         out["result_check"] = {k: rc[k] for k in ("ok", "planted_queries", "planted_columns_found", "planted_columns_expected", "sampled_queries",

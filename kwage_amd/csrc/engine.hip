@@ -424,7 +424,7 @@ int refine_setup(Slot *sl, const Tuning &tn, const SearchArgs &a, uint64_t total
 	ra.max_groups = (uint32_t)std::min<int64_t>(std::max<int64_t>(tn.refine_max_groups, 0), 16);      // (0: nothing is ever handed over)
 	uint64_t items = std::min<uint64_t>(std::max<uint64_t>(8ull*a.n_queries, 1u << 16), 1u << 20);
 	items = std::max<uint64_t>(std::min<uint64_t>(items, (256ull << 20)/item_bytes), 1024);
-	uint64_t units = std::min<uint64_t>(std::max<uint64_t>(8*total_rows/ra.seg_rows, 1u << 18), 1u << 24);
+	uint64_t units = std::min<uint64_t>(std::max<uint64_t>(32*total_rows/ra.seg_rows, 1u << 18), 1u << 25);       // (32 bytes each: at most 1 GiB)
 	if(unit_bytes){ units = std::max<uint64_t>(std::min<uint64_t>(units, (512ull << 20)/unit_bytes), 4096); }
 	if(tn.refine_list_cap > 0){ items = units = (uint64_t)std::min<int64_t>(tn.refine_list_cap, 1 << 20); }
 	// dynamic chunks: what a wave is likely to need for a few of its tiles (a wave with one or two tiles takes exactly what it needs)

@@ -740,7 +740,9 @@ __global__ __launch_bounds__(SEARCH_THREADS) void and_screen_kernel(SearchArgs a
 			}
 			if(ngroups == 0){ gone = true; break; }       // kwage.cpp:466-470 per tile: nothing left that could match
 			const uint32_t done = i + UNROLL;
-			if(may_hand_over && ngroups <= ra.max_groups && nrows - done >= ra.min_rows){
+			// (a long row list waits for its SECOND group of rows: after eight random rows a quarter of all tiles still holds a
+			// chance survivor, after sixteen one in fifteen -- and every item of a long list costs a dozen units of list space)
+			if(may_hand_over && ngroups <= ra.max_groups && nrows - done >= ra.min_rows && (done >= 2*UNROLL || nrows < 4*ra.seg_rows)){
 				may_hand_over = false;                    // (one attempt per tile)
 				const uint32_t nseg = (nrows - done + ra.seg_rows - 1)/ra.seg_rows;
 				uint32_t nc = 0;

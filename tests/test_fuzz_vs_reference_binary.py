@@ -121,7 +121,7 @@ def test_oracle_equals_reference_binary(oracle, tmp_path, seed):
 
 @needs_ref
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(int(os.environ.get("KWAGE_FUZZ_SEEDS", "12"))))      # (6-9 s each: CSV + JSON at three thresholds through two binaries; raise for a soak)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KWAGE_FUZZ_SEEDS", "20"))))      # (6-9 s each: CSV + JSON at three thresholds through two binaries; raise for a soak)
 def test_cli_equals_reference_binary(oracle, tmp_path, seed):
     from kwage_amd import native
     rng = np.random.default_rng(777 + seed)

@@ -61,7 +61,7 @@ import json; l=json.loads(open('$O/r05_long1t_bench.json').read().strip().splitl
 lines)
   python bench.py --steps 20 --warmup 5 > $O/r05_c2_bench.json 2> $O/r05_c2_bench.err
   for w in c2t c4 c5s c5 c3; do python bench.py --workload $w --no-cpu-baseline --steps 10 --warmup 3 > $O/r05_${w}_bench.json 2>/dev/null; echo "line $w done"; done
-  for w in c2 c2t c2q5k c3; do python bench.py --workload $w --early-exit --no-cpu-baseline --also none --steps 10 --warmup 3 > $O/r05_ee_${w}_bench.json 2>/dev/null; echo "ee line $w done"; done
+  for w in c2 c2t c2q5k c3; do python bench.py --workload $w --early-exit --no-cpu-baseline --also none --steps 100 --warmup 5 > $O/r05_ee_${w}_bench.json 2>/dev/null; echo "ee line $w done"; done
   ;;
 rocprof)
   cd /tmp; export TMPDIR=/tmp

@@ -90,6 +90,90 @@ def bench_table(rnd):
     return out
 
 
+def early_exit_table(rnd):
+    """The `early_exit` blocks of the lines (the same batch on the same resident matrix with KWAGE_SEARCH_EARLY_EXIT) and the
+    lines of whole runs with --early-exit; fetched bytes from the "X@ee" PMC passes."""
+    pmc = json.load(open(os.path.join(PROF, "pmc_traffic.json")))
+    out = ["| file | workload | nominal kernel ms | early-exit stage | its kernel ms | ms per step | speed-up of the kernel | fetched bytes (PMC) | fetched ÷ algorithmic | fetched ÷ time ÷ 8 TB/s | lists identical to the nominal kernel's | result_check |",
+           "|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    for base, d in bench_rows(rnd):
+        wl = d.get("config", {}).get("workload", "?").split(":")[0]
+        ee = d.get("early_exit")
+        if isinstance(ee, dict) and "kernel" in ee:
+            alg = (ee.get("nominal_rate") or {}).get("algorithmic_bytes")
+            fetched, frac = ee.get("fetched_bytes"), ee.get("frac_of_fetched")
+            if fetched is None:
+                for key, e in pmc.items():
+                    if key.endswith("@ee") and isinstance(e, dict) and e.get("kernel") == ee["kernel"] and e.get("algorithmic_bytes_per_launch") == alg and e.get("round") == rnd:
+                        fetched = e["hbm_read_bytes_per_launch"]
+                        frac = fetched / (ee["kernel_ms"] * 1e-3) / 1e9 / 8000.0
+            rc = ee.get("result_check") or {}
+            out.append("| `%s` › early_exit | %s | %s | `%s` | %s | %s | %s | %s | %s | %s | %s | %s |" % (
+                base, wl, fmt(d["roofline"].get("kernel_ms"), 4), ee["kernel"], fmt(ee.get("kernel_ms"), 4), fmt(ee.get("ms_per_step"), 4), fmt(ee.get("speedup_vs_nominal_kernel"), 2),
+                ("%d" % fetched) if fetched else "—", fmt(fetched / alg, 4) if (fetched and alg) else "—", fmt(frac, 4), ee.get("identical_to_nominal"), "ok" if rc.get("ok") else ("—" if not rc else "FAILED")))
+        elif d.get("config", {}).get("early_exit"):
+            r = d["roofline"]
+            alg = r.get("algorithmic_bytes_per_launch")
+            fetched = r.get("traffic")
+            if fetched is None:
+                for key, e in pmc.items():
+                    if key.endswith("@ee") and isinstance(e, dict) and e.get("kernel") == r.get("kernel") and e.get("algorithmic_bytes_per_launch") == alg and e.get("round") == rnd:
+                        fetched = e["hbm_read_bytes_per_launch"]
+            frac = fetched / (r["kernel_ms"] * 1e-3) / 1e9 / 8000.0 if (fetched and r.get("kernel_ms")) else None
+            rc = d.get("result_check") or {}
+            out.append("| `%s` (whole run with --early-exit) | %s | — | `%s` | %s | %s | — | %s | %s | %s | — | %s |" % (
+                base, wl, r.get("kernel"), fmt(r.get("kernel_ms"), 4), fmt(d.get("ms_per_step"), 4), ("%d" % fetched) if fetched else "—",
+                fmt(fetched / alg, 4) if (fetched and alg) else "—", fmt(frac, 4), "ok" if rc.get("ok") else ("—" if not rc else "FAILED")))
+    return out
+
+
+def boxes(rnd):
+    """uuid -> {pci, stream GB/s seen, files}: which box every line of the round was taken on (config.box)."""
+    seen = {}
+    for base, d in bench_rows(rnd):
+        box = (d.get("config") or {}).get("box")
+        if not isinstance(box, dict) or "›" in base:
+            continue
+        e = seen.setdefault(str(box.get("uuid")), {"pci": box.get("pci"), "name": box.get("name"), "stream_read_gbps": [], "files": []})
+        e["stream_read_gbps"].append(box.get("measured_stream_read_gbps"))
+        e["files"].append(base)
+    for p in sorted(glob.glob(os.path.join(PROF, rnd + "_*.json"))):
+        try:
+            d = json.load(open(p))
+        except Exception:
+            continue
+        box = d.get("box") if isinstance(d, dict) else None
+        if isinstance(box, dict) and "uuid" in box:
+            e = seen.setdefault(str(box.get("uuid")), {"pci": box.get("pci"), "name": box.get("name"), "stream_read_gbps": [], "files": []})
+            e["stream_read_gbps"].append(box.get("measured_stream_read_gbps"))
+            e["files"].append(os.path.basename(p))
+    return seen
+
+
+def boxes_table(rnd):
+    out = ["| box (device uuid) | PCI | streaming read seen (GB/s) | files taken on it |", "|---|---|---|---|"]
+    for uuid, e in sorted(boxes(rnd).items()):
+        vals = [v for v in e["stream_read_gbps"] if v]
+        out.append("| `%s` | %s | %s | %s |" % (uuid, e["pci"], ("%.0f – %.0f" % (min(vals), max(vals))) if vals else "—", ", ".join("`%s`" % f for f in e["files"])))
+    return out
+
+
+def cpu_table(rnd):
+    out = ["| file | CPU baseline | G bit-tests/s | threads | database | reference wall | whole hit list == the timed kernel's | bounded no-early-exit sample (G bit-tests/s, threads) |", "|---|---|---|---|---|---|---|---|"]
+    for base, d in bench_rows(rnd):
+        cb = d.get("cpu_baseline")
+        if not isinstance(cb, dict) or cb.get("value") is None:
+            continue
+        idb = cb.get("identical_db") or {}
+        smp = cb.get("no_early_exit_sample") or {}
+        out.append("| `%s` | %s%s | %s | %s | %s | %s | %s | %s |" % (
+            base, cb.get("kind"), "" if cb.get("extrapolated") else ", identical database", fmt(cb.get("value"), 1), cb.get("cores"),
+            ("%d files, %.1f GB, 2^%s rows (%s)" % (idb["files"], idb["db_bytes"] / 1e9, idb["log_2_rows"], idb.get("directory"))) if idb.get("files") else "bounded sample (extrapolated)",
+            ("%.2f s" % idb["reference_wall_s"]) if idb.get("reference_wall_s") else "—", idb.get("whole_list_identical", "—"),
+            ("%s, %s" % (fmt(smp.get("value"), 1), smp.get("cores"))) if smp else "—"))
+    return out
+
+
 def kernel_key(name):
     """'and_kernel<2,8,nt>' / 'and_kernel<2,8,true,false>' -> ('and_kernel', '2', '8'): the kernel and its first two template arguments."""
     base, _, rest = name.partition("<")
@@ -167,6 +251,15 @@ def render_tables():
     out = ["# profiles/TABLES.md — generated by `tools/render_tables.py` from the files in this directory; do not edit", ""]
     for rnd in rounds():
         out += ["## Round %s — `bench.py` lines (`%s_*.json`)" % (rnd[1:].lstrip("0"), rnd), ""] + bench_table(rnd) + [""]
+        et = early_exit_table(rnd)
+        if len(et) > 2:
+            out += ["### Early exit: the path `kwage` and `kwage_node` run by default (`early_exit` blocks and `--early-exit` runs)", ""] + et + [""]
+        ct = cpu_table(rnd)
+        if len(ct) > 2:
+            out += ["### CPU baseline (the reference `kwage`, OpenMP)", ""] + ct + [""]
+        bt = boxes_table(rnd)
+        if len(bt) > 2:
+            out += ["### Boxes (`config.box`: kwage_device_fingerprint)", ""] + bt + [""]
         rt = rocprof_table(rnd)
         if len(rt) > 2:
             out += ["### rocprofv3 kernel summaries (`%s_*_kernel_stats.csv`)" % rnd, ""] + rt + [""]
@@ -186,7 +279,14 @@ DESIGN_END = "<!-- GENERATED:measurements END -->"
 def design_block():
     """The newest round's tables as DESIGN.md carries them between its markers."""
     rnd = rounds()[0]
-    block = ["", "`bench.py` lines of round %s (`profiles/%s_*.json`):" % (rnd[1:].lstrip("0"), rnd), ""] + bench_table(rnd) + ["", "rocprofv3 summaries of the same commands:", ""] + rocprof_table(rnd)
+    block = ["", "`bench.py` lines of round %s (`profiles/%s_*.json`):" % (rnd[1:].lstrip("0"), rnd), ""] + bench_table(rnd)
+    et = early_exit_table(rnd)
+    if len(et) > 2:
+        block += ["", "Early exit -- the path `kwage` and `kwage_node` run by default (`early_exit` blocks of the lines above, and whole runs with `--early-exit`):", ""] + et
+    ct = cpu_table(rnd)
+    if len(ct) > 2:
+        block += ["", "CPU baseline (the reference `kwage`, OpenMP over files):", ""] + ct
+    block += ["", "rocprofv3 summaries of the same commands:", ""] + rocprof_table(rnd)
     for p in sorted(glob.glob(os.path.join(PROF, rnd + "_strong_scaling_proxy.json"))):
         block += ["", "Strong scaling, one-GPU proxy (`profiles/%s`):" % os.path.basename(p), ""] + proxy_table(p)
     block += [""]
@@ -214,6 +314,7 @@ def render_readme(idx):
            "Generated by `tools/render_tables.py` from `INDEX.json` (what each file is, the command that made it) and the directory listing;",
            "the numbers are in `TABLES.md`, generated from the files themselves. History of rounds 1–3 in prose: `HISTORY.md`.", ""]
     listed = set()
+    idx = {k: v for k, v in idx.items() if re.match(r"r\d\d$", k)}        # (the "boxes" key is generated, not a round)
     for rnd in sorted(idx, reverse=True):
         out += ["## Round %s (`%s_*`)" % (rnd[1:].lstrip("0"), rnd), "", "| file | what | command that produced it |", "|---|---|---|"]
         for e in idx[rnd]:
@@ -235,6 +336,9 @@ def main():
     if not os.path.exists(ipath):
         json.dump(bootstrap_index(), open(ipath, "w"), indent=1, ensure_ascii=False)
     idx = json.load(open(ipath))
+    # which box every line was taken on (config.box), per round: kept in the index beside the files' descriptions
+    idx["boxes"] = {rnd: boxes(rnd) for rnd in rounds() if boxes(rnd)}
+    json.dump(idx, open(ipath, "w"), indent=1, ensure_ascii=False)
     open(os.path.join(PROF, "README.md"), "w").write(render_readme(idx))
     # the newest round's tables inside DESIGN.md
     dpath = os.path.join(ROOT, "DESIGN.md")
