@@ -34,7 +34,7 @@ static const TuningName TUNING_NAMES[] = {
 	 {"walk_waves", &Tuning::walk_waves}, {"walk_one_wg_per_cu", &Tuning::walk_one_wg_per_cu},
 	{"walk_bands", &Tuning::walk_bands}, {"walk_bands_min_gib", &Tuning::walk_bands_min_gib},
 	{"and_vec", &Tuning::and_vec}, {"and_wide", &Tuning::and_wide}, {"and_wide_min_kib", &Tuning::and_wide_min_kib}, {"narrow", &Tuning::narrow}, {"force_segs", &Tuning::force_segs},
-	{"ee_refine", &Tuning::ee_refine}, {"refine_seg_rows", &Tuning::refine_seg_rows}, {"refine_min_rows", &Tuning::refine_min_rows}, {"refine_max_groups", &Tuning::refine_max_groups}, {"refine_unroll", &Tuning::refine_unroll}, {"refine_list_cap", &Tuning::refine_list_cap}, {"refine_static", &Tuning::refine_static}, {"screen_wpc", &Tuning::screen_wpc}, {"count_screen_wpc", &Tuning::count_screen_wpc}, {"count_screen_min_tiles", &Tuning::count_screen_min_tiles},
+	{"ee_refine", &Tuning::ee_refine}, {"refine_seg_rows", &Tuning::refine_seg_rows}, {"refine_min_rows", &Tuning::refine_min_rows}, {"refine_max_groups", &Tuning::refine_max_groups}, {"refine_unroll", &Tuning::refine_unroll}, {"refine_list_cap", &Tuning::refine_list_cap}, {"refine_static", &Tuning::refine_static}, {"screen_wpc", &Tuning::screen_wpc}, {"count_screen_wpc", &Tuning::count_screen_wpc}, {"count_screen_min_tiles", &Tuning::count_screen_min_tiles}, {"count_screen_check", &Tuning::count_screen_check},
 	{"count_walk", &Tuning::count_walk}, {"count_walk_wpc", &Tuning::count_walk_wpc}, {"count_walk_waves", &Tuning::count_walk_waves},
 	{"count_walk_min_rows", &Tuning::count_walk_min_rows},
 	{"hit_sort_host", &Tuning::hit_sort_host}, {"hit_copy_piece_kb", &Tuning::hit_copy_piece_kb}, {"shared_table_log2", &Tuning::shared_table_log2},
@@ -454,6 +454,7 @@ int refine_setup(Slot *sl, const Tuning &tn, const SearchArgs &a, uint64_t total
 	sl->ref_base[0] = ra.lc.base; sl->ref_base[1] = ra.li.base; sl->ref_base[2] = ra.lu.base;
 	sl->ref_cap[0] = ra.lc.cap; sl->ref_cap[1] = ra.li.cap; sl->ref_cap[2] = ra.lu.cap;
 	ra.queue_batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16, tiles/(8*std::max<uint64_t>(screen_waves, 1))));
+	ra.check_every = (tn.count_screen_check == 16 || tn.count_screen_check == 32 || tn.count_screen_check == 64) ? (uint32_t)tn.count_screen_check : 8u;
 	out->refine_wgs = (uint32_t)(ncu*8);          // 32 waves per CU, eight units each
 	out->emit_wgs = (uint32_t)(ncu*4);            // 16 waves per CU, four clusters at a time each
 	return KWAGE_OK;

@@ -295,13 +295,16 @@ struct Tuning {
 	int64_t force_segs = 0;         // KWAGE_FORCE_SEGS: cut every query's k-mer list into this many segments (tests)
 	int64_t ee_refine = 1;          // KWAGE_EE_REFINE: with early exit, tiles that still hold a candidate column after the first rows are handed over to the
 	                                //   refine launch, which reads 128-byte groups on a balanced grid (0: the tile's own wave walks on 1-2 KiB wide)
-	int64_t refine_seg_rows = 64;   // KWAGE_REFINE_SEG_ROWS: rows (k-mers at t < 1) per unit of the refine launch (t < 1: at most 127)
+	int64_t refine_seg_rows = 32;   // KWAGE_REFINE_SEG_ROWS: rows (k-mers at t < 1) per unit of the refine launch (t < 1: at most 120).  32: four units for what is left of a 150-base read
+	                                //   (100 k reads: 2.29 vs 2.48 with 64 and 3.18 with 128; 1 kb queries the same with all three -- profiles/r05_refine_knobs_ab.txt)
 	int64_t refine_min_rows = 32;   // KWAGE_REFINE_MIN_ROWS: a tile with fewer rows (k-mers) left finishes by itself
 	int64_t refine_max_groups = 4;  // KWAGE_REFINE_MAX_GROUPS: a tile is handed over once at most this many of its 128-byte groups hold a candidate column
 	int64_t refine_unroll = 8;      // KWAGE_REFINE_UNROLL: rows in flight per 128-byte group in the refine launch (8 or 16)
 	int64_t screen_wpc = 20;        // KWAGE_SCREEN_WPC: waves per CU of the persistent screen launch
 	int64_t count_screen_wpc = 32;  // KWAGE_COUNT_SCREEN_WPC: at most this many waves per CU in the count path's screen launch (fewer where the kernel's registers hold fewer)
 	int64_t count_screen_min_tiles = 8192;  // KWAGE_COUNT_SCREEN_MIN_TILES: at t < 1, batches with fewer (query, KiB tile) pairs keep the tiled kernel and its segments
+	int64_t count_screen_check = 8;     // KWAGE_COUNT_SCREEN_CHECK: k-mers between two looks at the bound in the count path's screen launch (8, 16, 32, 64; 8 = after every step:
+	                                //   short reads at t = 0.8 9 % sooner than with 16, 14 % sooner than with 32; C2 at t = 0.8 the same -- profiles/r05_refine_knobs_ab.txt)
 	int64_t refine_static = 1;      // KWAGE_REFINE_STATIC: half of every list is dealt out to the screen launch's waves beforehand (0: every place is reserved through the counters -- diagnostics: kwage_ctx_refine_stats then counts the hand-overs exactly)
 	int64_t refine_list_cap = 0;    // KWAGE_REFINE_LIST_CAP: capacity of each of the three lists of handed-over tiles (0 = from the batch; tests: full lists)
 	int64_t count_walk = 1;         // KWAGE_COUNT_WALK: the persistent count kernel where it applies

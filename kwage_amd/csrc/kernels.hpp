@@ -612,6 +612,7 @@ struct RefineArgs {
 	uint32_t min_rows;              // hand a tile over only when at least this many rows (k-mers) are left
 	uint32_t max_groups;            // ... and at most this many of its 128-byte groups hold a surviving column
 	uint32_t queue_batch;           // count_screen_kernel: tiles a wave draws from the queue at a time
+	uint32_t check_every;           // count_screen_kernel: k-mers between two looks at the bound (8, 16, 32 or 64)
 };
 
 // one bit per 8 lanes of a ballot: the 128-byte groups of a KiB-step with a lane set
@@ -947,8 +948,12 @@ struct WalkArgs {
 // fills the chip: ONE workgroup per CU, so every CU runs exactly the same number of waves -- with workgroups of four
 // waves the dispatcher's placement left some CUs with three workgroups and others with one: +0.8-0.9 % at C2's shape,
 // profiles/r03_walk_cu_shapes.txt)
+// (amdgpu_waves_per_eu(2, 2): the launch holds 8 waves per CU -- two per SIMD -- by construction, and the compiler must
+// know: left to aim for the occupancy its register count would allow, it serialised the UNROLL loads of a step into pairs
+// for CH = 4..7 (54 instead of 81 VGPRs, two rows in flight instead of four) once the early-exit test had left the loop in
+// round 5 -- C2's columns split 2 and 4 ways lost 18-22 %, profiles/r05_walk_occupancy_hint_ab.txt)
 template <int CH, int UNROLL>
-__global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void and_walk_kernel(SearchArgs a, WalkArgs wa, const uint32_t *__restrict__ rows,
+__global__ __launch_bounds__(WALK_WG_WAVES*WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void and_walk_kernel(SearchArgs a, WalkArgs wa, const uint32_t *__restrict__ rows,
                                                                       const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ nkmer)
 {
 	const uint32_t lane = threadIdx.x & (WAVE - 1);
@@ -1158,7 +1163,7 @@ __global__ __launch_bounds__(256) void band_bucket_kernel(const uint32_t *__rest
 // (the grid and a wave's share of the batch's POSITIONS are and_walk_kernel's: wa.total_slots, wa.per_wave; in band b a
 // wave takes, of every query piece it holds, the same fraction of the query's band-b bucket as the piece is of the query)
 template <int CH, int UNROLL>
-__global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void and_band_walk_kernel(SearchArgs a, BandArgs ba, WalkArgs wa, const uint32_t *__restrict__ rows2,
+__global__ __launch_bounds__(WALK_WG_WAVES*WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void and_band_walk_kernel(SearchArgs a, BandArgs ba, WalkArgs wa, const uint32_t *__restrict__ rows2,
                                                                            const uint32_t *__restrict__ loc, const uint64_t *__restrict__ pos_off,
                                                                            const uint32_t *__restrict__ nkmer)
 {
@@ -1581,7 +1586,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 // before n - threshold k-mers are in, and then needs a margin the random matches stay below: every tile reads the first
 // ~30 % of a query's rows at t = 0.8 whatever else happens -- the launch's floor.  What the tiled count_kernel adds to that
 // floor is the tail: a tile that HOLDS a column above the threshold is counted to the end, 1 KiB wide, by one wave.
-//   count_screen_kernel  count_kernel's tile loop on a persistent grid; every 16 k-mers (once the bound can bite): no column
+//   count_screen_kernel  count_kernel's tile loop on a persistent grid; every 8 k-mers (once the bound can bite): no column
 //                        can reach the threshold any more -> done; such columns in at most `max_groups` 128-byte groups and
 //                        `min_rows` k-mers to go -> the tile is handed over (cluster, items with their counters so far,
 //                        units of `seg_rows` k-mers); otherwise it goes on, and reports itself at the end of the list.
@@ -1590,7 +1595,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 template <int PLANES, int NH>
 __global__ __launch_bounds__(SEARCH_THREADS) void count_screen_kernel(SearchArgs a, RefineArgs ra)
 {
-	constexpr uint32_t CHECK = 16;            // k-mers between two looks at the bound
+	const uint32_t check_mask = ra.check_every - 1;       // k-mers between two looks at the bound (a power of two >= 8)
 	constexpr int KPS = (NH <= 2) ? 8 : 4;    // k-mers per step: 8 or 4*NH rows in flight
 	__shared__ WaveHitBuf hit_bufs[SEARCH_THREADS/WAVE];
 	WaveHitBuf *hbuf = &hit_bufs[threadIdx.x >> 6];
@@ -1655,7 +1660,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_screen_kernel(SearchArgs
 			else{ planes_add4<PLANES>(plane, m[0], m[1], m[2], m[3]); }
 			i += KPS;
 			const uint32_t remaining = nk - i;
-			if((i & (CHECK - 1)) != 0 || thr <= remaining){ continue; }
+			if((i & check_mask) != 0 || thr <= remaining){ continue; }
 			// kwage.cpp:478-481 per column: the columns that can still reach the threshold if every remaining k-mer matches
 			const u32x4 can = planes_ge<PLANES>(plane, thr - remaining) & real;
 			const uint32_t gb = group_bits(__ballot((can.x | can.y | can.z | can.w) != 0));
@@ -1921,8 +1926,10 @@ struct CountWalkArgs {
 	uint32_t *arrived;              // [waves][CWALK_LEVELS] arrivals at the tree node (first wave of the node's subtree, level); zero between searches
 };
 
+// (amdgpu_waves_per_eu(2, 3): 8 waves per CU by default, 12 at most by knob -- see and_walk_kernel: without the hint the
+// compiler splits the prefetched rows of a step to save registers it has no use for)
 template <int PLANES, int NH>
-__global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void count_walk_kernel(SearchArgs a, CountWalkArgs wa, const uint32_t *__restrict__ rows,
+__global__ __launch_bounds__(WALK_WG_WAVES*WAVE) __attribute__((amdgpu_waves_per_eu(2, 3))) void count_walk_kernel(SearchArgs a, CountWalkArgs wa, const uint32_t *__restrict__ rows,
                                                                     const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ nkmer,
                                                                     const uint32_t *__restrict__ qthr)
 {

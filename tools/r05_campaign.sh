@@ -112,6 +112,30 @@ node)
   python tools/node_pipeline_stats.py > $O/r05_node_pipeline_stats.txt 2>&1
   tail -30 $O/r05_node_pipeline_stats.txt
   ;;
+refine_knobs)
+  for shape in "1000 x 1 kb" "100k x 150 bp"; do
+    for seg in 32 64 128; do for un in 8 16; do
+      echo "== KWAGE_REFINE_SEG_ROWS=$seg KWAGE_REFINE_UNROLL=$un"; KWAGE_REFINE_SEG_ROWS=$seg KWAGE_REFINE_UNROLL=$un python tools/step_breakdown.py "$shape" 2>&1 | grep -E " ee " | grep "t=1 "
+    done; done
+    for mg in 2 8; do echo "== KWAGE_REFINE_MAX_GROUPS=$mg"; KWAGE_REFINE_MAX_GROUPS=$mg python tools/step_breakdown.py "$shape" 2>&1 | grep -E " ee " | grep "t=1 "; done
+    for wpc in 12 16; do echo "== KWAGE_SCREEN_WPC=$wpc"; KWAGE_SCREEN_WPC=$wpc python tools/step_breakdown.py "$shape" 2>&1 | grep -E " ee " | grep "t=1 "; done
+  done > $O/r05_refine_knobs_ab.txt 2>&1
+  cat $O/r05_refine_knobs_ab.txt | cut -c1-150
+  ;;
+count_check)
+  for ck in 8 16 32 64; do for w in c2t c5s; do
+    KWAGE_COUNT_SCREEN_CHECK=$ck python bench.py --workload $w --early-exit --no-cpu-baseline --no-sustained --also none --steps 30 --warmup 3 2>/dev/null | python -c "
+import json,sys
+l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$w check=$ck', l['ms_per_step'], l['roofline']['kernel'], l['roofline']['kernel_ms'], l['result_check']['ok'])"
+  done; done
+  for ck in 8 16 32; do echo "check=$ck"; KWAGE_COUNT_SCREEN_CHECK=$ck python tools/step_breakdown.py "100k x 150" 2>&1 | grep " ee " | grep "t=0.8"; done
+  ;;
+walk_hint)
+  for k in 1 2 4 8; do python bench.py --workload c2 --share-of $k --no-cpu-baseline --no-sustained --also none --no-early-exit-block --no-result-check --steps 20 --warmup 3 2>/dev/null | python -c "
+import json,sys
+l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c2 of $k', l['roofline']['kernel'], l['roofline']['kernel_ms'], l['roofline']['frac'], l['roofline']['frac_of_measured_stream'])"
+  done
+  ;;
 line)
   python bench.py --steps 20 --warmup 5 > $O/r05_c2_bench.json 2> $O/r05_c2_bench.err || { tail -30 $O/r05_c2_bench.err; exit 1; }
   python - <<PY

@@ -81,6 +81,9 @@ def main():
         % (launches, len(seqs), sum(max(len(s) - k + 1, 0) for s in seqs), n_cols, L, nh))
     bad = 0
     with ka.Context(0) as ctx:
+        import bench
+        fp = ctx.fingerprint()
+        say("# code hash %s (bench.kernel_code_hash: kernels.hpp + kmer_device.hpp + engine_state.hpp + engine.hip); box %s (%s)" % (bench.kernel_code_hash(), fp.get("uuid"), fp.get("pci")))
         g = ka.Group(ctx, k, nh, L, n_cols)
         g.add_columns(image, n_cols)
         g.finalize()
