@@ -463,14 +463,14 @@ int refine_setup(Slot *sl, const Tuning &tn, const SearchArgs &a, uint64_t total
 // Workgroups of count_screen_kernel<planes, nh> a CU holds at once (registers; asked of the runtime once per shape).
 uint32_t count_screen_blocks_per_cu(uint32_t planes, uint32_t nh)
 {
-	static int cache[5][5] = {};
-	const int pi = (planes <= 7) ? 0 : (planes <= 10) ? 1 : (planes <= 14) ? 2 : (planes <= 20) ? 3 : 4, ni = (int)std::min(std::max(nh, 1u), 5u) - 1;
+	static int cache[3][5] = {};
+	const int pi = (planes <= 7) ? 0 : (planes <= 10) ? 1 : 2, ni = (int)std::min(std::max(nh, 1u), 5u) - 1;
 	if(cache[pi][ni] == 0){
 		int nb = 0;
 		hipError_t e = hipErrorUnknown;
 #define KWAGE_OCC_NH(P, N) case N: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, count_screen_kernel<P, N>, SEARCH_THREADS, 0); break;
 #define KWAGE_OCC_P(I, P) case I: switch(ni + 1){ KWAGE_OCC_NH(P, 1) KWAGE_OCC_NH(P, 2) KWAGE_OCC_NH(P, 3) KWAGE_OCC_NH(P, 4) default: KWAGE_OCC_NH(P, 5) } break;
-		switch(pi){ KWAGE_OCC_P(0, 7) KWAGE_OCC_P(1, 10) KWAGE_OCC_P(2, 14) KWAGE_OCC_P(3, 20) default: KWAGE_OCC_P(4, 32) }
+		switch(pi){ KWAGE_OCC_P(0, 7) KWAGE_OCC_P(1, 10) default: KWAGE_OCC_P(2, 14) }
 #undef KWAGE_OCC_P
 #undef KWAGE_OCC_NH
 		if(e != hipSuccess || nb <= 0){ (void)hipGetLastError(); nb = 2; }
@@ -696,7 +696,7 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 		// (kernels.hpp count_screen_kernel).  Few long queries stay with the segments below: every tile has to read the first
 		// (1 - t) n k-mers before the bound can prune anything, and a handful of tiles that long would be the whole launch.
 		if(a.early_exit && tn.ee_refine && !narrow && tn.force_segs <= 0 && a.units_per_row >= WAVE
-		   && (uint64_t)a.n_queries*a.chunks >= (uint64_t)std::max<int64_t>(tn.count_screen_min_tiles, 1) && L->max_pos <= (1u << 21)){
+		   && (uint64_t)a.n_queries*a.chunks >= (uint64_t)std::max<int64_t>(tn.count_screen_min_tiles, 1) && planes <= 14){      // (queries of up to 16383 positions: 20 and 32 counter planes + eight rows in flight do not fit a wave's registers)
 			const uint64_t tiles = (uint64_t)a.n_queries*a.chunks;
 			// k-mers per unit: 64 (7 counter planes per unit); queries above 8192 positions: 1/128 of the longest (14 planes)
 			uint32_t seg = (uint32_t)std::min<int64_t>(std::max<int64_t>(tn.refine_seg_rows, 8), 120)/8*8;
@@ -713,7 +713,7 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 			const dim3 grid((uint32_t)(screen_waves/4)), block(SEARCH_THREADS);
 #define KWAGE_CS_NH(P, N) case N: KW_GATHER_LAUNCH(ge, true, false, (count_screen_kernel<P, N>), grid, block, 0, gs, a, rs.ra); break;
 #define KWAGE_CS_P(P) case P: switch(std::min(a.num_hash, 5u)){ KWAGE_CS_NH(P, 1) KWAGE_CS_NH(P, 2) KWAGE_CS_NH(P, 3) KWAGE_CS_NH(P, 4) default: KWAGE_CS_NH(P, 5) } break;
-			switch(planes){ KWAGE_CS_P(7) KWAGE_CS_P(10) KWAGE_CS_P(14) KWAGE_CS_P(20) default: KWAGE_CS_P(32) }
+			switch(planes){ KWAGE_CS_P(7) KWAGE_CS_P(10) default: KWAGE_CS_P(14) }
 #undef KWAGE_CS_P
 #undef KWAGE_CS_NH
 #define KWAGE_CR_NH(N) case N: if(up == 7){ KW_GATHER_LAUNCH(ge, false, false, (count_refine_kernel<N, 7>), dim3(rs.refine_wgs), block, 0, gs, a, rs.ra); } \
@@ -722,7 +722,7 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 #undef KWAGE_CR_NH
 #define KWAGE_CE_P(P) case P: if(up == 7){ KW_GATHER_LAUNCH(ge, false, true, (count_refine_emit_kernel<P, 7>), dim3(rs.emit_wgs), block, 0, gs, a, rs.ra); } \
 				else{ KW_GATHER_LAUNCH(ge, false, true, (count_refine_emit_kernel<P, (P >= 14 ? 14 : 7)>), dim3(rs.emit_wgs), block, 0, gs, a, rs.ra); } break;
-			switch(planes){ KWAGE_CE_P(7) KWAGE_CE_P(10) KWAGE_CE_P(14) KWAGE_CE_P(20) default: KWAGE_CE_P(32) }
+			switch(planes){ KWAGE_CE_P(7) KWAGE_CE_P(10) default: KWAGE_CE_P(14) }
 #undef KWAGE_CE_P
 			HIP_TRY(hipGetLastError());
 			return KWAGE_OK;

@@ -997,7 +997,10 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) __attribute__((amdgpu_waves_per
 			// the row end (last chunk(s) of the last column tile) are bounds-checked by the hardware -- they return 0
 			// without touching memory, and are never reported.
 			const uint32_t u0 = c*CH*WAVE + lane;
-			u32x4 acc[CH];
+			// (CH = 8: eight accumulators are 32 dwords -- exactly the widest register tuple -- and the compiler promoted the array
+			// to ONE 1024-bit value whose elements the cut-pair path inserts one by one: 3.2 KB of spills per lane, in the ISA since
+			// round 3 and found by tools/isa_check.py in round 5.  One element more and it stays eight separate vectors.)
+			u32x4 acc[CH == 8 ? CH + 1 : CH];
 #pragma unroll
 			for(int j = 0; j < CH; ++j){ acc[j] = ~(u32x4)(0u); }
 			for(uint32_t i = 0; i < nrows; i += UNROLL){
@@ -1592,8 +1595,11 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 //                        units of `seg_rows` k-mers); otherwise it goes on, and reports itself at the end of the list.
 //   count_refine_kernel  eight units per wave, 8 lanes x 16 B each: the unit's k-mers counted in UP planes -> slab.
 //   count_refine_emit_kernel  per cluster: item counters + the units' counters, threshold, one reservation per wave.
+// (amdgpu_waves_per_eu: the launch holds as many waves as the registers allow -- the host asks the runtime -- and that is
+// 2-3 per SIMD whatever the scheduler does; left alone it aimed higher and issued a step's eight rows two or three at a
+// time: see and_walk_kernel)
 template <int PLANES, int NH>
-__global__ __launch_bounds__(SEARCH_THREADS) void count_screen_kernel(SearchArgs a, RefineArgs ra)
+__global__ __launch_bounds__(SEARCH_THREADS) __attribute__((amdgpu_waves_per_eu(2, (PLANES <= 10) ? 3 : 2))) void count_screen_kernel(SearchArgs a, RefineArgs ra)
 {
 	const uint32_t check_mask = ra.check_every - 1;       // k-mers between two looks at the bound (a power of two >= 8)
 	constexpr int KPS = (NH <= 2) ? 8 : 4;    // k-mers per step: 8 or 4*NH rows in flight
@@ -1732,7 +1738,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_screen_kernel(SearchArgs
 // UP counter planes per unit (seg_rows k-mers < 2^UP).  A lane holds the NH row numbers of ONE k-mer of a block of eight
 // (fetched together, handed round by ds_bpermute); KPS k-mers' rows are in flight at a time.
 template <int NH, int UP>
-__global__ __launch_bounds__(SEARCH_THREADS) void count_refine_kernel(SearchArgs a, RefineArgs ra)
+__global__ __launch_bounds__(SEARCH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 3))) void count_refine_kernel(SearchArgs a, RefineArgs ra)
 {
 	constexpr int KPS = (NH <= 2) ? 8 : 4;
 	const uint32_t lane = threadIdx.x & (WAVE - 1), l = lane & 7u, sh = lane & ~7u;
@@ -1831,7 +1837,9 @@ __device__ __forceinline__ void count_kmers_prefetch(const uint8_t *db, uint64_t
 	// and the block is added to the PLANES-plane total once per block: the upper planes are touched once per 120 k-mers
 	// instead of once per eight -- the ripple through them was most of the 20-plane form's instructions (a wave spent 42 % of
 	// its time issuing them, profiles/r04_long1t_pmc_occupancy.json).
-	constexpr bool BLOCKS = (KPS == 8 && PLANES >= 14);
+	// (one hash function and up to 20 planes only: with more rows in flight per k-mer, or 32 planes, the 28 registers of the
+	// block counter are the ones that spill -- tools/isa_check.py)
+	constexpr bool BLOCKS = (KPS == 8 && PLANES >= 14 && PLANES <= 20 && NH == 1);
 	constexpr int BP = 7;
 	u32x4 blk[BP];
 	uint32_t in_blk = 0;
@@ -1926,10 +1934,10 @@ struct CountWalkArgs {
 	uint32_t *arrived;              // [waves][CWALK_LEVELS] arrivals at the tree node (first wave of the node's subtree, level); zero between searches
 };
 
-// (amdgpu_waves_per_eu(2, 3): 8 waves per CU by default, 12 at most by knob -- see and_walk_kernel: without the hint the
-// compiler splits the prefetched rows of a step to save registers it has no use for)
+// (no amdgpu_waves_per_eu hint here, unlike and_walk_kernel: with it the 14-plane-and-more forms with several hash
+// functions requested ONE k-mer's rows at a time -- tools/isa_check.py compares every kernel's loads in flight with round 4's)
 template <int PLANES, int NH>
-__global__ __launch_bounds__(WALK_WG_WAVES*WAVE) __attribute__((amdgpu_waves_per_eu(2, 3))) void count_walk_kernel(SearchArgs a, CountWalkArgs wa, const uint32_t *__restrict__ rows,
+__global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void count_walk_kernel(SearchArgs a, CountWalkArgs wa, const uint32_t *__restrict__ rows,
                                                                     const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ nkmer,
                                                                     const uint32_t *__restrict__ qthr)
 {

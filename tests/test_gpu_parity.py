@@ -375,8 +375,25 @@ def test_early_exit_screen_then_refine(ka, ctx, oracle, n_cols, num_hash, densit
                     r = g.search(b, thr, ka.SEARCH_EARLY_EXIT)
                     assert r.search_kernel.startswith(want) != (knobs.get("ee_refine") == 0), (r.search_kernel, knobs)
                     assert np.array_equal(r.hits, ref.hits) and np.array_equal(r.num_query_kmer, ref.num_query_kmer), (n_cols, thr, knobs, rep)
-    # one query of 20 k positions among the others: units of 1/128 of it, 14 counter planes per unit
-    seqs2 = seqs[:40] + [(genome * 7)[:20500], rand_seq(rng, 9000)]
+    # append mode with early exit (what kwage_node and the multi-GPU hosts submit): the screen / refine launches append to a
+    # caller-owned list with a column base, no run table
+    import ctypes as C
+    import torch
+    from kwage_amd.native import check, lib
+    for thr in (1.0, 0.8):
+        ref = g.search(b, thr, 0)
+        buf = torch.empty((1 + len(ref.hits) + 16, 3), dtype=torch.int32, device="cuda:0")
+        n, h = C.c_uint64(), C.c_void_p()
+        with ctx.tuning(count_screen_min_tiles=1):
+            check(lib().kwage_search_device_append_submit(g._h, b._h, C.c_float(thr), ka.SEARCH_EARLY_EXIT, buf.data_ptr() + 12, buf.shape[0] - 1, buf.data_ptr(), 1000, 1, C.byref(h)))
+            check(lib().kwage_search_device_collect(h, C.byref(n), None, None))
+        assert n.value == len(ref.hits)
+        host = buf.cpu().numpy().view(np.uint32)
+        got = sorted(map(tuple, host[1:1 + n.value].tolist()))
+        assert got == sorted((int(q), int(c) + 1000, int(m)) for q, c, m in zip(ref.hits["query"], ref.hits["column"], ref.hits["num_match"])), (n_cols, thr)
+    # one query of 12 k positions among the others: units of 1/128 of it, 14 counter planes per unit (queries above 16383
+    # positions -- 20 counter planes -- keep the tiled kernel at t < 1)
+    seqs2 = seqs[:40] + [(genome * 5)[:12500], rand_seq(rng, 9000)]
     b2 = ka.Batch(ctx, seqs2)
     for thr in (1.0, 0.7):
         ref = g.search(b2, thr, 0)
