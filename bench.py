@@ -510,7 +510,7 @@ def result_check(members, results, threshold, n_hit=2, n_miss=1):
 # ------------------------------------------------------------------------------------------------------
 # early_exit: the default path of the command-line programs, measured on the resident matrix
 # ------------------------------------------------------------------------------------------------------
-def early_exit_block(args, name, members, s, threshold, flags, nominal):
+def early_exit_block(args, name, members, s, threshold, flags, nominal, pmc_applies=True):
     """The batch that was just timed, searched again with KWAGE_SEARCH_EARLY_EXIT: warm-up, then args.steps steps through
     the two search slots exactly like the timed region.  -> {ms_per_step, kernel, kernel_ms, nominal_rate (the
     ALGORITHMIC bytes of the batch over the time -- bytes the early exit mostly does not read, labelled as such),
@@ -545,7 +545,8 @@ def early_exit_block(args, name, members, s, threshold, flags, nominal):
     k_ms = float(np.mean(kernel_ms))
     alg = int(sum(r.algorithmic_bytes for r in last))
     kernel = getattr(last[0], "search_kernel", "")
-    fetched, fsrc = measured_traffic(name, kernel, True)
+    # (the PMC passes were taken on the whole workload: a share of a strong split has none)
+    fetched, fsrc = measured_traffic(name, kernel, True) if pmc_applies else (None, {"status": "no PMC pass for a share of a strong split"})
     same = all(np.array_equal(a.hits, b.hits) and np.array_equal(a.num_query_kmer, b.num_query_kmer) for a, b in zip(last, nominal))
     out = {"ms_per_step": round(dt / nsteps * 1e3, 4), "steps": nsteps, "kernel": kernel, "kernel_ms": round(k_ms, 4),
            "kernel_ms_min": round(float(np.min(kernel_ms)), 4), "kernel_ms_max": round(float(np.max(kernel_ms)), 4),
@@ -834,7 +835,7 @@ def measure(env, args, name, headline, force_scaling=None):
     ee = None
     if not args.no_early_exit_block and not args.early_exit:
         try:
-            ee = early_exit_block(args, name, members, s, threshold, flags, probe)
+            ee = early_exit_block(args, name, members, s, threshold, flags, probe, pmc_applies=not (scaling == "strong" and split > 1))
         except Exception as exc:
             ee = {"ok": False, "error": repr(exc)}
     ee_ok = 1.0 if (ee is None or ee.get("ok", True)) else 0.0

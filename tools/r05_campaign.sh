@@ -136,6 +136,9 @@ import json,sys
 l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c2 of $k', l['roofline']['kernel'], l['roofline']['kernel_ms'], l['roofline']['frac'], l['roofline']['frac_of_measured_stream'])"
   done
   ;;
+two_ranks)
+  KWAGE_BENCH_BACKEND=gloo KWAGE_BENCH_ONE_DEVICE=1 python bench.py --gpus 2 --also c3_strong --no-cpu-baseline --steps 10 --warmup 3 > $O/r05_c2_bench_two_ranks_one_gpu_gloo_also_c3_strong.json 2>$O/two_ranks.err || tail -20 $O/two_ranks.err
+  ;;
 line)
   python bench.py --steps 20 --warmup 5 > $O/r05_c2_bench.json 2> $O/r05_c2_bench.err || { tail -30 $O/r05_c2_bench.err; exit 1; }
   python - <<PY
