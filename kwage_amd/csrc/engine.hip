@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cctype>
 #include <cstring>
@@ -34,7 +35,7 @@ static const TuningName TUNING_NAMES[] = {
 	 {"walk_waves", &Tuning::walk_waves}, {"walk_one_wg_per_cu", &Tuning::walk_one_wg_per_cu},
 	{"walk_bands", &Tuning::walk_bands}, {"walk_bands_min_gib", &Tuning::walk_bands_min_gib},
 	{"and_vec", &Tuning::and_vec}, {"and_wide", &Tuning::and_wide}, {"and_wide_min_kib", &Tuning::and_wide_min_kib}, {"narrow", &Tuning::narrow}, {"force_segs", &Tuning::force_segs},
-	{"ee_refine", &Tuning::ee_refine}, {"refine_seg_rows", &Tuning::refine_seg_rows}, {"refine_min_rows", &Tuning::refine_min_rows}, {"refine_max_groups", &Tuning::refine_max_groups}, {"refine_unroll", &Tuning::refine_unroll}, {"refine_list_cap", &Tuning::refine_list_cap}, {"refine_static", &Tuning::refine_static}, {"screen_wpc", &Tuning::screen_wpc}, {"count_screen_wpc", &Tuning::count_screen_wpc}, {"count_screen_min_tiles", &Tuning::count_screen_min_tiles}, {"count_screen_check", &Tuning::count_screen_check},
+	{"ee_refine", &Tuning::ee_refine}, {"refine_seg_rows", &Tuning::refine_seg_rows}, {"refine_min_rows", &Tuning::refine_min_rows}, {"refine_max_groups", &Tuning::refine_max_groups}, {"refine_unroll", &Tuning::refine_unroll}, {"refine_list_cap", &Tuning::refine_list_cap}, {"refine_static", &Tuning::refine_static}, {"screen_wpc", &Tuning::screen_wpc}, {"count_screen_wpc", &Tuning::count_screen_wpc}, {"count_screen_min_tiles", &Tuning::count_screen_min_tiles}, {"count_screen_check", &Tuning::count_screen_check}, {"count_trunc", &Tuning::count_trunc},
 	{"count_walk", &Tuning::count_walk}, {"count_walk_wpc", &Tuning::count_walk_wpc}, {"count_walk_waves", &Tuning::count_walk_waves},
 	{"count_walk_min_rows", &Tuning::count_walk_min_rows},
 	{"hit_sort_host", &Tuning::hit_sort_host}, {"hit_copy_piece_kb", &Tuning::hit_copy_piece_kb}, {"shared_table_log2", &Tuning::shared_table_log2},
@@ -330,34 +331,52 @@ void launch_count_planes(uint32_t planes, const SearchArgs &a, hipStream_t s, co
 	}
 }
 
-template <int PLANES, int NH>
-void launch_count_walk(const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s, const StageEvents &ge)
+template <int PLANES, int NH, bool TRUNC>
+void launch_count_walk(const SearchArgs &a, const CountWalkArgs &wa, const RefineArgs &ra, const WalkShape &w, hipStream_t s, const StageEvents &ge)
 {
-	if(w.lds > 48*1024){ (void)hipFuncSetAttribute((const void*)count_walk_kernel<PLANES, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds); }
-	KW_GATHER_LAUNCH(ge, true, true, (count_walk_kernel<PLANES, NH>), dim3(w.wgs), dim3(w.wg_waves*WAVE), w.lds, s, a, wa, a.rows, a.pos_off, a.nkmer, a.qthr);
+	if(w.lds > 48*1024){ (void)hipFuncSetAttribute((const void*)count_walk_kernel<PLANES, NH, TRUNC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds); }
+	// (TRUNC: the refine and emit launches end the stage)
+	KW_GATHER_LAUNCH(ge, true, !TRUNC, (count_walk_kernel<PLANES, NH, TRUNC>), dim3(w.wgs), dim3(w.wg_waves*WAVE), w.lds, s, a, wa, ra, a.rows, a.pos_off, a.nkmer, a.qthr);
 }
 
-template <int PLANES>
-void launch_count_walk_nh(const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s, const StageEvents &ge)
+template <int PLANES, bool TRUNC>
+void launch_count_walk_nh(const SearchArgs &a, const CountWalkArgs &wa, const RefineArgs &ra, const WalkShape &w, hipStream_t s, const StageEvents &ge)
 {
 	switch(a.num_hash){
-		case 1: launch_count_walk<PLANES, 1>(a, wa, w, s, ge); break;
-		case 2: launch_count_walk<PLANES, 2>(a, wa, w, s, ge); break;
-		case 3: launch_count_walk<PLANES, 3>(a, wa, w, s, ge); break;
-		case 4: launch_count_walk<PLANES, 4>(a, wa, w, s, ge); break;
-		default: launch_count_walk<PLANES, 5>(a, wa, w, s, ge); break;
+		case 1: launch_count_walk<PLANES, 1, TRUNC>(a, wa, ra, w, s, ge); break;
+		case 2: launch_count_walk<PLANES, 2, TRUNC>(a, wa, ra, w, s, ge); break;
+		case 3: launch_count_walk<PLANES, 3, TRUNC>(a, wa, ra, w, s, ge); break;
+		case 4: launch_count_walk<PLANES, 4, TRUNC>(a, wa, ra, w, s, ge); break;
+		default: launch_count_walk<PLANES, 5, TRUNC>(a, wa, ra, w, s, ge); break;
 	}
 }
 
-void launch_count_walk_planes(uint32_t planes, const SearchArgs &a, const CountWalkArgs &wa, const WalkShape &w, hipStream_t s, const StageEvents &ge)
+template <bool TRUNC>
+void launch_count_walk_planes(uint32_t planes, const SearchArgs &a, const CountWalkArgs &wa, const RefineArgs &ra, const WalkShape &w, hipStream_t s, const StageEvents &ge)
 {
 	switch(planes){
-		case 7: launch_count_walk_nh<7>(a, wa, w, s, ge); break;
-		case 10: launch_count_walk_nh<10>(a, wa, w, s, ge); break;
-		case 14: launch_count_walk_nh<14>(a, wa, w, s, ge); break;
-		case 20: launch_count_walk_nh<20>(a, wa, w, s, ge); break;
-		default: launch_count_walk_nh<32>(a, wa, w, s, ge); break;
+		case 7: launch_count_walk_nh<7, TRUNC>(a, wa, ra, w, s, ge); break;
+		case 10: launch_count_walk_nh<10, TRUNC>(a, wa, ra, w, s, ge); break;
+		case 14: launch_count_walk_nh<14, TRUNC>(a, wa, ra, w, s, ge); break;
+		case 20: launch_count_walk_nh<20, TRUNC>(a, wa, ra, w, s, ge); break;
+		default: launch_count_walk_nh<32, TRUNC>(a, wa, ra, w, s, ge); break;
 	}
+}
+
+struct RefineSetup { RefineArgs ra; uint32_t refine_wgs, emit_wgs; };
+
+// The refine and emit launches of the count path's early-exit forms (count_screen_kernel, the truncated count walk).
+void launch_count_refine_and_emit(uint32_t planes, int up, const SearchArgs &a, const RefineSetup &rs, hipStream_t gs, const StageEvents &ge)
+{
+	const dim3 block(SEARCH_THREADS);
+#define KWAGE_CR_NH(N) case N: if(up == 7){ KW_GATHER_LAUNCH(ge, false, false, (count_refine_kernel<N, 7>), dim3(rs.refine_wgs), block, 0, gs, a, rs.ra); } \
+		else{ KW_GATHER_LAUNCH(ge, false, false, (count_refine_kernel<N, 14>), dim3(rs.refine_wgs), block, 0, gs, a, rs.ra); } break;
+	switch(std::min(a.num_hash, 5u)){ KWAGE_CR_NH(1) KWAGE_CR_NH(2) KWAGE_CR_NH(3) KWAGE_CR_NH(4) default: KWAGE_CR_NH(5) }
+#undef KWAGE_CR_NH
+#define KWAGE_CE_P(P) case P: if(up == 7){ KW_GATHER_LAUNCH(ge, false, true, (count_refine_emit_kernel<P, 7>), dim3(rs.emit_wgs), block, 0, gs, a, rs.ra); } \
+		else{ KW_GATHER_LAUNCH(ge, false, true, (count_refine_emit_kernel<P, (P >= 14 ? 14 : 7)>), dim3(rs.emit_wgs), block, 0, gs, a, rs.ra); } break;
+	switch(planes){ KWAGE_CE_P(7) KWAGE_CE_P(10) KWAGE_CE_P(14) KWAGE_CE_P(20) default: KWAGE_CE_P(32) }
+#undef KWAGE_CE_P
 }
 
 template <int PLANES>
@@ -411,10 +430,9 @@ int reserve_zeroed(DevBuf &buf, uint64_t bytes, hipStream_t s)
 // atomic --, the rest is reserved in chunks through three counters, zeroed on the gather stream before every stage.
 // `item_bytes`: mask (t = 1: 128) or counters (t < 1: planes x 128) per item; `unit_bytes`: partial counters per unit
 // (t < 1 only).
-struct RefineSetup { RefineArgs ra; uint32_t refine_wgs, emit_wgs; };
-
 int refine_setup(Slot *sl, const Tuning &tn, const SearchArgs &a, uint64_t total_rows, uint64_t max_rows, uint32_t max_seg, uint64_t item_bytes, uint64_t unit_bytes,
-                 uint64_t tiles, uint64_t screen_waves, uint64_t ncu, hipStream_t gs, RefineSetup *out)
+                 uint64_t tiles, uint64_t screen_waves, uint64_t ncu, hipStream_t gs, RefineSetup *out,
+                 uint64_t exact_clusters = 0, uint64_t exact_items = 0, uint64_t exact_units = 0)
 {
 	int rc;
 	RefineArgs &ra = out->ra;
@@ -427,21 +445,26 @@ int refine_setup(Slot *sl, const Tuning &tn, const SearchArgs &a, uint64_t total
 	uint64_t units = std::min<uint64_t>(std::max<uint64_t>(32*total_rows/ra.seg_rows, 1u << 18), 1u << 25);       // (32 bytes each: at most 1 GiB)
 	if(unit_bytes){ units = std::max<uint64_t>(std::min<uint64_t>(units, (512ull << 20)/unit_bytes), 4096); }
 	if(tn.refine_list_cap > 0){ items = units = (uint64_t)std::min<int64_t>(tn.refine_list_cap, 1 << 20); }
+	uint64_t clusters = items;
+	// (the truncated count walk names its capacities: a place for every pair and group, units by memory)
+	if(exact_units){ clusters = exact_clusters; items = exact_items; units = exact_units; }
+	if(exact_units && tn.refine_list_cap > 0){ clusters = items = units = (uint64_t)std::min<int64_t>(tn.refine_list_cap, 1 << 20); }       // (tests: full lists)
 	// dynamic chunks: what a wave is likely to need for a few of its tiles (a wave with one or two tiles takes exactly what it needs)
 	const uint64_t tiles_per_wave = (tiles + screen_waves - 1)/std::max<uint64_t>(screen_waves, 1);
 	auto list = [&](uint64_t cap, uint64_t stat_max, uint64_t chunk_max) {
 		RefineList ls;
 		ls.cap = (uint32_t)cap;
-		ls.stat = tn.refine_static ? (uint32_t)std::min<uint64_t>(stat_max, cap/2/std::max<uint64_t>(screen_waves, 1)) : 0u;
+		// (exact capacities: every place is taken exactly when it is needed -- no static parts, no chunks, nothing left unused)
+		ls.stat = (tn.refine_static && !exact_units) ? (uint32_t)std::min<uint64_t>(stat_max, cap/2/std::max<uint64_t>(screen_waves, 1)) : 0u;
 		ls.base = (uint32_t)(ls.stat*screen_waves);
-		ls.chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(chunk_max, tiles_per_wave/4));
+		ls.chunk = exact_units ? 1u : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(chunk_max, tiles_per_wave/4));
 		return ls;
 	};
-	ra.lc = list(items, 32, 32);
+	ra.lc = list(clusters, 32, 32);
 	ra.li = list(items, 64, 64);
 	ra.lu = list(units, 256, 256);
 	if((rc = sl->ref_counters.reserve(8*sizeof(uint32_t)))){ return rc; }
-	if((rc = sl->ref_clusters.reserve(items*sizeof(RefineCluster)))){ return rc; }
+	if((rc = sl->ref_clusters.reserve(clusters*sizeof(RefineCluster)))){ return rc; }
 	if((rc = sl->ref_masks.reserve(items*item_bytes))){ return rc; }
 	if((rc = sl->ref_units.reserve(units*sizeof(RefineUnit)))){ return rc; }
 	if(unit_bytes && (rc = sl->ref_slab.reserve(units*unit_bytes))){ return rc; }
@@ -716,16 +739,92 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 			switch(planes){ KWAGE_CS_P(7) KWAGE_CS_P(10) default: KWAGE_CS_P(14) }
 #undef KWAGE_CS_P
 #undef KWAGE_CS_NH
-#define KWAGE_CR_NH(N) case N: if(up == 7){ KW_GATHER_LAUNCH(ge, false, false, (count_refine_kernel<N, 7>), dim3(rs.refine_wgs), block, 0, gs, a, rs.ra); } \
-				else{ KW_GATHER_LAUNCH(ge, false, false, (count_refine_kernel<N, 14>), dim3(rs.refine_wgs), block, 0, gs, a, rs.ra); } break;
-			switch(std::min(a.num_hash, 5u)){ KWAGE_CR_NH(1) KWAGE_CR_NH(2) KWAGE_CR_NH(3) KWAGE_CR_NH(4) default: KWAGE_CR_NH(5) }
-#undef KWAGE_CR_NH
-#define KWAGE_CE_P(P) case P: if(up == 7){ KW_GATHER_LAUNCH(ge, false, true, (count_refine_emit_kernel<P, 7>), dim3(rs.emit_wgs), block, 0, gs, a, rs.ra); } \
-				else{ KW_GATHER_LAUNCH(ge, false, true, (count_refine_emit_kernel<P, (P >= 14 ? 14 : 7)>), dim3(rs.emit_wgs), block, 0, gs, a, rs.ra); } break;
-			switch(planes){ KWAGE_CE_P(7) KWAGE_CE_P(10) default: KWAGE_CE_P(14) }
-#undef KWAGE_CE_P
+			launch_count_refine_and_emit(planes, up, a, rs, gs, ge);
 			HIP_TRY(hipGetLastError());
 			return KWAGE_OK;
+		}
+		// Early exit over FEW LONG queries (fewer tiles than the screen form wants, or more counter planes than it holds): every
+		// tile has to read the first (1 - t) n k-mers plus a margin before kwage.cpp:478-481 can rule anything out, and a handful of
+		// tiles that long would be the whole launch -- so that part is walked by the BALANCED persistent count kernel over the
+		// first kcut(q) k-mers of every query (count_walk_kernel<.., TRUNC>), the columns that can still reach the threshold are
+		// handed over with their counters, and the refine launch counts their remaining k-mers in 128-byte groups.  kcut comes
+		// from the density of the matrix's DENSEST column (sampled at finalize): the smallest K with  K - (n - thr)  >=  pm K + 4.5 sqrt(pm (1 - pm) K) + 8,
+		// pm = that density ^ num_hash -- an estimate that decides how much is read, never what is reported.
+		if(a.early_exit && tn.ee_refine && tn.count_trunc && tn.count_walk && !narrow && tn.force_segs <= 0 && a.units_per_row >= WAVE && L->total_pos > 0){
+			const uint32_t nq = a.n_queries;
+			// The DENSEST column decides: a 128-byte group stays alive while any of its 1024 columns can still reach the threshold,
+			// and columns are not equally dense (every sample's filter has its own fill; the synthetic workloads' planted columns
+			// are 15 % denser than the rest).  + 3 sigma of what 4096 sampled rows can say about one column.
+			const double col = std::min(1.0, std::max(0.0, g->density_max) + 3.0*std::sqrt(0.25/4096.0));
+			const double pm = std::min(0.9, std::max(0.0005, std::pow(col, (double)a.num_hash)));
+			static const bool trunc_debug = getenv("KWAGE_TRUNC_DEBUG") != nullptr;
+			if(trunc_debug){ fprintf(stderr, "[kwage_amd] truncated count walk: sampled density %.5f, densest column %.5f, per-k-mer match probability planned with %.5f\n", g->density, g->density_max, pm); }
+			if((rc = sl->trunc_host.reserve(((uint64_t)nq + 1)*sizeof(uint64_t) + (uint64_t)nq*sizeof(uint32_t)))){ return rc; }
+			uint64_t *h_soff = (uint64_t*)sl->trunc_host.p;
+			uint32_t *h_kcut = (uint32_t*)(h_soff + nq + 1);
+			uint64_t walked = 0, max_rest = 0, rest_total = 0;
+			h_soff[0] = 0;
+			for(uint32_t i = 0; i < nq; ++i){
+				const uint64_t npos = L->h_pos_off[i + 1] - L->h_pos_off[i];
+				uint64_t kc = npos;
+				if(npos >= 64){
+					const uint32_t thr = (uint32_t)(threshold*(float)npos);      // kwage.cpp:388 on the positions (an upper bound of the distinct k-mers)
+					const double need = (double)(npos - std::min<uint64_t>(thr, npos));
+					double K = (need + 8.0)/(1.0 - pm);
+					for(int it = 0; it < 8; ++it){ K = (need + 8.0 + 4.5*std::sqrt(pm*(1.0 - pm)*K))/(1.0 - pm); }
+					const uint64_t k8 = ((uint64_t)K + 7)/8*8;
+					if(k8*20 <= npos*17){ kc = k8; }                              // (worth it when at least 15 % of the list is left out)
+				}
+				h_kcut[i] = (uint32_t)kc;
+				h_soff[i + 1] = h_soff[i] + kc;
+				walked += kc;
+				max_rest = std::max(max_rest, npos - kc);
+				rest_total += npos - kc;
+			}
+			const uint64_t slots = (uint64_t)a.chunks*walked;
+			const uint64_t chip_waves = ncu*(uint64_t)std::max<int64_t>(tn.count_walk_wpc, 1);
+			const uint64_t min_rows = (tn.count_walk_min_rows >= 0) ? (uint64_t)tn.count_walk_min_rows : (uint64_t)WALK_MIN_ROWS_PER_WAVE*chip_waves;
+			// units of 1/128 of the longest remainder (at least refine_seg_rows k-mers): 7 counter planes per unit up to 120 k-mers, 14 beyond
+			uint64_t seg = (uint64_t)std::min<int64_t>(std::max<int64_t>(tn.refine_seg_rows, 8), 120)/8*8;
+			seg = std::max<uint64_t>(seg, ((max_rest + 127)/128 + 7)/8*8);
+			const int up = (seg <= 120) ? 7 : 14;
+			uint64_t units_worst = 0;
+			for(uint32_t i = 0; i < nq && seg; ++i){
+				const uint64_t rest = (L->h_pos_off[i + 1] - L->h_pos_off[i]) - h_kcut[i];
+				units_worst += (uint64_t)a.chunks*8*((rest + seg - 1)/seg);
+			}
+			// Lists: a place for every pair and every 128-byte group of it (few tiles: that is affordable), and for the units
+			// as many as a GiB of partial counters holds -- every group of every pair surviving is not what they are sized for;
+			// a pair that finds them full is counted to the end by the wave that holds it (count_walk_kernel).
+			const uint64_t tiles = (uint64_t)nq*a.chunks;
+			const uint64_t units_cap = std::max<uint64_t>(4096, std::min<uint64_t>(units_worst, (1ull << 30)/((uint64_t)up*128 + sizeof(RefineUnit))));
+			if(walked*10 <= L->total_pos*7 && slots*a.num_hash >= min_rows && seg <= 16376 && rest_total > 0 && tiles*8*(uint64_t)planes*128 <= (1ull << 30)){
+				const uint64_t want_waves = (tn.count_walk_waves > 0) ? std::min<uint64_t>((uint64_t)tn.count_walk_waves, slots)
+					: std::max<uint64_t>(1, std::min<uint64_t>(chip_waves, slots*a.num_hash/WALK_MIN_ROWS_PER_WAVE));
+				const WalkShape shape = walk_shape(tn, want_waves, ncu);
+				const uint64_t waves = (uint64_t)shape.wgs*shape.wg_waves;
+				RefineSetup rs;
+				if((rc = refine_setup(sl, tn, a, rest_total, 0, (uint32_t)seg, (uint64_t)planes*128, (uint64_t)up*128, tiles, waves, ncu, gs, &rs, tiles, tiles*8, units_cap))){ return rc; }
+				rs.ra.seg_rows = (uint32_t)seg;
+				if((rc = sl->trunc_dev.reserve(((uint64_t)nq + 1)*sizeof(uint64_t) + (uint64_t)nq*sizeof(uint32_t)))){ return rc; }
+				HIP_TRY(hipMemcpyAsync(sl->trunc_dev.p, sl->trunc_host.p, ((uint64_t)nq + 1)*sizeof(uint64_t) + (uint64_t)nq*sizeof(uint32_t), hipMemcpyHostToDevice, gs));
+				CountWalkArgs wa;
+				wa.total_slots = slots;
+				wa.per_wave = (slots + waves - 1)/waves;
+				wa.coltiles = a.chunks;
+				if((rc = sl->cwalk_slab.reserve(waves*2*planes*1024))){ return rc; }
+				if((rc = reserve_zeroed(sl->cwalk_arrived, waves*CWALK_LEVELS*sizeof(uint32_t), gs))){ return rc; }
+				wa.slab = (uint32_t*)sl->cwalk_slab.p;
+				wa.arrived = (uint32_t*)sl->cwalk_arrived.p;
+				wa.slot_off = (const uint64_t*)sl->trunc_dev.p;
+				wa.kcut = (const uint32_t*)((const uint64_t*)sl->trunc_dev.p + nq + 1);
+				a.segs = 1;
+				snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_walk_kernel<%u,%u,trunc>+refine<%d>", planes, std::min(a.num_hash, 5u), up);
+				launch_count_walk_planes<true>(planes, a, wa, rs.ra, shape, gs, ge);
+				launch_count_refine_and_emit(planes, up, a, rs, gs, ge);
+				HIP_TRY(hipGetLastError());
+				return KWAGE_OK;
+			}
 		}
 		if(tn.count_walk && !a.early_exit && !narrow && tn.force_segs <= 0 && L->total_pos > 0){
 			const uint64_t slots = (uint64_t)a.chunks*L->total_pos;
@@ -747,7 +846,8 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 				a.segs = 1;
 				// (shape: planes, hashes, the next step's rows prefetched, eight k-mers per step with 14 planes and more)
 				snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_walk_kernel<%u,%u,pf%s>", planes, std::min(a.num_hash, 5u), planes >= 14 ? ",8" : "");
-				launch_count_walk_planes(planes, a, wa, shape, gs, ge);
+				wa.slot_off = nullptr; wa.kcut = nullptr;
+				launch_count_walk_planes<false>(planes, a, wa, RefineArgs(), shape, gs, ge);
 				HIP_TRY(hipGetLastError());
 				return KWAGE_OK;
 			}
@@ -1164,6 +1264,7 @@ extern "C" void kwage_shutdown(kwage_ctx *ctx)
 		sl->walk_or.release(); sl->walk_done.release();
 		sl->band_rows.release(); sl->band_loc.release(); sl->band_or.release(); sl->band_state.release(); sl->cwalk_slab.release(); sl->cwalk_arrived.release();
 		sl->ref_counters.release(); sl->ref_clusters.release(); sl->ref_masks.release(); sl->ref_units.release(); sl->ref_slab.release();
+		sl->trunc_dev.release(); sl->trunc_host.release();
 		for(int i = 0; i < 4; ++i){ if(sl->ev[i]){ (void)hipEventDestroy(sl->ev[i]); } }
 		if(sl->kmer_done){ (void)hipEventDestroy(sl->kmer_done); }
 		if(sl->gather_done){ (void)hipEventDestroy(sl->gather_done); }

@@ -262,6 +262,8 @@ struct Slot {
 	DevBuf cwalk_slab, cwalk_arrived;
 	// early exit, screen + refine (kernels.hpp and_screen_kernel): the three counters and the lists of the tiles handed over
 	DevBuf ref_counters, ref_clusters, ref_masks, ref_units, ref_slab;
+	DevBuf trunc_dev;              // the truncated count walk's per-query arrays: [slot_off: (n + 1) x u64 | kcut: n x u32]
+	PinBuf trunc_host;             // their host image (pinned: the copy is queued, the slot keeps it until the search is collected)
 	uint32_t ref_base[3] = {0, 0, 0}, ref_cap[3] = {0, 0, 0};      // of the last such search (kwage_ctx_refine_stats)
 	uint64_t staged_hits = 0;
 	kwage_hit *ext_hits = nullptr;      // caller-owned device buffer (kwage_search_device) or null
@@ -303,6 +305,8 @@ struct Tuning {
 	int64_t screen_wpc = 20;        // KWAGE_SCREEN_WPC: waves per CU of the persistent screen launch
 	int64_t count_screen_wpc = 32;  // KWAGE_COUNT_SCREEN_WPC: at most this many waves per CU in the count path's screen launch (fewer where the kernel's registers hold fewer)
 	int64_t count_screen_min_tiles = 8192;  // KWAGE_COUNT_SCREEN_MIN_TILES: at t < 1, batches with fewer (query, KiB tile) pairs keep the tiled kernel and its segments
+	int64_t count_trunc = 1;        // KWAGE_COUNT_TRUNC: early exit over few long queries at t < 1: the persistent count kernel over the first k-mers of every
+	                                //   query (as many as the bound needs before it can rule a column out), the survivors refined (0: segments, every row read)
 	int64_t count_screen_check = 8;     // KWAGE_COUNT_SCREEN_CHECK: k-mers between two looks at the bound in the count path's screen launch (8, 16, 32, 64; 8 = after every step:
 	                                //   short reads at t = 0.8 9 % sooner than with 16, 14 % sooner than with 32; C2 at t = 0.8 the same -- profiles/r05_refine_knobs_ab.txt)
 	int64_t refine_static = 1;      // KWAGE_REFINE_STATIC: half of every list is dealt out to the screen launch's waves beforehand (0: every place is reserved through the counters -- diagnostics: kwage_ctx_refine_stats then counts the hand-overs exactly)
@@ -373,6 +377,8 @@ struct kwage_group {
 	bool mixes_regions = false;
 	std::vector<uint8_t> h_valid;
 	bool finalized = false;
+	double density = 0.25;         // share of set bits among the real columns, and ...
+	double density_max = 1.0;      // ... in the DENSEST column, both from a few thousand rows sampled at finalize: the latter plans the truncated count walk
 	// sparse group (kwage_group_create_sparse): the matrix holds only the listed rows of every file, in this order
 	// (sorted, distinct); row indices from the k-mer stage are translated to positions in the list before the gather
 	std::vector<uint32_t> h_row_map;

@@ -1595,6 +1595,50 @@ __global__ __launch_bounds__(SEARCH_THREADS) void count_kernel(SearchArgs a)
 //                        units of `seg_rows` k-mers); otherwise it goes on, and reports itself at the end of the list.
 //   count_refine_kernel  eight units per wave, 8 lanes x 16 B each: the unit's k-mers counted in UP planes -> slab.
 //   count_refine_emit_kernel  per cluster: item counters + the units' counters, threshold, one reservation per wave.
+// Hand a (query, KiB tile) over to the refine launch at k-mer `k_done` of `nk`: one cluster, one item (its PLANES counters so
+// far) per 128-byte group of `gb`, one unit per item and segment of ra.seg_rows remaining k-mers.  False: a list is full
+// (nothing was handed over).  Wave-uniform arguments except `plane`; every lane calls.
+template <int PLANES>
+__device__ __forceinline__ bool count_hand_over(const RefineArgs &ra, RefineChunk &cc, RefineChunk &ci, RefineChunk &cu, uint32_t q, uint32_t c, uint32_t gb,
+                                                const u32x4 (&plane)[PLANES], uint32_t k_done, uint32_t nk, uint64_t rq_off)
+{
+	const uint32_t lane = threadIdx.x & (WAVE - 1);
+	const uint32_t ngroups = __popc(gb);
+	const uint32_t nseg = (nk - k_done + ra.seg_rows - 1)/ra.seg_rows;
+	const uint32_t nu = ngroups*nseg;
+	const uint32_t c0 = refine_take(ra, 0, cc, 1);
+	const uint32_t i0 = (c0 != REFINE_NONE) ? refine_take(ra, 1, ci, ngroups) : REFINE_NONE;
+	const uint32_t un0 = (i0 != REFINE_NONE) ? refine_take(ra, 2, cu, nu) : REFINE_NONE;
+	if(un0 == REFINE_NONE){
+		if(c0 != REFINE_NONE){ refine_none_clusters(ra, c0, c0 + 1); }
+		return false;
+	}
+	if(lane == 0){
+		RefineCluster cl; cl.q = q; cl.kstep_groups = (c << 8) | gb; cl.first_item = i0; cl.n = nk;
+		cl.first_unit = un0; cl.nseg = nseg; cl.pad0 = 0; cl.pad1 = 0;
+		ra.clusters[c0] = cl;
+	}
+	const uint32_t k = lane >> 3;
+	if((gb >> k) & 1u){
+		const uint32_t it = i0 + __popc(gb & ((1u << k) - 1u));
+		u32x4 *dst = reinterpret_cast<u32x4*>(ra.masks) + (uint64_t)it*PLANES*8 + (lane & 7u);
+#pragma unroll
+		for(int p = 0; p < PLANES; ++p){ dst[p*8] = plane[p]; }
+	}
+	for(uint32_t e = lane; e < nu; e += WAVE){
+		const uint32_t j = e / nseg, sg = e % nseg;
+		RefineUnit un;
+		un.item = i0 + j;
+		un.r0 = k_done + sg*ra.seg_rows;                               // (k-mers, not rows)
+		un.r1 = min(nk, un.r0 + ra.seg_rows);
+		un.unit0 = c*WAVE + nth_set_bit(gb, j)*8u;
+		un.rq_lo = (uint32_t)rq_off; un.rq_hi = (uint32_t)(rq_off >> 32);
+		un.q = q; un.pad = 0;
+		ra.units[un0 + e] = un;
+	}
+	return true;
+}
+
 // (amdgpu_waves_per_eu: the launch holds as many waves as the registers allow -- the host asks the runtime -- and that is
 // 2-3 per SIMD whatever the scheduler does; left alone it aimed higher and issued a step's eight rows two or three at a
 // time: see and_walk_kernel)
@@ -1681,38 +1725,9 @@ __global__ __launch_bounds__(SEARCH_THREADS) __attribute__((amdgpu_waves_per_eu(
 				const u32x4 off = can & ~planes_ge<PLANES>(plane, on_track);
 				if(__any((off.x | off.y | off.z | off.w) != 0)){ continue; }
 				may_hand_over = false;                    // (one attempt per tile)
-				const uint32_t nseg = (remaining + ra.seg_rows - 1)/ra.seg_rows;
-				const uint32_t nu = ngroups*nseg;
-				const uint32_t c0 = refine_take(ra, 0, cc, 1);
-				const uint32_t i0 = (c0 != REFINE_NONE) ? refine_take(ra, 1, ci, ngroups) : REFINE_NONE;
-				const uint32_t un0 = (i0 != REFINE_NONE) ? refine_take(ra, 2, cu, nu) : REFINE_NONE;
-				if(un0 == REFINE_NONE){
-					if(c0 != REFINE_NONE){ refine_none_clusters(ra, c0, c0 + 1); }
+				if(!count_hand_over<PLANES>(ra, cc, ci, cu, q, c, gb, plane, i, nk, rq_off)){
 					lists_full = true;
 					continue;
-				}
-				if(lane == 0){
-					RefineCluster cl; cl.q = q; cl.kstep_groups = (c << 8) | gb; cl.first_item = i0; cl.n = nk;
-					cl.first_unit = un0; cl.nseg = nseg; cl.pad0 = 0; cl.pad1 = 0;
-					ra.clusters[c0] = cl;
-				}
-				const uint32_t k = lane >> 3;
-				if((gb >> k) & 1u){
-					const uint32_t it = i0 + __popc(gb & ((1u << k) - 1u));
-					u32x4 *dst = reinterpret_cast<u32x4*>(ra.masks) + (uint64_t)it*PLANES*8 + (lane & 7u);
-#pragma unroll
-					for(int p = 0; p < PLANES; ++p){ dst[p*8] = plane[p]; }
-				}
-				for(uint32_t e = lane; e < nu; e += WAVE){
-					const uint32_t j = e / nseg, sg = e % nseg;
-					RefineUnit un;
-					un.item = i0 + j;
-					un.r0 = i + sg*ra.seg_rows;                                    // (k-mers, not rows)
-					un.r1 = min(nk, un.r0 + ra.seg_rows);
-					un.unit0 = c*WAVE + nth_set_bit(gb, j)*8u;
-					un.rq_lo = (uint32_t)rq_off; un.rq_hi = (uint32_t)(rq_off >> 32);
-					un.q = q; un.pad = 0;
-					ra.units[un0 + e] = un;
 				}
 				gone = true;
 				break;
@@ -1932,12 +1947,17 @@ struct CountWalkArgs {
 	uint32_t coltiles;              // 1 KiB column tiles per row
 	uint32_t *slab;                 // [waves][2][PLANES][4][64] partial counters of cut pairs (overwritten before they are read)
 	uint32_t *arrived;              // [waves][CWALK_LEVELS] arrivals at the tree node (first wave of the node's subtree, level); zero between searches
+	// TRUNC (early exit over few long queries at t < 1): only the first kcut[q] k-mers of query q are walked -- what the bound
+	// max + remaining < threshold needs before it can rule a column out (the host's estimate from the matrix's density) -- and
+	// the columns that can still reach the threshold go to the refine launch with their counters (count_hand_over)
+	const uint64_t *slot_off;       // n_queries + 1: prefix of min(positions, kcut) -- the slots of the launch
+	const uint32_t *kcut;           // n_queries
 };
 
 // (no amdgpu_waves_per_eu hint here, unlike and_walk_kernel: with it the 14-plane-and-more forms with several hash
 // functions requested ONE k-mer's rows at a time -- tools/isa_check.py compares every kernel's loads in flight with round 4's)
-template <int PLANES, int NH>
-__global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void count_walk_kernel(SearchArgs a, CountWalkArgs wa, const uint32_t *__restrict__ rows,
+template <int PLANES, int NH, bool TRUNC>
+__global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void count_walk_kernel(SearchArgs a, CountWalkArgs wa, RefineArgs ra, const uint32_t *__restrict__ rows,
                                                                     const uint64_t *__restrict__ pos_off, const uint32_t *__restrict__ nkmer,
                                                                     const uint32_t *__restrict__ qthr)
 {
@@ -1950,27 +1970,37 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void count_walk_kernel(SearchAr
 	WaveHitBuf *hbuf = &hit_bufs[threadIdx.x >> 6];
 	WaveHitState hst;
 	const uint32_t ct = wa.coltiles;
+	// the slots of the launch: every query's positions -- TRUNC: its first kcut positions -- times the column tiles
+	const uint64_t *__restrict__ soff = TRUNC ? wa.slot_off : pos_off;
+	RefineChunk cc, ci, cu;               // TRUNC: the wave's static places of the refine lists
+	if(TRUNC){
+		cc.next = gw*ra.lc.stat; cc.end = cc.next + ra.lc.stat;
+		ci.next = gw*ra.li.stat; ci.end = ci.next + ra.li.stat;
+		cu.next = gw*ra.lu.stat; cu.end = cu.next + ra.lu.stat;
+	}
 
-	// the query that holds slot s: the largest q with ct*pos_off[q] <= s
+	// the query that holds slot s: the largest q with ct*soff[q] <= s
 	uint32_t q = 0;
 	{
 		uint32_t hi = a.n_queries;
 		while(hi - q > 1){
 			const uint32_t mid = q + (hi - q)/2;
-			if((uint64_t)ct*pos_off[mid] <= s){ q = mid; } else { hi = mid; }
+			if((uint64_t)ct*soff[mid] <= s){ q = mid; } else { hi = mid; }
 		}
 	}
 
 	while(s < s1){
-		const uint64_t p0 = pos_off[q];
-		const uint64_t npos = pos_off[q + 1] - p0;
+		const uint64_t p0s = soff[q];
+		const uint64_t npos = soff[q + 1] - p0s;
 		if(npos == 0){ ++q; continue; }
-		const uint64_t rem = s - (uint64_t)ct*p0;
+		const uint64_t rem = s - (uint64_t)ct*p0s;
 		const uint32_t c = __builtin_amdgcn_readfirstlane((uint32_t)(rem / npos));
 		const uint32_t j0 = __builtin_amdgcn_readfirstlane((uint32_t)(rem % npos));
 		const uint32_t take = (uint32_t)min(npos - j0, s1 - s);
 		const uint32_t j1 = j0 + take;
-		const uint32_t n = nkmer[q];
+		const uint32_t nk = nkmer[q];
+		const uint32_t n = TRUNC ? min(nk, wa.kcut[q]) : nk;     // the k-mers walked here (TRUNC: the rest is the refine launch's)
+		const uint64_t p0 = TRUNC ? pos_off[q] : p0s;            // where the query's rows lie
 		const uint32_t jv1 = min(j1, n);                     // positions past the distinct k-mers hold no rows
 		if(j0 < jv1){
 			const uint32_t u0 = c*WAVE + lane;
@@ -1986,7 +2016,7 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void count_walk_kernel(SearchAr
 			bool emit = true;
 			if(j0 != 0 || jv1 != n){
 				// the run of waves that hold a part of this pair, and this wave's place in it
-				const uint64_t pair_start = (uint64_t)ct*p0 + (uint64_t)c*npos;        // slot of the pair's position 0
+				const uint64_t pair_start = (uint64_t)ct*p0s + (uint64_t)c*npos;       // slot of the pair's position 0
 				const uint32_t first_w = (uint32_t)(pair_start / wa.per_wave);
 				const uint32_t parts = (uint32_t)((pair_start + n - 1) / wa.per_wave) - first_w + 1;
 				uint32_t rep = gw - first_w;                                           // first wave (relative) of the subtree whose sum this wave holds
@@ -2018,12 +2048,30 @@ __global__ __launch_bounds__(WALK_WG_WAVES*WAVE) void count_walk_kernel(SearchAr
 					rep = parent;
 				}
 			}
-			if(emit){ emit_count_hits_buffered<PLANES>(a, hbuf, hst, q, unit, plane, qthr[q], (uint64_t)q*a.runs_per_query + c, live); }
+			if(emit){
+				if(TRUNC && n < nk){
+					// kwage.cpp:478-481 per column: the columns that can still reach the threshold if every remaining k-mer matches go on
+					const uint32_t thr = qthr[q], remaining = nk - n;
+					u32x4 can = live ? reinterpret_cast<const u32x4*>(a.valid)[unit] : (u32x4)(0u);
+					if(thr > remaining){ can &= planes_ge<PLANES>(plane, thr - remaining); }
+					const uint32_t gb = group_bits(__ballot((can.x | can.y | can.z | can.w) != 0));
+					if(gb && !count_hand_over<PLANES>(ra, cc, ci, cu, q, c, gb, plane, n, nk, p0*NH)){
+						// the lists are full: this wave counts the pair's remaining k-mers itself and reports it (correct, not balanced)
+						count_kmers_prefetch<PLANES, NH, (PLANES >= 14) ? 8 : 4>(a.db, a.stride, rows + (p0 + n)*NH, nk - n, unit, plane);
+						emit_count_hits_buffered<PLANES>(a, hbuf, hst, q, unit, plane, thr, (uint64_t)q*a.runs_per_query + c, live);
+					}
+				}
+				else{ emit_count_hits_buffered<PLANES>(a, hbuf, hst, q, unit, plane, qthr[q], (uint64_t)q*a.runs_per_query + c, live); }
+			}
 		}
 		s += take;
 		if(j1 == npos && c + 1 == ct){ ++q; }
 	}
 	wave_hits_flush(a, hbuf, hst);          // one reservation for everything the wave found
+	if(TRUNC){
+		refine_none_clusters(ra, cc.next, cc.end);
+		refine_none_units(ra, cu.next, cu.end);
+	}
 }
 
 // Narrow databases, count path: G queries per wave (see and_narrow_kernel).  A shorter k-mer list is padded

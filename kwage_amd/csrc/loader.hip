@@ -1052,6 +1052,30 @@ extern "C" int kwage_group_finalize(kwage_group *g)
 	int rc = set_device(ctx);
 	if(rc){ return rc; }
 	HIP_TRY(hipMemcpyAsync(g->d_valid, g->h_valid.data(), g->stride, hipMemcpyHostToDevice, ctx->stream));
+	// the matrix's bit density, from a few thousand rows (microseconds): what the early exit over long queries at t < 1 plans with
+	// (and its densest column's: what the bound has to rule out before a 128-byte group can be dropped)
+	g->density = 0.25;
+	g->density_max = 1.0;          // (unknown: nothing is ever planned to be ruled out early)
+	if(g->num_columns && g->nrows){
+		const uint32_t n_sample = (uint32_t)std::min<uint64_t>(g->nrows, 4096);
+		unsigned long long *d_probe = nullptr, h_probe[2] = {0, 0};
+		if(hipMalloc((void**)&d_probe, 2*sizeof(unsigned long long)) == hipSuccess){
+			hipError_t e = hipMemsetAsync(d_probe, 0, 2*sizeof(unsigned long long), ctx->stream);
+			if(e == hipSuccess){
+				hipLaunchKernelGGL(density_probe_kernel, dim3(n_sample), dim3(256), 0, ctx->stream, g->d_bits, g->stride, g->nrows, g->d_valid, n_sample, d_probe);
+				hipLaunchKernelGGL(column_density_probe_kernel, dim3((uint32_t)((g->next_byte + 255)/256)), dim3(256), 0, ctx->stream, g->d_bits, g->stride, g->nrows, g->d_valid,
+				                   g->next_byte, n_sample, (unsigned int*)(d_probe + 1));
+				e = hipMemcpyAsync(h_probe, d_probe, sizeof(h_probe), hipMemcpyDeviceToHost, ctx->stream);
+			}
+			if(e == hipSuccess){ e = hipStreamSynchronize(ctx->stream); }
+			if(e == hipSuccess){
+				g->density = (double)h_probe[0]/((double)n_sample*(double)g->num_columns);
+				g->density_max = (double)(h_probe[1] & 0xFFFFFFFFull)/(double)n_sample;
+			}
+			else{ (void)hipGetLastError(); }
+			(void)hipFree(d_probe);
+		}
+	}
 	HIP_TRY(hipStreamSynchronize(ctx->stream));
 	release_mapping(ctx);          // the last file's copies are done
 	g->finalized = true;

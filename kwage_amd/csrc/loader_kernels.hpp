@@ -147,6 +147,45 @@ __global__ void gather_rows_kernel(const uint8_t *db, uint64_t stride, const uin
 }
 
 
+// Share of set bits among the real columns of `n_sample` rows spread evenly over the matrix: one workgroup per sampled
+// row.  What the early exit at threshold < 1 needs to know before it can rule a column out after the first k-mers of a
+// long query (engine.hip: the truncated count walk) -- an estimate, never a condition of correctness.
+__global__ __launch_bounds__(256) void density_probe_kernel(const uint8_t *db, uint64_t stride, uint64_t nrows, const uint8_t *valid, uint32_t n_sample,
+                                                            unsigned long long *set_bits)
+{
+	const uint64_t row = (uint64_t)blockIdx.x*nrows/n_sample;
+	const dwords4 *r = reinterpret_cast<const dwords4*>(db + row*stride), *v = reinterpret_cast<const dwords4*>(valid);
+	unsigned long long c = 0;
+	for(uint64_t u = threadIdx.x; u < stride/16; u += blockDim.x){
+		const dwords4 x = r[u] & v[u];
+		c += __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
+	}
+	for(int d = 32; d >= 1; d >>= 1){ c += __shfl_down(c, d); }
+	if((threadIdx.x & 63) == 0 && c){ atomicAdd(set_bits, c); }
+}
+
+// The DENSEST column among the same sampled rows: one thread per byte of a row (eight columns), its eight counts over the
+// n_sample rows, the largest of them into *max_count.  Columns are not equally dense -- every sample's filter has its own
+// fill -- and a bound that rules out the average column leaves every 128-byte group alive that holds a denser one.
+__global__ __launch_bounds__(256) void column_density_probe_kernel(const uint8_t *db, uint64_t stride, uint64_t nrows, const uint8_t *valid, uint64_t row_bytes,
+                                                                   uint32_t n_sample, unsigned int *max_count)
+{
+	const uint64_t b = (uint64_t)blockIdx.x*blockDim.x + threadIdx.x;
+	if(b >= row_bytes){ return; }
+	const uint32_t real = valid[b];
+	uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	for(uint32_t i = 0; i < n_sample; ++i){
+		const uint32_t x = db[((uint64_t)i*nrows/n_sample)*stride + b] & real;
+#pragma unroll
+		for(int k = 0; k < 8; ++k){ cnt[k] += (x >> k) & 1u; }
+	}
+	uint32_t m = 0;
+#pragma unroll
+	for(int k = 0; k < 8; ++k){ m = max(m, cnt[k]); }
+	if(m){ atomicMax(max_count, m); }
+}
+
+
 // The gather kernels' access pattern on an empty block, to compare candidate PLACEMENTS of a matrix (loader.hip,
 // choose_placement): every wave reads `rows_per_wave` pseudo-random rows, four at a time, `chunks` KiB-steps of each
 // (`lanes` lanes x 16 B per step, never past the row's stride).  One workgroup of 8 waves per CU (dynamic LDS pad).

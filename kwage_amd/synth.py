@@ -46,6 +46,11 @@ WORKLOADS: Dict[str, Workload] = {
     # few LONG queries against C2's matrix (the early-exit path's other extreme: 200 x 5 kb)
     "c2q5k": Workload("200 x 5 kb queries against 100k samples x 2^23-bit filters, 1 hash, t=1.0", 100_000, 23, 31, 1, 200, 5000, 1.0,
                       num_genomes=32, genome_len=50_000),
+    # ... and at t = 0.8: the early-exit path's truncated count walk (few long queries, the count path)
+    "c2q5kt": Workload("200 x 5 kb queries against 100k samples x 2^23-bit filters, 1 hash, t=0.8", 100_000, 23, 31, 1, 200, 5000, 0.8,
+                       num_genomes=32, genome_len=50_000),
+    "c2q100kt": Workload("10 x 100 kb queries against 100k samples x 2^23-bit filters, 1 hash, t=0.8", 100_000, 23, 31, 1, 10, 100_000, 0.8,
+                         num_genomes=8, genome_len=400_000),
     # BASELINE.json configs[2]
     "c3": Workload("C3: 1M samples x 2^20-bit filters, 100k x 150 bp queries, 1 hash, t=1.0", 1_000_000, 20, 31, 1,
                    100_000, 150, 1.0, num_genomes=64, genome_len=150_000),

@@ -406,6 +406,67 @@ def test_early_exit_screen_then_refine(ka, ctx, oracle, n_cols, num_hash, densit
     g.close()
 
 
+@pytest.mark.parametrize("n_cols,num_hash,q8", [(20000, 1, 64), (100000, 2, 160), (40000, 3, 190)])
+def test_early_exit_long_queries_truncated_walk(ka, ctx, oracle, n_cols, num_hash, q8):
+    """FEW LONG queries at t < 1 with early exit: the truncated count walk -- the persistent count kernel over the first
+    k-mers of every query (as many as the bound max + remaining < threshold needs before it can rule out the matrix's
+    DENSEST column, sampled at finalize), the columns that can still reach the threshold handed over with their counters
+    (after the tree has summed the parts of pairs cut across dozens of waves), their remaining k-mers counted by the refine
+    launch.  Exact, mutated and foreign queries of 3 k ... 40 k positions (14 and 20 counter planes), natural wave counts and
+    shares of a handful of positions, lists of five places (nearly every pair is then counted to the end by the wave that
+    holds it).  Every variant returns the list of the search without early exit, which is checked against the oracle on
+    the rows read back from the device."""
+    rng = np.random.default_rng(n_cols + num_hash)
+    k, L = 31, 18                                  # (2^18 rows: the planted columns stay well below all ones -- the densest column plans the truncation)
+    g = ka.Group(ctx, k, num_hash, L, n_cols)
+    g.add_random_columns(n_cols, 77 + num_hash, q8)
+    genome = rand_seq(rng, 42000)
+    gb = ka.Batch(ctx, [genome])
+    _, rows = ka.hash_batch(ctx, k, num_hash, L, gb)
+    gb.close()
+    cols = sorted({0, 1030, n_cols // 2, n_cols - 1})
+    for col in cols:
+        r = rows[0].reshape(-1)
+        g.set_bits(r, np.full(r.shape, col, dtype=np.uint64))
+    g.finalize()
+    seqs3 = [genome[:3000], genome[100:20100], rand_seq(rng, 12000), genome[5:40005], rand_seq(rng, 3000), genome[7:9007]]
+    for j in (1, 3):                               # substitutions every ~90 bases: counts between the threshold and num_query_kmer
+        q = list(seqs3[j])
+        for pos in range(11, len(q), 90):
+            q[pos] = "ACGT"[("ACGT".index(q[pos]) + 1) % 4]
+        seqs3.append("".join(q))
+    b3 = ka.Batch(ctx, seqs3)
+    used = set()
+    for thr in (0.9, 0.8, 0.5):
+        ref = g.search(b3, thr, 0)
+        thr32 = float(np.float32(thr))
+        per_q = ref.per_query()
+        for qi in (0, 2, 6):                         # against the oracle on the rows these queries address, read back from HBM
+            kmers = oracle.unique_kmers(seqs3[qi], k)
+            matrix = g.read_rows(oracle.row_indices(kmers, k, num_hash, L).reshape(-1))
+            assert per_q[qi] == oracle.search_row_matrix(matrix, num_hash, n_cols, len(kmers), thr32), (n_cols, thr, qi)
+        assert {c for c, _ in per_q[0]} >= set(cols)
+        for waves in (0, 7, 3001):
+            with ctx.tuning(count_walk_min_rows=1, count_walk_waves=waves):
+                for rep in range(2):
+                    r = g.search(b3, thr, ka.SEARCH_EARLY_EXIT)
+                    used.add((thr, r.search_kernel))
+                    assert np.array_equal(r.hits, ref.hits) and np.array_equal(r.num_query_kmer, ref.num_query_kmer), (n_cols, thr, waves, rep, r.search_kernel)
+        # lists of five places: nearly every pair finds them full and is counted to the end by the wave that holds it
+        for waves in (0, 3001):
+            with ctx.tuning(count_walk_min_rows=1, count_walk_waves=waves, refine_list_cap=5):
+                r = g.search(b3, thr, ka.SEARCH_EARLY_EXIT)
+                assert np.array_equal(r.hits, ref.hits) and np.array_equal(r.num_query_kmer, ref.num_query_kmer), (n_cols, thr, waves, "full lists", r.search_kernel)
+        with ctx.tuning(count_trunc=0):
+            r = g.search(b3, thr, ka.SEARCH_EARLY_EXIT)
+            assert "trunc" not in r.search_kernel and np.array_equal(r.hits, ref.hits)
+    assert any(t == 0.9 and "trunc>+refine<" in name for t, name in used), used
+    left = ctx.scratch_nonzero()
+    assert not any(left.values()), left              # the tree's arrival counters are zero again
+    b3.close()
+    g.close()
+
+
 @pytest.mark.parametrize("n_cols,n_queries", [(1, 12000), (3, 5000), (9, 1500), (8193, 2), (8193, 33), (100000, 1), (100001, 17), (70000, 300)])
 def test_device_hit_sort_key_widths(ka, ctx, n_cols, n_queries, monkeypatch):
     """The device sort packs (query, column) into query_bits + column_bits of one key: widths from 0 bits (one

@@ -60,7 +60,7 @@ import json; l=json.loads(open('$O/r05_long1t_bench.json').read().strip().splitl
   ;;
 lines)
   python bench.py --steps 20 --warmup 5 > $O/r05_c2_bench.json 2> $O/r05_c2_bench.err
-  for w in c2t c4 c5s c5 c3; do python bench.py --workload $w --no-cpu-baseline --steps 10 --warmup 3 > $O/r05_${w}_bench.json 2>/dev/null; echo "line $w done"; done
+  for w in c2t c4 c5s c5 c3 c2q5kt c2q100kt; do python bench.py --workload $w --no-cpu-baseline --steps 10 --warmup 3 > $O/r05_${w}_bench.json 2>/dev/null; echo "line $w done"; done
   for w in c2 c2t c2q5k c3; do python bench.py --workload $w --early-exit --no-cpu-baseline --also none --steps 100 --warmup 5 > $O/r05_ee_${w}_bench.json 2>/dev/null; echo "ee line $w done"; done
   ;;
 rocprof)
@@ -80,7 +80,7 @@ rocprof)
   cd $R
   ;;
 pmc)
-  python tools/pmc_refresh.py --round r05 c2 c2+bands c2t c3 c4 c5s c5 narrow narrowt long1t c2+ee c3+ee c2q5k+ee c2t+ee > $O/pmc_refresh.txt 2>&1 || true
+  python tools/pmc_refresh.py --round r05 c2 c2+bands c2t c3 c4 c5s c5 narrow narrowt long1t c2+ee c3+ee c2q5k+ee c2t+ee c2q5kt+ee c2q100kt+ee > $O/pmc_refresh.txt 2>&1 || true
   cp gpurun_out/pmc_r05/pmc_traffic.json gpurun_out/pmc_r05/r05_*_pmc_fetch_size.json $O/
   tail -20 $O/pmc_refresh.txt
   ;;
@@ -138,6 +138,10 @@ l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c2 of $k', l['ro
   ;;
 two_ranks)
   KWAGE_BENCH_BACKEND=gloo KWAGE_BENCH_ONE_DEVICE=1 python bench.py --gpus 2 --also c3_strong --no-cpu-baseline --steps 10 --warmup 3 > $O/r05_c2_bench_two_ranks_one_gpu_gloo_also_c3_strong.json 2>$O/two_ranks.err || tail -20 $O/two_ranks.err
+  ;;
+trunc_ab)
+  for shape in "200 x 5 kb" "10 x 100 kb" "1 x 10 kb"; do for tr in 0 1; do echo "== KWAGE_COUNT_TRUNC=$tr"; KWAGE_COUNT_TRUNC=$tr python tools/step_breakdown.py "$shape" 2>&1 | grep -E "t=0.8 "; done; done > $O/r05_count_trunc_ab.txt 2>&1
+  cat $O/r05_count_trunc_ab.txt | cut -c1-230
   ;;
 line)
   python bench.py --steps 20 --warmup 5 > $O/r05_c2_bench.json 2> $O/r05_c2_bench.err || { tail -30 $O/r05_c2_bench.err; exit 1; }
