@@ -355,7 +355,8 @@ template <bool TRUNC>
 void launch_count_walk_planes(uint32_t planes, const SearchArgs &a, const CountWalkArgs &wa, const RefineArgs &ra, const WalkShape &w, hipStream_t s, const StageEvents &ge)
 {
 	switch(planes){
-		case 7: launch_count_walk_nh<7, TRUNC>(a, wa, ra, w, s, ge); break;
+		// (the truncated form counts a query of up to 127 k-mers with ten planes: the caller sizes slab and lists for that)
+		case 7: launch_count_walk_nh<TRUNC ? 10 : 7, TRUNC>(a, wa, ra, w, s, ge); break;
 		case 10: launch_count_walk_nh<10, TRUNC>(a, wa, ra, w, s, ge); break;
 		case 14: launch_count_walk_nh<14, TRUNC>(a, wa, ra, w, s, ge); break;
 		case 20: launch_count_walk_nh<20, TRUNC>(a, wa, ra, w, s, ge); break;
@@ -752,6 +753,7 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 		// pm = that density ^ num_hash -- an estimate that decides how much is read, never what is reported.
 		if(a.early_exit && tn.ee_refine && tn.count_trunc && tn.count_walk && !narrow && tn.force_segs <= 0 && a.units_per_row >= WAVE && L->total_pos > 0){
 			const uint32_t nq = a.n_queries;
+			const uint32_t tplanes = std::max<uint32_t>(planes, 10);      // (no 7-plane instantiation of this form)
 			// The DENSEST column decides: a 128-byte group stays alive while any of its 1024 columns can still reach the threshold,
 			// and columns are not equally dense (every sample's filter has its own fill; the synthetic workloads' planted columns
 			// are 15 % denser than the rest).  + 3 sigma of what 4096 sampled rows can say about one column.
@@ -798,13 +800,13 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 			// a pair that finds them full is counted to the end by the wave that holds it (count_walk_kernel).
 			const uint64_t tiles = (uint64_t)nq*a.chunks;
 			const uint64_t units_cap = std::max<uint64_t>(4096, std::min<uint64_t>(units_worst, (1ull << 30)/((uint64_t)up*128 + sizeof(RefineUnit))));
-			if(walked*10 <= L->total_pos*7 && slots*a.num_hash >= min_rows && seg <= 16376 && rest_total > 0 && tiles*8*(uint64_t)planes*128 <= (1ull << 30)){
+			if(walked*10 <= L->total_pos*7 && slots*a.num_hash >= min_rows && seg <= 16376 && rest_total > 0 && tiles*8*(uint64_t)tplanes*128 <= (1ull << 30)){
 				const uint64_t want_waves = (tn.count_walk_waves > 0) ? std::min<uint64_t>((uint64_t)tn.count_walk_waves, slots)
 					: std::max<uint64_t>(1, std::min<uint64_t>(chip_waves, slots*a.num_hash/WALK_MIN_ROWS_PER_WAVE));
 				const WalkShape shape = walk_shape(tn, want_waves, ncu);
 				const uint64_t waves = (uint64_t)shape.wgs*shape.wg_waves;
 				RefineSetup rs;
-				if((rc = refine_setup(sl, tn, a, rest_total, 0, (uint32_t)seg, (uint64_t)planes*128, (uint64_t)up*128, tiles, waves, ncu, gs, &rs, tiles, tiles*8, units_cap))){ return rc; }
+				if((rc = refine_setup(sl, tn, a, rest_total, 0, (uint32_t)seg, (uint64_t)tplanes*128, (uint64_t)up*128, tiles, waves, ncu, gs, &rs, tiles, tiles*8, units_cap))){ return rc; }
 				rs.ra.seg_rows = (uint32_t)seg;
 				if((rc = sl->trunc_dev.reserve(((uint64_t)nq + 1)*sizeof(uint64_t) + (uint64_t)nq*sizeof(uint32_t)))){ return rc; }
 				HIP_TRY(hipMemcpyAsync(sl->trunc_dev.p, sl->trunc_host.p, ((uint64_t)nq + 1)*sizeof(uint64_t) + (uint64_t)nq*sizeof(uint32_t), hipMemcpyHostToDevice, gs));
@@ -812,16 +814,16 @@ int launch_search_stage(Slot *sl, kwage_group *g, kwage_batch *b, const KmerLayo
 				wa.total_slots = slots;
 				wa.per_wave = (slots + waves - 1)/waves;
 				wa.coltiles = a.chunks;
-				if((rc = sl->cwalk_slab.reserve(waves*2*planes*1024))){ return rc; }
+				if((rc = sl->cwalk_slab.reserve(waves*2*tplanes*1024))){ return rc; }
 				if((rc = reserve_zeroed(sl->cwalk_arrived, waves*CWALK_LEVELS*sizeof(uint32_t), gs))){ return rc; }
 				wa.slab = (uint32_t*)sl->cwalk_slab.p;
 				wa.arrived = (uint32_t*)sl->cwalk_arrived.p;
 				wa.slot_off = (const uint64_t*)sl->trunc_dev.p;
 				wa.kcut = (const uint32_t*)((const uint64_t*)sl->trunc_dev.p + nq + 1);
 				a.segs = 1;
-				snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_walk_kernel<%u,%u,trunc>+refine<%d>", planes, std::min(a.num_hash, 5u), up);
-				launch_count_walk_planes<true>(planes, a, wa, rs.ra, shape, gs, ge);
-				launch_count_refine_and_emit(planes, up, a, rs, gs, ge);
+				snprintf(sl->kernel_name, sizeof(sl->kernel_name), "count_walk_kernel<%u,%u,trunc>+refine<%d>", tplanes, std::min(a.num_hash, 5u), up);
+				launch_count_walk_planes<true>(tplanes, a, wa, rs.ra, shape, gs, ge);
+				launch_count_refine_and_emit(tplanes, up, a, rs, gs, ge);
 				HIP_TRY(hipGetLastError());
 				return KWAGE_OK;
 			}

@@ -1691,23 +1691,29 @@ __global__ __launch_bounds__(SEARCH_THREADS) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
 		for(int p = 0; p < PLANES; ++p){ plane[p] = (u32x4)(0u); }
 		bool may_hand_over = !lists_full, gone = false;
+		// A 128-byte group none of whose columns can reach the threshold any more is not READ any more (its eight lanes sit the
+		// loads out; their counters stay where they are, below the bound for good): a tile that goes on -- more groups alive than
+		// the refine launch takes, a column not on track yet, the lists full -- costs what its live groups cost.
+		bool alive = true;
 		uint32_t i = 0;
 		for(; i + KPS <= nk; ){
-			u32x4 m[KPS];
+			if(alive){
+				u32x4 m[KPS];
 #pragma unroll
-			for(int u = 0; u < KPS; ++u){
-				u32x4 x[NH];
+				for(int u = 0; u < KPS; ++u){
+					u32x4 x[NH];
 #pragma unroll
-				for(int h = 0; h < NH; ++h){
-					const uint32_t r = rq[(i + u)*NH + h];
-					x[h] = load16<true>(reinterpret_cast<const u32x4*>(a.db + (uint64_t)r*a.stride) + unit);
+					for(int h = 0; h < NH; ++h){
+						const uint32_t r = rq[(i + u)*NH + h];
+						x[h] = load16<true>(reinterpret_cast<const u32x4*>(a.db + (uint64_t)r*a.stride) + unit);
+					}
+					m[u] = x[0];
+#pragma unroll
+					for(int h = 1; h < NH; ++h){ m[u] &= x[h]; }    // kmer_match &= slice
 				}
-				m[u] = x[0];
-#pragma unroll
-				for(int h = 1; h < NH; ++h){ m[u] &= x[h]; }    // kmer_match &= slice
+				if constexpr(KPS == 8){ planes_add8<PLANES>(plane, m); }
+				else{ planes_add4<PLANES>(plane, m[0], m[1], m[2], m[3]); }
 			}
-			if constexpr(KPS == 8){ planes_add8<PLANES>(plane, m); }
-			else{ planes_add4<PLANES>(plane, m[0], m[1], m[2], m[3]); }
 			i += KPS;
 			const uint32_t remaining = nk - i;
 			if((i & check_mask) != 0 || thr <= remaining){ continue; }
@@ -1716,6 +1722,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) __attribute__((amdgpu_waves_per_eu(
 			const uint32_t gb = group_bits(__ballot((can.x | can.y | can.z | can.w) != 0));
 			const uint32_t ngroups = __popc(gb);
 			if(ngroups == 0){ gone = true; break; }
+			alive = ((gb >> (lane >> 3)) & 1u) != 0;
 			if(may_hand_over && ngroups <= ra.max_groups && remaining >= ra.min_rows){
 				// Only columns that are ON TRACK -- matching at the threshold's rate so far: count >= threshold x i / n -- are worth
 				// the refine launch, which counts every handed-over group to the END of the list.  A column that can still reach the
@@ -1735,6 +1742,7 @@ __global__ __launch_bounds__(SEARCH_THREADS) __attribute__((amdgpu_waves_per_eu(
 		}
 		if(gone){ continue; }
 		for(; i < nk; ++i){
+			if(!alive){ continue; }
 			u32x4 mm = ~(u32x4)(0u);
 #pragma unroll
 			for(int h = 0; h < NH; ++h){

@@ -80,11 +80,9 @@ def main():
             continue
         ng = N_GROUPS.get(wl, 1)
         dominant = max(gather, key=lambda k: sum(gather[k]))
-        # (a stage of several launches -- screen + refine + emit -- counts once per step: the dispatches of its first kernel)
-        first = [k for k in gather if "_screen_kernel" in k]
-        if not first and any("_refine_kernel" in k for k in gather):    # (the truncated count walk hands over to the refine launches)
-            first = [k for k in gather if "count_walk_kernel" in k]
-        steps = (len(gather[first[0]]) if first else sum(len(v) for v in gather.values())) / float(ng)
+        # (a stage of several launches -- screen or truncated walk, then refine + emit -- counts once per step and group: the
+        # dispatches of its FIRST kernel, which is the one gather kernel of the stage that is not a refine launch)
+        steps = sum(len(v) for k, v in gather.items() if "_refine" not in k) / float(ng)
         per_step = sum(sum(v) for v in gather.values()) * 1024.0 * factor / steps
         summary = {"workload": wl, "bench_line": line, "calibration": {"stream_read_dispatches": len(cal), "known_bytes": known, "factor": factor},
                    "kernels": {short(k): {"dispatches": len(v), "FETCH_SIZE_avg_KiB": sum(v) / len(v)} for k, v in agg.items()}}

@@ -80,7 +80,7 @@ rocprof)
   cd $R
   ;;
 pmc)
-  python tools/pmc_refresh.py --round r05 c2 c2+bands c2t c3 c4 c5s c5 narrow narrowt long1t c2+ee c3+ee c2q5k+ee c2t+ee c2q5kt+ee c2q100kt+ee > $O/pmc_refresh.txt 2>&1 || true
+  python tools/pmc_refresh.py --round r05 c2 c2+bands c2t c3 c4 c5s c5 narrow narrowt long1t c2+ee c3+ee c2q5k+ee c2t+ee c2q5kt+ee c2q100kt+ee c4+ee c5s+ee c5+ee > $O/pmc_refresh.txt 2>&1 || true
   cp gpurun_out/pmc_r05/pmc_traffic.json gpurun_out/pmc_r05/r05_*_pmc_fetch_size.json $O/
   tail -20 $O/pmc_refresh.txt
   ;;
@@ -142,6 +142,10 @@ two_ranks)
 trunc_ab)
   for shape in "200 x 5 kb" "10 x 100 kb" "1 x 10 kb"; do for tr in 0 1; do echo "== KWAGE_COUNT_TRUNC=$tr"; KWAGE_COUNT_TRUNC=$tr python tools/step_breakdown.py "$shape" 2>&1 | grep -E "t=0.8 "; done; done > $O/r05_count_trunc_ab.txt 2>&1
   cat $O/r05_count_trunc_ab.txt | cut -c1-230
+  ;;
+c5_groups)
+  python tools/c5_ee_groups.py > $O/r05_c5_ee_groups.txt 2>&1
+  cut -c1-300 $O/r05_c5_ee_groups.txt
   ;;
 line)
   python bench.py --steps 20 --warmup 5 > $O/r05_c2_bench.json 2> $O/r05_c2_bench.err || { tail -30 $O/r05_c2_bench.err; exit 1; }
