@@ -158,6 +158,7 @@ _SIGNATURES = [
     ("kwage_bloom_counter_finish", C.c_int, [_P, C.c_float, C.c_uint32, C.POINTER(SampleInfo), C.c_char_p, C.POINTER(Params), C.POINTER(C.c_int)]),
     ("kwage_repack_db", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_char_p), C.c_uint32]),
     ("kwage_db_read_header", C.c_int, [C.c_char_p, C.POINTER(DbHeader)]),
+    ("kwage_db_read_slices", C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.c_uint64, C.c_void_p]),
     ("kwage_db_compress", C.c_int, [C.c_char_p, C.c_char_p, C.c_uint32]),
     ("kwage_db_decompress", C.c_int, [C.c_char_p, C.c_char_p]),
     ("kwage_dbinfo_open", C.c_int, [C.c_char_p, C.POINTER(_P)]),
