@@ -431,7 +431,7 @@ int kwage_db_read_header(const char *path, kwage_db_header *out);
 
 /* The listed slices of one .db file (host only; raw or compressed), n * ceil(num_filter / 8) bytes in list order:
  * what the reference's seekg + read per addressed slice fetches (kwage.cpp:414-416), and what the sparse groups
- * (kwage_group_create_sparse) are loaded through -- raw files out of a read-only mapping, several threads for long lists. */
+ * (kwage_group_create_sparse) are loaded through -- several threads for long lists. */
 int kwage_db_read_slices(const char *path, const uint32_t *rows, uint64_t n, unsigned char *out);
 
 /* Compressed container (host only).  The reference ships a slice CODEC (slice_z.h: raw deflate,

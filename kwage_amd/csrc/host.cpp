@@ -19,7 +19,6 @@
 #include <thread>
 
 #include <fcntl.h>
-#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -343,8 +342,6 @@ bool DbSliceSource::open(const std::string &path, std::string &err)
 
 void DbSliceSource::close()
 {
-	if(map){ (void)munmap(const_cast<unsigned char*>(map), (size_t)map_len); }
-	map = nullptr; map_len = 0; map_tried = false;
 	if(fd >= 0){ ::close(fd); fd = -1; }
 	offsets.clear();
 }
@@ -410,38 +407,6 @@ bool DbSliceSource::read_row_list(const uint32_t *rows, uint64_t n, unsigned cha
 	const unsigned nt = (n >= 4096 && max_threads > 1) ? host_threads(max_threads) : 1;
 	std::atomic<uint64_t> next(0);
 	std::atomic<bool> bad(false);
-	// Raw files: the slices are copied out of a read-only mapping of the file -- a pread per 256-byte slice is a system call
-	// per slice, three times what the copy costs out of the page cache (KWAGE_SPARSE_MMAP=0, or a mapping that fails: pread).
-	static const bool mmap_ok = []() { const char *e = getenv("KWAGE_SPARSE_MMAP"); return !(e && e[0] == '0'); }();
-	if(header.compression == KWAGE_COMPRESSION_NONE && mmap_ok && !map_tried && n >= 64){
-		map_tried = true;
-		const uint64_t len = DB_HEADER_BYTES + nrows*slice_size;      // (open() checked that the file is at least this long)
-		void *m = mmap(nullptr, (size_t)len, PROT_READ, MAP_SHARED, fd, 0);
-		if(m != MAP_FAILED){
-			(void)madvise(m, (size_t)len, MADV_RANDOM);
-			map = (const unsigned char*)m;
-			map_len = len;
-		}
-	}
-	if(map){
-		const unsigned char *base = map + DB_HEADER_BYTES;
-		const uint64_t w = slice_size;
-		auto copy = [&]() {
-			const uint64_t grain = 4096, ahead = 16;
-			for(uint64_t b = next.fetch_add(grain); b < n; b = next.fetch_add(grain)){
-				const uint64_t e = std::min(n, b + grain);
-				for(uint64_t i = b; i < e; ++i){
-					if(i + ahead < e){ __builtin_prefetch(base + (uint64_t)rows[i + ahead]*w); }
-					memcpy(dst + i*w, base + (uint64_t)rows[i]*w, w);
-				}
-			}
-		};
-		std::vector<std::thread> pool;
-		for(unsigned t = 1; t < nt; ++t){ pool.emplace_back(copy); }
-		copy();
-		for(auto &t : pool){ t.join(); }
-		return true;
-	}
 	auto work = [&]() {
 		z_stream z;
 		const bool packed = (header.compression != KWAGE_COMPRESSION_NONE);

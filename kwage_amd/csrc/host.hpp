@@ -64,10 +64,6 @@ struct DbSliceSource {
 	kwage_db_header header{};
 	uint64_t slice_size = 0, nrows = 0;
 	std::vector<uint64_t> offsets;          // compressed only: nrows + 1 absolute file offsets
-	// raw files, read_row_list: the file mapped read-only (made at the first list; nullptr: pread per slice)
-	const unsigned char *map = nullptr;
-	uint64_t map_len = 0;
-	bool map_tried = false;
 	bool open(const std::string &path, std::string &err);
 	bool read_rows(uint64_t r0, uint64_t nr, unsigned char *dst, std::string &err);   // nr*slice_size bytes
 	// the listed slices (any order), n*slice_size bytes: what the reference's seekg + read per addressed slice does

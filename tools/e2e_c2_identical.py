@@ -172,15 +172,6 @@ def main():
         result["whole_database_load"] = {"threshold": thr0, "wall_s": round(t_full, 3), "same_report": bool(same_full),
                                          "verbose": [ln.strip() for ln in err_full.splitlines() if "loaded" in ln and "GB/s" in ln]}
         ok_all = ok_all and same_full
-        # ... and with a pread per addressed slice instead of the copy out of the file's mapping (the loader before round 5's last change)
-        t_pread, out_pread, err_pread = run(native.KWAGE_BIN, thr0, dict(os.environ, KWAGE_VERBOSE="1", KWAGE_SPARSE_MMAP="0"), 2)
-        same_pread = oracle.parse_csv(out_pread) == oracle.parse_csv(run(native.KWAGE_BIN, thr0, dict(os.environ), 1)[1])
-        say("t = %g with KWAGE_SPARSE_MMAP=0 (a pread per addressed slice instead of the copy out of the file's mapping), best of 2: wall %.2f s; same report: %s" % (thr0, t_pread, same_pread))
-        for ln in [ln.strip() for ln in err_pread.splitlines() if ("loaded" in ln and "GB/s" in ln)]:
-            say("      " + ln)
-        result["pread_per_slice"] = {"threshold": thr0, "wall_s": round(t_pread, 3), "same_report": bool(same_pread),
-                                     "verbose": [ln.strip() for ln in err_pread.splitlines() if "loaded" in ln and "GB/s" in ln]}
-        ok_all = ok_all and same_pread
         result["reports_identical"] = bool(ok_all)
         say("reports identical: %s" % ok_all)
         os.makedirs(os.path.dirname(args.out), exist_ok=True)
