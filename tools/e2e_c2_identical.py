@@ -162,6 +162,15 @@ def main():
             for ln in split:
                 say("      " + ln)
             result["runs"]["%g" % thr] = rec
+        # the reference with the HOST THREADS THE GPU PROGRAM USES for its file reads (16: a GPU's share of the host's CPUs on this
+        # pool): the 49-thread figure above is the reference at its best on a whole 256-CPU host
+        if os.access(oracle.REF_KWAGE, os.X_OK):
+            result["reference_16_threads"] = {}
+            for thr in [float(x) for x in args.thresholds.split(",")]:
+                t16, out16, _ = run(oracle.REF_KWAGE, thr, dict(os.environ, OMP_NUM_THREADS="16"), 2)
+                say("t = %g: reference kwage with OMP_NUM_THREADS=16 (the host threads kwage_amd/bin/kwage reads the files with), best of 2: wall %.2f s = %.2f G bit-tests/s"
+                    % (thr, t16, bit_tests / t16 / 1e9))
+                result["reference_16_threads"]["%g" % thr] = {"wall_s": round(t16, 3), "g_bit_tests_per_s": round(bit_tests / t16 / 1e9, 2)}
         # the same command with the WHOLE database loaded (KWAGE_SPARSE=0): what a host that keeps the database resident pays once
         thr0 = float(args.thresholds.split(",")[0])
         t_full, out_full, err_full = run(native.KWAGE_BIN, thr0, dict(os.environ, KWAGE_VERBOSE="1", KWAGE_SPARSE="0"), 1)
