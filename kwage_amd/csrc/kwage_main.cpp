@@ -486,6 +486,124 @@ int main(int argc, char *argv[])
 				}
 				uint64_t pass_left = budget;
 				const bool one_unit_per_pass = env_u64("KWAGE_ONE_UNIT_PER_PASS", 0) != 0;      // measurement hook: the schedule before units shared passes
+
+				// ---- t = 1, small query set, slices fetched on demand: SCREEN, THEN FETCH.  The reference's early exit
+				// (kwage.cpp:466-481) gives a (query, file) pair up after a handful of slices and never READS the rest -- for a one-shot
+				// run against files in the page cache that is most of its speed.  Here: the slices of every query's first
+				// KWAGE_SPARSE_SCREEN (default 32) k-mers are fetched from every file and searched (a column that misses one of them
+				// cannot hold all of the query's), then only the files that hold a candidate column are fetched again, with the slices
+				// of the queries that have one, and those queries searched in full.  Same report; I/O of the order the reference's.
+				const uint64_t screen_kmers = env_u64("KWAGE_SPARSE_SCREEN", 32);
+				auto load_sparse_unit = [&](const kwage_params &p, const vector<uint32_t> &mem, const vector<uint32_t> &rows, ResidentUnit &u) {
+					uint64_t span_bytes = 0;
+					vector<const char*> paths;
+					for(uint32_t fi : mem){
+						span_bytes = (span_bytes + 15)/16*16 + ((uint64_t)files[fi].header.num_filter + 7)/8;
+						paths.push_back(files[fi].path.c_str());
+					}
+					u.kmer_len = p.kmer_len;
+					check(kwage_group_create_sparse(ctx, &p, span_bytes*8, rows.data(), rows.size(), &u.group));
+					vector<uint64_t> firsts(paths.size());
+					check(kwage_group_add_db_files(u.group, paths.data(), (uint32_t)paths.size(), firsts.data(), nullptr));
+					for(size_t m = 0; m < mem.size(); ++m){
+						DbFileEntry &f = files[mem[m]];
+						f.first_column = firsts[m];
+						u.cols.files.push_back(&f);
+						u.cols.file_index.push_back(mem[m]);
+					}
+					check(kwage_group_finalize(u.group));
+					gb_loaded += (double)kwage_group_row_bytes(u.group)*(double)rows.size()/1e9;
+				};
+				auto span_fits = [&](const vector<uint32_t> &mem, uint64_t nrows) {
+					uint64_t span_bytes = 0;
+					for(uint32_t fi : mem){ span_bytes = (span_bytes + 15)/16*16 + ((uint64_t)files[fi].header.num_filter + 7)/8; }
+					return ((span_bytes + 127)/128*128)*nrows <= budget;
+				};
+				auto screen_then_fetch = [&](const kwage_params &p, const vector<uint32_t> &members, size_t n_rows_all) -> bool {
+					struct Drop { kwage_group *&g; ~Drop() { if(g){ kwage_group_destroy(g); g = nullptr; } } };
+					const QueryBatch *full[2] = {&typed_all, &disk_all};
+					QueryBatch heads[2], subs[2];
+					const uint64_t head_len = screen_kmers + p.kmer_len - 1;
+					for(int s = 0; s < 2; ++s){
+						heads[s].clear();
+						subs[s].clear();
+						for(size_t i = 0; i < full[s]->size(); ++i){
+							const uint64_t o = full[s]->offsets[i], len = full[s]->offsets[i + 1] - o;
+							heads[s].add(full[s]->ids[i], full[s]->bases.substr(o, min(len, head_len)), nullptr);
+						}
+					}
+					vector<uint32_t> head_rows;
+					addressed_rows(ctx, p, heads[0], head_rows);
+					addressed_rows(ctx, p, heads[1], head_rows);
+					if(head_rows.empty() || head_rows.size()*4 > n_rows_all || !span_fits(members, head_rows.size())){ return false; }
+					double t0 = now_s();
+					vector<char> file_in(files.size(), 0);
+					{
+						ResidentUnit scr;
+						Drop drop{scr.group};
+						load_sparse_unit(p, members, head_rows, scr);
+						t_load += now_s() - t0;
+						t0 = now_s();
+						for(int s = 0; s < 2; ++s){
+							if(heads[s].size() == 0){ continue; }
+							kwage_batch *b = nullptr;
+							check(kwage_batch_create(ctx, heads[s].bases.data(), heads[s].offsets.data(), (uint32_t)heads[s].size(), &b));
+							kwage_result *res = nullptr;
+							const int rc = kwage_search(scr.group, b, 1.0f, 0, &res);
+							kwage_batch_destroy(b);
+							check(rc);
+							vector<char> keep(heads[s].size(), 0);
+							for(uint64_t i = 0; i < res->n_hits; ++i){
+								uint32_t fi = 0, local = 0;
+								scr.cols.locate(res->hits[i].column, fi, local);
+								file_in[fi] = 1;
+								keep[res->hits[i].query] = 1;
+							}
+							for(size_t i = 0; i < heads[s].size(); ++i){
+								// a head without a valid k-mer (N's) says nothing about a longer query: that query meets every file
+								const uint64_t len = full[s]->offsets[i + 1] - full[s]->offsets[i];
+								if(res->num_query_kmer[i] == 0 && len > head_len){
+									keep[i] = 1;
+									for(uint32_t fi : members){ file_in[fi] = 1; }
+								}
+								if(keep[i]){
+									subs[s].add(full[s]->ids[i], full[s]->bases.substr(full[s]->offsets[i], len), full[s]->deflines.empty() ? nullptr : &full[s]->deflines[i]);
+								}
+							}
+							kwage_result_free(res);
+						}
+						t_search += now_s() - t0;
+					}
+					vector<uint32_t> files2;
+					for(uint32_t fi : members){ if(file_in[fi]){ files2.push_back(fi); } }
+					if(verbose){
+						lock_guard<mutex> lk(merge_lock);
+						cerr << "[kwage] device " << devices[di] << " screened 2^" << p.log_2_filter_len << " slices: " << head_rows.size() << " slices of " << members.size()
+							<< " files for the first " << screen_kmers << " k-mers; " << (subs[0].size() + subs[1].size()) << " of " << (typed_all.size() + disk_all.size())
+							<< " queries hold a candidate, in " << files2.size() << " files" << endl;
+					}
+					if(files2.empty() || subs[0].size() + subs[1].size() == 0){ return true; }       // nothing can match
+					vector<uint32_t> rows2;
+					addressed_rows(ctx, p, subs[0], rows2);
+					addressed_rows(ctx, p, subs[1], rows2);
+					// the candidate files, as many at a time as the budget holds
+					for(size_t m0 = 0; m0 < files2.size(); ){
+						size_t m1 = m0 + 1;
+						while(m1 < files2.size() && span_fits(vector<uint32_t>(files2.begin() + m0, files2.begin() + m1 + 1), rows2.size())){ ++m1; }
+						t0 = now_s();
+						vector<ResidentUnit> unit(1);
+						Drop drop{unit[0].group};
+						load_sparse_unit(p, vector<uint32_t>(files2.begin() + m0, files2.begin() + m1), rows2, unit[0]);
+						t_load += now_s() - t0;
+						t0 = now_s();
+						PreloadedQueries typed(subs[0]), from_disk(subs[1]);
+						search_stream(ctx, unit, typed, cli.threshold, flags, max_batch_bases, local_cmdline);
+						search_stream(ctx, unit, from_disk, cli.threshold, flags, max_batch_bases, local_files);
+						t_search += now_s() - t0;
+						m0 = m1;
+					}
+					return true;
+				};
 				for(const auto &grp_entry : groups){
 					const vector<uint32_t> members = share_of(grp_entry.second, di);
 					if(members.empty()){ continue; }
@@ -502,6 +620,7 @@ int main(int argc, char *argv[])
 						addressed_rows(ctx, p, disk_all, rows);
 						if((sparse_mode == "1") || (uint64_t)rows.size()*8 <= (1ull << p.log_2_filter_len)){
 							if(rows.empty()){ continue; }          // no valid k-mer in any query: nothing can match (kwage.cpp:369-371)
+							if(screen_kmers && cli.threshold == 1.0f && screen_then_fetch(p, members, rows.size())){ continue; }
 							sparse_rows = make_shared<vector<uint32_t> >(std::move(rows));
 						}
 					}

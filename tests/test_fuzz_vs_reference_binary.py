@@ -142,6 +142,10 @@ def test_cli_equals_reference_binary(oracle, tmp_path, seed):
             # whole files with the query set preloaded, whole files with the queries streamed batch by batch
             assert _run(native.KWAGE_BIN, db, fasta, cmd, thr, fmt, {"KWAGE_SPARSE": "1"}) == got, (seed, thr, fmt)
             assert _run(native.KWAGE_BIN, db, fasta, cmd, thr, fmt, {"KWAGE_SPARSE": "0"}) == got, (seed, thr, fmt)
+            if float(np.float32(float(thr))) == 1.0:
+                # ... and, at t = 1, the sparse fetch screened on every query's first k-mers (2: even these short queries qualify; 0: never)
+                for head in ("2", "0"):
+                    assert _run(native.KWAGE_BIN, db, fasta, cmd, thr, fmt, {"KWAGE_SPARSE": "1", "KWAGE_SPARSE_SCREEN": head}) == got, (seed, thr, fmt, head)
             if seed % 4 == 0:
                 assert _run(native.KWAGE_BIN, db, fasta, cmd, thr, fmt, {"KWAGE_SPARSE_BASES": "1"}) == got, (seed, thr, fmt)
             if seed % 4 == 2:

@@ -573,9 +573,54 @@ def test_cli_matches_reference_output(ka, oracle, case):
         assert score(got) == score(exp)
     if len(case["db"]) == 1 and case["name"] != "multi":
         assert got == exp                               # single file: byte-identical
-    for mode in ({"KWAGE_SPARSE": "1"}, {"KWAGE_SPARSE": "0"}, {"KWAGE_SPARSE_BASES": "1"}):      # sparse fetch / whole files / streamed
+    # sparse fetch (at t = 1 screened on the first 32 / 2 k-mers of every query first, or not at all) / whole files / streamed
+    for mode in ({"KWAGE_SPARSE": "1"}, {"KWAGE_SPARSE": "1", "KWAGE_SPARSE_SCREEN": "2"}, {"KWAGE_SPARSE": "1", "KWAGE_SPARSE_SCREEN": "0"}, {"KWAGE_SPARSE": "0"}, {"KWAGE_SPARSE_BASES": "1"}):
         r2 = subprocess.run(args, cwd=cdir, capture_output=True, env=dict(os.environ, **mode))
         assert r2.returncode == 0 and r2.stdout == r.stdout, mode
+
+
+def test_cli_sparse_fetch_screened_on_first_kmers(oracle, tmp_path):
+    """`kwage` at t = 1 with slices fetched on demand: the slices of every query's first KWAGE_SPARSE_SCREEN k-mers come
+    first and only files with a candidate column are fetched for the rest (kwage_main.cpp, screen_then_fetch).  Same bytes
+    as without the screen and as the whole-file path, and the reference binary's lines: hits in some files only, a query
+    whose head holds no valid k-mer (N's) but whose tail does, one shorter than the head, one shorter than k, one with no
+    hit at all; with a budget that takes the candidate files one at a time; verbose line says what was screened."""
+    from kwage_amd import native
+    rng = np.random.default_rng(4242)
+    k, nh, L = 31, 2, 14
+    genome, other = rand_seq(rng, 3000), rand_seq(rng, 1500)
+    db = tmp_path / "db"
+    db.mkdir()
+    for f, (ncol, planted) in enumerate(((2048, genome), (300, None), (2048, other), (64, genome), (1000, None))):
+        img = _make_random_db(rng, L, ncol, 0.4)
+        if planted is not None:
+            for r in oracle.row_indices(oracle.unique_kmers(planted, k), k, nh, L).reshape(-1):
+                img[r, (5 + f) // 8] |= np.uint8(1 << ((5 + f) % 8))
+        infos = [oracle.FilterInfo(run_accession=oracle.str_to_accession("SRR%07d" % (f * 10000 + j + 1))) for j in range(ncol)]
+        oracle.write_db(str(db / ("f%d.db" % f)), k, nh, L, img, ncol, infos)
+    seqs = [genome[200:1700], "N" * 70 + genome[500:1500], rand_seq(rng, 900), genome[:40], "ACGT", other[100:1400].lower(), genome[1000:1300] + "N" + other[:300]]
+    fa = tmp_path / "q.fa"
+    fa.write_text("".join(">q%d\n%s\n" % (i, s) for i, s in enumerate(seqs)))
+    args = ["-d", str(db), "-i", str(fa), "-t", "1.0", "--o.csv", genome[300:700]]
+
+    def run(env):
+        r = subprocess.run([native.KWAGE_BIN] + args, capture_output=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        return r.stdout, r.stderr.decode()
+    plain, _ = run({"KWAGE_SPARSE": "0"})
+    assert plain.count(b"\n") > 4
+    outs = {}
+    for head in ("0", "4", "32", "100000"):
+        outs[head], err = run({"KWAGE_SPARSE": "1", "KWAGE_SPARSE_SCREEN": head, "KWAGE_VERBOSE": "1"})
+        assert outs[head] == plain, head
+        assert ("screened 2^14 slices" in err) == (head in ("4", "32")), (head, err[-1500:])
+    # the candidate files one at a time (a budget below one file's rows), and the default mode
+    small, err = run({"KWAGE_SPARSE": "1", "KWAGE_SPARSE_SCREEN": "32", "KWAGE_MAX_GROUP_BYTES": str(256 * 3000), "KWAGE_VERBOSE": "1"})
+    assert small == plain and " of 8 queries hold a candidate, in 5 files" in err, err[-1500:]     # (5: the query with N's up front meets every file)
+    assert run({})[0] == plain
+    if os.access(oracle.REF_KWAGE, os.X_OK):
+        ref = subprocess.run([oracle.REF_KWAGE] + args, capture_output=True, env=dict(os.environ, OMP_NUM_THREADS="1"))
+        assert ref.returncode == 0 and sorted(ref.stdout.splitlines()) == sorted(plain.splitlines())
 
 
 def test_sparse_group_gives_the_same_hits(ka, ctx, oracle, tmp_path):

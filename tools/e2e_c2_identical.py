@@ -142,7 +142,7 @@ def main():
             if have_ref:
                 t_ref, out_ref, _ = run(oracle.REF_KWAGE, thr, dict(os.environ, OMP_NUM_THREADS=str(threads)), 2)
             t_gpu, out_gpu, err_gpu = run(native.KWAGE_BIN, thr, dict(os.environ, KWAGE_VERBOSE="1"), 2)
-            split = [ln.strip() for ln in err_gpu.splitlines() if ("loaded" in ln and "GB/s" in ln) or "from the start of main" in ln or ": init " in ln]
+            split = [ln.strip() for ln in err_gpu.splitlines() if ("loaded" in ln and "GB/s" in ln) or "from the start of main" in ln or ": init " in ln or " screened 2^" in ln]
             g = oracle.parse_csv(out_gpu)
             n_hits = sum(len(v) for v in g.values())
             rec = {"threshold": thr, "kwage_amd_wall_s": round(t_gpu, 3), "kwage_amd_verbose": split, "hits": n_hits,
@@ -171,6 +171,14 @@ def main():
                 say("t = %g: reference kwage with OMP_NUM_THREADS=16 (the host threads kwage_amd/bin/kwage reads the files with), best of 2: wall %.2f s = %.2f G bit-tests/s"
                     % (thr, t16, bit_tests / t16 / 1e9))
                 result["reference_16_threads"]["%g" % thr] = {"wall_s": round(t16, 3), "g_bit_tests_per_s": round(bit_tests / t16 / 1e9, 2)}
+        # t = 1 without the screen on every query's first k-mers (KWAGE_SPARSE_SCREEN=0): every addressed slice of every file fetched
+        t_ns, out_ns, err_ns = run(native.KWAGE_BIN, 1.0, dict(os.environ, KWAGE_VERBOSE="1", KWAGE_SPARSE_SCREEN="0"), 2)
+        same_ns = oracle.parse_csv(out_ns) == oracle.parse_csv(run(native.KWAGE_BIN, 1.0, dict(os.environ), 1)[1])
+        say("t = 1 with KWAGE_SPARSE_SCREEN=0 (every addressed slice of every file fetched, no screen on the queries' first k-mers), best of 2: wall %.2f s; same report: %s" % (t_ns, same_ns))
+        for ln in [ln.strip() for ln in err_ns.splitlines() if ("loaded" in ln and "GB/s" in ln)]:
+            say("      " + ln)
+        result["no_screen"] = {"threshold": 1.0, "wall_s": round(t_ns, 3), "same_report": bool(same_ns), "verbose": [ln.strip() for ln in err_ns.splitlines() if "loaded" in ln and "GB/s" in ln]}
+        ok_all = ok_all and same_ns
         # the same command with the WHOLE database loaded (KWAGE_SPARSE=0): what a host that keeps the database resident pays once
         thr0 = float(args.thresholds.split(",")[0])
         t_full, out_full, err_full = run(native.KWAGE_BIN, thr0, dict(os.environ, KWAGE_VERBOSE="1", KWAGE_SPARSE="0"), 1)
