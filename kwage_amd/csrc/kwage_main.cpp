@@ -25,6 +25,9 @@
 //                     searched: "auto" (default) loads only the slices the queries address when they address at most
 //                     1/8 of a group's rows -- I/O proportional to the queries, like the reference's seek + read per
 //                     slice --, "1" always does, "0" always loads whole files
+//   KWAGE_SPARSE_SCREEN  at -t 1 with slices fetched on demand: the slices of every query's first N k-mers (default 32;
+//                     0 = off) are fetched and searched first, and only files that hold a candidate column are
+//                     fetched for the rest -- the reads the reference's early exit never makes (kwage.cpp:466-481)
 //   KWAGE_VERBOSE     1 = per-stage wall times on stderr
 #include "cli_common.hpp"
 
@@ -538,6 +541,9 @@ int main(int argc, char *argv[])
 					if(head_rows.empty() || head_rows.size()*4 > n_rows_all || !span_fits(members, head_rows.size())){ return false; }
 					double t0 = now_s();
 					vector<char> file_in(files.size(), 0);
+					// per file and query source: the queries with a candidate column in it (increasing; a query with several columns once)
+					map<uint32_t, vector<uint32_t> > cand[2];
+					vector<uint32_t> everywhere[2];
 					{
 						ResidentUnit scr;
 						Drop drop{scr.group};
@@ -558,12 +564,14 @@ int main(int argc, char *argv[])
 								scr.cols.locate(res->hits[i].column, fi, local);
 								file_in[fi] = 1;
 								keep[res->hits[i].query] = 1;
+								cand[s][fi].push_back(res->hits[i].query);
 							}
 							for(size_t i = 0; i < heads[s].size(); ++i){
 								// a head without a valid k-mer (N's) says nothing about a longer query: that query meets every file
 								const uint64_t len = full[s]->offsets[i + 1] - full[s]->offsets[i];
 								if(res->num_query_kmer[i] == 0 && len > head_len){
 									keep[i] = 1;
+									everywhere[s].push_back((uint32_t)i);
 									for(uint32_t fi : members){ file_in[fi] = 1; }
 								}
 								if(keep[i]){
@@ -583,6 +591,63 @@ int main(int argc, char *argv[])
 							<< " queries hold a candidate, in " << files2.size() << " files" << endl;
 					}
 					if(files2.empty() || subs[0].size() + subs[1].size() == 0){ return true; }       // nothing can match
+					// FILE BY FILE where that is much less to fetch: a file gets the slices of ITS OWN candidate queries only (a thousand
+					// queries with a candidate each in three of fifty files: a sixteenth of what the union of the queries costs in every
+					// candidate file).  Every file is a load and a search of its own, so only for a few hundred files.
+					{
+						auto width = [&](uint32_t fi) { return ((uint64_t)files[fi].header.num_filter + 7)/8; };
+						auto rows_of = [&](int s, uint32_t i) {
+							const uint64_t len = full[s]->offsets[i + 1] - full[s]->offsets[i];
+							return (len >= p.kmer_len) ? (len - p.kmer_len + 1)*p.num_hash : 0;
+						};
+						uint64_t all_rows = 0, union_bytes = 0, own_bytes = 0;
+						for(int s = 0; s < 2; ++s){ for(size_t i = 0; i < subs[s].size(); ++i){ const uint64_t len = subs[s].offsets[i + 1] - subs[s].offsets[i]; all_rows += (len >= p.kmer_len) ? (len - p.kmer_len + 1)*p.num_hash : 0; } }
+						for(uint32_t fi : files2){
+							union_bytes += all_rows*width(fi);
+							uint64_t own = 0;
+							for(int s = 0; s < 2; ++s){
+								for(uint32_t i : everywhere[s]){ own += rows_of(s, i); }
+								auto it = cand[s].find(fi);
+								if(it == cand[s].end()){ continue; }
+								uint32_t last = 0xFFFFFFFFu;
+								for(uint32_t i : it->second){ if(i != last){ own += rows_of(s, i); last = i; } }
+							}
+							own_bytes += own*width(fi);
+						}
+						if(files2.size() <= 256 && own_bytes*2 <= union_bytes){
+							for(uint32_t fi : files2){
+								QueryBatch own[2];
+								for(int s = 0; s < 2; ++s){
+									own[s].clear();
+									vector<char> in(full[s]->size(), 0);
+									for(uint32_t i : everywhere[s]){ in[i] = 1; }
+									auto it = cand[s].find(fi);
+									if(it != cand[s].end()){ for(uint32_t i : it->second){ in[i] = 1; } }
+									for(size_t i = 0; i < full[s]->size(); ++i){
+										if(!in[i]){ continue; }
+										const uint64_t o = full[s]->offsets[i];
+										own[s].add(full[s]->ids[i], full[s]->bases.substr(o, full[s]->offsets[i + 1] - o), full[s]->deflines.empty() ? nullptr : &full[s]->deflines[i]);
+									}
+								}
+								vector<uint32_t> rows_f;
+								addressed_rows(ctx, p, own[0], rows_f);
+								addressed_rows(ctx, p, own[1], rows_f);
+								if(rows_f.empty()){ continue; }
+								t0 = now_s();
+								vector<ResidentUnit> unit(1);
+								Drop drop{unit[0].group};
+								load_sparse_unit(p, vector<uint32_t>(1, fi), rows_f, unit[0]);
+								t_load += now_s() - t0;
+								t0 = now_s();
+								PreloadedQueries typed(own[0]), from_disk(own[1]);
+								search_stream(ctx, unit, typed, cli.threshold, flags, max_batch_bases, local_cmdline);
+								search_stream(ctx, unit, from_disk, cli.threshold, flags, max_batch_bases, local_files);
+								t_search += now_s() - t0;
+							}
+							if(verbose){ lock_guard<mutex> lk(merge_lock); cerr << "[kwage] device " << devices[di] << " candidate files fetched one by one, each with the slices of its own candidate queries" << endl; }
+							return true;
+						}
+					}
 					vector<uint32_t> rows2;
 					addressed_rows(ctx, p, subs[0], rows2);
 					addressed_rows(ctx, p, subs[1], rows2);

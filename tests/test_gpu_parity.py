@@ -588,10 +588,10 @@ def test_cli_sparse_fetch_screened_on_first_kmers(oracle, tmp_path):
     from kwage_amd import native
     rng = np.random.default_rng(4242)
     k, nh, L = 31, 2, 14
-    genome, other = rand_seq(rng, 3000), rand_seq(rng, 1500)
+    genome, other, third = rand_seq(rng, 3000), rand_seq(rng, 1500), rand_seq(rng, 1200)
     db = tmp_path / "db"
     db.mkdir()
-    for f, (ncol, planted) in enumerate(((2048, genome), (300, None), (2048, other), (64, genome), (1000, None))):
+    for f, (ncol, planted) in enumerate(((2048, genome), (300, None), (2048, other), (64, genome), (1000, third))):
         img = _make_random_db(rng, L, ncol, 0.4)
         if planted is not None:
             for r in oracle.row_indices(oracle.unique_kmers(planted, k), k, nh, L).reshape(-1):
@@ -621,6 +621,15 @@ def test_cli_sparse_fetch_screened_on_first_kmers(oracle, tmp_path):
     if os.access(oracle.REF_KWAGE, os.X_OK):
         ref = subprocess.run([oracle.REF_KWAGE] + args, capture_output=True, env=dict(os.environ, OMP_NUM_THREADS="1"))
         assert ref.returncode == 0 and sorted(ref.stdout.splitlines()) == sorted(plain.splitlines())
+    # three queries with their candidates in different files: every candidate file is fetched on its own, with its own queries' slices
+    fa2 = tmp_path / "q2.fa"
+    fa2.write_text(">a\n%s\n>b\n%s\n>c\n%s\n" % (genome[200:1200], other[100:1100], third[:1000]))
+    args = ["-d", str(db), "-i", str(fa2), "-t", "1.0", "--o.json"]
+    plain, _ = run({"KWAGE_SPARSE": "0"})
+    got, err = run({"KWAGE_SPARSE": "1", "KWAGE_VERBOSE": "1"})
+    assert got == plain and plain.count(b"num_kmers_found") >= 4
+    assert "3 of 3 queries hold a candidate, in 4 files" in err and "fetched one by one" in err, err[-1500:]
+    assert run({"KWAGE_SPARSE": "1", "KWAGE_SPARSE_SCREEN": "0"})[0] == plain
 
 
 def test_sparse_group_gives_the_same_hits(ka, ctx, oracle, tmp_path):
