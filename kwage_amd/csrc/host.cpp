@@ -326,8 +326,10 @@ bool DbSliceSource::open(const std::string &path, std::string &err)
 		err = path + ": unsupported compression code (only 0 = none and 2 = deflate container)";
 		return false;
 	}
+	// (the size first: a damaged log_2_filter_len must not make this allocate -- and zero -- a table of up to 32 GiB)
+	if(fsize < DB_HEADER_BYTES + 8*(nrows + 1)){ err = path + ": truncated slice offset table"; return false; }
 	offsets.resize(nrows + 1);
-	if(fsize < DB_HEADER_BYTES + 8*(nrows + 1) || !pread_all(fd, offsets.data(), 8*(nrows + 1), DB_HEADER_BYTES)){
+	if(!pread_all(fd, offsets.data(), 8*(nrows + 1), DB_HEADER_BYTES)){
 		err = path + ": truncated slice offset table";
 		return false;
 	}
