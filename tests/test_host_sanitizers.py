@@ -30,3 +30,21 @@ def test_host_entry_points_under_asan_and_ubsan(tmp_path):
     # the walk really went through damaged inputs, and most calls succeeded
     calls, refused = [int(x) for x in r.stdout.split("UBSan:")[1].replace(" calls,", "").split(" of them")[0].split()]
     assert calls > 50000 and 500 < refused < calls // 4
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not found")
+def test_command_line_host_logic_under_asan_and_ubsan(tmp_path):
+    """cli_common.hpp's report writers replay the hit lists of the reference-written expected_t*.csv fixtures and must give the
+    reference's CSV and JSON files byte for byte; the option parser and the query sources run beside them (tests/sanitize/cli_sanitize.cpp)."""
+    exe = str(tmp_path / "cli_sanitize")
+    csrc = os.path.join(ROOT, "kwage_amd", "csrc")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+           "-I" + os.path.join(ROOT, "include"), "-I" + csrc, os.path.join(csrc, "host.cpp"),
+           os.path.join(ROOT, "tests", "sanitize", "cli_sanitize.cpp"), "-o", exe, "-lz", "-lpthread"]
+    b = subprocess.run(cmd, capture_output=True, text=True, cwd=csrc)
+    assert b.returncode == 0, b.stderr[-3000:]
+    r = subprocess.run([exe, GOLDEN], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-4000:])
+    assert "reports replayed byte for byte, no report" in r.stdout
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr and "LeakSanitizer" not in r.stderr and "FAILED" not in r.stderr, r.stderr[-4000:]
