@@ -216,7 +216,37 @@ int print_plan(const vector<string> &db_paths, int n_ranks)
 			}
 			cout << "]}";
 		}
-		cout << "]}" << endl;
+		cout << "]";
+		// with a budget (KWAGE_MAX_GROUP_BYTES): every rank's passes as plan_passes cuts them, the ranks padded to the same number
+		const uint64_t budget = env_u64("KWAGE_MAX_GROUP_BYTES", 0);
+		if(budget){
+			size_t n_passes = 1;
+			vector<vector<vector<Unit> > > per_rank((size_t)n_ranks);
+			for(int r = 0; r < n_ranks; ++r){
+				per_rank[(size_t)r] = plan_passes(groups, files, (size_t)r, budget);
+				n_passes = max(n_passes, per_rank[(size_t)r].size());
+			}
+			cout << ", \"budget\": " << budget << ", \"passes\": " << n_passes << ", \"rank_passes\": [";
+			for(int r = 0; r < n_ranks; ++r){
+				per_rank[(size_t)r].resize(n_passes);
+				cout << (r ? ", " : "") << "[";
+				for(size_t ps = 0; ps < n_passes; ++ps){
+					cout << (ps ? ", " : "") << "[";
+					for(size_t ui = 0; ui < per_rank[(size_t)r][ps].size(); ++ui){
+						const Unit &u = per_rank[(size_t)r][ps][ui];
+						cout << (ui ? ", " : "") << "{\"group\": " << u.gi << ", \"global_base\": " << u.base << ", \"span_columns\": " << u.span_columns << ", \"files\": [";
+						for(size_t f = 0; f < u.files.size(); ++f){
+							cout << (f ? ", " : "") << "{\"path\": \"" << files[u.files[f]].path << "\", \"first_column\": " << u.first_column[f] << "}";
+						}
+						cout << "]}";
+					}
+					cout << "]";
+				}
+				cout << "]";
+			}
+			cout << "]";
+		}
+		cout << "}" << endl;
 	}
 	catch(const char *error){
 		cerr << "Caught the error " << error << endl;

@@ -174,3 +174,56 @@ def test_node_plan_is_the_python_hosts_partition(tmp_path, oracle):
                     at += 1
                 assert s["span_columns"] == span * 8
                 next_base += s["span_columns"]
+
+
+def test_node_plan_cuts_passes_that_fit_the_budget(tmp_path, oracle):
+    """KWAGE_NODE_PLAN=1 with KWAGE_MAX_GROUP_BYTES: every rank's passes as `plan_passes` cuts them (no device touched).  Every
+    file of a rank's share lies in exactly one unit, in order; a unit's files follow each other on 16-byte boundaries; the
+    matrices of a pass (128-byte row strides x 2^L rows) fit the budget -- except a unit of ONE file that alone exceeds it
+    and has a pass to itself; the global base of a unit is its share's base plus the share-relative first column of its first
+    file; all ranks have the same number of passes."""
+    import numpy as np
+    rng = np.random.default_rng(11)
+    widths = {"a": [int(x) for x in rng.integers(1, 1500, size=23)], "b": [2048, 1, 2048, 7, 640, 4000]}
+    lens = {"a": 10, "b": 12}
+    for sub, nh in (("a", 1), ("b", 2)):
+        os.makedirs(tmp_path / "db" / sub)
+        for f, n in enumerate(widths[sub]):
+            rows = rng.integers(0, 256, size=(1 << lens[sub], (n + 7) // 8), dtype=np.uint8)
+            infos = [oracle.FilterInfo(run_accession=oracle.str_to_accession("SRR%07d" % (1000 * f + j))) for j in range(n)]
+            oracle.write_db(str(tmp_path / "db" / sub / ("f%02d.db" % f)), 31, nh, lens[sub], rows, n, infos)
+    nf_of = lambda p: widths[os.path.basename(os.path.dirname(p))][int(os.path.basename(p)[1:3])]
+    L_of = lambda p: lens[os.path.basename(os.path.dirname(p))]
+    for ranks in (1, 2, 4):
+        for budget in (1, 128 << 10, 300 << 10, 1 << 20, 1 << 40):
+            r = subprocess.run([NODE, "-d", "db", "-t", "1", "ACGTACGTACGTACGTACGTACGTACGTACGTAAA"], cwd=tmp_path, capture_output=True, timeout=60,
+                               env=_env(KWAGE_NODE_RANKS=str(ranks), KWAGE_NODE_PLAN="1", KWAGE_MAX_GROUP_BYTES=str(budget)))
+            assert r.returncode == 0, r.stderr.decode()
+            plan = json.loads(r.stdout)
+            assert plan["budget"] == budget and len(plan["rank_passes"]) == ranks
+            assert all(len(ps) == plan["passes"] for ps in plan["rank_passes"])
+            assert max(sum(1 for p in ps if p) for ps in plan["rank_passes"]) == plan["passes"] or plan["passes"] == 1       # no empty tail pass everywhere
+            if budget == 1 << 40:
+                assert plan["passes"] == 1
+            for rank, passes in enumerate(plan["rank_passes"]):
+                # the files of this rank's shares, group after group, in order
+                share_files = [(gi, f["path"], g["shares"][rank]["global_base"], f["first_column"])
+                               for gi, g in enumerate(plan["groups"]) for f in g["shares"][rank]["files"]]
+                seen = []
+                for units in passes:
+                    used = 0
+                    for u in units:
+                        span = 0
+                        for f in u["files"]:
+                            span = (span + 15) // 16 * 16
+                            assert f["first_column"] == span * 8
+                            span += (nf_of(f["path"]) + 7) // 8
+                            seen.append((u["group"], f["path"]))
+                        assert u["span_columns"] == span * 8
+                        first = next(x for x in share_files if x[1] == u["files"][0]["path"])
+                        assert u["global_base"] == first[2] + first[3] and u["group"] == first[0]
+                        assert len({L_of(f["path"]) for f in u["files"]}) == 1
+                        used += ((span + 127) // 128 * 128) << L_of(u["files"][0]["path"])
+                    alone = len(units) == 1 and len(units[0]["files"]) == 1
+                    assert used <= budget or alone, (ranks, budget, rank, used)
+                assert seen == [(gi, p) for gi, p, _, _ in share_files], (ranks, budget, rank)
