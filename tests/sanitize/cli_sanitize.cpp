@@ -201,6 +201,6 @@ int main(int argc, char **argv)
 	catch(const char *e){ cerr << "exception: " << e << endl; return 2; }
 	catch(const string &e){ cerr << "exception: " << e << endl; return 2; }
 	if(fails){ return 1; }
-	cout << "command-line host logic under ASan + UBSan: reports replayed byte for byte, no report" << endl;
+	cout << "command-line host logic under the sanitizers: reports replayed byte for byte, no report" << endl;
 	return 0;
 }

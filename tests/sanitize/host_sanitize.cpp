@@ -215,6 +215,6 @@ int main(int argc, char **argv)
 			(void)kwage_optimal_bloom_param(31, nk, pr, 33, 5, &out);
 		}
 	}
-	printf("host entry points under ASan + UBSan: %lu calls, %lu of them refused their (damaged) input, no report\n", calls, failures);
+	printf("host entry points under the sanitizers: %lu calls, %lu of them refused their (damaged) input, no report\n", calls, failures);
 	return 0;
 }

@@ -1,5 +1,5 @@
 """The host side of the C ABI (`.db` reader raw + compressed, slice lists, metadata strings, FASTA/FASTQ(.gz) iterator, accession
-codec) built from kwage_amd/csrc/host.cpp with g++ -fsanitize=address,undefined and walked over the reference-written fixtures and
+codec) built from kwage_amd/csrc/host.cpp with g++ -fsanitize=address,undefined -- and again with -fsanitize=thread -- and walked over the reference-written fixtures and
 over damaged copies of them (cut at every kind of boundary, bytes flipped where lengths and offsets live, random bytes):
 tests/sanitize/host_sanitize.cpp.  Sanitizers run on the CPU build only (the GPU pool refuses them); no device is touched."""
 import os
@@ -13,10 +13,16 @@ from conftest import GOLDEN
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+SANITIZERS = {"asan+ubsan": ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"],
+              "tsan": ["-fsanitize=thread"]}       # (the reader pools of read_rows / read_row_list, the compressor's threads, the query prefetcher)
+REPORTS = ("AddressSanitizer", "runtime error", "LeakSanitizer", "ThreadSanitizer")
+
+
 @pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not found")
-def test_host_entry_points_under_asan_and_ubsan(tmp_path):
+@pytest.mark.parametrize("kind", list(SANITIZERS))
+def test_host_entry_points_under_sanitizers(tmp_path, kind):
     exe = str(tmp_path / "host_sanitize")
-    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+    cmd = ["g++", "-std=c++17", "-O1", "-g"] + SANITIZERS[kind] + ["-fno-omit-frame-pointer",
            "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "kwage_amd", "csrc", "host.cpp"),
            os.path.join(ROOT, "tests", "sanitize", "host_sanitize.cpp"), "-o", exe, "-lz", "-lpthread"]
     b = subprocess.run(cmd, capture_output=True, text=True, cwd=os.path.join(ROOT, "kwage_amd", "csrc"))
@@ -26,19 +32,20 @@ def test_host_entry_points_under_asan_and_ubsan(tmp_path):
     r = subprocess.run([exe, GOLDEN, str(scratch)], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-4000:])
-    assert "no report" in r.stdout and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stderr[-4000:]
+    assert "no report" in r.stdout and not any(x in r.stderr for x in REPORTS), r.stderr[-4000:]
     # the walk really went through damaged inputs, and most calls succeeded
-    calls, refused = [int(x) for x in r.stdout.split("UBSan:")[1].replace(" calls,", "").split(" of them")[0].split()]
+    calls, refused = [int(x) for x in r.stdout.split("sanitizers:")[1].replace(" calls,", "").split(" of them")[0].split()]
     assert calls > 50000 and 500 < refused < calls // 4
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not found")
-def test_command_line_host_logic_under_asan_and_ubsan(tmp_path):
+@pytest.mark.parametrize("kind", list(SANITIZERS))
+def test_command_line_host_logic_under_sanitizers(tmp_path, kind):
     """cli_common.hpp's report writers replay the hit lists of the reference-written expected_t*.csv fixtures and must give the
     reference's CSV and JSON files byte for byte; the option parser and the query sources run beside them (tests/sanitize/cli_sanitize.cpp)."""
     exe = str(tmp_path / "cli_sanitize")
     csrc = os.path.join(ROOT, "kwage_amd", "csrc")
-    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+    cmd = ["g++", "-std=c++17", "-O1", "-g"] + SANITIZERS[kind] + ["-fno-omit-frame-pointer",
            "-I" + os.path.join(ROOT, "include"), "-I" + csrc, os.path.join(csrc, "host.cpp"),
            os.path.join(ROOT, "tests", "sanitize", "cli_sanitize.cpp"), "-o", exe, "-lz", "-lpthread"]
     b = subprocess.run(cmd, capture_output=True, text=True, cwd=csrc)
@@ -47,4 +54,4 @@ def test_command_line_host_logic_under_asan_and_ubsan(tmp_path):
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-4000:])
     assert "reports replayed byte for byte, no report" in r.stdout
-    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr and "LeakSanitizer" not in r.stderr and "FAILED" not in r.stderr, r.stderr[-4000:]
+    assert not any(x in r.stderr for x in REPORTS + ("FAILED",)), r.stderr[-4000:]
