@@ -18,6 +18,13 @@ SANITIZERS = {"asan+ubsan": ["-fsanitize=address,undefined", "-fno-sanitize-reco
 REPORTS = ("AddressSanitizer", "runtime error", "LeakSanitizer", "ThreadSanitizer")
 
 
+def _skip_if_runtime_cannot_start(r):
+    # (a sanitizer runtime that cannot lay out its shadow memory under this kernel's address-space settings says so and exits
+    # before main: nothing was tested, nothing failed)
+    if r.returncode != 0 and ("unexpected memory mapping" in r.stderr or "Shadow memory range interleaves" in r.stderr or "ReserveShadowMemoryRange failed" in r.stderr):
+        pytest.skip("the sanitizer runtime cannot start here: " + r.stderr.strip().splitlines()[0][:200])
+
+
 @pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not found")
 @pytest.mark.parametrize("kind", list(SANITIZERS))
 def test_host_entry_points_under_sanitizers(tmp_path, kind):
@@ -31,6 +38,7 @@ def test_host_entry_points_under_sanitizers(tmp_path, kind):
     scratch.mkdir()
     r = subprocess.run([exe, GOLDEN, str(scratch)], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    _skip_if_runtime_cannot_start(r)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-4000:])
     assert "no report" in r.stdout and not any(x in r.stderr for x in REPORTS), r.stderr[-4000:]
     # the walk really went through damaged inputs, and most calls succeeded
@@ -52,6 +60,7 @@ def test_command_line_host_logic_under_sanitizers(tmp_path, kind):
     assert b.returncode == 0, b.stderr[-3000:]
     r = subprocess.run([exe, GOLDEN], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    _skip_if_runtime_cannot_start(r)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-4000:])
     assert "reports replayed byte for byte, no report" in r.stdout
     assert not any(x in r.stderr for x in REPORTS + ("FAILED",)), r.stderr[-4000:]
