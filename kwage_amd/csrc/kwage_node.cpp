@@ -20,8 +20,9 @@
 // only this program links it.  No row data ever crosses xGMI.
 //
 //   KWAGE_NODE_RANKS    number of ranks (default: the number of visible devices); rank r uses device r
-//   KWAGE_NODE_PLAN     1: print the plan (groups, every rank's files, global column bases) as JSON and stop; no device is
-//                       touched or counted -- the number of ranks must come from KWAGE_NODE_RANKS
+//   KWAGE_NODE_PLAN     1: print the plan (groups, every rank's files, global column bases; under KWAGE_MAX_GROUP_BYTES also
+//                       every rank's passes) as JSON and stop; no device is touched or counted -- the number of ranks must
+//                       come from KWAGE_NODE_RANKS
 //   KWAGE_NODE_STATS    1: rank 0 reports on stderr what the search phase took: wall, sum of gather-kernel time, exchange, filing
 //   KWAGE_NODE_REHEARSE 1: rehearsal on a machine with fewer GPUs than ranks -- every rank uses device 0 and the records
 //                       travel through a shared host segment instead of RCCL (which refuses two ranks on one device).
